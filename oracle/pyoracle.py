@@ -1,0 +1,212 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings of
+  * oracle/liboracle.so            our CPU restatement (oracle/src/*.cpp), and
+  * oracle/_ref/libssvio_ref.so    the real reference arithmetic (oracle/ref_driver.cpp + /root/reference
+                                   sources, built by oracle/Makefile; prebuilt file travels to the GPU box).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+_REF_SO = os.path.join(_HERE, "_ref", "libssvio_ref.so")
+
+dbl_p = C.POINTER(C.c_double)
+u8_p = C.POINTER(C.c_ubyte)
+i32_p = C.POINTER(C.c_int32)
+f32_p = C.POINTER(C.c_float)
+
+
+def _p(a, t):
+    if a is None:
+        return None
+    return a.ctypes.data_as(t)
+
+
+def build(force=False):
+    """Compile liboracle.so (always possible) and, when /root/reference exists, the reference .so."""
+    srcs = [os.path.join(_HERE, "src", f) for f in os.listdir(os.path.join(_HERE, "src"))]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(_ORACLE_SO) or os.path.getmtime(_ORACLE_SO) < newest:
+        subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/include/ssvio") and (
+            force or not os.path.exists(_REF_SO)
+            or os.path.getmtime(_REF_SO) < os.path.getmtime(os.path.join(_HERE, "ref_driver.cpp"))):
+        subprocess.check_call(["make", "-C", _HERE, "-j8", "ref"], stdout=subprocess.DEVNULL)
+
+
+class KeyPoint(C.Structure):
+    """cv::KeyPoint layout (28 bytes)."""
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int)]
+
+
+class MatchParams(C.Structure):
+    _fields_ = [("band_px", C.c_float), ("min_disp", C.c_float), ("max_disp", C.c_float),
+                ("max_dist", C.c_int), ("max_octave_diff", C.c_int), ("scale_factor", C.c_float)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("outer_rounds", C.c_int), ("iters", C.c_int), ("chi2_th", C.c_double),
+                ("huber_delta", C.c_double), ("inlier_ratio", C.c_double), ("jac_mode", C.c_int)]
+
+
+_oracle = None
+_ref = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        build()
+        _oracle = C.CDLL(_ORACLE_SO)
+        for name, rt in (("orc_ic_angle", C.c_float), ("orc_fast_atan2", C.c_float),
+                         ("orc_brief_pattern", C.POINTER(C.c_int8))):
+            if hasattr(_oracle, name):
+                getattr(_oracle, name).restype = rt
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(_REF_SO) or os.path.isdir("/root/reference/include/ssvio")
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        build()
+        _ref = C.CDLL(_REF_SO)
+    return _ref
+
+
+# ------------------------------------------------------------------ BA
+def _ba_args(pr, poses, points):
+    return (pr["P"], _p(poses, dbl_p), _p(pr["pose_fixed"], u8_p), pr["L"], _p(points, dbl_p),
+            _p(pr["point_fixed"], u8_p), pr["E"], _p(pr["edge_pose"], i32_p), _p(pr["edge_point"], i32_p),
+            _p(pr["edge_uv"], dbl_p), _p(pr["edge_cam"], u8_p), _p(pr["K"], dbl_p), _p(pr["cam_ext"], dbl_p))
+
+
+def ba_solve(pr, which="oracle", outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891,
+             inlier_ratio=0.7, jac_mode=1):
+    """Run the BA on a problem dict (ssvio_amd.synth.make_ba_problem layout). which = oracle | ref."""
+    poses = np.ascontiguousarray(pr["poses"], dtype=np.float64).copy()
+    points = np.ascontiguousarray(pr["points"], dtype=np.float64).copy()
+    E = pr["E"]
+    chi2 = np.zeros(E)
+    cap = outer_rounds * iters + 8
+    s_chi = np.zeros(cap); s_lam = np.zeros(cap); s_tr = np.zeros(cap, dtype=np.int32)
+    n = C.c_int(0)
+    if which == "ref":
+        rounds = ref_lib().ref_ba_solve(*_ba_args(pr, poses, points), outer_rounds, iters,
+                                        C.c_double(chi2_th), C.c_double(huber_delta), C.c_double(inlier_ratio),
+                                        _p(chi2, dbl_p), cap, C.byref(n), _p(s_chi, dbl_p), _p(s_lam, dbl_p),
+                                        _p(s_tr, i32_p))
+        outl = (chi2 > chi2_th).astype(np.uint8)
+    else:
+        opt = BaOptions(outer_rounds, iters, chi2_th, huber_delta, inlier_ratio, jac_mode)
+        outl = np.zeros(E, dtype=np.uint8)
+        rounds = oracle_lib().orc_ba_solve(*_ba_args(pr, poses, points), C.byref(opt), _p(chi2, dbl_p),
+                                           _p(outl, u8_p), cap, C.byref(n), _p(s_chi, dbl_p),
+                                           _p(s_lam, dbl_p), _p(s_tr, i32_p))
+    k = n.value
+    return dict(rounds=rounds, poses=poses, points=points, edge_chi2=chi2, edge_outlier=outl,
+                chi2=s_chi[:k].copy(), lam=s_lam[:k].copy(), trials=s_tr[:k].copy())
+
+
+def ba_linearize(pr, huber_delta=5.891, jac_mode=0):
+    P, L, E = pr["P"], pr["L"], pr["E"]
+    Hpp = np.zeros((P, 6, 6)); bp = np.zeros((P, 6)); Hll = np.zeros((L, 3, 3)); bl = np.zeros((L, 3))
+    Hpl = np.zeros((E, 6, 3)); err = np.zeros((E, 2)); chi = C.c_double(0)
+    poses = np.ascontiguousarray(pr["poses"]); points = np.ascontiguousarray(pr["points"])
+    oracle_lib().orc_ba_linearize(*_ba_args(pr, poses, points), C.c_double(huber_delta), jac_mode,
+                                  _p(Hpp, dbl_p), _p(bp, dbl_p), _p(Hll, dbl_p), _p(bl, dbl_p),
+                                  _p(Hpl, dbl_p), _p(err, dbl_p), C.byref(chi))
+    return dict(Hpp=Hpp, bp=bp, Hll=Hll, bl=bl, Hpl=Hpl, err=err, chi2=chi.value)
+
+
+def edge_eval(pose, p, uv, K, ext, huber_delta=5.891, which="oracle", jac_mode=1):
+    pose = np.ascontiguousarray(pose, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
+    uv = np.ascontiguousarray(uv, dtype=np.float64); K = np.ascontiguousarray(K, dtype=np.float64)
+    ext = np.ascontiguousarray(ext, dtype=np.float64)
+    e = np.zeros(2); Ji = np.zeros((2, 6)); Jj = np.zeros((2, 3)); chi = C.c_double(0); rho = np.zeros(3)
+    if which == "ref":
+        ref_lib().ref_edge_eval(_p(pose, dbl_p), _p(p, dbl_p), _p(uv, dbl_p), _p(K, dbl_p), _p(ext, dbl_p),
+                                C.c_double(huber_delta), _p(e, dbl_p), _p(Ji, dbl_p), _p(Jj, dbl_p),
+                                C.byref(chi), _p(rho, dbl_p))
+    else:
+        oracle_lib().orc_edge_eval(_p(pose, dbl_p), _p(p, dbl_p), _p(uv, dbl_p), _p(K, dbl_p), _p(ext, dbl_p),
+                                   C.c_double(huber_delta), jac_mode, _p(e, dbl_p), _p(Ji, dbl_p),
+                                   _p(Jj, dbl_p), C.byref(chi), _p(rho, dbl_p))
+    return dict(e=e, Ji=Ji, Jj=Jj, chi2=chi.value, rho=rho)
+
+
+def se3_exp(a, which="oracle"):
+    a = np.ascontiguousarray(a, dtype=np.float64); out = np.zeros(7)
+    (ref_lib().ref_se3_exp if which == "ref" else oracle_lib().orc_se3_exp)(_p(a, dbl_p), _p(out, dbl_p))
+    return out
+
+
+def pose_oplus(pose, d, which="oracle"):
+    pose = np.ascontiguousarray(pose, dtype=np.float64); d = np.ascontiguousarray(d, dtype=np.float64)
+    out = np.zeros(7)
+    (ref_lib().ref_pose_oplus if which == "ref" else oracle_lib().orc_pose_oplus)(
+        _p(pose, dbl_p), _p(d, dbl_p), _p(out, dbl_p))
+    return out
+
+
+def se3_act(pose, p, which="oracle"):
+    pose = np.ascontiguousarray(pose, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.zeros(3)
+    (ref_lib().ref_se3_act if which == "ref" else oracle_lib().orc_se3_act)(
+        _p(pose, dbl_p), _p(p, dbl_p), _p(out, dbl_p))
+    return out
+
+
+def pose_only(pr, which="oracle", rounds=4, iters=10, chi2_th=5.991, huber_delta=1.0):
+    pose = np.ascontiguousarray(pr["pose"], dtype=np.float64).copy()
+    M = pr["M"]
+    inl = np.zeros(M, dtype=np.uint8)
+    xyz = np.ascontiguousarray(pr["xyz"]); uv = np.ascontiguousarray(pr["uv"]); K = np.ascontiguousarray(pr["K"])
+    if which == "ref":
+        n = ref_lib().ref_pose_only(_p(pose, dbl_p), _p(K, dbl_p), M, _p(xyz, dbl_p), _p(uv, dbl_p), rounds,
+                                    iters, C.c_double(chi2_th), _p(inl, u8_p))
+    else:
+        n = oracle_lib().orc_pose_only(_p(pose, dbl_p), _p(K, dbl_p), M, _p(xyz, dbl_p), _p(uv, dbl_p), rounds,
+                                       iters, C.c_double(chi2_th), C.c_double(huber_delta), _p(inl, u8_p))
+    return dict(pose=pose, inliers=inl, n_inliers=n)
+
+
+def triangulate(uvL, uvR, K, baseline, T_wc=None, which="oracle"):
+    uvL = np.ascontiguousarray(uvL, dtype=np.float64); uvR = np.ascontiguousarray(uvR, dtype=np.float64)
+    n = uvL.shape[0]
+    xyz = np.zeros((n, 3)); ok = np.zeros(n, dtype=np.uint8); ratio = np.zeros(n)
+    fx, fy, cx, cy = [float(v) for v in K]
+    if which == "ref":
+        assert T_wc is None
+        ref_lib().ref_triangulate(n, _p(uvL, dbl_p), _p(uvR, dbl_p), C.c_double(fx), C.c_double(fy),
+                                  C.c_double(cx), C.c_double(cy), C.c_double(baseline), _p(xyz, dbl_p),
+                                  _p(ok, u8_p), _p(ratio, dbl_p))
+    else:
+        T = None if T_wc is None else np.ascontiguousarray(T_wc, dtype=np.float64)
+        oracle_lib().orc_triangulate(n, _p(uvL, dbl_p), _p(uvR, dbl_p), C.c_double(fx), C.c_double(fy),
+                                     C.c_double(cx), C.c_double(cy), C.c_double(baseline), _p(T, dbl_p),
+                                     _p(xyz, dbl_p), _p(ok, u8_p), _p(ratio, dbl_p))
+    return dict(xyz=xyz, ok=ok, ratio=ratio)

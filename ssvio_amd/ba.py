@@ -1,0 +1,82 @@
+"""Local bundle adjustment through libssx.so -- host-side marshalling for Backend::OptimizeActiveMap
+(/root/reference/src/ssvio/backend.cpp:78-245).
+
+`problem` is a dict of flat arrays in the layout of ssx_ba_problem (include/ssx.h); see
+ssvio_amd.synth.make_ba_problem.  Every function here calls the HIP library; nothing is computed in
+Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BaOptions, BaProblem, BaResult, Context, dbl_p, i32_p, ptr, u8_p
+
+JAC_ANALYTIC = 0
+JAC_NUMERIC_G2O = 1
+
+
+def _problem_struct(pr, keep):
+    poses = np.ascontiguousarray(pr["poses"], dtype=np.float64)
+    points = np.ascontiguousarray(pr["points"], dtype=np.float64)
+    pose_fixed = None if pr.get("pose_fixed") is None else np.ascontiguousarray(pr["pose_fixed"], dtype=np.uint8)
+    point_fixed = None if pr.get("point_fixed") is None else np.ascontiguousarray(pr["point_fixed"], dtype=np.uint8)
+    edge_pose = np.ascontiguousarray(pr["edge_pose"], dtype=np.int32)
+    edge_point = np.ascontiguousarray(pr["edge_point"], dtype=np.int32)
+    edge_uv = np.ascontiguousarray(pr["edge_uv"], dtype=np.float64)
+    edge_cam = None if pr.get("edge_cam") is None else np.ascontiguousarray(pr["edge_cam"], dtype=np.uint8)
+    keep.extend([poses, points, pose_fixed, point_fixed, edge_pose, edge_point, edge_uv, edge_cam])
+    s = BaProblem()
+    s.P = int(poses.shape[0]); s.poses = ptr(poses, dbl_p); s.pose_fixed = ptr(pose_fixed, u8_p)
+    s.L = int(points.shape[0]); s.points = ptr(points, dbl_p); s.point_fixed = ptr(point_fixed, u8_p)
+    s.E = int(edge_pose.shape[0]); s.edge_pose = ptr(edge_pose, i32_p); s.edge_point = ptr(edge_point, i32_p)
+    s.edge_uv = ptr(edge_uv, dbl_p); s.edge_cam = ptr(edge_cam, u8_p)
+    for i, v in enumerate(np.asarray(pr["K"], dtype=np.float64).ravel()[:4]):
+        s.K[i] = float(v)
+    for i, v in enumerate(np.asarray(pr["cam_ext"], dtype=np.float64).ravel()[:14]):
+        s.cam_ext[i] = float(v)
+    return s
+
+
+def ba_solve(ctx: Context, pr, outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891,
+             inlier_ratio=0.7, jac_mode=JAC_ANALYTIC, allreduce=None, rank=0, world_size=1,
+             want_edges=True):
+    """Backend::OptimizeActiveMap's optimisation (defaults = backend.cpp:109,163,175,178,195)."""
+    keep = []
+    s = _problem_struct(pr, keep)
+    opt = BaOptions()
+    ctx.lib.ssx_ba_default_options(C.byref(opt))
+    opt.outer_rounds = outer_rounds; opt.iters = iters; opt.chi2_th = chi2_th
+    opt.huber_delta = huber_delta; opt.inlier_ratio = inlier_ratio; opt.jac_mode = jac_mode
+    opt.rank = rank; opt.world_size = world_size
+    if allreduce is not None:
+        cb = _lib.ALLREDUCE_FN(allreduce)
+        keep.append(cb)
+        opt.allreduce = cb
+    res = BaResult()
+    poses = np.zeros((s.P, 7)); points = np.zeros((s.L, 3))
+    chi2 = np.zeros(s.E) if want_edges else None
+    outl = np.zeros(s.E, dtype=np.uint8) if want_edges else None
+    res.poses_out = ptr(poses, dbl_p); res.points_out = ptr(points, dbl_p)
+    res.edge_chi2 = ptr(chi2, dbl_p); res.edge_outlier = ptr(outl, u8_p)
+    ctx.check(ctx.lib.ssx_ba_solve(ctx.handle, C.byref(s), C.byref(opt), C.byref(res)))
+    k = min(res.n_iters, _lib.SSX_BA_MAX_STATS)
+    return dict(rounds=res.rounds, n_iters=res.n_iters, poses=poses, points=points, edge_chi2=chi2,
+                edge_outlier=outl, chi2=np.array(res.iter_chi2[:k]), lam=np.array(res.iter_lambda[:k]),
+                trials=np.array(res.iter_trials[:k]), n_inliers=res.n_inliers, n_outliers=res.n_outliers,
+                ms_total=res.ms_total)
+
+
+def ba_linearize(ctx: Context, pr, huber_delta=5.891, jac_mode=JAC_ANALYTIC):
+    """One linearisation (blocks of the normal equations) -- kernel-level parity hook."""
+    keep = []
+    s = _problem_struct(pr, keep)
+    P, L, E = s.P, s.L, s.E
+    Hpp = np.zeros((P, 6, 6)); bp = np.zeros((P, 6)); Hll = np.zeros((L, 3, 3)); bl = np.zeros((L, 3))
+    Hpl = np.zeros((E, 6, 3)); err = np.zeros((E, 2)); chi = C.c_double(0)
+    ctx.check(ctx.lib.ssx_ba_linearize(ctx.handle, C.byref(s), C.c_double(huber_delta), jac_mode,
+                                       ptr(Hpp, dbl_p), ptr(bp, dbl_p), ptr(Hll, dbl_p), ptr(bl, dbl_p),
+                                       ptr(Hpl, dbl_p), ptr(err, dbl_p), C.byref(chi)))
+    return dict(Hpp=Hpp, bp=bp, Hll=Hll, bl=bl, Hpl=Hpl, err=err, chi2=chi.value)

@@ -1,0 +1,81 @@
+"""Build libssx.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m ssvio_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting
+ssvio_amd/libssx.so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libssx.so")
+ARCH = "gfx950"
+
+COMMON = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result", "-fvisibility=hidden", "-DSSX_BUILD"]
+# files whose results must be bit-identical to the CPU oracle (integer / f32 image arithmetic): forbid
+# fused multiply-add contraction so every float operation rounds exactly like the scalar C++ restatement
+PER_FILE = {
+    "orb.hip": ["-ffp-contract=off"],
+    "stereo.hip": ["-ffp-contract=off"],
+}
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libssx.so cannot be built (there is no CPU fallback)")
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _newest_dep() -> float:
+    t = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            t = max(t, os.path.getmtime(os.path.join(root, f)))
+    return max(t, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def _compile(cc, src):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    cmd = [cc, *COMMON, *PER_FILE.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
+    return obj, r.stderr
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_dep():
+        return LIB
+    cc = hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(cc, s), srcs))
+    if verbose:
+        for _, err in results:
+            if err.strip():
+                print(err, file=sys.stderr)
+    objs = [o for o, _ in results]
+    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

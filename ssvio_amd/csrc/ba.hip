@@ -1,0 +1,1050 @@
+// ssvio_amd/csrc/ba.hip -- local bundle adjustment on gfx950 (ssx_ba_solve / ssx_ba_linearize).
+//
+// Replaces the arithmetic behind Backend::OptimizeActiveMap (/root/reference/src/ssvio/backend.cpp:78-245):
+// g2o's SparseOptimizer + BlockSolver<6,3> + OptimizationAlgorithmLevenberg over ssvio's
+// VertexPose / VertexXYZ / EdgeProjection (include/ssvio/g2otypes.hpp).  No g2o, no Eigen: the normal
+// equations are built, Schur-reduced, solved and applied by the kernels below; the host only runs the
+// LM accept/reject logic on a handful of scalars per trial.
+//
+// Data layout in HBM (one arena per ctx, grow-only):
+//   edges are SORTED BY LANDMARK (then by pose inside a landmark) on upload so that all observations of
+//   a landmark are contiguous; landmarks are grouped into CHUNKS of whole landmarks with <= 256 edges.
+//   One 256-thread workgroup (4 waves) owns one chunk in every per-edge / per-landmark kernel, so every
+//   per-landmark reduction (Hll, bl, Schur terms, back-substitution) happens in LDS without atomics.
+//   Per-edge arrays are structure-of-arrays (W[k][E], uv[2][E] ...) so that lane i touches element i:
+//   every global access of a wave is one contiguous 512-byte segment.
+//
+// Determinism: no floating-point atomics anywhere.  Cross-edge sums inside a chunk are done by
+// "owned entries" (each thread owns a few output scalars and adds the contributions in edge order);
+// cross-chunk sums are done by a reduction kernel that walks the per-chunk slabs in chunk order.
+//
+// Kernels (small-pose path, free poses <= SSX_BA_SMALL_P; the local window of ssvio is 12):
+//   k_linearize<JAC>      per LM iteration : residuals, Jacobians, Huber weights, W_e = Ji^T w Jj,
+//                                            Hll/bl per landmark, Hpp/bp slab per chunk, chi2 slab
+//   k_reduce_lin          per LM iteration : slabs -> Hpp, bp, chi2, max|diag|
+//   k_schur               per LM trial     : (Hll+lambda I)^-1, W D^-1 W^T and W D^-1 bl slabs per chunk
+//   k_reduce_schur        per LM trial     : slabs -> dense reduced system S (without lambda), b_s
+//   k_solve               per LM trial     : one wave: (S + lambda I) x = b_s by LDS Cholesky, exp(x) * T
+//   k_backsub_residual    per LM trial     : x_l = D^-1 (bl - W^T x_p), new points, new residuals, chi2 slab
+//   k_reduce_trial        per LM trial     : slabs -> tempChi, scale, outlier count
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+#include "ctx.hpp"
+#include "se3.hpp"
+
+namespace {
+
+using ssx::Cam;
+
+constexpr int CH = 256;            // threads per chunk workgroup == max edges per chunk
+constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
+constexpr int UPPER6 = 21;
+
+// upper-triangular (r<=c) index tables of a 6x6 block
+__constant__ int8_t c_u6_r[UPPER6] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+__constant__ int8_t c_u6_c[UPPER6] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+
+struct BaDev {
+  // problem (uploaded once per ssx_ba_solve)
+  int P, L, E, nP, nLm, nCh, nBlk;
+  const int* pose_free;     // P: free index or -1
+  const uint8_t* lm_fixed;  // nLm (compact landmarks = landmarks that have edges)
+  const int* lm_id;         // nLm -> original landmark
+  const int* lm_ptr;        // nLm+1 -> first sorted edge
+  const int* ch_lm;         // nCh+1 -> first compact landmark
+  const int* e_pose;        // E (sorted)
+  const int* e_lmc;         // E compact landmark index
+  const uint8_t* e_cam;     // E
+  const uint8_t* e_dup;     // E: 1 = same (landmark,pose) as the previous sorted edge
+  const double* e_uv;       // [2][E]
+  const int8_t* blk_pa;     // nBlk upper blocks (pa<=pb) of the reduced system
+  const int8_t* blk_pb;
+  Cam K;
+  double ext[14];
+  double huber_delta, chi2_th;
+  // state
+  double* pose[2];          // [P*7]
+  double* point[2];         // [L*3]
+  // linearisation
+  double* W;                // [18][E]
+  double* err_lin;          // [2][E]
+  double* err_trial;        // [2][E]
+  double* Hll;              // [6][nLm]
+  double* bl;               // [3][nLm]
+  double* lin_slab;         // nCh x (nP*27 + 2)
+  double* Hpp;              // nP x 21
+  double* bp;               // nP x 6
+  double* schur_slab;       // nCh x (nBlk*36 + nP*6)
+  double* S;                // n x n (n = 6 nP), without lambda
+  double* bs;               // n
+  double* xp;               // n
+  double* trial_slab;       // nCh x 3
+  double* scal;             // 16 scalars
+};
+
+// scal[] slots
+enum { SC_CHI2_CUR = 0, SC_MAXDIAG = 1, SC_SOLVE_OK = 2, SC_SCALE_P = 3, SC_TEMP_CHI = 4, SC_SCALE_L = 5,
+       SC_NOUT = 6, SC_N = 16 };
+
+__device__ __forceinline__ double block_sum_256(double v, double* s)
+{
+  // fixed-shape tree: deterministic
+  const int t = threadIdx.x;
+  s[t] = v;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) s[t] += s[t + o];
+    __syncthreads();
+  }
+  const double r = s[0];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ double block_max_256(double v, double* s)
+{
+  const int t = threadIdx.x;
+  s[t] = v;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) s[t] = fmax(s[t], s[t + o]);
+    __syncthreads();
+  }
+  const double r = s[0];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_linearize: residual + Jacobians + quadratic form of every edge of one chunk.
+// restates BlockSolver::buildSystem (thirdparty/g2o/g2o/core/block_solver.hpp:463-521) +
+// BaseBinaryEdge::constructQuadraticForm (base_binary_edge.hpp:61-134) for EdgeProjection.
+// ------------------------------------------------------------------------------------------------
+template <int JAC>
+__global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
+{
+  __shared__ double sJi[12][CH];      // Jacobian wrt pose, [component][edge] (bank-conflict-free columns)
+  __shared__ double sW1[CH], sR0[CH], sR1[CH];
+  __shared__ double sL[9][CH];        // per-edge landmark contributions (6 Hll + 3 bl)
+  __shared__ int sPose[CH];
+  __shared__ double sRed[CH];
+
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
+  const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
+  const int ne = e1 - e0, nl = lm1 - lm0;
+  const double* pose = d.pose[cur];
+  const double* point = d.point[cur];
+
+  double rho0 = 0.0;
+  sPose[t] = -1;
+  if (t < ne) {
+    const int e = e0 + t;
+    const int p = d.e_pose[e];
+    const int lc = d.e_lmc[e];
+    const int lid = d.lm_id[lc];
+    const int pf = d.pose_free[p];
+    const bool lfree = !d.lm_fixed[lc];
+    double T[7], X[3];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) T[k] = pose[p * 7 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[k] = point[lid * 3 + k];
+    const double* ext = d.ext + 7 * d.e_cam[e];
+    const double u = d.e_uv[e], v = d.e_uv[d.E + e];
+    double er[2], p1[3], pc[3], Ji[12], Jj[6];
+    ssx::edge_error(T, X, ext, d.K, u, v, er, p1, pc);
+    if (JAC == SSX_JAC_NUMERIC_G2O) ssx::edge_jac_numeric(T, X, ext, d.K, u, v, Ji, Jj);
+    else ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
+    double w;
+    ssx::huber(er[0] * er[0] + er[1] * er[1], d.huber_delta, rho0, w);
+    d.err_lin[e] = er[0];
+    d.err_lin[d.E + e] = er[1];
+    const double r0 = -er[0] * w, r1 = -er[1] * w;
+    // W = Ji^T w Jj  (6x3), only when both vertices are free (block_solver.hpp:196-222)
+    const bool both = (pf >= 0) && lfree;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        d.W[(size_t)(a * 3 + b) * d.E + e] = both ? (Ji[a] * w * Jj[b] + Ji[6 + a] * w * Jj[3 + b]) : 0.0;
+    sPose[t] = pf;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) sJi[k][t] = Ji[k];
+    sW1[t] = w; sR0[t] = r0; sR1[t] = r1;
+    // landmark contributions: Hll (6 unique) + bl
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = a; b < 3; ++b) sL[q++][t] = lfree ? (Jj[a] * w * Jj[b] + Jj[3 + a] * w * Jj[3 + b]) : 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) sL[6 + a][t] = lfree ? (Jj[a] * r0 + Jj[3 + a] * r1) : 0.0;
+  }
+  __syncthreads();
+
+  // per-landmark sums in edge order (one thread per landmark of the chunk)
+  double maxd = 0.0;
+  if (t < nl) {
+    const int lc = lm0 + t;
+    const int a0 = d.lm_ptr[lc] - e0, a1 = d.lm_ptr[lc + 1] - e0;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = a0; j < a1; ++j)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[k] += sL[k][j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d.Hll[(size_t)k * d.nLm + lc] = acc[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.bl[(size_t)k * d.nLm + lc] = acc[6 + k];
+    maxd = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+  }
+
+  // pose blocks: owned entries, contributions added in edge order
+  double* slab = d.lin_slab + (size_t)c * (d.nP * 27 + 2);
+  for (int idx = t; idx < d.nP * 27; idx += CH) {
+    const int p = idx / 27, k = idx - p * 27;
+    double acc = 0.0;
+    if (k < UPPER6) {
+      const int r = c_u6_r[k], cc = c_u6_c[k];
+      for (int j = 0; j < ne; ++j)
+        if (sPose[j] == p) acc += sJi[r][j] * sW1[j] * sJi[cc][j] + sJi[6 + r][j] * sW1[j] * sJi[6 + cc][j];
+    } else {
+      const int a = k - UPPER6;
+      for (int j = 0; j < ne; ++j)
+        if (sPose[j] == p) acc += sJi[a][j] * sR0[j] + sJi[6 + a][j] * sR1[j];
+    }
+    slab[idx] = acc;
+  }
+  const double chi = block_sum_256(rho0, sRed);
+  const double md = block_max_256(maxd, sRed);
+  if (t == 0) {
+    slab[d.nP * 27] = chi;
+    slab[d.nP * 27 + 1] = md;
+  }
+}
+
+// slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|  (computeLambdaInit,
+// optimization_algorithm_levenberg.cpp:152-166, wants the max over pose AND landmark diagonals)
+__global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d)
+{
+  const int n = d.nP * 27;
+  const int stride = n + 2;
+  const int idx = blockIdx.x * CH + threadIdx.x;
+  if (idx < n) {
+    double acc = 0.0;
+    for (int c = 0; c < d.nCh; ++c) acc += d.lin_slab[(size_t)c * stride + idx];
+    const int p = idx / 27, k = idx - p * 27;
+    if (k < UPPER6) d.Hpp[p * UPPER6 + k] = acc;
+    else d.bp[p * 6 + (k - UPPER6)] = acc;
+  }
+  if (blockIdx.x == 0) {
+    __shared__ double sRed[CH];
+    double chi = 0.0, md = 0.0;
+    for (int c = threadIdx.x; c < d.nCh; c += CH) {
+      // per-thread partials are combined by the fixed tree below: deterministic for a given nCh
+      chi += d.lin_slab[(size_t)c * stride + n];
+      md = fmax(md, d.lin_slab[(size_t)c * stride + n + 1]);
+    }
+    chi = block_sum_256(chi, sRed);
+    md = block_max_256(md, sRed);
+    if (threadIdx.x == 0) {
+      d.scal[SC_CHI2_CUR] = chi;
+      d.scal[SC_MAXDIAG] = md;   // landmark part; the pose part is folded in by k_maxdiag_pose
+    }
+  }
+}
+
+__global__ void k_maxdiag_pose(BaDev d)
+{
+  // single thread: fold the pose-block diagonals into SC_MAXDIAG (nP <= 16)
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double m = d.scal[SC_MAXDIAG];
+    const int diag[6] = {0, 6, 11, 15, 18, 20};
+    for (int p = 0; p < d.nP; ++p)
+      for (int k = 0; k < 6; ++k) m = fmax(m, fabs(d.Hpp[p * UPPER6 + diag[k]]));
+    d.scal[SC_MAXDIAG] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_schur: landmark elimination for one chunk at damping lambda.
+// restates the marginalisation loop of BlockSolver::solve (block_solver.hpp:342-393):
+//   Dinv = (Hll + lambda I)^-1 ; c_i += W_i Dinv bl ; S_ij -= (W_i Dinv) W_j^T  (upper blocks)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* sW = reinterpret_cast<double*>(smem);            // [18][CH]
+  double* sBD = sW + 18 * CH;                              // [18][CH]
+  double* sC = sBD + 18 * CH;                              // [6][CH]
+  double* sDinv = sC + 6 * CH;                             // [9][CH] per landmark
+  double* sDb = sDinv + 9 * CH;                            // [3][CH]
+  uint8_t* sSlot = reinterpret_cast<uint8_t*>(sDb + 3 * CH);  // [nl][nP] -> edge slot or 0xFF
+  int* sLm = reinterpret_cast<int*>(sSlot + CH * SSX_BA_SMALL_P);  // [CH] local landmark of each edge
+
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
+  const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
+  const int ne = e1 - e0, nl = lm1 - lm0;
+  const int nP = d.nP;
+
+  for (int i = t; i < nl * nP; i += CH) sSlot[i] = 0xFF;
+  int pf = -1;
+  bool leader = false;
+  if (t < ne) {
+    const int e = e0 + t;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) sW[k * CH + t] = d.W[(size_t)k * d.E + e];
+    const int lc = d.e_lmc[e];
+    sLm[t] = lc - lm0;
+    pf = d.pose_free[d.e_pose[e]];
+    leader = (pf >= 0) && !d.lm_fixed[lc] && !d.e_dup[e];
+  }
+  if (t < nl) {
+    const int lc = lm0 + t;
+    double D[6], Di[9];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) D[k] = d.Hll[(size_t)k * d.nLm + lc];
+    D[0] += lambda; D[3] += lambda; D[5] += lambda;
+    ssx::inv3_sym(D, Di);
+    const double b0 = d.bl[lc], b1 = d.bl[(size_t)d.nLm + lc], b2 = d.bl[(size_t)2 * d.nLm + lc];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sDinv[k * CH + t] = Di[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) sDb[r * CH + t] = Di[r * 3] * b0 + Di[r * 3 + 1] * b1 + Di[r * 3 + 2] * b2;
+  }
+  __syncthreads();
+  if (leader) {
+    // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
+    const int e = e0 + t;
+    for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j)
+#pragma unroll
+      for (int k = 0; k < 18; ++k) sW[k * CH + t] += sW[k * CH + j];
+    (void)e;
+    const int l = sLm[t];
+    sSlot[l * nP + pf] = (uint8_t)t;
+    double Di[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Di[k] = sDinv[k * CH + l];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double w0 = sW[(a * 3) * CH + t], w1 = sW[(a * 3 + 1) * CH + t], w2 = sW[(a * 3 + 2) * CH + t];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) sBD[(a * 3 + b) * CH + t] = w0 * Di[b] + w1 * Di[3 + b] + w2 * Di[6 + b];
+      sC[a * CH + t] = w0 * sDb[l] + w1 * sDb[CH + l] + w2 * sDb[2 * CH + l];
+    }
+  }
+  __syncthreads();
+
+  double* slab = d.schur_slab + (size_t)c * (d.nBlk * 36 + nP * 6);
+  const int nS = d.nBlk * 36;
+  for (int idx = t; idx < nS; idx += CH) {
+    const int blk = idx / 36, rc = idx - blk * 36;
+    const int r = rc / 6, cc = rc - r * 6;
+    const int pa = d.blk_pa[blk], pb = d.blk_pb[blk];
+    double acc = 0.0;
+    for (int l = 0; l < nl; ++l) {
+      const int ea = sSlot[l * nP + pa], eb = sSlot[l * nP + pb];
+      if (ea != 0xFF && eb != 0xFF)
+        acc += sBD[(r * 3) * CH + ea] * sW[(cc * 3) * CH + eb] + sBD[(r * 3 + 1) * CH + ea] * sW[(cc * 3 + 1) * CH + eb] +
+               sBD[(r * 3 + 2) * CH + ea] * sW[(cc * 3 + 2) * CH + eb];
+    }
+    slab[idx] = acc;
+  }
+  for (int idx = t; idx < nP * 6; idx += CH) {
+    const int p = idx / 6, a = idx - p * 6;
+    double acc = 0.0;
+    for (int l = 0; l < nl; ++l) {
+      const int ea = sSlot[l * nP + p];
+      if (ea != 0xFF) acc += sC[a * CH + ea];
+    }
+    slab[nS + idx] = acc;
+  }
+}
+
+// slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c)
+__global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d)
+{
+  const int nS = d.nBlk * 36;
+  const int stride = nS + d.nP * 6;
+  const int n = 6 * d.nP;
+  const int idx = blockIdx.x * CH + threadIdx.x;
+  if (idx >= stride) return;
+  double acc = 0.0;
+  for (int c = 0; c < d.nCh; ++c) acc += d.schur_slab[(size_t)c * stride + idx];
+  if (idx < nS) {
+    const int blk = idx / 36, rc = idx - blk * 36;
+    const int r = rc / 6, cc = rc - r * 6;
+    const int pa = d.blk_pa[blk], pb = d.blk_pb[blk];
+    double h = 0.0;
+    if (pa == pb) {
+      const int rr = r < cc ? r : cc, c2 = r < cc ? cc : r;
+      // index of (rr,c2) in the 21-entry upper layout
+      const int k = rr * 6 - (rr * (rr - 1)) / 2 + (c2 - rr);
+      h = d.Hpp[pa * UPPER6 + k];
+    }
+    const double v = h - acc;
+    d.S[(size_t)(6 * pa + r) * n + 6 * pb + cc] = v;
+    if (pa != pb) d.S[(size_t)(6 * pb + cc) * n + 6 * pa + r] = v;
+  } else {
+    const int j = idx - nS;
+    d.bs[j] = d.bp[j] - acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_solve: ONE wave.  (S + lambda I) x = bs by Cholesky in LDS (the role of LinearSolverCSparse::solve,
+// thirdparty/g2o/g2o/solvers/csparse/linear_solver_csparse.h:106-142: false when not SPD), then the pose
+// update T <- exp(x) T into the trial buffer (SparseOptimizer::update, sparse_optimizer.cpp:433-446) and
+// the pose part of computeScale (optimization_algorithm_levenberg.cpp:168-175).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_solve(BaDev d, double lambda, int cur)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = 6 * d.nP;
+  const int ld = n + 1;                 // +1 pad: column walks hit different banks
+  double* A = reinterpret_cast<double*>(smem);   // n x ld, lower triangle used
+  double* y = A + (size_t)n * ld;
+  __shared__ int sOk;
+  const int t = threadIdx.x;
+  for (int i = t; i < n * n; i += 64) {
+    const int r = i / n, c = i - r * n;
+    A[r * ld + c] = d.S[i] + (r == c ? lambda : 0.0);
+  }
+  if (t == 0) sOk = 1;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    // column j: A[j][j] = sqrt(A[j][j]); A[i][j] /= A[j][j]; trailing update
+    const double djj = A[j * ld + j];
+    if (!(djj > 0.0) || !isfinite(djj)) { if (t == 0) sOk = 0; break; }   // uniform across the wave
+    const double dj = sqrt(djj);
+    __syncthreads();
+    for (int i = j + t; i < n; i += 64) A[i * ld + j] = (i == j) ? dj : A[i * ld + j] / dj;
+    __syncthreads();
+    // A[i][k] -= A[i][j] * A[k][j]  for j < k <= i
+    const int m = n - j - 1;
+    for (int q = t; q < m * m; q += 64) {
+      const int i = j + 1 + q / m, k = j + 1 + (q - (q / m) * m);
+      if (k <= i) A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const int ok = sOk;
+  if (ok) {
+    // forward: L y = bs ; backward: L^T x = y    (sequential in i, lanes split the dot product)
+    for (int i = 0; i < n; ++i) {
+      double part = 0.0;
+      for (int k = t; k < i; k += 64) part += A[i * ld + k] * y[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+      if (t == 0) y[i] = (d.bs[i] - part) / A[i * ld + i];
+      __syncthreads();
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double part = 0.0;
+      for (int k = i + 1 + t; k < n; k += 64) part += A[k * ld + i] * y[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+      if (t == 0) y[i] = (y[i] - part) / A[i * ld + i];
+      __syncthreads();
+    }
+  } else {
+    for (int i = t; i < n; i += 64) y[i] = 0.0;
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += 64) d.xp[i] = y[i];
+  // pose update into the trial buffer
+  const double* src = d.pose[cur];
+  double* dst = d.pose[cur ^ 1];
+  for (int p = t; p < d.P; p += 64) {
+    const int pf = d.pose_free[p];
+    double T[7], out[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) T[k] = src[p * 7 + k];
+    if (pf >= 0) {
+      double dx[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dx[k] = y[pf * 6 + k];
+      ssx::pose_oplus(T, dx, out);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) out[k] = T[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) dst[p * 7 + k] = out[k];
+  }
+  if (t == 0) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += y[j] * (lambda * y[j] + d.bp[j]);
+    d.scal[SC_SOLVE_OK] = ok ? 1.0 : 0.0;
+    d.scal[SC_SCALE_P] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_backsub_residual: landmark back-substitution (block_solver.hpp:422-442), landmark update, and the
+// residuals / robust chi2 of the TRIAL state (computeActiveErrors + activeRobustChi2,
+// sparse_optimizer.cpp:63-116).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, double lambda, int cur)
+{
+  __shared__ double sPt[3][CH];
+  __shared__ double sRed[CH];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
+  const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
+  const int ne = e1 - e0, nl = lm1 - lm0;
+  const double* pt_src = d.point[cur];
+  double* pt_dst = d.point[cur ^ 1];
+  double scale_l = 0.0;
+  if (t < nl) {
+    const int lc = lm0 + t;
+    const int lid = d.lm_id[lc];
+    double X[3] = {pt_src[lid * 3], pt_src[lid * 3 + 1], pt_src[lid * 3 + 2]};
+    if (!d.lm_fixed[lc]) {
+      double D[6], Di[9];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) D[k] = d.Hll[(size_t)k * d.nLm + lc];
+      D[0] += lambda; D[3] += lambda; D[5] += lambda;
+      ssx::inv3_sym(D, Di);
+      const double b[3] = {d.bl[lc], d.bl[(size_t)d.nLm + lc], d.bl[(size_t)2 * d.nLm + lc]};
+      double cl[3] = {b[0], b[1], b[2]};
+      for (int e = d.lm_ptr[lc]; e < d.lm_ptr[lc + 1]; ++e) {
+        const int pf = d.pose_free[d.e_pose[e]];
+        if (pf < 0) continue;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double xa = d.xp[pf * 6 + a];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) cl[k] -= d.W[(size_t)(a * 3 + k) * d.E + e] * xa;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
+        scale_l += xl * (lambda * xl + b[r]);
+        X[r] += xl;
+      }
+    }
+    pt_dst[lid * 3] = X[0]; pt_dst[lid * 3 + 1] = X[1]; pt_dst[lid * 3 + 2] = X[2];
+    sPt[0][t] = X[0]; sPt[1][t] = X[1]; sPt[2][t] = X[2];
+  }
+  __syncthreads();
+  double rho0 = 0.0, nout = 0.0;
+  if (t < ne) {
+    const int e = e0 + t;
+    const int p = d.e_pose[e];
+    const int l = d.e_lmc[e] - lm0;
+    const double* pose = d.pose[cur ^ 1];
+    double T[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) T[k] = pose[p * 7 + k];
+    const double X[3] = {sPt[0][l], sPt[1][l], sPt[2][l]};
+    double er[2], p1[3], pc[3], w;
+    ssx::edge_error(T, X, d.ext + 7 * d.e_cam[e], d.K, d.e_uv[e], d.e_uv[d.E + e], er, p1, pc);
+    d.err_trial[e] = er[0];
+    d.err_trial[d.E + e] = er[1];
+    const double c2 = er[0] * er[0] + er[1] * er[1];
+    ssx::huber(c2, d.huber_delta, rho0, w);
+    nout = (c2 > d.chi2_th) ? 1.0 : 0.0;
+  }
+  const double chi = block_sum_256(rho0, sRed);
+  const double sl = block_sum_256(scale_l, sRed);
+  const double no = block_sum_256(nout, sRed);
+  if (t == 0) {
+    d.trial_slab[c * 3] = chi;
+    d.trial_slab[c * 3 + 1] = sl;
+    d.trial_slab[c * 3 + 2] = no;
+  }
+}
+
+__global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d)
+{
+  __shared__ double sRed[CH];
+  double chi = 0.0, sl = 0.0, no = 0.0;
+  for (int c = threadIdx.x; c < d.nCh; c += CH) {
+    chi += d.trial_slab[c * 3];
+    sl += d.trial_slab[c * 3 + 1];
+    no += d.trial_slab[c * 3 + 2];
+  }
+  chi = block_sum_256(chi, sRed);
+  sl = block_sum_256(sl, sRed);
+  no = block_sum_256(no, sRed);
+  if (threadIdx.x == 0) {
+    d.scal[SC_TEMP_CHI] = chi;
+    d.scal[SC_SCALE_L] = sl;
+    d.scal[SC_NOUT] = no;
+  }
+}
+
+// plain residual pass on the CURRENT state (used when iters == 0 and by ssx_ba_linearize)
+__global__ void k_copy_state(BaDev d, int from)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.P * 7) d.pose[from ^ 1][i] = d.pose[from][i];
+  if (i < d.L * 3) d.point[from ^ 1][i] = d.point[from][i];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct BaWorkspace {
+  DevBuf arena;      // everything on the device
+  HostBuf stage;     // pinned upload / download staging
+  HostBuf scal;      // pinned scalars read back per trial
+};
+
+static void ssx_ba_workspace_free(BaWorkspace* w)
+{
+  if (!w) return;
+  w->arena.release();
+  w->stage.release();
+  w->scal.release();
+  delete w;
+}
+
+namespace {
+
+struct Layout {
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; }
+};
+
+struct HostPrep {
+  int P, L, E, nP, nLm, nCh, nBlk;
+  std::vector<int> pose_free, lm_id, lm_ptr, ch_lm, e_pose, e_lmc, perm;
+  std::vector<uint8_t> lm_fixed, e_cam, e_dup;
+  std::vector<double> e_uv;
+  std::vector<int8_t> blk_pa, blk_pb;
+};
+
+ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
+{
+  const int P = pr->P, L = pr->L, E = pr->E;
+  if (P <= 0 || L < 0 || E < 0 || !pr->poses || (L && !pr->points) ||
+      (E && (!pr->edge_pose || !pr->edge_point || !pr->edge_uv))) {
+    ctx->set_error("ssx_ba: invalid problem (P=%d L=%d E=%d or null arrays)", P, L, E);
+    return SSX_ERR_INVALID_ARG;
+  }
+  h.P = P; h.L = L; h.E = E;
+  h.pose_free.assign(P, -1);
+  h.nP = 0;
+  for (int i = 0; i < P; ++i)
+    if (!(pr->pose_fixed && pr->pose_fixed[i])) h.pose_free[i] = h.nP++;
+  // counting sort of the edges by landmark
+  std::vector<int> cnt(L + 1, 0);
+  for (int e = 0; e < E; ++e) {
+    const int l = pr->edge_point[e], p = pr->edge_pose[e];
+    if (l < 0 || l >= L || p < 0 || p >= P) {
+      ctx->set_error("ssx_ba: edge %d references pose %d / point %d out of range", e, p, l);
+      return SSX_ERR_INVALID_ARG;
+    }
+    cnt[l + 1]++;
+  }
+  h.lm_id.clear(); h.lm_ptr.clear(); h.lm_fixed.clear();
+  std::vector<int> lm_compact(L, -1), start(L + 1, 0);
+  for (int l = 0; l < L; ++l) start[l + 1] = start[l] + cnt[l + 1];
+  for (int l = 0; l < L; ++l) {
+    if (cnt[l + 1] == 0) continue;
+    if (cnt[l + 1] > CH) {
+      ctx->set_error("ssx_ba: landmark %d has %d observations (> %d per landmark unsupported)", l, cnt[l + 1], CH);
+      return SSX_ERR_UNSUPPORTED;
+    }
+    lm_compact[l] = (int)h.lm_id.size();
+    h.lm_id.push_back(l);
+    h.lm_ptr.push_back(start[l]);
+    h.lm_fixed.push_back(pr->point_fixed ? (pr->point_fixed[l] ? 1 : 0) : 0);
+  }
+  h.lm_ptr.push_back(E);
+  h.nLm = (int)h.lm_id.size();
+  h.perm.assign(E, 0);
+  {
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int e = 0; e < E; ++e) h.perm[fill[pr->edge_point[e]]++] = e;
+  }
+  // inside a landmark: stable sort by pose so that duplicates of a (landmark,pose) pair are adjacent
+  for (int lc = 0; lc < h.nLm; ++lc)
+    std::stable_sort(h.perm.begin() + h.lm_ptr[lc], h.perm.begin() + h.lm_ptr[lc + 1],
+                     [&](int a, int b) { return pr->edge_pose[a] < pr->edge_pose[b]; });
+  h.e_pose.resize(E); h.e_lmc.resize(E); h.e_cam.resize(E); h.e_dup.assign(E, 0); h.e_uv.resize(2 * (size_t)E);
+  for (int s = 0; s < E; ++s) {
+    const int e = h.perm[s];
+    h.e_pose[s] = pr->edge_pose[e];
+    h.e_lmc[s] = lm_compact[pr->edge_point[e]];
+    h.e_cam[s] = pr->edge_cam ? (pr->edge_cam[e] ? 1 : 0) : 0;
+    h.e_uv[s] = pr->edge_uv[2 * (size_t)e];
+    h.e_uv[(size_t)E + s] = pr->edge_uv[2 * (size_t)e + 1];
+    if (s > 0 && h.e_lmc[s] == h.e_lmc[s - 1] && h.e_pose[s] == h.e_pose[s - 1]) h.e_dup[s] = 1;
+  }
+  // chunks of whole landmarks, <= CH edges and <= CH landmarks each
+  h.ch_lm.clear();
+  h.ch_lm.push_back(0);
+  int acc_e = 0, acc_l = 0;
+  for (int lc = 0; lc < h.nLm; ++lc) {
+    const int k = h.lm_ptr[lc + 1] - h.lm_ptr[lc];
+    if (acc_e + k > CH || acc_l + 1 > CH) {
+      h.ch_lm.push_back(lc);
+      acc_e = 0; acc_l = 0;
+    }
+    acc_e += k; acc_l += 1;
+  }
+  if (h.nLm > 0) h.ch_lm.push_back(h.nLm);
+  h.nCh = (int)h.ch_lm.size() - 1;
+  if (h.nCh < 0) h.nCh = 0;
+  h.blk_pa.clear(); h.blk_pb.clear();
+  if (h.nP <= SSX_BA_SMALL_P)
+    for (int a = 0; a < h.nP; ++a)
+      for (int b = a; b < h.nP; ++b) { h.blk_pa.push_back((int8_t)a); h.blk_pb.push_back((int8_t)b); }
+  h.nBlk = (int)h.blk_pa.size();
+  return SSX_OK;
+}
+
+struct Upload {
+  BaDev d;
+  size_t bytes_total;
+};
+
+// carve the arena and upload the problem
+ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, double huber_delta, double chi2_th,
+                  BaDev& d)
+{
+  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+  BaWorkspace* ws = ctx->ba;
+  const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm, nCh = h.nCh, nBlk = h.nBlk;
+  const int n = 6 * nP;
+  Layout in;   // input blob (mirrored in pinned staging)
+  const size_t o_pose_free = in.take(sizeof(int) * P);
+  const size_t o_lm_fixed = in.take(nLm);
+  const size_t o_lm_id = in.take(sizeof(int) * nLm);
+  const size_t o_lm_ptr = in.take(sizeof(int) * (nLm + 1));
+  const size_t o_ch_lm = in.take(sizeof(int) * (nCh + 1));
+  const size_t o_e_pose = in.take(sizeof(int) * E);
+  const size_t o_e_lmc = in.take(sizeof(int) * E);
+  const size_t o_e_cam = in.take(E);
+  const size_t o_e_dup = in.take(E);
+  const size_t o_e_uv = in.take(sizeof(double) * 2 * E);
+  const size_t o_blk_pa = in.take(nBlk + 1);
+  const size_t o_blk_pb = in.take(nBlk + 1);
+  const size_t o_pose0 = in.take(sizeof(double) * 7 * P);
+  const size_t o_point0 = in.take(sizeof(double) * 3 * (L + 1));
+  const size_t in_bytes = in.off;
+  Layout all = in;
+  const size_t o_pose1 = all.take(sizeof(double) * 7 * P);
+  const size_t o_point1 = all.take(sizeof(double) * 3 * (L + 1));
+  const size_t o_W = all.take(sizeof(double) * 18 * (size_t)E);
+  const size_t o_err_lin = all.take(sizeof(double) * 2 * (size_t)E);
+  const size_t o_err_trial = all.take(sizeof(double) * 2 * (size_t)E);
+  const size_t o_Hll = all.take(sizeof(double) * 6 * (size_t)nLm);
+  const size_t o_bl = all.take(sizeof(double) * 3 * (size_t)nLm);
+  const size_t o_lin_slab = all.take(sizeof(double) * (size_t)(nCh + 1) * (nP * 27 + 2));
+  const size_t o_Hpp = all.take(sizeof(double) * (nP + 1) * UPPER6);
+  const size_t o_bp = all.take(sizeof(double) * (nP + 1) * 6);
+  const size_t o_schur = all.take(sizeof(double) * (size_t)(nCh + 1) * (nBlk * 36 + nP * 6));
+  const size_t o_S = all.take(sizeof(double) * ((size_t)n * n + 1));
+  const size_t o_bs = all.take(sizeof(double) * (n + 1));
+  const size_t o_xp = all.take(sizeof(double) * (n + 1));
+  const size_t o_trial = all.take(sizeof(double) * 3 * (nCh + 1));
+  const size_t o_scal = all.take(sizeof(double) * SC_N);
+
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SSX_HIP_TRY(ctx, ws->arena.reserve(all.off));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(std::max(in_bytes, sizeof(double) * (7 * (size_t)P + 3 * (size_t)L + 2 * (size_t)E))));
+  SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * SC_N));
+  char* hs = ws->stage.as<char>();
+  memcpy(hs + o_pose_free, h.pose_free.data(), sizeof(int) * P);
+  if (nLm) {
+    memcpy(hs + o_lm_fixed, h.lm_fixed.data(), nLm);
+    memcpy(hs + o_lm_id, h.lm_id.data(), sizeof(int) * nLm);
+  }
+  memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (nLm + 1));
+  memcpy(hs + o_ch_lm, h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
+  if (E) {
+    memcpy(hs + o_e_pose, h.e_pose.data(), sizeof(int) * E);
+    memcpy(hs + o_e_lmc, h.e_lmc.data(), sizeof(int) * E);
+    memcpy(hs + o_e_cam, h.e_cam.data(), E);
+    memcpy(hs + o_e_dup, h.e_dup.data(), E);
+    memcpy(hs + o_e_uv, h.e_uv.data(), sizeof(double) * 2 * E);
+  }
+  if (nBlk) {
+    memcpy(hs + o_blk_pa, h.blk_pa.data(), nBlk);
+    memcpy(hs + o_blk_pb, h.blk_pb.data(), nBlk);
+  }
+  memcpy(hs + o_pose0, pr->poses, sizeof(double) * 7 * P);
+  if (L) memcpy(hs + o_point0, pr->points, sizeof(double) * 3 * L);
+  char* base = ws->arena.as<char>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  // the second state buffer starts as a copy (landmarks without edges are never rewritten)
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_pose1, base + o_pose0, sizeof(double) * 7 * P, hipMemcpyDeviceToDevice, ctx->stream));
+  if (L)
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_point1, base + o_point0, sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, ctx->stream));
+
+  d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk;
+  d.pose_free = (const int*)(base + o_pose_free);
+  d.lm_fixed = (const uint8_t*)(base + o_lm_fixed);
+  d.lm_id = (const int*)(base + o_lm_id);
+  d.lm_ptr = (const int*)(base + o_lm_ptr);
+  d.ch_lm = (const int*)(base + o_ch_lm);
+  d.e_pose = (const int*)(base + o_e_pose);
+  d.e_lmc = (const int*)(base + o_e_lmc);
+  d.e_cam = (const uint8_t*)(base + o_e_cam);
+  d.e_dup = (const uint8_t*)(base + o_e_dup);
+  d.e_uv = (const double*)(base + o_e_uv);
+  d.blk_pa = (const int8_t*)(base + o_blk_pa);
+  d.blk_pb = (const int8_t*)(base + o_blk_pb);
+  d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
+  for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
+  d.huber_delta = huber_delta; d.chi2_th = chi2_th;
+  d.pose[0] = (double*)(base + o_pose0); d.pose[1] = (double*)(base + o_pose1);
+  d.point[0] = (double*)(base + o_point0); d.point[1] = (double*)(base + o_point1);
+  d.W = (double*)(base + o_W);
+  d.err_lin = (double*)(base + o_err_lin);
+  d.err_trial = (double*)(base + o_err_trial);
+  d.Hll = (double*)(base + o_Hll); d.bl = (double*)(base + o_bl);
+  d.lin_slab = (double*)(base + o_lin_slab);
+  d.Hpp = (double*)(base + o_Hpp); d.bp = (double*)(base + o_bp);
+  d.schur_slab = (double*)(base + o_schur);
+  d.S = (double*)(base + o_S); d.bs = (double*)(base + o_bs); d.xp = (double*)(base + o_xp);
+  d.trial_slab = (double*)(base + o_trial);
+  d.scal = (double*)(base + o_scal);
+  return SSX_OK;
+}
+
+size_t schur_lds_bytes() { return sizeof(double) * (18 + 18 + 6 + 9 + 3) * CH + CH * SSX_BA_SMALL_P + sizeof(int) * CH; }
+
+ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, int jac, int cur)
+{
+  if (d.nCh > 0) {
+    if (jac == SSX_JAC_NUMERIC_G2O) hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur);
+    else hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur);
+  }
+  const int n27 = d.nP * 27;
+  hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (n27 + CH - 1) / CH)), dim3(CH), 0, ctx->stream, d);
+  hipLaunchKernelGGL(k_maxdiag_pose, dim3(1), dim3(64), 0, ctx->stream, d);
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  return SSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ssx_ba_default_options(ssx_ba_options* o)
+{
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->outer_rounds = 5;
+  o->iters = 10;
+  o->chi2_th = 5.891;
+  o->huber_delta = 5.891;
+  o->inlier_ratio = 0.7;
+  o->jac_mode = SSX_JAC_ANALYTIC;
+  o->rank = 0;
+  o->world_size = 1;
+}
+
+ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double huber_delta, int32_t jac_mode,
+                            double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* err,
+                            double* chi2)
+{
+  if (!ctx || !prob) return SSX_ERR_INVALID_ARG;
+  HostPrep h;
+  ssx_status st = prepare(ctx, prob, h);
+  if (st != SSX_OK) return st;
+  if (h.nP > SSX_BA_SMALL_P) { ctx->set_error("ssx_ba_linearize: %d free poses > %d", h.nP, SSX_BA_SMALL_P); return SSX_ERR_UNSUPPORTED; }
+  BaDev d;
+  st = upload(ctx, prob, h, huber_delta, 5.891, d);
+  if (st != SSX_OK) return st;
+  st = launch_linearize(ctx, d, jac_mode, 0);
+  if (st != SSX_OK) return st;
+  const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm;
+  std::vector<double> hHpp((size_t)nP * UPPER6 + 1), hbp((size_t)nP * 6 + 1), hHll((size_t)6 * nLm + 1), hbl((size_t)3 * nLm + 1),
+      hW((size_t)18 * E + 1), herr((size_t)2 * E + 1), hscal(SC_N);
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hHpp.data(), d.Hpp, sizeof(double) * nP * UPPER6, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hbp.data(), d.bp, sizeof(double) * nP * 6, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hHll.data(), d.Hll, sizeof(double) * 6 * nLm, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hbl.data(), d.bl, sizeof(double) * 3 * nLm, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hW.data(), d.W, sizeof(double) * 18 * (size_t)E, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(herr.data(), d.err_lin, sizeof(double) * 2 * (size_t)E, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal.data(), d.scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  static const int U_R[UPPER6] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+  static const int U_C[UPPER6] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+  if (Hpp) memset(Hpp, 0, sizeof(double) * 36 * P);
+  if (bp) memset(bp, 0, sizeof(double) * 6 * P);
+  for (int p = 0; p < P; ++p) {
+    const int pf = h.pose_free[p];
+    if (pf < 0) continue;
+    if (Hpp)
+      for (int k = 0; k < UPPER6; ++k) {
+        Hpp[36 * (size_t)p + U_R[k] * 6 + U_C[k]] = hHpp[(size_t)pf * UPPER6 + k];
+        Hpp[36 * (size_t)p + U_C[k] * 6 + U_R[k]] = hHpp[(size_t)pf * UPPER6 + k];
+      }
+    if (bp) for (int k = 0; k < 6; ++k) bp[6 * (size_t)p + k] = hbp[(size_t)pf * 6 + k];
+  }
+  if (Hll) memset(Hll, 0, sizeof(double) * 9 * L);
+  if (bl) memset(bl, 0, sizeof(double) * 3 * L);
+  for (int lc = 0; lc < nLm; ++lc) {
+    const int l = h.lm_id[lc];
+    if (Hll) {
+      const double a00 = hHll[lc], a01 = hHll[(size_t)nLm + lc], a02 = hHll[(size_t)2 * nLm + lc];
+      const double a11 = hHll[(size_t)3 * nLm + lc], a12 = hHll[(size_t)4 * nLm + lc], a22 = hHll[(size_t)5 * nLm + lc];
+      double* o = Hll + 9 * (size_t)l;
+      o[0] = a00; o[1] = a01; o[2] = a02; o[3] = a01; o[4] = a11; o[5] = a12; o[6] = a02; o[7] = a12; o[8] = a22;
+    }
+    if (bl) for (int k = 0; k < 3; ++k) bl[3 * (size_t)l + k] = hbl[(size_t)k * nLm + lc];
+  }
+  for (int s = 0; s < E; ++s) {
+    const int e = h.perm[s];
+    if (Hpl) for (int k = 0; k < 18; ++k) Hpl[18 * (size_t)e + k] = hW[(size_t)k * E + s];
+    if (err) { err[2 * (size_t)e] = herr[s]; err[2 * (size_t)e + 1] = herr[(size_t)E + s]; }
+  }
+  if (chi2) *chi2 = hscal[SC_CHI2_CUR];
+  return SSX_OK;
+}
+
+ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_options* opt_in,
+                        ssx_ba_result* res)
+{
+  if (!ctx || !prob || !res) return SSX_ERR_INVALID_ARG;
+  ssx_ba_options opt;
+  if (opt_in) opt = *opt_in; else ssx_ba_default_options(&opt);
+  HostPrep h;
+  ssx_status st = prepare(ctx, prob, h);
+  if (st != SSX_OK) return st;
+  if (h.nP > SSX_BA_SMALL_P) {
+    ctx->set_error("ssx_ba_solve: %d free poses > %d (large-window path not built yet)", h.nP, SSX_BA_SMALL_P);
+    return SSX_ERR_UNSUPPORTED;
+  }
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  BaDev d;
+  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, d);
+  if (st != SSX_OK) return st;
+  BaWorkspace* ws = ctx->ba;
+  double* hscal = ws->scal.as<double>();
+  const int n = 6 * d.nP;
+  const int nCh = d.nCh;
+  const size_t lds_schur = schur_lds_bytes();
+  const size_t lds_solve = sizeof(double) * ((size_t)n * (n + 1) + n + 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    attr_set = true;
+  }
+  const int nSchurEntries = d.nBlk * 36 + d.nP * 6;
+
+  res->rounds = 0; res->n_iters = 0; res->n_inliers = 0; res->n_outliers = 0;
+  int cur = 0;                 // index of the accepted state buffer
+  bool have_trial_err = false; // err_trial holds the errors of the last trial evaluated
+  int round = 0;
+  const bool active = (d.nP + 0 > 0 || d.nLm > 0) && nCh > 0;
+  while (round < opt.outer_rounds) {
+    // ---- one g2o optimize(iters): OptimizationAlgorithmLevenberg::solve per iteration ----
+    double lambda = -1.0, ni = 2.0;
+    for (int it = 0; it < opt.iters && active; ++it) {
+      st = launch_linearize(ctx, d, opt.jac_mode, cur);
+      if (st != SSX_OK) return st;
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      double currentChi = hscal[SC_CHI2_CUR];
+      if (it == 0) { lambda = 1e-5 * hscal[SC_MAXDIAG]; ni = 2.0; }
+      double rho = 0.0, tempChi = currentChi;
+      int qmax = 0;
+      bool lambda_bad = false;
+      do {
+        if (n > 0) {
+          hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, lambda);
+          hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + CH - 1) / CH), dim3(CH), 0, ctx->stream, d);
+        }
+        hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), lds_solve, ctx->stream, d, lambda, cur);
+        hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, lambda, cur);
+        hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d);
+        SSX_HIP_TRY(ctx, hipGetLastError());
+        SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        have_trial_err = true;
+        const bool ok2 = hscal[SC_SOLVE_OK] != 0.0;
+        tempChi = hscal[SC_TEMP_CHI];
+        res->n_outliers = (int)hscal[SC_NOUT];
+        if (!ok2) tempChi = std::numeric_limits<double>::max();
+        rho = currentChi - tempChi;
+        double scale = hscal[SC_SCALE_P] + hscal[SC_SCALE_L];
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+          cur ^= 1;   // accept: the trial buffers become the state
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          if (!std::isfinite(lambda)) { lambda_bad = true; break; }
+        }
+        qmax++;
+      } while (rho < 0 && qmax < 10);
+      if (res->n_iters < SSX_BA_MAX_STATS) {
+        res->iter_chi2[res->n_iters] = tempChi;
+        res->iter_lambda[res->n_iters] = lambda;
+        res->iter_trials[res->n_iters] = qmax;
+      }
+      res->n_iters++;
+      if (qmax == 10 || rho == 0 || lambda_bad) break;
+    }
+    res->rounds++;
+    // outlier statistics of this round from the errors of the last evaluated trial (backend.cpp:181-194)
+    const int cnt_out = res->n_outliers, cnt_in = d.E - cnt_out;
+    res->n_inliers = cnt_in;
+    const double ratio = (d.E > 0) ? cnt_in / double(cnt_in + cnt_out) : 1.0;
+    if (ratio > opt.inlier_ratio) break;
+    ++round;
+  }
+
+  // ---- download ----
+  char* hs = ws->stage.as<char>();
+  double* h_pose = reinterpret_cast<double*>(hs);
+  double* h_point = h_pose + 7 * (size_t)d.P;
+  double* h_err = h_point + 3 * (size_t)d.L;
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(h_pose, d.pose[cur], sizeof(double) * 7 * d.P, hipMemcpyDeviceToHost, ctx->stream));
+  if (d.L) SSX_HIP_TRY(ctx, hipMemcpyAsync(h_point, d.point[cur], sizeof(double) * 3 * d.L, hipMemcpyDeviceToHost, ctx->stream));
+  const bool want_err = (res->edge_chi2 || res->edge_outlier) && d.E > 0;
+  if (want_err) {
+    if (!have_trial_err) {   // iters == 0: errors of the input state
+      st = launch_linearize(ctx, d, SSX_JAC_ANALYTIC, cur);
+      if (st != SSX_OK) return st;
+    }
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(h_err, have_trial_err ? d.err_trial : d.err_lin, sizeof(double) * 2 * (size_t)d.E,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+  }
+  SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (res->poses_out) memcpy(res->poses_out, h_pose, sizeof(double) * 7 * d.P);
+  if (res->points_out && d.L) memcpy(res->points_out, h_point, sizeof(double) * 3 * d.L);
+  if (want_err) {
+    for (int s = 0; s < d.E; ++s) {
+      const int e = h.perm[s];
+      const double c2 = h_err[s] * h_err[s] + h_err[(size_t)d.E + s] * h_err[(size_t)d.E + s];
+      if (res->edge_chi2) res->edge_chi2[e] = c2;
+      if (res->edge_outlier) res->edge_outlier[e] = c2 > opt.chi2_th;
+    }
+  }
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  res->ms_total = ms;
+  res->ms_setup = 0.f;
+  return SSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// ssvio_amd/csrc/ctx.hip -- context lifetime for libssx.so (include/ssx.h).
+#include "ctx.hpp"
+
+extern "C" {
+
+int ssx_version(void) { return SSX_VERSION; }
+
+int ssx_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+ssx_status ssx_ctx_create(const ssx_config* cfg, ssx_ctx** out)
+{
+  if (!out) return SSX_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SSX_ERR_NO_DEVICE;  // no CPU fallback, by design
+  const int dev = cfg ? cfg->device : 0;
+  if (dev < 0 || dev >= n) return SSX_ERR_INVALID_ARG;
+  if (hipSetDevice(dev) != hipSuccess) return SSX_ERR_HIP;
+  ssx_ctx* c = new ssx_ctx();
+  c->device = dev;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  if (cfg && cfg->stream) {
+    c->stream = static_cast<hipStream_t>(cfg->stream);
+    c->own_stream = false;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return SSX_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  (void)hipEventCreate(&c->ev0);
+  (void)hipEventCreate(&c->ev1);
+  *out = c;
+  return SSX_OK;
+}
+
+void ssx_ctx_destroy(ssx_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ba && ctx->ba_free) ctx->ba_free(ctx->ba);
+  if (ctx->orb && ctx->orb_free) ctx->orb_free(ctx->orb);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* ssx_last_error(const ssx_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+ssx_status ssx_ctx_synchronize(ssx_ctx* ctx)
+{
+  if (!ctx) return SSX_ERR_INVALID_ARG;
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SSX_OK;
+}
+
+void* ssx_ctx_stream(ssx_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""Deterministic synthetic inputs for the hot path.
+
+There is no KITTI data and no network here or on the GPU box, so every test and bench input is
+generated: "KITTI-00-shaped" means the intrinsics, image size and stereo baseline of the reference's
+config/kitti_00.yaml:3-26 (fx=fy=718.856, cx=607.1928, cy=185.2157, 1241x376, bf=386.1448).
+
+Nothing in this module touches the GPU, the oracle or the reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)   # fx fy cx cy  (kitti_00.yaml:3-6)
+KITTI_BF = 386.1448                                  # kitti_00.yaml:26
+KITTI_W, KITTI_H = 1241, 376                         # kitti_00.yaml:23-24
+KITTI_BASELINE = KITTI_BF / KITTI_K[0]               # system.cpp:69-70
+
+IDENT_POSE = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64)  # qx qy qz qw tx ty tz
+
+
+def quat_mul(a, b):
+    """Hamilton product, (x,y,z,w) order."""
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by + ay * bw + az * bx - ax * bz,
+        aw * bz + az * bw + ax * by - ay * bx,
+        aw * bw - ax * bx - ay * by - az * bz])
+
+
+def quat_rot(q, p):
+    x, y, z, w = q
+    R = np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return R @ p
+
+
+def small_rot_quat(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.array([0.5 * w[0], 0.5 * w[1], 0.5 * w[2], 1.0])
+    s = np.sin(th / 2) / th
+    return np.array([s * w[0], s * w[1], s * w[2], np.cos(th / 2)])
+
+
+def stereo_cam_ext(baseline=KITTI_BASELINE):
+    """cam_ext[2x7]: left = identity, right = (I, (-baseline,0,0))  (system.cpp:63,71)."""
+    ext = np.zeros((2, 7))
+    ext[:, 3] = 1.0
+    ext[1, 4] = -baseline
+    return ext
+
+
+def make_ba_problem(P=10, L=4000, obs_per_lm=5, seed=1, frac_fixed=0.15, frac_gross=0.03,
+                    pix_sigma=0.5, gross_sigma=30.0, pose_t_noise=0.02, pose_r_noise=0.002,
+                    point_noise=0.0, loop=False, fix_first_pose=False, K=KITTI_K):
+    """Synthetic BA graph of SURVEY.md section 8-D.
+
+    C3 (local BA): P=10, L=4000, obs_per_lm=5 -> E=20000, 15 % fixed landmarks, no pose fixed
+    (as Backend::OptimizeActiveMap, backend.cpp:93-103).  C4 (global BA): P=500, L=80000,
+    obs_per_lm=6, loop=True, fix_first_pose=True.
+
+    Returns a dict of flat arrays in the layout of ssx_ba_problem (include/ssx.h).
+    """
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = K
+    # ground-truth poses T_cw (world -> camera)
+    gt = np.zeros((P, 7))
+    centers = np.zeros((P, 3))
+    yaw = np.zeros(P)
+    if loop:
+        R = 400.0 / (2 * np.pi)
+        for i in range(P):
+            a = 2 * np.pi * i / P
+            centers[i] = (R * np.sin(a), 0.0, R * (1 - np.cos(a)))
+            yaw[i] = a   # heading rotates about y
+    else:
+        for i in range(P):
+            centers[i] = (0.0, 0.0, 0.8 * i)
+    for i in range(P):
+        # R_wc = rot_y(yaw): camera z axis points along heading
+        q_wc = np.array([0.0, np.sin(yaw[i] / 2), 0.0, np.cos(yaw[i] / 2)])
+        q_cw = q_wc * np.array([-1, -1, -1, 1])
+        gt[i, :4] = q_cw
+        gt[i, 4:] = -quat_rot(q_cw, centers[i])
+
+    first = rng.integers(0, max(P - obs_per_lm + 1, 1), size=L)
+    local = np.stack([rng.uniform(-15, 15, L), rng.uniform(-3, 3, L), rng.uniform(6, 46, L)], 1)
+    pts = np.zeros((L, 3))
+    for j in range(L):
+        i0 = first[j]
+        q_cw = gt[i0, :4]
+        q_wc = q_cw * np.array([-1, -1, -1, 1])
+        pts[j] = quat_rot(q_wc, local[j]) + centers[i0]
+
+    k = min(obs_per_lm, P)
+    E = L * k
+    edge_pose = np.zeros(E, dtype=np.int32)
+    edge_point = np.zeros(E, dtype=np.int32)
+    edge_uv = np.zeros((E, 2))
+    e = 0
+    for j in range(L):
+        for d in range(k):
+            i = (first[j] + d) % P
+            pc = quat_rot(gt[i, :4], pts[j]) + gt[i, 4:]
+            edge_pose[e] = i
+            edge_point[e] = j
+            edge_uv[e] = (fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy)
+            e += 1
+    edge_uv += rng.normal(0, pix_sigma, edge_uv.shape)
+    gross = rng.random(E) < frac_gross
+    edge_uv[gross] += rng.normal(0, gross_sigma, (int(gross.sum()), 2))
+
+    poses = gt.copy()
+    for i in range(P):
+        if fix_first_pose and i == 0:
+            continue
+        dq = small_rot_quat(rng.uniform(-pose_r_noise, pose_r_noise, 3))
+        q = quat_mul(dq, poses[i, :4])
+        poses[i, :4] = q / np.linalg.norm(q)
+        poses[i, 4:] = quat_rot(dq, poses[i, 4:]) + rng.uniform(-pose_t_noise, pose_t_noise, 3)
+    points = pts + (rng.normal(0, point_noise, pts.shape) if point_noise > 0 else 0.0)
+    point_fixed = (rng.random(L) < frac_fixed).astype(np.uint8)
+    pose_fixed = np.zeros(P, dtype=np.uint8)
+    if fix_first_pose:
+        pose_fixed[0] = 1
+    return dict(P=P, L=L, E=E, poses=np.ascontiguousarray(poses), pose_fixed=pose_fixed,
+                points=np.ascontiguousarray(points), point_fixed=point_fixed,
+                edge_pose=edge_pose, edge_point=edge_point, edge_uv=np.ascontiguousarray(edge_uv),
+                edge_cam=np.zeros(E, dtype=np.uint8), K=np.array(K, dtype=np.float64),
+                cam_ext=stereo_cam_ext(), gt_poses=gt, gt_points=pts)
+
+
+def make_pose_only_problem(M=200, seed=3, frac_gross=0.1, K=KITTI_K):
+    """One frame of FrontEnd::EstimateCurrentPose (frontend.cpp:184-300): M map points, noisy pose."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = K
+    dq = small_rot_quat(rng.uniform(-0.02, 0.02, 3))
+    gt = np.concatenate([dq / np.linalg.norm(dq), rng.uniform(-0.3, 0.3, 3)])
+    xyz = np.stack([rng.uniform(-12, 12, M), rng.uniform(-3, 3, M), rng.uniform(5, 45, M)], 1)
+    uv = np.zeros((M, 2))
+    for i in range(M):
+        pc = quat_rot(gt[:4], xyz[i]) + gt[4:]
+        uv[i] = (fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy)
+    uv += rng.normal(0, 0.5, uv.shape)
+    gross = rng.random(M) < frac_gross
+    uv[gross] += rng.normal(0, 25.0, (int(gross.sum()), 2))
+    # KeyPoint coordinates are float32 in the reference (cv::Point2f -> double, frontend.cpp:214,222)
+    uv = uv.astype(np.float32).astype(np.float64)
+    init = IDENT_POSE.copy()
+    return dict(M=M, pose=init, gt_pose=gt, K=np.array(K), xyz=np.ascontiguousarray(xyz),
+                uv=np.ascontiguousarray(uv))
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic stereo images: textured left image + piecewise-planar disparity
+# ----------------------------------------------------------------------------------------------
+def _smooth_noise(rng, h, w, cell):
+    gh, gw = h // cell + 2, w // cell + 2
+    g = rng.random((gh, gw)).astype(np.float32)
+    ys = np.arange(h, dtype=np.float32) / cell
+    xs = np.arange(w, dtype=np.float32) / cell
+    y0 = ys.astype(np.int32); x0 = xs.astype(np.int32)
+    fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def make_stereo_pair(seed=0, h=KITTI_H, w=KITTI_W, n_blobs=4000, bf=KITTI_BF):
+    """Left image = band-limited noise octaves + random bright/dark blobs and L-corners;
+    right image = left warped by a piecewise-planar disparity map d = bf/z, z in [4,80] m
+    (d in [4.8,96.5] px), zero vertical disparity, + N(0,2) noise.  Returns (left,right,disp)."""
+    rng = np.random.default_rng(1000 + seed)
+    img = np.zeros((h, w), dtype=np.float32)
+    for cell, amp in ((64, 60.0), (16, 40.0), (4, 24.0)):
+        img += amp * (_smooth_noise(rng, h, w, cell) - 0.5)
+    img += 128.0
+    bx = rng.integers(4, w - 12, n_blobs); by = rng.integers(4, h - 12, n_blobs)
+    bs = rng.integers(3, 9, n_blobs); bv = rng.choice([-70.0, 70.0, -110.0, 110.0], n_blobs)
+    kind = rng.integers(0, 2, n_blobs)
+    for x, y, s, v, k in zip(bx, by, bs, bv, kind):
+        if k == 0:
+            img[y:y + s, x:x + s] += v
+        else:   # L-corner
+            img[y:y + s, x:x + 2] += v
+            img[y + s - 2:y + s, x:x + s] += v
+    left = np.clip(img, 0, 255).astype(np.uint8)
+    # piecewise-planar depth: vertical strips with linear depth ramps
+    n_strip = 6
+    edges = np.linspace(0, w, n_strip + 1).astype(int)
+    z = np.zeros((h, w), dtype=np.float32)
+    for s in range(n_strip):
+        z0, z1 = rng.uniform(4, 80, 2)
+        ramp = np.linspace(z0, z1, h, dtype=np.float32)[:, None]
+        z[:, edges[s]:edges[s + 1]] = ramp
+    disp = (bf / z).astype(np.float32)
+    xs = np.arange(w, dtype=np.float32)[None, :] + disp      # right(u) = left(u + d)
+    x0 = np.clip(np.floor(xs).astype(np.int32), 0, w - 1)
+    x1 = np.clip(x0 + 1, 0, w - 1)
+    fx = np.clip(xs - np.floor(xs), 0, 1)
+    rows = np.arange(h)[:, None]
+    lf = left.astype(np.float32)
+    right = lf[rows, x0] * (1 - fx) + lf[rows, x1] * fx
+    right += rng.normal(0, 2.0, right.shape).astype(np.float32)
+    right = np.clip(np.rint(right), 0, 255).astype(np.uint8)
+    return left, right, disp
