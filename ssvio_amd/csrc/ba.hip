@@ -8,7 +8,7 @@
 //
 // Data layout in HBM (one arena per ctx, grow-only):
 //   edges are SORTED BY LANDMARK (then by pose inside a landmark) on upload so that all observations of
-//   a landmark are contiguous; landmarks are grouped into CHUNKS of whole landmarks with <= 256 edges.
+//   a landmark are contiguous; landmarks are grouped into CHUNKS of whole landmarks with <= 255 edges.
 //   One 256-thread workgroup (4 waves) owns one chunk in every per-edge / per-landmark kernel, so every
 //   per-landmark reduction (Hll, bl, Schur terms, back-substitution) happens in LDS without atomics.
 //   Per-edge arrays are structure-of-arrays (W[k][E], uv[2][E] ...) so that lane i touches element i:
@@ -40,7 +40,8 @@ namespace {
 
 using ssx::Cam;
 
-constexpr int CH = 256;            // threads per chunk workgroup == max edges per chunk
+constexpr int CH = 256;            // threads per chunk workgroup
+constexpr int CH_E = 255;          // max edges per chunk (edge slot 0xFF is the 'no observation' marker)
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
 
@@ -655,8 +656,8 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   for (int l = 0; l < L; ++l) start[l + 1] = start[l] + cnt[l + 1];
   for (int l = 0; l < L; ++l) {
     if (cnt[l + 1] == 0) continue;
-    if (cnt[l + 1] > CH) {
-      ctx->set_error("ssx_ba: landmark %d has %d observations (> %d per landmark unsupported)", l, cnt[l + 1], CH);
+    if (cnt[l + 1] > CH_E) {
+      ctx->set_error("ssx_ba: landmark %d has %d observations (> %d per landmark unsupported)", l, cnt[l + 1], CH_E);
       return SSX_ERR_UNSUPPORTED;
     }
     lm_compact[l] = (int)h.lm_id.size();
@@ -691,7 +692,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   int acc_e = 0, acc_l = 0;
   for (int lc = 0; lc < h.nLm; ++lc) {
     const int k = h.lm_ptr[lc + 1] - h.lm_ptr[lc];
-    if (acc_e + k > CH || acc_l + 1 > CH) {
+    if (acc_e + k > CH_E || acc_l + 1 > CH) {
       h.ch_lm.push_back(lc);
       acc_e = 0; acc_l = 0;
     }
