@@ -210,3 +210,165 @@ def triangulate(uvL, uvR, K, baseline, T_wc=None, which="oracle"):
                                      C.c_double(cx), C.c_double(cy), C.c_double(baseline), _p(T, dbl_p),
                                      _p(xyz, dbl_p), _p(ok, u8_p), _p(ratio, dbl_p))
     return dict(xyz=xyz, ok=ok, ratio=ratio)
+
+
+# ------------------------------------------------------------------ ORB / stereo
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 2
+    return a
+
+
+def orb_params(nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    return OrbParams(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+
+def fast_roi(img, threshold, cap=1 << 16):
+    img = _img(img)
+    xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); sc = np.zeros(cap, np.int32)
+    n = oracle_lib().orc_fast_roi(_p(img, u8_p), img.strides[0], img.shape[0], img.shape[1], threshold, cap,
+                                  _p(xs, i32_p), _p(ys, i32_p), _p(sc, i32_p))
+    assert n <= cap
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def is_fast_corner(img, x, y, threshold):
+    img = _img(img)
+    return bool(oracle_lib().orc_is_fast_corner(_p(img, u8_p), img.strides[0], int(x), int(y), int(threshold)))
+
+
+def orb_grid_fast(img, mask=None, ini_th=20, min_th=7, cap=1 << 18):
+    img = _img(img)
+    mask = None if mask is None else _img(mask)
+    out = np.zeros(cap, dtype=KP_DTYPE)
+    n = oracle_lib().orc_orb_grid_fast(_p(img, u8_p), img.strides[0], img.shape[0], img.shape[1],
+                                       _p(mask, u8_p), 0 if mask is None else mask.strides[0], ini_th, min_th, cap,
+                                       out.ctypes.data_as(C.c_void_p))
+    assert n <= cap
+    return out[:n].copy()
+
+
+def octree(cand, minX, maxX, minY, maxY, N):
+    cand = np.ascontiguousarray(cand, dtype=KP_DTYPE)
+    out = np.zeros(max(len(cand), 1), dtype=KP_DTYPE)
+    n = oracle_lib().orc_octree(cand.ctypes.data_as(C.c_void_p), len(cand), minX, maxX, minY, maxY, N, len(out),
+                                out.ctypes.data_as(C.c_void_p))
+    return out[:n].copy()
+
+
+def orb_detect(img, mask=None, prm=None, cap=1 << 16):
+    img = _img(img)
+    mask = None if mask is None else _img(mask)
+    prm = prm or orb_params()
+    out = np.zeros(cap, dtype=KP_DTYPE)
+    n = oracle_lib().orc_orb_detect(_p(img, u8_p), img.strides[0], img.shape[0], img.shape[1], _p(mask, u8_p),
+                                    0 if mask is None else mask.strides[0], C.byref(prm), cap,
+                                    out.ctypes.data_as(C.c_void_p))
+    assert n <= cap
+    return out[:n].copy()
+
+
+def orb_extract(img, mask=None, prm=None, cap=1 << 16):
+    img = _img(img)
+    mask = None if mask is None else _img(mask)
+    prm = prm or orb_params()
+    kps = np.zeros(cap, dtype=KP_DTYPE); desc = np.zeros((cap, 32), dtype=np.uint8)
+    n = oracle_lib().orc_orb_extract(_p(img, u8_p), img.strides[0], img.shape[0], img.shape[1], _p(mask, u8_p),
+                                     0 if mask is None else mask.strides[0], C.byref(prm), cap,
+                                     kps.ctypes.data_as(C.c_void_p), _p(desc, u8_p))
+    assert n <= cap
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def orb_describe_at(img, kps_in, prm=None):
+    img = _img(img)
+    prm = prm or orb_params()
+    kps_in = np.ascontiguousarray(kps_in, dtype=KP_DTYPE)
+    kps = np.zeros(len(kps_in), dtype=KP_DTYPE); desc = np.zeros((len(kps_in), 32), dtype=np.uint8)
+    n = oracle_lib().orc_orb_describe_at(_p(img, u8_p), img.strides[0], img.shape[0], img.shape[1], C.byref(prm),
+                                         kps_in.ctypes.data_as(C.c_void_p), len(kps_in),
+                                         kps.ctypes.data_as(C.c_void_p), _p(desc, u8_p))
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def level_sizes(rows, cols, scale_factor=1.2, nlevels=8):
+    r = np.zeros(nlevels, np.int32); c = np.zeros(nlevels, np.int32)
+    oracle_lib().orc_level_sizes(rows, cols, C.c_float(scale_factor), nlevels, _p(r, i32_p), _p(c, i32_p))
+    return r, c
+
+
+def features_per_level(nfeatures, scale_factor=1.2, nlevels=8):
+    o = np.zeros(nlevels, np.int32)
+    oracle_lib().orc_features_per_level(nfeatures, C.c_float(scale_factor), nlevels, _p(o, i32_p))
+    return o
+
+
+def umax():
+    o = np.zeros(16, np.int32)
+    oracle_lib().orc_umax(_p(o, i32_p))
+    return o
+
+
+def resize_linear(src, drows, dcols):
+    src = _img(src)
+    dst = np.zeros((drows, dcols), np.uint8)
+    oracle_lib().orc_resize_linear(_p(src, u8_p), src.strides[0], src.shape[0], src.shape[1], _p(dst, u8_p),
+                                   dst.strides[0], drows, dcols)
+    return dst
+
+
+def gauss7(src):
+    src = _img(src)
+    dst = np.zeros_like(src)
+    oracle_lib().orc_gauss7(_p(src, u8_p), src.strides[0], src.shape[0], src.shape[1], _p(dst, u8_p), dst.strides[0])
+    return dst
+
+
+def ic_angle(img, x, y):
+    img = _img(img)
+    return float(oracle_lib().orc_ic_angle(_p(img, u8_p), img.strides[0], C.c_float(x), C.c_float(y)))
+
+
+def fast_atan2(y, x):
+    return float(oracle_lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def sincos_deg(a):
+    c = C.c_float(0); s = C.c_float(0)
+    oracle_lib().orc_sincos_deg(C.c_float(a), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def brief(blurred, x, y, angle):
+    blurred = _img(blurred)
+    d = np.zeros(32, np.uint8)
+    oracle_lib().orc_brief(_p(blurred, u8_p), blurred.strides[0], C.c_float(x), C.c_float(y), C.c_float(angle),
+                           _p(d, u8_p))
+    return d
+
+
+def brief_pattern():
+    p = oracle_lib().orc_brief_pattern()
+    return np.ctypeslib.as_array(p, shape=(256, 4)).copy()
+
+
+def match_params(band_px=2.0, min_disp=0.0, max_disp=120.0, max_dist=80, max_octave_diff=1, scale_factor=1.2):
+    return MatchParams(band_px, min_disp, max_disp, max_dist, max_octave_diff, scale_factor)
+
+
+def stereo_match(kL, dL, kR, dR, prm=None):
+    prm = prm or match_params()
+    kL = np.ascontiguousarray(kL, dtype=KP_DTYPE); kR = np.ascontiguousarray(kR, dtype=KP_DTYPE)
+    dL = np.ascontiguousarray(dL, dtype=np.uint8); dR = np.ascontiguousarray(dR, dtype=np.uint8)
+    idx = np.zeros(len(kL), np.int32); dist = np.zeros(len(kL), np.int32)
+    oracle_lib().orc_stereo_match(kL.ctypes.data_as(C.c_void_p), _p(dL, u8_p), len(kL),
+                                  kR.ctypes.data_as(C.c_void_p), _p(dR, u8_p), len(kR), C.byref(prm),
+                                  _p(idx, i32_p), _p(dist, i32_p))
+    return idx, dist
+
+
+def bf_match(dq, dt):
+    dq = np.ascontiguousarray(dq, dtype=np.uint8); dt = np.ascontiguousarray(dt, dtype=np.uint8)
+    idx = np.zeros(len(dq), np.int32); dist = np.zeros(len(dq), np.int32)
+    oracle_lib().orc_bf_match(_p(dq, u8_p), len(dq), _p(dt, u8_p), len(dt), _p(idx, i32_p), _p(dist, i32_p))
+    return idx, dist

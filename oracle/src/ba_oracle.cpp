@@ -591,7 +591,13 @@ static void ba_setup(BA& ba, int P, double* poses, const uint8_t* pose_fixed, in
   ba.pose_fixed = pose_fixed; ba.point_fixed = point_fixed;
   ba.edge_pose = edge_pose; ba.edge_point = edge_point; ba.edge_uv = edge_uv; ba.edge_cam = edge_cam;
   ba.K = cam_from(K4); ba.ext = cam_ext14; ba.huber_delta = huber_delta; ba.jac_mode = jac_mode;
+  // SparseOptimizer::initializeOptimization (sparse_optimizer.cpp:237): edges whose vertices are ALL fixed
+  // are not active -- they contribute neither to chi2 nor to the system.  (g2o never computes their _error,
+  // so the reference would read uninitialised memory through edge->chi2(); we report their chi2 at the
+  // input state instead, see orc_ba_solve.)
   ba.active.assign(E, 1);
+  for (int e = 0; e < E; ++e)
+    if (pose_fixed && pose_fixed[edge_pose[e]] && point_fixed && point_fixed[edge_point[e]]) ba.active[e] = 0;
 }
 
 // Backend::OptimizeActiveMap outer loop, src/ssvio/backend.cpp:175-203.
@@ -605,9 +611,17 @@ int orc_ba_solve(int P, double* poses, const uint8_t* pose_fixed, int L, double*
   ba_setup(ba, P, poses, pose_fixed, L, points, point_fixed, E, edge_pose, edge_point, edge_uv, edge_cam,
            K4, cam_ext14, opt->huber_delta, opt->jac_mode);
   BA::Stats st;
+  // errors of the inactive (all-fixed) edges: constant, evaluated once
+  std::vector<double> inactive_err(2 * (size_t)E, 0.0);
+  for (int e = 0; e < E; ++e)
+    if (!ba.active[e])
+      edge_error(poses + 7 * edge_pose[e], points + 3 * edge_point[e], cam_ext14 + 7 * (edge_cam ? edge_cam[e] : 0),
+                 ba.K, edge_uv + 2 * e, &inactive_err[2 * e]);
   int round = 0, rounds_done = 0;
   while (round < opt->outer_rounds) {
     ba.init_structure();          // initializeOptimization()
+    for (int e = 0; e < E; ++e)
+      if (!ba.active[e]) { ba.err[2 * e] = inactive_err[2 * e]; ba.err[2 * e + 1] = inactive_err[2 * e + 1]; }
     ba.optimize(opt->iters, &st);
     ++rounds_done;
     int cnt_outlier = 0, cnt_inlier = 0;

@@ -167,6 +167,8 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
     ssx::huber(er[0] * er[0] + er[1] * er[1], d.huber_delta, rho0, w);
     d.err_lin[e] = er[0];
     d.err_lin[d.E + e] = er[1];
+    // an edge whose vertices are both fixed is not active in g2o (sparse_optimizer.cpp:237): no chi2 term
+    if (pf < 0 && !lfree) rho0 = 0.0;
     const double r0 = -er[0] * w, r1 = -er[1] * w;
     // W = Ji^T w Jj  (6x3), only when both vertices are free (block_solver.hpp:196-222)
     const bool both = (pf >= 0) && lfree;
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, double lambda,
     d.err_trial[d.E + e] = er[1];
     const double c2 = er[0] * er[0] + er[1] * er[1];
     ssx::huber(c2, d.huber_delta, rho0, w);
+    if (d.pose_free[p] < 0 && d.lm_fixed[d.e_lmc[e]]) rho0 = 0.0;   // inactive edge (all vertices fixed)
     nout = (c2 > d.chi2_th) ? 1.0 : 0.0;
   }
   const double chi = block_sum_256(rho0, sRed);

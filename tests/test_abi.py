@@ -1,0 +1,76 @@
+"""CPU: libssx.so loads without a GPU, exports every symbol include/ssx.h declares, and the ctypes mirrors
+of the ABI structs have the C sizes.  No compute call is made (there is no GPU here and no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "ssx.h")
+
+
+def declared_symbols():
+    src = open(HDR).read()
+    return sorted(set(re.findall(r"SSX_API[^;(]*?\b(ssx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from ssvio_amd import build
+    lib_path = build.build()
+    assert os.path.exists(lib_path)
+    import ssvio_amd
+    lib = ssvio_amd.load()
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.ssx_version() == 100
+
+
+def test_no_cpu_fallback_without_device():
+    import ssvio_amd
+    lib = ssvio_amd.load()
+    if lib.ssx_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(ssvio_amd.SsxError) as e:
+        ssvio_amd.Context(0)
+    assert e.value.status == -2   # SSX_ERR_NO_DEVICE
+
+
+def test_struct_layout_matches_ctypes():
+    from ssvio_amd import _lib
+    names = {"ssx_config": _lib.Config, "ssx_ba_problem": _lib.BaProblem, "ssx_ba_options": _lib.BaOptions,
+             "ssx_ba_result": _lib.BaResult}
+    for extra in ("ssx_keypoint", "ssx_orb_params", "ssx_match_params", "ssx_stereo_rig"):
+        cls = getattr(_lib, {"ssx_keypoint": "KeyPoint", "ssx_orb_params": "OrbParams",
+                             "ssx_match_params": "MatchParams", "ssx_stereo_rig": "StereoRig"}[extra], None)
+        if cls is not None and extra in open(HDR).read():
+            names[extra] = cls
+    prog = '#include <stdio.h>\n#include "ssx.h"\nint main(){' + "".join(
+        f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    sizes = dict(zip(out[0::2], map(int, out[1::2])))
+    for n, cls in names.items():
+        assert sizes[n] == C.sizeof(cls), (n, sizes[n], C.sizeof(cls))
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under ssvio_amd/ or include/ may reference it"""
+    bad = []
+    for root in (os.path.join(ROOT, "ssvio_amd"), os.path.join(ROOT, "include")):
+        for dp, _, files in os.walk(root):
+            if "build" in dp.split(os.sep):
+                continue
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".inc")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"\bpyoracle\b|liboracle|oracle/src|from oracle|import oracle|libssvio_ref", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

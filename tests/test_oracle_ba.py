@@ -1,0 +1,117 @@
+"""CPU: the BA / pose-only / SE3 / triangulation oracle is pinned against the REAL reference arithmetic
+(tests/golden/ref_golden.npz, produced by oracle/_ref = reference g2otypes.hpp/algorithm.hpp + g2o + Sophus
+compiled from /root/reference) and, when that library is present, against it live.
+
+Why the BA bars are not 1e-9: the reference linearises with g2o's central differences (delta = 1e-9), whose
+rounding noise (~1e-6 relative in J) makes the LM trajectory itself sensitive to the last bit of every
+operation.  Two faithful implementations agree on lambda and the trial counts exactly, on the robust chi2
+trajectory to ~1e-7, on the median residual to <1e-5 px and on 99.5 % of residuals to 1e-4 px; the worst
+residual (on landmarks whose depth is barely observable) differs by up to ~6e-4 px.  DESIGN.md discusses it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ssvio_amd import synth
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz"))
+BA_CASES = ["tiny", "mid", "C3", "gauge"]
+
+
+def _problem(name):
+    P, L, k, seed, fix = [int(v) for v in GOLD[f"ba_{name}_cfg"]]
+    pr = synth.make_ba_problem(P=P, L=L, obs_per_lm=k, seed=seed, fix_first_pose=bool(fix))
+    s = np.array([pr["poses"].sum(), pr["points"].sum(), pr["edge_uv"].sum()])
+    np.testing.assert_allclose(s, GOLD[f"ba_{name}_input_sum"], rtol=1e-13)   # generator did not drift
+    return pr
+
+
+def _edge_chi2_sel(name, r):
+    if f"ba_{name}_edge_sel" in GOLD:
+        return r["edge_chi2"][GOLD[f"ba_{name}_edge_sel"]]
+    return r["edge_chi2"]
+
+
+@pytest.mark.parametrize("name", BA_CASES)
+@pytest.mark.parametrize("jac", [1, 0])
+def test_ba_oracle_matches_reference_golden(po, name, jac):
+    pr = _problem(name)
+    o = po.ba_solve(pr, "oracle", jac_mode=jac)
+    assert o["rounds"] == int(GOLD[f"ba_{name}_rounds"])
+    assert len(o["chi2"]) == len(GOLD[f"ba_{name}_chi2"])
+    np.testing.assert_array_equal(o["trials"], GOLD[f"ba_{name}_trials"])
+    np.testing.assert_allclose(o["chi2"], GOLD[f"ba_{name}_chi2"], rtol=2e-5)
+    np.testing.assert_allclose(o["lam"], GOLD[f"ba_{name}_lam"], rtol=5e-3)
+    assert np.abs(o["poses"] - GOLD[f"ba_{name}_poses"]).max() < 5e-6
+    d = np.abs(np.sqrt(_edge_chi2_sel(name, o)) - np.sqrt(GOLD[f"ba_{name}_edge_chi2"]))
+    if f"ba_{name}_edge_sel" not in GOLD:
+        # edges whose vertices are all fixed are inactive in g2o (sparse_optimizer.cpp:237); the reference
+        # never computes their error (edge->chi2() reads uninitialised memory), so they are not compared
+        act = ~(pr["pose_fixed"][pr["edge_pose"]].astype(bool) & pr["point_fixed"][pr["edge_point"]].astype(bool))
+        d = d[act]
+    assert np.median(d) < (5e-5 if name == "tiny" else 1e-5)   # the 4-pose toy graph is the least constrained
+    assert np.percentile(d, 99) < 1e-3
+    assert d.max() < 2e-3
+
+
+def test_edge_known_answers(po):
+    """EdgeProjection::computeError, g2o numeric Jacobian, Huber rho -- single-edge vectors from the reference."""
+    ext = synth.stereo_cam_ext()
+    for i in range(len(GOLD["edge_chi2"])):
+        args = (GOLD["edge_pose"][i], GOLD["edge_pt"][i], GOLD["edge_uv"][i], synth.KITTI_K, ext[int(GOLD["edge_cam"][i])])
+        n = po.edge_eval(*args, jac_mode=1)
+        a = po.edge_eval(*args, jac_mode=0)
+        np.testing.assert_allclose(n["e"], GOLD["edge_e"][i], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(n["chi2"], GOLD["edge_chi2"][i], rtol=1e-12)
+        np.testing.assert_allclose(n["rho"], GOLD["edge_rho"][i], rtol=1e-12, atol=1e-15)
+        # numeric J: identical algorithm, noise of the central difference itself ~1e-4 absolute
+        np.testing.assert_allclose(n["Ji"], GOLD["edge_Ji"][i], rtol=0, atol=5e-4)
+        np.testing.assert_allclose(n["Jj"], GOLD["edge_Jj"][i], rtol=0, atol=5e-4)
+        # analytic J agrees with the reference's numeric J to the numeric J's own accuracy
+        scale = np.abs(GOLD["edge_Ji"][i]).max()
+        assert np.abs(a["Ji"] - GOLD["edge_Ji"][i]).max() / scale < 1e-5
+        assert np.abs(a["Jj"] - GOLD["edge_Jj"][i]).max() / np.abs(GOLD["edge_Jj"][i]).max() < 1e-5
+    assert (GOLD["edge_rho"][:, 1] < 1).sum() >= 3 and (GOLD["edge_rho"][:, 1] == 1).sum() >= 3   # both Huber branches
+
+
+def test_se3_known_answers(po):
+    for i, t in enumerate(GOLD["se3_tangent"]):
+        np.testing.assert_allclose(po.se3_exp(t), GOLD["se3_exp"][i], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(po.pose_oplus(GOLD["se3_base"], t), GOLD["se3_oplus"][i], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(po.se3_act(po.se3_exp(t), GOLD["se3_act_p"]), GOLD["se3_act"][i], rtol=0, atol=1e-13)
+
+
+def test_triangulation_known_answers(po):
+    t = po.triangulate(GOLD["tri_uvL"], GOLD["tri_uvR"], synth.KITTI_K, synth.KITTI_BASELINE)
+    np.testing.assert_array_equal(t["ok"], GOLD["tri_ok"])
+    assert 0 < GOLD["tri_ok"].sum() < len(GOLD["tri_ok"])                 # accepted and rejected cases present
+    ok = GOLD["tri_ok"].astype(bool)
+    np.testing.assert_allclose(t["xyz"][ok], GOLD["tri_xyz"][ok], rtol=1e-9)
+    # the sigma3/sigma2 ratio the reference tests against 1e-2 (algorithm.hpp:39)
+    big = GOLD["tri_ratio"] > 1e-6
+    np.testing.assert_allclose(t["ratio"][big], GOLD["tri_ratio"][big], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["po200", "po60"])
+def test_pose_only_known_answers(po, name):
+    M, seed, fg = [int(v) for v in GOLD[f"{name}_cfg"]]
+    pp = synth.make_pose_only_problem(M=M, seed=seed, frac_gross=fg / 100.0)
+    np.testing.assert_allclose([pp["xyz"].sum(), pp["uv"].sum()], GOLD[f"{name}_input_sum"], rtol=1e-13)
+    r = po.pose_only(pp)
+    assert r["n_inliers"] == int(GOLD[f"{name}_n"])
+    np.testing.assert_array_equal(r["inliers"], GOLD[f"{name}_inliers"])
+    np.testing.assert_allclose(r["pose"], GOLD[f"{name}_pose"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.ref
+def test_live_reference_agrees_with_golden(po, ref_available):
+    """when oracle/_ref is built (always in the build container) the stored vectors are what it produces"""
+    if not ref_available:
+        pytest.skip("oracle/_ref/libssvio_ref.so not available")
+    pr = _problem("mid")
+    r = po.ba_solve(pr, "ref")
+    np.testing.assert_allclose(r["chi2"], GOLD["ba_mid_chi2"], rtol=1e-12)
+    np.testing.assert_allclose(r["poses"], GOLD["ba_mid_poses"], rtol=0, atol=1e-12)
+    t = po.triangulate(GOLD["tri_uvL"], GOLD["tri_uvR"], synth.KITTI_K, synth.KITTI_BASELINE, which="ref")
+    np.testing.assert_array_equal(t["ok"], GOLD["tri_ok"])
