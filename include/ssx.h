@@ -139,6 +139,120 @@ SSX_API ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, do
                             double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* err,
                             double* chi2);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * ORB extraction -- replaces the bodies of ssvio::ORBextractor::Detect / DetectAndCompute
+ * (include/ssvio/orbextractor.hpp:50-59, src/ssvio/orbextractor.cpp:755-842, 687-753) and everything
+ * they call: cv::FAST per grid cell, DistributeOctTree, ComputePyramid (cv::resize), IC_Angle
+ * (cv::fastAtan2), cv::GaussianBlur 7x7 sigma 2, computeOrbDescriptor (steered BRIEF-256).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {          /* binary layout of cv::KeyPoint (28 bytes) */
+  float x, y;             /* pt */
+  float size, angle, response;
+  int32_t octave, class_id;
+} ssx_keypoint;
+
+typedef struct {          /* ORBextractor ctor arguments (orbextractor.hpp:44-45, system.cpp:117-128) */
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels;
+  int32_t ini_th_fast, min_th_fast;
+} ssx_orb_params;
+
+SSX_API void ssx_orb_default_params(ssx_orb_params* p); /* 2000, 1.2, 8, 20, 7 (config/kitti_00.yaml:41-49) */
+
+/* ORBextractor::Detect: single-level grid FAST + octree.  mask may be NULL (all 255).  Empty image:
+ * returns SSX_OK with *n = 0 (the reference silently returns, orbextractor.cpp:758-759).
+ * Output: keypoints {pt, size 7, angle -1, response = FAST score, octave 0, class_id -1}. */
+SSX_API ssx_status ssx_orb_detect(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
+                                  const uint8_t* mask, int32_t mask_stride, const ssx_orb_params* prm,
+                                  int32_t cap, ssx_keypoint* kps_out, int32_t* n);
+
+/* ORBextractor::DetectAndCompute: 8-level pyramid ORB.  desc_out: cap x 32 bytes (CV_8U N x 32). */
+SSX_API ssx_status ssx_orb_extract(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
+                                   const uint8_t* mask, int32_t mask_stride, const ssx_orb_params* prm,
+                                   int32_t cap, ssx_keypoint* kps_out, uint8_t* desc_out, int32_t* n);
+
+/* Parity / profiling hooks: copies of intermediate buffers of the LAST ssx_orb_extract / ssx_orb_detect /
+ * ssx_stereo_* call on this ctx, image `image` of that call (0 = left / only image, 1 = right ...).
+ *   level image (u8, rows x cols returned), blurred level image, and the grid-FAST candidates of a level
+ *   (keypoints relative to the 16-px border, reference order = cell-row-major then row-major in the cell). */
+SSX_API ssx_status ssx_orb_stage_level(ssx_ctx* ctx, int32_t image, int32_t level, int32_t blurred,
+                                       uint8_t* out, int32_t out_cap, int32_t* rows, int32_t* cols);
+SSX_API ssx_status ssx_orb_stage_candidates(ssx_ctx* ctx, int32_t image, int32_t level, int32_t cap,
+                                            ssx_keypoint* out, int32_t* n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stereo association + triangulation.
+ * The north_star asks for row-band Hamming matching; the reference itself associates by LK optical flow
+ * (FrontEnd::FindFeaturesInRight, src/ssvio/frontend.cpp:346-428) and only matches descriptors in loop
+ * closing with OpenCV BruteForce-Hamming (src/ssvio/loopclosing.cpp:105-145) -- whose semantics (minimum
+ * distance, lowest train index wins ties) this matcher keeps inside the row band.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  float band_px;            /* |vL - vR| <= band_px * scale_factor^octave_L */
+  float min_disp, max_disp; /* uL - uR in [min_disp, max_disp] */
+  int32_t max_dist;         /* accept iff best Hamming distance <= max_dist */
+  int32_t max_octave_diff;  /* |octave_L - octave_R| <= this */
+  float scale_factor;
+} ssx_match_params;
+
+SSX_API void ssx_match_default_params(ssx_match_params* p); /* 2, 0, 120, 80, 1, 1.2 */
+
+/* match_idx[i] = index of the right keypoint or -1; dist[i] = best distance found (257 = no candidate). */
+SSX_API ssx_status ssx_stereo_match(ssx_ctx* ctx, const ssx_keypoint* kL, const uint8_t* dL, int32_t nL,
+                                    const ssx_keypoint* kR, const uint8_t* dR, int32_t nR,
+                                    const ssx_match_params* prm, int32_t* match_idx, int32_t* dist);
+
+/* Brute-force Hamming match() of loopclosing.cpp:108 (query -> train), next-row N2. */
+SSX_API ssx_status ssx_bf_match(ssx_ctx* ctx, const uint8_t* dq, int32_t nq, const uint8_t* dt, int32_t nt,
+                                int32_t* idx, int32_t* dist);
+
+typedef struct {           /* the rig System::GenerateSteroCamera builds (src/ssvio/system.cpp:54-113) */
+  double fx, fy, cx, cy;
+  double baseline;         /* Camera.Base.Line / fx */
+} ssx_stereo_rig;
+
+/* ssvio::triangulation (include/ssvio/algorithm.hpp:23-45) for left = [I|0], right = [I|(-baseline,0,0)] with
+ * Camera::pixel2camera (src/ssvio/camera.cpp:25-30); ok = sigma3/sigma2 < 1e-2 && z > 0 (frontend.cpp:466,528).
+ * T_wc (nullable, 7 doubles) maps the camera-frame point to the world (frontend.cpp:503,531). */
+SSX_API ssx_status ssx_triangulate(ssx_ctx* ctx, int32_t n, const double* uvL, const double* uvR,
+                                   const ssx_stereo_rig* rig, const double* T_wc, double* xyz_out,
+                                   uint8_t* ok_out);
+
+/* One stereo frame, fully on the device: extract left+right (one batched launch sequence), row-band match,
+ * triangulate the matches.  Replaces DetectFeatures + FindFeaturesInRight + BuidInitMap/TriangulateNewPoints
+ * of the front-end (frontend.cpp:302-544) for the north_star pipeline.  All outputs are optional. */
+typedef struct {
+  int32_t cap;                    /* capacity of every per-keypoint array below */
+  ssx_keypoint *kpsL, *kpsR;
+  uint8_t *descL, *descR;         /* cap x 32 */
+  int32_t nL, nR;                 /* out */
+  int32_t* match_idx;             /* nL */
+  int32_t* match_dist;            /* nL */
+  double* xyz;                    /* nL x 3 (valid where ok) */
+  uint8_t* ok;                    /* nL */
+  int32_t n_matched, n_triangulated;  /* out */
+} ssx_stereo_frame_out;
+
+SSX_API ssx_status ssx_stereo_frame(ssx_ctx* ctx, const uint8_t* imgL, const uint8_t* imgR, int32_t stride,
+                                    int32_t rows, int32_t cols, const ssx_orb_params* orb,
+                                    const ssx_match_params* mp, const ssx_stereo_rig* rig, const double* T_wc,
+                                    ssx_stereo_frame_out* out);
+
+/* Batched, device-resident variant for throughput: `pairs` stereo pairs already in HBM
+ * (imgs_dev = [pairs][2][rows][stride] u8, DEVICE pointer).  Results stay on the device inside the ctx;
+ * counts_out (host, pairs x 4 int32: nL, nR, n_matched, n_triangulated) is the only download.
+ * Use ssx_stereo_batch_fetch to copy one pair's results out afterwards. */
+SSX_API ssx_status ssx_stereo_batch_dev(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs_dev, int32_t stride,
+                                        int32_t rows, int32_t cols, const ssx_orb_params* orb,
+                                        const ssx_match_params* mp, const ssx_stereo_rig* rig,
+                                        int32_t* counts_out);
+SSX_API ssx_status ssx_stereo_batch_fetch(ssx_ctx* ctx, int32_t pair, ssx_stereo_frame_out* out);
+/* Timing hook: enqueue the batch again on the already-resident inputs WITHOUT any host synchronisation or
+ * download (bench.py brackets a run of these with HIP events). */
+SSX_API ssx_status ssx_stereo_batch_enqueue(ssx_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,25 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+
+class OrbParams(C.Structure):
+    """ORBextractor ctor arguments (orbextractor.hpp:44-45)."""
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class MatchParams(C.Structure):
+    _fields_ = [("band_px", C.c_float), ("min_disp", C.c_float), ("max_disp", C.c_float),
+                ("max_dist", C.c_int32), ("max_octave_diff", C.c_int32), ("scale_factor", C.c_float)]
+
+
+class StereoRig(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("baseline", C.c_double)]
+
+
+class StereoFrameOut(C.Structure):
+    _fields_ = [("cap", C.c_int32), ("kpsL", C.c_void_p), ("kpsR", C.c_void_p), ("descL", u8_p), ("descR", u8_p),
+                ("nL", C.c_int32), ("nR", C.c_int32), ("match_idx", i32_p), ("match_dist", i32_p),
+                ("xyz", dbl_p), ("ok", u8_p), ("n_matched", C.c_int32), ("n_triangulated", C.c_int32)]

@@ -618,11 +618,6 @@ static void ssx_ba_workspace_free(BaWorkspace* w)
 
 namespace {
 
-struct Layout {
-  size_t off = 0;
-  size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; }
-};
-
 struct HostPrep {
   int P, L, E, nP, nLm, nCh, nBlk;
   std::vector<int> pose_free, lm_id, lm_ptr, ch_lm, e_pose, e_lmc, perm;

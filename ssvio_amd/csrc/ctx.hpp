@@ -56,6 +56,12 @@ struct HostBuf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// bump allocator for carving one arena into 256-byte aligned sub-buffers
+struct Layout {
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; }
+};
+
 struct BaWorkspace;   // ba.hip
 struct OrbWorkspace;  // orb.hip
 

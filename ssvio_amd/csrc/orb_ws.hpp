@@ -1,0 +1,130 @@
+// ssvio_amd/csrc/orb_ws.hpp -- device-side view and per-ctx workspace of the ORB / stereo front-end.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace ssxorb {
+
+constexpr int MAX_LEVELS = 8;
+constexpr int CELL_CAP = 256;      // candidates kept per grid cell (31x32 interior: NMS leaves < 250)
+constexpr int CAND_CAP = 16384;    // candidates per (image, level) fed to the octree
+constexpr int NODE_CAP = 16384;    // octree nodes alive per (image, level)  (>= 4 x per-level budget + 4)
+constexpr int SEL_CAP = 4096;      // selected keypoints per (image, level)
+constexpr int EDGE_THRESHOLD = 19; // orbextractor.cpp:13
+constexpr int OCT_THREADS = 1024;
+
+struct Cell {
+  int16_t x0, y0;   // ROI origin in the level image
+  int16_t w, h;     // ROI size (cell + 6, clipped)
+  int16_t ox, oy;   // j*wCell, i*hCell added to ROI-local coordinates (orbextractor.cpp:816-817)
+  int16_t level, pad;
+};
+
+// per (image, level) octree scratch, laid out at fixed byte offsets inside one block of OCT_BYTES
+struct OctLayout {
+  static constexpr size_t candx = 0;                                        // u16[CAND_CAP]
+  static constexpr size_t candy = candx + 2 * CAND_CAP;                     // u16[CAND_CAP]
+  static constexpr size_t candr = candy + 2 * CAND_CAP;                     // u8 [CAND_CAP]
+  static constexpr size_t keys = candr + CAND_CAP;                          // u16[2][CAND_CAP]
+  static constexpr size_t nodeat = keys + 4 * CAND_CAP;                     // u16[2][CAND_CAP]
+  static constexpr size_t escan = nodeat + 4 * CAND_CAP;                    // u64[CAND_CAP+8]
+  static constexpr size_t nodes = escan + 8 * (CAND_CAP + 8);               // Node[2][NODE_CAP] (16 B each)
+  static constexpr size_t proc = nodes + 2 * 16 * (size_t)NODE_CAP;         // u16[NODE_CAP]
+  static constexpr size_t expa = proc + 2 * NODE_CAP;                       // u16[NODE_CAP]
+  static constexpr size_t expb = expa + 2 * NODE_CAP;                       // u16[NODE_CAP]
+  static constexpr size_t c4 = expb + 2 * NODE_CAP;                         // u64[NODE_CAP] quadrant counts per proc
+  static constexpr size_t kid4 = c4 + 8 * (size_t)NODE_CAP;                 // u64[NODE_CAP] child ids per proc
+  static constexpr size_t ccp = kid4 + 8 * (size_t)NODE_CAP;                // u32[NODE_CAP] scan of child counts
+  static constexpr size_t exp_ = ccp + 4 * (size_t)NODE_CAP;                // u32[NODE_CAP] scan of expandable counts
+  static constexpr size_t newpos = exp_ + 4 * (size_t)NODE_CAP;             // u16[NODE_CAP] survivors' new id
+  static constexpr size_t sortk = newpos + 2 * NODE_CAP;                    // u32[NODE_CAP] phase-2 sort keys
+  static constexpr size_t total = ((sortk + 4 * (size_t)NODE_CAP) + 255) & ~size_t(255);
+};
+
+struct OctNode {      // 16 bytes
+  uint16_t b, e;      // key range [b, e)
+  int16_t ulx, uly, brx, bry;
+  uint16_t pidx;      // index in the processing list of the current round
+  uint8_t no_more;    // bNoMore
+  uint8_t div;        // marked for division in the current round
+};
+
+struct OrbDev {
+  // geometry
+  int I;                         // images in the batch
+  int nlevels;
+  int lvl_rows[MAX_LEVELS], lvl_cols[MAX_LEVELS], lvl_pitch[MAX_LEVELS];
+  size_t lvl_off[MAX_LEVELS];    // byte offset of a level inside one image's pyramid
+  size_t pyr_bytes;              // bytes of one image's pyramid
+  float scale[MAX_LEVELS];       // mvScaleFactor
+  int feat[MAX_LEVELS];          // mnFeaturesPerLevel (or nfeatures for the single-level Detect)
+  int lvl_cell0[MAX_LEVELS + 1]; // first cell of each level
+  int n_cells;
+  int ini_th, min_th;
+  int has_mask;
+  int detect_only;               // ORBextractor::Detect: level 0 only, no orientation / descriptors
+  int out_cap;                   // keypoints per image in the output arrays
+  // buffers
+  const Cell* cells;
+  uint8_t* pyr;                  // [I][pyr_bytes]
+  uint8_t* maskpyr;              // [I][pyr_bytes] (only when has_mask)
+  uint8_t* blur;                 // [I][pyr_bytes]
+  int* cell_count;               // [I][n_cells]
+  uint32_t* cell_cand;           // [I][n_cells][CELL_CAP]   x | y<<12 | score<<24 (relative to the 16-px border)
+  uint8_t* oct;                  // [I][nlevels][OctLayout::total]
+  int* lvl_ncand;                // [I][nlevels]
+  int* sel_count;                // [I][nlevels]
+  uint32_t* sel;                 // [I][nlevels][SEL_CAP] packed like cell_cand
+  float* sel_angle;              // [I][nlevels][SEL_CAP]
+  int* status;                   // [I] bit0: candidate overflow, bit1: node overflow, bit2: output overflow
+  // outputs
+  uint8_t* out_kps;              // [I][out_cap] x 28 bytes (ssx_keypoint)
+  uint8_t* out_desc;             // [I][out_cap][32]
+  int* out_n;                    // [I]
+};
+
+void launch_octree(const OrbDev& o, hipStream_t s);   // octree.hip
+
+}  // namespace ssxorb
+
+// host-side plan + buffers (one per ctx; re-planned when the geometry / parameters change)
+struct OrbWorkspace {
+  DevBuf arena;        // pyramids, candidates, octree scratch, outputs
+  DevBuf input;        // uploaded host images (host-pointer entry points)
+  DevBuf stereo;       // match / triangulation results of the batch entry points
+  HostBuf stage;       // pinned staging
+  ssxorb::OrbDev dev{};
+  // plan key
+  int rows = 0, cols = 0, I = 0, nlevels = 0, nfeatures = 0, ini_th = 0, min_th = 0, has_mask = 0, detect_only = 0;
+  float scale_factor = 0.f;
+  bool planned = false;
+  // batch state (ssx_stereo_batch_dev / _enqueue / _fetch)
+  const uint8_t* batch_imgs = nullptr;
+  int batch_pairs = 0, batch_stride = 0;
+  ssx_orb_params batch_orb{};
+  ssx_match_params batch_mp{};
+  ssx_stereo_rig batch_rig{};
+  // stereo result views inside `stereo`
+  int* match_idx = nullptr;
+  int* match_dist = nullptr;
+  double* xyz = nullptr;
+  uint8_t* tri_ok = nullptr;
+  int* pair_counts = nullptr;   // [pairs][4]
+};
+
+namespace ssxorb {
+OrbWorkspace* get_ws(ssx_ctx* ctx);
+// plan (allocate + upload cell tables) for I images of rows x cols; returns SSX_OK or an error
+ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& prm, bool has_mask, bool detect_only);
+// run the extraction pipeline on level-0 images already placed in the pyramid buffers
+ssx_status run_pipeline(ssx_ctx* ctx);
+// stage level 0 from a device/host-layout buffer [I][rows][stride]
+// download the keypoints / descriptors of one image of the last run (synchronises the stream)
+ssx_status fetch_image(ssx_ctx* ctx, int image, int cap, ssx_keypoint* kps_out, uint8_t* desc_out, int32_t* n);
+ssx_status stage_level0(ssx_ctx* ctx, const uint8_t* imgs_dev, int stride, size_t img_bytes, const uint8_t* masks_dev,
+                        int mask_stride, size_t mask_bytes);
+}  // namespace ssxorb

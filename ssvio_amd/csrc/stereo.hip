@@ -1,0 +1,561 @@
+// ssvio_amd/csrc/stereo.hip -- stereo association and triangulation on gfx950.
+//
+//   k_row_bucket     counting sort of the right keypoints by image row (LDS histogram + scan)
+//   k_match          ROW-BAND Hamming matcher, one wave per left keypoint: only the right keypoints whose row lies
+//                    in the band are visited; 256-bit XOR + 4 x popcount per candidate; wave-wide min-reduce on
+//                    (distance << 16 | right index) = minimum distance, lowest index wins ties
+//                    (the semantics of OpenCV BruteForce-Hamming match(), /root/reference/src/ssvio/loopclosing.cpp:24,108)
+//   k_bf_match       the unrestricted brute-force matcher of loop closing (loopclosing.cpp:105-110)
+//   k_triangulate    ssvio::triangulation (/root/reference/include/ssvio/algorithm.hpp:23-45): DLT rows of the two 3x4
+//                    poses, 4x4 SVD by one-sided Jacobi in registers (f64), sigma3/sigma2 < 1e-2 and z > 0
+//
+// The reference has no row-band matcher (its stereo association is LK optical flow, frontend.cpp:374-384); the
+// matching rule is the one defined with the oracle (oracle/src/stereo_oracle.cpp) and is bit-exact against it.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "ctx.hpp"
+#include "orb_ws.hpp"
+
+namespace ssxorb {
+
+namespace {
+
+struct MatchDev {
+  int pairs, out_cap, rows;
+  const ssx_keypoint* kps;   // [2*pairs][out_cap]
+  const uint8_t* desc;       // [2*pairs][out_cap][32]
+  const int* n;              // [2*pairs]
+  int* row_ptr;              // [pairs][rows + 2]
+  int* sorted;               // [pairs][out_cap]
+  int* match_idx;            // [pairs][out_cap]
+  int* match_dist;           // [pairs][out_cap]
+  double* xyz;               // [pairs][out_cap][3]
+  uint8_t* ok;               // [pairs][out_cap]
+  int* counts;               // [pairs][4]
+  ssx_match_params mp;
+  ssx_stereo_rig rig;
+  double T_wc[7];
+  int has_T;
+  float scale[32];
+};
+
+constexpr int BUCKET_ROWS_MAX = 4096;
+
+__global__ __launch_bounds__(1024) void k_row_bucket(MatchDev m)
+{
+  __shared__ int hist[BUCKET_ROWS_MAX + 1];
+  __shared__ int wsum[17];
+  const int pair = blockIdx.x, t = threadIdx.x;
+  const int nR = min(m.n[2 * pair + 1], m.out_cap);
+  const ssx_keypoint* kR = m.kps + (size_t)(2 * pair + 1) * m.out_cap;
+  int* row_ptr = m.row_ptr + (size_t)pair * (m.rows + 2);
+  int* sorted = m.sorted + (size_t)pair * m.out_cap;
+  const int R = m.rows + 1;
+  for (int i = t; i <= R; i += 1024) hist[i] = 0;
+  __syncthreads();
+  for (int j = t; j < nR; j += 1024) {
+    int r = (int)kR[j].y;
+    r = r < 0 ? 0 : (r >= R ? R - 1 : r);
+    atomicAdd(&hist[r], 1);
+  }
+  __syncthreads();
+  // exclusive scan of hist[0..R) by 1024 threads: contiguous chunks + wave scan
+  const int chunk = (R + 1023) / 1024;
+  const int lo = min(t * chunk, R), hi = min(lo + chunk, R);
+  int mine = 0;
+  for (int i = lo; i < hi; ++i) mine += hist[i];
+  int inc = mine;
+  const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  if (t == 0) { int run = 0; for (int w = 0; w < 16; ++w) { const int x = wsum[w]; wsum[w] = run; run += x; } wsum[16] = run; }
+  __syncthreads();
+  int run = wsum[wave] + inc - mine;
+  for (int i = lo; i < hi; ++i) { const int c = hist[i]; row_ptr[i] = run; hist[i] = run; run += c; }
+  if (t == 0) row_ptr[R] = wsum[16];
+  __syncthreads();
+  for (int j = t; j < nR; j += 1024) {
+    int r = (int)kR[j].y;
+    r = r < 0 ? 0 : (r >= R ? R - 1 : r);
+    sorted[atomicAdd(&hist[r], 1)] = j;   // order inside a row is irrelevant: the reduction key carries the index
+  }
+}
+
+__device__ __forceinline__ int hamming256(const uint8_t* a, const uint8_t* b)
+{
+  const unsigned long long* x = reinterpret_cast<const unsigned long long*>(a);
+  const unsigned long long* y = reinterpret_cast<const unsigned long long*>(b);
+  return __popcll(x[0] ^ y[0]) + __popcll(x[1] ^ y[1]) + __popcll(x[2] ^ y[2]) + __popcll(x[3] ^ y[3]);
+}
+
+__global__ __launch_bounds__(256) void k_match(MatchDev m)
+{
+  const int pair = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  const int nL = min(m.n[2 * pair], m.out_cap), nR = min(m.n[2 * pair + 1], m.out_cap);
+  if (i >= nL) return;
+  const ssx_keypoint* kL = m.kps + (size_t)(2 * pair) * m.out_cap;
+  const ssx_keypoint* kR = m.kps + (size_t)(2 * pair + 1) * m.out_cap;
+  const uint8_t* dL = m.desc + (size_t)(2 * pair) * m.out_cap * 32;
+  const uint8_t* dR = m.desc + (size_t)(2 * pair + 1) * m.out_cap * 32;
+  const int* row_ptr = m.row_ptr + (size_t)pair * (m.rows + 2);
+  const int* sorted = m.sorted + (size_t)pair * m.out_cap;
+  const ssx_keypoint a = kL[i];
+  const int ol = a.octave < 0 ? 0 : (a.octave > 31 ? 31 : a.octave);
+  const float band = m.mp.band_px * m.scale[ol];
+  const int R = m.rows + 1;
+  int r0 = (int)floorf(a.y - band), r1 = (int)floorf(a.y + band);
+  r0 = r0 < 0 ? 0 : (r0 >= R ? R - 1 : r0);
+  r1 = r1 < 0 ? 0 : (r1 >= R ? R - 1 : r1);
+  const int c0 = (nR > 0) ? row_ptr[r0] : 0, c1 = (nR > 0) ? row_ptr[r1 + 1] : 0;
+  // my descriptor in registers
+  const unsigned long long* da = reinterpret_cast<const unsigned long long*>(dL + (size_t)i * 32);
+  const unsigned long long a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3];
+  unsigned best = (257u << 16) | 0xFFFFu;
+  for (int c = c0 + lane; c < c1; c += 64) {
+    const int j = sorted[c];
+    const ssx_keypoint b = kR[j];
+    const float dv = a.y - b.y;
+    if (dv > band || -dv > band) continue;
+    int doct = a.octave - b.octave;
+    doct = doct < 0 ? -doct : doct;
+    if (doct > m.mp.max_octave_diff) continue;
+    const float disp = a.x - b.x;
+    if (disp < m.mp.min_disp || disp > m.mp.max_disp) continue;
+    const unsigned long long* db = reinterpret_cast<const unsigned long long*>(dR + (size_t)j * 32);
+    const int d = __popcll(a0 ^ db[0]) + __popcll(a1 ^ db[1]) + __popcll(a2 ^ db[2]) + __popcll(a3 ^ db[3]);
+    const unsigned key = ((unsigned)d << 16) | (unsigned)j;
+    best = min(best, key);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+  if (lane == 0) {
+    const int d = (int)(best >> 16), j = (int)(best & 0xFFFFu);
+    m.match_dist[(size_t)pair * m.out_cap + i] = d;
+    m.match_idx[(size_t)pair * m.out_cap + i] = (d <= 256 && d <= m.mp.max_dist) ? j : -1;
+  }
+}
+
+// generic brute force: query block x all train descriptors (host-array entry point ssx_bf_match)
+__global__ __launch_bounds__(256) void k_bf_match(const uint8_t* dq, int nq, const uint8_t* dt, int nt, int* idx, int* dist)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= nq) return;
+  unsigned best = (257u << 16) | 0xFFFFu;
+  for (int j = lane; j < nt; j += 64) {
+    const int d = hamming256(dq + (size_t)i * 32, dt + (size_t)j * 32);
+    best = min(best, ((unsigned)d << 16) | (unsigned)j);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+  if (lane == 0) {
+    const int d = (int)(best >> 16);
+    dist[i] = d;
+    idx[i] = d <= 256 ? (int)(best & 0xFFFFu) : -1;
+  }
+}
+
+// ---- 4x4 SVD by one-sided Jacobi, everything in registers (loops fully unrolled: static indices) ----
+__device__ __forceinline__ void jacobi_pair(double* U, double* V, int p, int q, bool& rotated)
+{
+  double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    alpha += U[r * 4 + p] * U[r * 4 + p];
+    beta += U[r * 4 + q] * U[r * 4 + q];
+    gamma += U[r * 4 + p] * U[r * 4 + q];
+  }
+  if (fabs(gamma) <= 1e-15 * sqrt(alpha * beta) || gamma == 0.0) return;
+  rotated = true;
+  const double zeta = (beta - alpha) / (2.0 * gamma);
+  const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double up = U[r * 4 + p], uq = U[r * 4 + q];
+    U[r * 4 + p] = c * up - s * uq;
+    U[r * 4 + q] = s * up + c * uq;
+    const double vp = V[r * 4 + p], vq = V[r * 4 + q];
+    V[r * 4 + p] = c * vp - s * vq;
+    V[r * 4 + q] = s * vp + c * vq;
+  }
+}
+
+__device__ __forceinline__ void triangulate_one(double uL, double vL, double uR, double vR, const ssx_stereo_rig& rig,
+                                                const double* T_wc, double* xyz, uint8_t* ok)
+{
+  const double x1 = (uL - rig.cx) / rig.fx * 1.0, y1 = (vL - rig.cy) / rig.fy * 1.0;
+  const double x2 = (uR - rig.cx) / rig.fx * 1.0, y2 = (vR - rig.cy) / rig.fy * 1.0;
+  const double tx = -rig.baseline;
+  double U[16] = {-1, 0, x1, 0, 0, -1, y1, 0, -1, 0, x2, x2 * 0.0 - tx, 0, -1, y2, y2 * 0.0 - 0.0};
+  double V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    bool rotated = false;
+    jacobi_pair(U, V, 0, 1, rotated); jacobi_pair(U, V, 0, 2, rotated); jacobi_pair(U, V, 0, 3, rotated);
+    jacobi_pair(U, V, 1, 2, rotated); jacobi_pair(U, V, 1, 3, rotated); jacobi_pair(U, V, 2, 3, rotated);
+    if (!rotated) break;
+  }
+  double n[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += U[r * 4 + c] * U[r * 4 + c];
+    n[c] = sqrt(s);
+  }
+  // smallest and second smallest singular value, ties resolved like the oracle's stable descending sort:
+  // ord = [0,1,2,3]; swap when n[ord[j]] > n[ord[i]] (j > i)
+  int ord[4] = {0, 1, 2, 3};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 4; ++j) {
+      const bool sw = n[ord[j]] > n[ord[i]];
+      const int a = ord[i], b = ord[j];
+      ord[i] = sw ? b : a; ord[j] = sw ? a : b;
+    }
+  const int cmin = ord[3], c2 = ord[2];
+  double vx = 0, vy = 0, vz = 0, vw = 0, smin = 0, s2 = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c == cmin) { vx = V[0 * 4 + c]; vy = V[1 * 4 + c]; vz = V[2 * 4 + c]; vw = V[3 * 4 + c]; smin = n[c]; }
+    if (c == c2) s2 = n[c];
+  }
+  double p[3] = {vx / vw, vy / vw, vz / vw};
+  const double ratio = smin / s2;
+  *ok = ((ratio < 1e-2) && (p[2] > 0)) ? 1 : 0;
+  if (T_wc) {
+    const double qx = T_wc[0], qy = T_wc[1], qz = T_wc[2], qw = T_wc[3];
+    double ux = qy * p[2] - qz * p[1], uy = qz * p[0] - qx * p[2], uz = qx * p[1] - qy * p[0];
+    ux += ux; uy += uy; uz += uz;
+    const double rx = p[0] + qw * ux + (qy * uz - qz * uy);
+    const double ry = p[1] + qw * uy + (qz * ux - qx * uz);
+    const double rz = p[2] + qw * uz + (qx * uy - qy * ux);
+    p[0] = rx + T_wc[4]; p[1] = ry + T_wc[5]; p[2] = rz + T_wc[6];
+  }
+  xyz[0] = p[0]; xyz[1] = p[1]; xyz[2] = p[2];
+}
+
+__global__ __launch_bounds__(256) void k_triangulate_matches(MatchDev m)
+{
+  const int pair = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nL = min(m.n[2 * pair], m.out_cap);
+  if (i >= nL) return;
+  const int j = m.match_idx[(size_t)pair * m.out_cap + i];
+  double* xyz = m.xyz + ((size_t)pair * m.out_cap + i) * 3;
+  uint8_t* ok = m.ok + (size_t)pair * m.out_cap + i;
+  if (j < 0) { xyz[0] = 0; xyz[1] = 0; xyz[2] = 0; *ok = 0; return; }
+  const ssx_keypoint a = m.kps[(size_t)(2 * pair) * m.out_cap + i];
+  const ssx_keypoint b = m.kps[(size_t)(2 * pair + 1) * m.out_cap + j];
+  // cv::Point2f widened to double (frontend.cpp:458-465)
+  triangulate_one((double)a.x, (double)a.y, (double)b.x, (double)b.y, m.rig, m.has_T ? m.T_wc : nullptr, xyz, ok);
+}
+
+__global__ __launch_bounds__(256) void k_triangulate_uv(int n, const double* uvL, const double* uvR, ssx_stereo_rig rig,
+                                                        MatchDev m, double* xyz, uint8_t* ok)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  triangulate_one(uvL[2 * i], uvL[2 * i + 1], uvR[2 * i], uvR[2 * i + 1], rig, m.has_T ? m.T_wc : nullptr, xyz + 3 * (size_t)i,
+                  ok + i);
+}
+
+__global__ __launch_bounds__(256) void k_pair_counts(MatchDev m)
+{
+  __shared__ int s[2];
+  const int pair = blockIdx.x, t = threadIdx.x;
+  const int nL = min(m.n[2 * pair], m.out_cap);
+  if (t < 2) s[t] = 0;
+  __syncthreads();
+  int nm = 0, nt = 0;
+  for (int i = t; i < nL; i += 256) {
+    nm += m.match_idx[(size_t)pair * m.out_cap + i] >= 0;
+    nt += m.ok[(size_t)pair * m.out_cap + i] != 0;
+  }
+  atomicAdd(&s[0], nm);
+  atomicAdd(&s[1], nt);
+  __syncthreads();
+  if (t == 0) {
+    int* c = m.counts + 4 * (size_t)pair;
+    c[0] = nL; c[1] = min(m.n[2 * pair + 1], m.out_cap); c[2] = s[0]; c[3] = s[1];
+  }
+}
+
+void fill_scale(MatchDev& m)
+{
+  m.scale[0] = 1.0f;
+  for (int i = 1; i < 32; ++i) m.scale[i] = m.scale[i - 1] * m.mp.scale_factor;   // mvScaleFactor
+}
+
+// allocate the stereo result buffers for `pairs` pairs and build the device view
+ssx_status make_match_dev(ssx_ctx* ctx, int pairs, const ssx_match_params& mp, const ssx_stereo_rig& rig, const double* T_wc,
+                          MatchDev& m)
+{
+  OrbWorkspace* ws = get_ws(ctx);
+  const OrbDev& d = ws->dev;
+  if (d.lvl_rows[0] + 2 > BUCKET_ROWS_MAX) { ctx->set_error("ssx_stereo: image too tall for the row buckets"); return SSX_ERR_UNSUPPORTED; }
+  if (d.out_cap > 65535) { ctx->set_error("ssx_stereo: more than 65535 keypoints per image"); return SSX_ERR_UNSUPPORTED; }
+  Layout lay;
+  const size_t o_rp = lay.take(sizeof(int) * (size_t)pairs * (d.lvl_rows[0] + 2));
+  const size_t o_sorted = lay.take(sizeof(int) * (size_t)pairs * d.out_cap);
+  const size_t o_idx = lay.take(sizeof(int) * (size_t)pairs * d.out_cap);
+  const size_t o_dist = lay.take(sizeof(int) * (size_t)pairs * d.out_cap);
+  const size_t o_xyz = lay.take(sizeof(double) * 3 * (size_t)pairs * d.out_cap);
+  const size_t o_ok = lay.take((size_t)pairs * d.out_cap);
+  const size_t o_cnt = lay.take(sizeof(int) * 4 * (size_t)pairs);
+  SSX_HIP_TRY(ctx, ws->stereo.reserve(lay.off));
+  char* base = ws->stereo.as<char>();
+  m.pairs = pairs; m.out_cap = d.out_cap; m.rows = d.lvl_rows[0];
+  m.kps = reinterpret_cast<const ssx_keypoint*>(d.out_kps); m.desc = d.out_desc; m.n = d.out_n;
+  m.row_ptr = (int*)(base + o_rp); m.sorted = (int*)(base + o_sorted);
+  m.match_idx = (int*)(base + o_idx); m.match_dist = (int*)(base + o_dist);
+  m.xyz = (double*)(base + o_xyz); m.ok = (uint8_t*)(base + o_ok); m.counts = (int*)(base + o_cnt);
+  m.mp = mp; m.rig = rig;
+  m.has_T = T_wc ? 1 : 0;
+  for (int i = 0; i < 7; ++i) m.T_wc[i] = T_wc ? T_wc[i] : (i == 3 ? 1.0 : 0.0);
+  fill_scale(m);
+  ws->match_idx = m.match_idx; ws->match_dist = m.match_dist; ws->xyz = m.xyz; ws->tri_ok = m.ok; ws->pair_counts = m.counts;
+  return SSX_OK;
+}
+
+ssx_status launch_stereo(ssx_ctx* ctx, const MatchDev& m)
+{
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_row_bucket, dim3(m.pairs), dim3(1024), 0, s, m);
+  hipLaunchKernelGGL(k_match, dim3((m.out_cap + 3) / 4, m.pairs), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(k_triangulate_matches, dim3((m.out_cap + 255) / 256, m.pairs), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(k_pair_counts, dim3(m.pairs), dim3(256), 0, s, m);
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  return SSX_OK;
+}
+
+ssx_status fetch_pair(ssx_ctx* ctx, int pair, ssx_stereo_frame_out* out)
+{
+  OrbWorkspace* ws = get_ws(ctx);
+  const OrbDev& d = ws->dev;
+  int c[4];
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(c, ws->pair_counts + 4 * (size_t)pair, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t nL = 0, nR = 0;
+  ssx_status st = fetch_image(ctx, 2 * pair, out->cap, out->kpsL, out->descL, &nL);
+  if (st != SSX_OK) return st;
+  st = fetch_image(ctx, 2 * pair + 1, out->cap, out->kpsR, out->descR, &nR);
+  if (st != SSX_OK) return st;
+  out->nL = nL; out->nR = nR; out->n_matched = c[2]; out->n_triangulated = c[3];
+  if (nL > 0) {
+    if (out->match_idx) SSX_HIP_TRY(ctx, hipMemcpyAsync(out->match_idx, ws->match_idx + (size_t)pair * d.out_cap, sizeof(int) * nL, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->match_dist) SSX_HIP_TRY(ctx, hipMemcpyAsync(out->match_dist, ws->match_dist + (size_t)pair * d.out_cap, sizeof(int) * nL, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->xyz) SSX_HIP_TRY(ctx, hipMemcpyAsync(out->xyz, ws->xyz + (size_t)pair * d.out_cap * 3, sizeof(double) * 3 * nL, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->ok) SSX_HIP_TRY(ctx, hipMemcpyAsync(out->ok, ws->tri_ok + (size_t)pair * d.out_cap, nL, hipMemcpyDeviceToHost, ctx->stream));
+    SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return SSX_OK;
+}
+
+}  // namespace
+}  // namespace ssxorb
+
+using namespace ssxorb;
+
+extern "C" {
+
+void ssx_match_default_params(ssx_match_params* p)
+{
+  if (!p) return;
+  p->band_px = 2.0f; p->min_disp = 0.0f; p->max_disp = 120.0f; p->max_dist = 80; p->max_octave_diff = 1; p->scale_factor = 1.2f;
+}
+
+ssx_status ssx_stereo_match(ssx_ctx* ctx, const ssx_keypoint* kL, const uint8_t* dL, int32_t nL, const ssx_keypoint* kR,
+                            const uint8_t* dR, int32_t nR, const ssx_match_params* prm, int32_t* match_idx, int32_t* dist)
+{
+  if (!ctx || !prm || nL < 0 || nR < 0 || (nL && (!kL || !dL || !match_idx || !dist)) || (nR && (!kR || !dR)))
+    return SSX_ERR_INVALID_ARG;
+  if (nL == 0) return SSX_OK;
+  if (nL > 65535 || nR > 65535) { ctx->set_error("ssx_stereo_match: more than 65535 keypoints"); return SSX_ERR_UNSUPPORTED; }
+  OrbWorkspace* ws = get_ws(ctx);
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int cap = std::max(nL, std::max(nR, 1));
+  // rows covered by the buckets: max right y + 2
+  float ymax = 0.f;
+  for (int j = 0; j < nR; ++j) ymax = std::max(ymax, kR[j].y);
+  for (int i = 0; i < nL; ++i) ymax = std::max(ymax, kL[i].y);
+  const int rows = std::min((int)ymax + 2, BUCKET_ROWS_MAX - 2);
+  Layout lay;
+  const size_t o_k = lay.take(sizeof(ssx_keypoint) * 2 * (size_t)cap);
+  const size_t o_d = lay.take((size_t)64 * cap);
+  const size_t o_n = lay.take(sizeof(int) * 2);
+  const size_t in_bytes = lay.off;
+  const size_t o_rp = lay.take(sizeof(int) * (rows + 2));
+  const size_t o_sorted = lay.take(sizeof(int) * (size_t)cap);
+  const size_t o_idx = lay.take(sizeof(int) * (size_t)cap);
+  const size_t o_dist = lay.take(sizeof(int) * (size_t)cap);
+  SSX_HIP_TRY(ctx, ws->input.reserve(lay.off));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(lay.off));
+  char* hs = ws->stage.as<char>();
+  memcpy(hs + o_k, kL, sizeof(ssx_keypoint) * nL);
+  if (nR) memcpy(hs + o_k + sizeof(ssx_keypoint) * cap, kR, sizeof(ssx_keypoint) * nR);
+  memcpy(hs + o_d, dL, (size_t)32 * nL);
+  if (nR) memcpy(hs + o_d + (size_t)32 * cap, dR, (size_t)32 * nR);
+  int nn[2] = {nL, nR};
+  memcpy(hs + o_n, nn, sizeof(nn));
+  char* base = ws->input.as<char>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  MatchDev m{};
+  m.pairs = 1; m.out_cap = cap; m.rows = rows;
+  m.kps = (const ssx_keypoint*)(base + o_k); m.desc = (const uint8_t*)(base + o_d); m.n = (const int*)(base + o_n);
+  m.row_ptr = (int*)(base + o_rp); m.sorted = (int*)(base + o_sorted);
+  m.match_idx = (int*)(base + o_idx); m.match_dist = (int*)(base + o_dist);
+  m.mp = *prm;
+  fill_scale(m);
+  hipLaunchKernelGGL(k_row_bucket, dim3(1), dim3(1024), 0, ctx->stream, m);
+  hipLaunchKernelGGL(k_match, dim3((cap + 3) / 4, 1), dim3(256), 0, ctx->stream, m);
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(match_idx, m.match_idx, sizeof(int) * nL, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(dist, m.match_dist, sizeof(int) * nL, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SSX_OK;
+}
+
+ssx_status ssx_bf_match(ssx_ctx* ctx, const uint8_t* dq, int32_t nq, const uint8_t* dt, int32_t nt, int32_t* idx,
+                        int32_t* dist)
+{
+  if (!ctx || nq < 0 || nt < 0 || (nq && (!dq || !idx || !dist)) || (nt && !dt)) return SSX_ERR_INVALID_ARG;
+  if (nq == 0) return SSX_OK;
+  if (nt > 65535) { ctx->set_error("ssx_bf_match: more than 65535 train descriptors"); return SSX_ERR_UNSUPPORTED; }
+  OrbWorkspace* ws = get_ws(ctx);
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Layout lay;
+  const size_t o_q = lay.take((size_t)32 * nq);
+  const size_t o_t = lay.take((size_t)32 * std::max(nt, 1));
+  const size_t in_bytes = lay.off;
+  const size_t o_i = lay.take(sizeof(int) * nq);
+  const size_t o_d = lay.take(sizeof(int) * nq);
+  SSX_HIP_TRY(ctx, ws->input.reserve(lay.off));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(lay.off));
+  char* hs = ws->stage.as<char>();
+  memcpy(hs + o_q, dq, (size_t)32 * nq);
+  if (nt) memcpy(hs + o_t, dt, (size_t)32 * nt);
+  char* base = ws->input.as<char>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_bf_match, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, (const uint8_t*)(base + o_q), nq,
+                     (const uint8_t*)(base + o_t), nt, (int*)(base + o_i), (int*)(base + o_d));
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(idx, base + o_i, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(dist, base + o_d, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SSX_OK;
+}
+
+ssx_status ssx_triangulate(ssx_ctx* ctx, int32_t n, const double* uvL, const double* uvR, const ssx_stereo_rig* rig,
+                           const double* T_wc, double* xyz_out, uint8_t* ok_out)
+{
+  if (!ctx || !rig || n < 0 || (n && (!uvL || !uvR || !xyz_out || !ok_out))) return SSX_ERR_INVALID_ARG;
+  if (n == 0) return SSX_OK;
+  OrbWorkspace* ws = get_ws(ctx);
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Layout lay;
+  const size_t o_l = lay.take(sizeof(double) * 2 * (size_t)n);
+  const size_t o_r = lay.take(sizeof(double) * 2 * (size_t)n);
+  const size_t in_bytes = lay.off;
+  const size_t o_x = lay.take(sizeof(double) * 3 * (size_t)n);
+  const size_t o_k = lay.take((size_t)n);
+  SSX_HIP_TRY(ctx, ws->input.reserve(lay.off));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(lay.off));
+  char* hs = ws->stage.as<char>();
+  memcpy(hs + o_l, uvL, sizeof(double) * 2 * n);
+  memcpy(hs + o_r, uvR, sizeof(double) * 2 * n);
+  char* base = ws->input.as<char>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  MatchDev m{};
+  m.has_T = T_wc ? 1 : 0;
+  for (int i = 0; i < 7; ++i) m.T_wc[i] = T_wc ? T_wc[i] : (i == 3 ? 1.0 : 0.0);
+  hipLaunchKernelGGL(k_triangulate_uv, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, (const double*)(base + o_l),
+                     (const double*)(base + o_r), *rig, m, (double*)(base + o_x), (uint8_t*)(base + o_k));
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(xyz_out, base + o_x, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(ok_out, base + o_k, n, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SSX_OK;
+}
+
+ssx_status ssx_stereo_frame(ssx_ctx* ctx, const uint8_t* imgL, const uint8_t* imgR, int32_t stride, int32_t rows,
+                            int32_t cols, const ssx_orb_params* orb, const ssx_match_params* mp, const ssx_stereo_rig* rig,
+                            const double* T_wc, ssx_stereo_frame_out* out)
+{
+  if (!ctx || !imgL || !imgR || !orb || !mp || !rig || !out) return SSX_ERR_INVALID_ARG;
+  ssx_status st = plan(ctx, rows, cols, 2, *orb, false, false);
+  if (st != SSX_OK) return st;
+  OrbWorkspace* ws = get_ws(ctx);
+  const size_t bytes = (size_t)rows * cols;
+  SSX_HIP_TRY(ctx, ws->input.reserve(2 * bytes + 512));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(2 * bytes + 512));
+  uint8_t* hs = ws->stage.as<uint8_t>();
+  for (int y = 0; y < rows; ++y) {
+    memcpy(hs + (size_t)y * cols, imgL + (size_t)y * stride, cols);
+    memcpy(hs + bytes + (size_t)y * cols, imgR + (size_t)y * stride, cols);
+  }
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->input.p, hs, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
+  st = stage_level0(ctx, ws->input.as<uint8_t>(), cols, bytes, nullptr, 0, 0);
+  if (st != SSX_OK) return st;
+  st = run_pipeline(ctx);
+  if (st != SSX_OK) return st;
+  MatchDev m{};
+  st = make_match_dev(ctx, 1, *mp, *rig, T_wc, m);
+  if (st != SSX_OK) return st;
+  st = launch_stereo(ctx, m);
+  if (st != SSX_OK) return st;
+  return fetch_pair(ctx, 0, out);
+}
+
+ssx_status ssx_stereo_batch_enqueue(ssx_ctx* ctx)
+{
+  if (!ctx || !ctx->orb || !ctx->orb->batch_imgs) return SSX_ERR_INVALID_ARG;
+  OrbWorkspace* ws = ctx->orb;
+  const size_t img_bytes = (size_t)ws->rows * ws->batch_stride;
+  ssx_status st = stage_level0(ctx, ws->batch_imgs, ws->batch_stride, img_bytes, nullptr, 0, 0);
+  if (st != SSX_OK) return st;
+  st = run_pipeline(ctx);
+  if (st != SSX_OK) return st;
+  MatchDev m{};
+  st = make_match_dev(ctx, ws->batch_pairs, ws->batch_mp, ws->batch_rig, nullptr, m);
+  if (st != SSX_OK) return st;
+  return launch_stereo(ctx, m);
+}
+
+ssx_status ssx_stereo_batch_dev(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs_dev, int32_t stride, int32_t rows,
+                                int32_t cols, const ssx_orb_params* orb, const ssx_match_params* mp,
+                                const ssx_stereo_rig* rig, int32_t* counts_out)
+{
+  if (!ctx || pairs < 1 || !imgs_dev || !orb || !mp || !rig || stride < cols) return SSX_ERR_INVALID_ARG;
+  ssx_status st = plan(ctx, rows, cols, 2 * pairs, *orb, false, false);
+  if (st != SSX_OK) return st;
+  OrbWorkspace* ws = get_ws(ctx);
+  ws->batch_imgs = imgs_dev; ws->batch_pairs = pairs; ws->batch_stride = stride;
+  ws->batch_orb = *orb; ws->batch_mp = *mp; ws->batch_rig = *rig;
+  st = ssx_stereo_batch_enqueue(ctx);
+  if (st != SSX_OK) return st;
+  if (counts_out) {
+    std::vector<int> status(2 * (size_t)pairs);
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(counts_out, ws->pair_counts, sizeof(int) * 4 * pairs, hipMemcpyDeviceToHost, ctx->stream));
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(status.data(), ws->dev.status, sizeof(int) * 2 * pairs, hipMemcpyDeviceToHost, ctx->stream));
+    SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 2 * pairs; ++i)
+      if (status[i]) { ctx->set_error("ssx_stereo_batch: internal capacity exceeded on image %d (bits %d)", i, status[i]); return SSX_ERR_CAPACITY; }
+  }
+  return SSX_OK;
+}
+
+ssx_status ssx_stereo_batch_fetch(ssx_ctx* ctx, int32_t pair, ssx_stereo_frame_out* out)
+{
+  if (!ctx || !ctx->orb || !out || pair < 0 || pair >= ctx->orb->batch_pairs) return SSX_ERR_INVALID_ARG;
+  return fetch_pair(ctx, pair, out);
+}
+
+}  // extern "C"

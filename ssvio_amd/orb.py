@@ -1,0 +1,176 @@
+"""ORB extraction / stereo matching / triangulation through libssx.so.
+
+`ORBextractor` mirrors the reference class surface (include/ssvio/orbextractor.hpp:44-59): same constructor
+arguments, `Detect(image, mask)` and `DetectAndCompute(image, mask)` with numpy arrays standing in for
+cv::Mat / std::vector<cv::KeyPoint> (KP_DTYPE has the binary layout of cv::KeyPoint).  Every method calls the
+HIP library; nothing is computed in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, Context, MatchParams, OrbParams, StereoFrameOut, StereoRig, dbl_p, i32_p, ptr, u8_p
+
+
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("CV_8UC1 image expected")   # the reference asserts image.type() == CV_8UC1
+    return a
+
+
+class ORBextractor:
+    """ssvio::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)."""
+
+    def __init__(self, ctx: Context, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7):
+        self.ctx = ctx
+        self.prm = OrbParams(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST))
+
+    def _cap(self):
+        return self.prm.nfeatures + 4 * self.prm.nlevels + 64
+
+    def Detect(self, image, mask=None):
+        """ORBextractor::Detect (orbextractor.cpp:755-842): returns keypoints; empty image -> empty result."""
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, dtype=KP_DTYPE)
+        image = _img(image)
+        mask = None if mask is None else _img(mask)
+        cap = self._cap()
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_orb_detect(
+            self.ctx.handle, ptr(image, u8_p), image.strides[0], image.shape[0], image.shape[1], ptr(mask, u8_p),
+            0 if mask is None else mask.strides[0], C.byref(self.prm), cap, kps.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return kps[:n.value].copy()
+
+    def DetectAndCompute(self, image, mask=None):
+        """ORBextractor::DetectAndCompute (orbextractor.cpp:687-753): (keypoints, N x 32 uint8 descriptors)."""
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, dtype=KP_DTYPE), np.zeros((0, 32), np.uint8)
+        image = _img(image)
+        mask = None if mask is None else _img(mask)
+        cap = self._cap()
+        kps = np.zeros(cap, dtype=KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_orb_extract(
+            self.ctx.handle, ptr(image, u8_p), image.strides[0], image.shape[0], image.shape[1], ptr(mask, u8_p),
+            0 if mask is None else mask.strides[0], C.byref(self.prm), cap, kps.ctypes.data_as(C.c_void_p),
+            ptr(desc, u8_p), C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    # parity hooks ------------------------------------------------------------------------------
+    def stage_level(self, level, blurred=False, image=0):
+        r = C.c_int32(0); c = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_orb_stage_level(self.ctx.handle, image, level, int(blurred), None, 0, C.byref(r), C.byref(c)))
+        out = np.zeros((r.value, c.value), np.uint8)
+        self.ctx.check(self.ctx.lib.ssx_orb_stage_level(self.ctx.handle, image, level, int(blurred), ptr(out, u8_p), out.size,
+                                                        C.byref(r), C.byref(c)))
+        return out
+
+    def stage_candidates(self, level, image=0, cap=1 << 17):
+        out = np.zeros(cap, dtype=KP_DTYPE); n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_orb_stage_candidates(self.ctx.handle, image, level, cap,
+                                                             out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out[:n.value].copy()
+
+
+def match_params(band_px=2.0, min_disp=0.0, max_disp=120.0, max_dist=80, max_octave_diff=1, scale_factor=1.2):
+    return MatchParams(band_px, min_disp, max_disp, max_dist, max_octave_diff, scale_factor)
+
+
+def stereo_rig(K=None, baseline=None):
+    from .synth import KITTI_BASELINE, KITTI_K
+    K = KITTI_K if K is None else K
+    return StereoRig(float(K[0]), float(K[1]), float(K[2]), float(K[3]), float(KITTI_BASELINE if baseline is None else baseline))
+
+
+def stereo_match(ctx: Context, kL, dL, kR, dR, prm=None):
+    prm = prm or match_params()
+    kL = np.ascontiguousarray(kL, dtype=KP_DTYPE); kR = np.ascontiguousarray(kR, dtype=KP_DTYPE)
+    dL = np.ascontiguousarray(dL, dtype=np.uint8).reshape(-1, 32); dR = np.ascontiguousarray(dR, dtype=np.uint8).reshape(-1, 32)
+    idx = np.zeros(len(kL), np.int32); dist = np.zeros(len(kL), np.int32)
+    ctx.check(ctx.lib.ssx_stereo_match(ctx.handle, kL.ctypes.data_as(C.c_void_p), ptr(dL, u8_p), len(kL),
+                                       kR.ctypes.data_as(C.c_void_p), ptr(dR, u8_p), len(kR), C.byref(prm),
+                                       ptr(idx, i32_p), ptr(dist, i32_p)))
+    return idx, dist
+
+
+def bf_match(ctx: Context, dq, dt):
+    dq = np.ascontiguousarray(dq, dtype=np.uint8).reshape(-1, 32); dt = np.ascontiguousarray(dt, dtype=np.uint8).reshape(-1, 32)
+    idx = np.zeros(len(dq), np.int32); dist = np.zeros(len(dq), np.int32)
+    ctx.check(ctx.lib.ssx_bf_match(ctx.handle, ptr(dq, u8_p), len(dq), ptr(dt, u8_p), len(dt), ptr(idx, i32_p), ptr(dist, i32_p)))
+    return idx, dist
+
+
+def triangulate(ctx: Context, uvL, uvR, rig=None, T_wc=None):
+    rig = rig or stereo_rig()
+    uvL = np.ascontiguousarray(uvL, dtype=np.float64).reshape(-1, 2); uvR = np.ascontiguousarray(uvR, dtype=np.float64).reshape(-1, 2)
+    n = len(uvL)
+    xyz = np.zeros((n, 3)); ok = np.zeros(n, np.uint8)
+    T = None if T_wc is None else np.ascontiguousarray(T_wc, dtype=np.float64)
+    ctx.check(ctx.lib.ssx_triangulate(ctx.handle, n, ptr(uvL, dbl_p), ptr(uvR, dbl_p), C.byref(rig), ptr(T, dbl_p),
+                                      ptr(xyz, dbl_p), ptr(ok, u8_p)))
+    return xyz, ok
+
+
+class _FrameBuffers:
+    def __init__(self, cap):
+        self.kL = np.zeros(cap, dtype=KP_DTYPE); self.kR = np.zeros(cap, dtype=KP_DTYPE)
+        self.dL = np.zeros((cap, 32), np.uint8); self.dR = np.zeros((cap, 32), np.uint8)
+        self.idx = np.zeros(cap, np.int32); self.dist = np.zeros(cap, np.int32)
+        self.xyz = np.zeros((cap, 3)); self.ok = np.zeros(cap, np.uint8)
+        o = StereoFrameOut()
+        o.cap = cap
+        o.kpsL = self.kL.ctypes.data_as(C.c_void_p); o.kpsR = self.kR.ctypes.data_as(C.c_void_p)
+        o.descL = ptr(self.dL, u8_p); o.descR = ptr(self.dR, u8_p)
+        o.match_idx = ptr(self.idx, i32_p); o.match_dist = ptr(self.dist, i32_p)
+        o.xyz = ptr(self.xyz, dbl_p); o.ok = ptr(self.ok, u8_p)
+        self.out = o
+
+    def result(self):
+        o = self.out
+        nL, nR = o.nL, o.nR
+        return dict(kL=self.kL[:nL].copy(), dL=self.dL[:nL].copy(), kR=self.kR[:nR].copy(), dR=self.dR[:nR].copy(),
+                    match_idx=self.idx[:nL].copy(), match_dist=self.dist[:nL].copy(), xyz=self.xyz[:nL].copy(),
+                    ok=self.ok[:nL].copy(), n_matched=o.n_matched, n_triangulated=o.n_triangulated)
+
+
+def stereo_frame(ctx: Context, imgL, imgR, orb: OrbParams | None = None, mp=None, rig=None, T_wc=None):
+    """extract L+R, row-band match, triangulate -- one call (ssx_stereo_frame)."""
+    imgL = _img(imgL); imgR = _img(imgR)
+    assert imgL.shape == imgR.shape and imgL.strides == imgR.strides
+    orb = orb or OrbParams(2000, 1.2, 8, 20, 7)
+    mp = mp or match_params(scale_factor=orb.scale_factor)
+    rig = rig or stereo_rig()
+    fb = _FrameBuffers(orb.nfeatures + 4 * orb.nlevels + 64)
+    T = None if T_wc is None else np.ascontiguousarray(T_wc, dtype=np.float64)
+    ctx.check(ctx.lib.ssx_stereo_frame(ctx.handle, ptr(imgL, u8_p), ptr(imgR, u8_p), imgL.strides[0], imgL.shape[0],
+                                       imgL.shape[1], C.byref(orb), C.byref(mp), C.byref(rig), ptr(T, dbl_p), C.byref(fb.out)))
+    return fb.result()
+
+
+def stereo_batch_dev(ctx: Context, imgs_dev_ptr: int, pairs: int, stride: int, rows: int, cols: int, orb=None, mp=None, rig=None):
+    """`imgs_dev_ptr`: DEVICE pointer to [pairs][2][rows][stride] u8 (e.g. a torch.uint8 CUDA tensor's data_ptr()).
+    Returns counts[pairs, 4] = nL, nR, n_matched, n_triangulated.  Results stay on the device."""
+    orb = orb or OrbParams(2000, 1.2, 8, 20, 7)
+    mp = mp or match_params(scale_factor=orb.scale_factor)
+    rig = rig or stereo_rig()
+    counts = np.zeros((pairs, 4), np.int32)
+    ctx.check(ctx.lib.ssx_stereo_batch_dev(ctx.handle, pairs, C.c_void_p(imgs_dev_ptr), stride, rows, cols, C.byref(orb),
+                                           C.byref(mp), C.byref(rig), ptr(counts, i32_p)))
+    return counts
+
+
+def stereo_batch_enqueue(ctx: Context):
+    ctx.check(ctx.lib.ssx_stereo_batch_enqueue(ctx.handle))
+
+
+def stereo_batch_fetch(ctx: Context, pair: int, cap: int):
+    fb = _FrameBuffers(cap)
+    ctx.check(ctx.lib.ssx_stereo_batch_fetch(ctx.handle, pair, C.byref(fb.out)))
+    return fb.result()

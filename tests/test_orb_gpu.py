@@ -1,0 +1,168 @@
+"""GPU parity of the ORB front-end (pyramid, grid FAST, octree, orientation, blur, BRIEF), the row-band matcher
+and the triangulation against the CPU oracle: BIT-EXACT for every integer / byte / index / f32 output, 1e-9
+relative for the f64 triangulated points.  (The oracle itself is "parity unpinned vs OpenCV", see
+tests/test_oracle_orb.py; what is proven here is HIP == CPU restatement.)"""
+import numpy as np
+import pytest
+
+from ssvio_amd import orb as sorb
+from ssvio_amd.synth import KITTI_BASELINE, KITTI_K, make_stereo_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair_small():
+    return make_stereo_pair(seed=7, h=160, w=260, n_blobs=260)
+
+
+@pytest.fixture(scope="module")
+def pair_kitti():
+    return make_stereo_pair(seed=0)
+
+
+def test_pyramid_and_blur_bit_exact(ctx, po, pair_kitti):
+    L = pair_kitti[0]
+    ex = sorb.ORBextractor(ctx)
+    ex.DetectAndCompute(L)
+    rows, cols = po.level_sizes(L.shape[0], L.shape[1])
+    prev = L
+    for l in range(8):
+        lvl = ex.stage_level(l)
+        assert lvl.shape == (rows[l], cols[l])
+        ref = L if l == 0 else po.resize_linear(prev, rows[l], cols[l])
+        assert np.array_equal(lvl, ref), f"pyramid level {l}"
+        assert np.array_equal(ex.stage_level(l, blurred=True), po.gauss7(ref)), f"blur level {l}"
+        prev = ref
+
+
+def test_grid_fast_candidates_bit_exact(ctx, po, pair_kitti, pair_small):
+    for img in (pair_kitti[0], pair_kitti[1], pair_small[0]):
+        ex = sorb.ORBextractor(ctx, nfeatures=2000)
+        ex.Detect(img)
+        g = ex.stage_candidates(0)
+        o = po.orb_grid_fast(img)
+        assert len(g) == len(o) and g.tobytes() == o.tobytes()
+
+
+@pytest.mark.parametrize("nfeat", [100, 300, 2000])
+def test_detect_bit_exact(ctx, po, pair_kitti, nfeat):
+    """ORBextractor::Detect with the reference's three budgets (kitti_00.yaml:37-39 and the C2 setting)."""
+    L = pair_kitti[0]
+    g = sorb.ORBextractor(ctx, nfeatures=nfeat).Detect(L)
+    o = po.orb_detect(L, prm=po.orb_params(nfeatures=nfeat))
+    assert len(g) == len(o) and g.tobytes() == o.tobytes()
+
+
+def test_detect_with_mask_bit_exact(ctx, po, pair_kitti):
+    """FrontEnd::DetectFeatures masks 21x21 boxes around existing features (frontend.cpp:304-312)."""
+    L = pair_kitti[0]
+    first = sorb.ORBextractor(ctx, nfeatures=300).Detect(L)
+    mask = np.full(L.shape, 255, np.uint8)
+    for k in first:
+        x, y = int(round(float(k["x"]))), int(round(float(k["y"])))
+        mask[max(y - 10, 0):y + 11, max(x - 10, 0):x + 11] = 0
+    g = sorb.ORBextractor(ctx, nfeatures=100).Detect(L, mask)
+    o = po.orb_detect(L, mask=mask, prm=po.orb_params(nfeatures=100))
+    assert len(g) == len(o) > 0 and g.tobytes() == o.tobytes()
+
+
+@pytest.mark.parametrize("which", ["kitti_left", "kitti_right", "small"])
+def test_extract_bit_exact(ctx, po, pair_kitti, pair_small, which):
+    img = {"kitti_left": pair_kitti[0], "kitti_right": pair_kitti[1], "small": pair_small[0]}[which]
+    prm = dict(nfeatures=2000, nlevels=8) if which != "small" else dict(nfeatures=300, nlevels=4)
+    gk, gd = sorb.ORBextractor(ctx, nfeatures=prm["nfeatures"], nlevels=prm["nlevels"]).DetectAndCompute(img)
+    ok, od = po.orb_extract(img, prm=po.orb_params(**prm))
+    assert len(gk) == len(ok)
+    assert gk.tobytes() == ok.tobytes()            # positions, size, angle (f32), response, octave: bit-exact
+    assert np.array_equal(gd, od)                  # 256-bit descriptors
+
+
+def test_extract_with_mask_and_empty(ctx, po, pair_small):
+    L = pair_small[0]
+    mask = np.full(L.shape, 255, np.uint8); mask[:, :120] = 0
+    gk, gd = sorb.ORBextractor(ctx, nfeatures=300, nlevels=4).DetectAndCompute(L, mask)
+    ok, od = po.orb_extract(L, mask=mask, prm=po.orb_params(nfeatures=300, nlevels=4))
+    assert gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+    k, d = sorb.ORBextractor(ctx).DetectAndCompute(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    flat = np.full((200, 300), 90, np.uint8)        # no texture: no corners at either threshold
+    k, d = sorb.ORBextractor(ctx, nfeatures=300, nlevels=4).DetectAndCompute(flat)
+    assert len(k) == 0
+
+
+def test_stereo_match_bit_exact(ctx, po, pair_kitti):
+    L, R, _ = pair_kitti
+    kL, dL = po.orb_extract(L); kR, dR = po.orb_extract(R)
+    for mp in (dict(), dict(band_px=1.0, max_dist=50), dict(max_octave_diff=0, max_disp=60.0)):
+        gi, gd = sorb.stereo_match(ctx, kL, dL, kR, dR, sorb.match_params(**mp))
+        oi, od = po.stereo_match(kL, dL, kR, dR, po.match_params(**mp))
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert (gi >= 0).sum() > 100
+    # edge cases: empty right / empty left
+    gi, gd = sorb.stereo_match(ctx, kL, dL, kR[:0], dR[:0])
+    assert (gi == -1).all() and (gd == 257).all()
+    assert len(sorb.stereo_match(ctx, kL[:0], dL[:0], kR, dR)[0]) == 0
+    bi, bd = sorb.bf_match(ctx, dL[:500], dR)
+    oi, od = po.bf_match(dL[:500], dR)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od)
+
+
+def test_triangulate_matches_oracle_and_reference_golden(ctx, po):
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz"))
+    xyz, ok = sorb.triangulate(ctx, G["tri_uvL"], G["tri_uvR"])
+    np.testing.assert_array_equal(ok, G["tri_ok"])                      # vs the REAL reference function
+    m = G["tri_ok"].astype(bool)
+    np.testing.assert_allclose(xyz[m], G["tri_xyz"][m], rtol=1e-9)
+    o = po.triangulate(G["tri_uvL"], G["tri_uvR"], KITTI_K, KITTI_BASELINE)
+    np.testing.assert_allclose(xyz, o["xyz"], rtol=1e-12, atol=1e-12)
+    T = np.array([0.01, -0.02, 0.03, 0.9993, 1.0, -2.0, 0.5]); T[:4] /= np.linalg.norm(T[:4])
+    xyz2, _ = sorb.triangulate(ctx, G["tri_uvL"], G["tri_uvR"], T_wc=T)
+    o2 = po.triangulate(G["tri_uvL"], G["tri_uvR"], KITTI_K, KITTI_BASELINE, T_wc=T)
+    np.testing.assert_allclose(xyz2, o2["xyz"], rtol=1e-12, atol=1e-12)
+
+
+def test_stereo_frame_end_to_end(ctx, po, pair_kitti):
+    """extract + match + triangulate in one device-resident call == the oracle pipeline, bit for bit"""
+    L, R, disp = pair_kitti
+    r = sorb.stereo_frame(ctx, L, R)
+    kL, dL = po.orb_extract(L); kR, dR = po.orb_extract(R)
+    assert r["kL"].tobytes() == kL.tobytes() and r["kR"].tobytes() == kR.tobytes()
+    assert np.array_equal(r["dL"], dL) and np.array_equal(r["dR"], dR)
+    oi, od = po.stereo_match(kL, dL, kR, dR)
+    assert np.array_equal(r["match_idx"], oi) and np.array_equal(r["match_dist"], od)
+    m = oi >= 0
+    uvL = np.stack([kL["x"][m], kL["y"][m]], 1).astype(np.float64)
+    uvR = np.stack([kR["x"][oi[m]], kR["y"][oi[m]]], 1).astype(np.float64)
+    t = po.triangulate(uvL, uvR, KITTI_K, KITTI_BASELINE)
+    np.testing.assert_array_equal(r["ok"][m], t["ok"])
+    np.testing.assert_allclose(r["xyz"][m], t["xyz"], rtol=1e-12, atol=1e-12)
+    assert r["n_matched"] == int(m.sum()) and r["n_triangulated"] == int(t["ok"].sum())
+    # sanity against the synthetic ground truth: depth = bf / disparity
+    good = m & (r["ok"] == 1)
+    z = r["xyz"][good, 2]
+    d_true = disp[np.clip(np.round(kL["y"][good]).astype(int), 0, 375), np.clip(np.round(kL["x"][good]).astype(int), 0, 1240)]
+    rel = np.abs(z - 386.1448 / d_true) / (386.1448 / d_true)
+    assert np.median(rel) < 0.05
+
+
+def test_stereo_batch_matches_single_frames(ctx, po):
+    """the batched device-resident path (bench.py's path) gives, per pair, exactly the single-frame results"""
+    import torch
+    pairs = 3
+    imgs = np.stack([np.stack(make_stereo_pair(seed=s)[:2]) for s in range(pairs)])     # [pairs][2][H][W]
+    dev = torch.from_numpy(imgs).to("cuda:0")
+    torch.cuda.synchronize()
+    counts = sorb.stereo_batch_dev(ctx, dev.data_ptr(), pairs, imgs.shape[3], imgs.shape[2], imgs.shape[3])
+    for p in range(pairs):
+        single = sorb.stereo_frame(ctx, imgs[p, 0], imgs[p, 1])
+        # re-run the batch (the single-frame call re-planned the workspace) and fetch pair p
+        counts = sorb.stereo_batch_dev(ctx, dev.data_ptr(), pairs, imgs.shape[3], imgs.shape[2], imgs.shape[3])
+        b = sorb.stereo_batch_fetch(ctx, p, cap=4096)
+        assert counts[p].tolist() == [len(single["kL"]), len(single["kR"]), single["n_matched"], single["n_triangulated"]]
+        for key in ("kL", "kR"):
+            assert b[key].tobytes() == single[key].tobytes()
+        for key in ("dL", "dR", "match_idx", "match_dist", "ok"):
+            assert np.array_equal(b[key], single[key])
+        np.testing.assert_array_equal(b["xyz"], single["xyz"])
