@@ -311,6 +311,7 @@ def umax():
 
 def resize_linear(src, drows, dcols):
     src = _img(src)
+    drows, dcols = int(drows), int(dcols)
     dst = np.zeros((drows, dcols), np.uint8)
     oracle_lib().orc_resize_linear(_p(src, u8_p), src.strides[0], src.shape[0], src.shape[1], _p(dst, u8_p),
                                    dst.strides[0], drows, dcols)

@@ -83,6 +83,14 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise SsxError(SSX_ERR_NO_DEVICE, f"{LIB_PATH} not built; run `python -m ssvio_amd.build` "
                                               "(the HIP library is the only compute path)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 and
+        # refuses to see the GPU when a different copy (/opt/rocm) was loaded first.  Import torch BEFORE
+        # dlopen-ing libssx.so so that its DT_NEEDED libamdhip64.so.7 resolves to the copy torch loaded
+        # (bench.py and the RCCL hook need torch.cuda / torch.distributed in the same process).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.ssx_last_error.restype = C.c_char_p
         lib.ssx_last_error.argtypes = [C.c_void_p]
