@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X stereo-SLAM compute core.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): stereo frames/s of the front-end hot path on 1241x376 synthetic stereo, 2000 ORB features
+per image: pyramid + grid FAST + octree + orientation + blur + BRIEF on both images, row-band Hamming matching,
+DLT triangulation -- configs[1] of BASELINE.json ("C2").  One STEP = one batch of B stereo pairs per GPU, already
+resident in HBM when the timed region starts; nothing is downloaded inside the timed region.  N > 1 runs one
+process per GPU on independent pairs (replicas, no data-path collective): weak scaling.
+
+Also reported in the same JSON line: BA LM-iterations/s of the local bundle adjustment (configs[2], "C3": 10
+keyframes, 4000 landmarks, 20000 edges) -- landmark-sharded over the N GPUs with the RCCL all-reduce hook when
+N > 1 --, the roofline of the dominant front-end kernel (HIP-event timing, live), and the CPU baseline (the CPU
+oracle = a scalar single-thread port of the same algorithms; plus the reference's own g2o BA when
+oracle/_ref/libssvio_ref.so is present).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def level_pixels(rows, cols, scale=1.2, nlevels=8):
+    px = []
+    s = np.float32(1.0)
+    for l in range(nlevels):
+        inv = np.float32(1.0) / s
+        px.append(int(np.rint(np.float32(cols) * inv)) * int(np.rint(np.float32(rows) * inv)))
+        s = np.float32(s * np.float32(scale))
+    return px
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU (batch per launch)")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="stereo pairs timed on the CPU baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    import ssvio_amd
+    from ssvio_amd import _lib, ba, orb
+    from ssvio_amd.synth import KITTI_H, KITTI_W, make_ba_problem, make_stereo_pair
+
+    stream = torch.cuda.Stream(device=dev)
+    ctx = ssvio_amd.Context(local_rank, stream=stream.cuda_stream)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    # ---------------- front-end: B synthetic KITTI-shaped stereo pairs per GPU, resident in HBM ----------------
+    B = args.pairs
+    host = np.stack([np.stack(make_stereo_pair(seed=rank * 1000 + i)[:2]) for i in range(B)])   # [B][2][H][W] u8
+    imgs = torch.from_numpy(host).to(dev)
+    torch.cuda.synchronize(dev)
+    counts = orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)   # plans, runs once, syncs
+    for _ in range(args.warmup):
+        orb.stereo_batch_enqueue(ctx)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        orb.stereo_batch_enqueue(ctx)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames = world * B * args.steps
+    value = frames / elapsed
+
+    # ---------------- per-kernel time with HIP events (same workload, profiling on) ----------------
+    _lib.profile_begin(ctx)
+    PROF_STEPS = 3
+    for _ in range(PROF_STEPS):
+        orb.stereo_batch_enqueue(ctx)
+    kt = _lib.profile_end(ctx)
+    px = level_pixels(KITTI_H, KITTI_W)
+    I = 2 * B
+    n_cand = None
+    # algorithmic bytes one LAUNCH of each kernel must move (per image x I images)
+    kp_total = int(counts[:, 0].sum() + counts[:, 1].sum())
+    algo = {
+        "k_resize": lambda calls: I * (sum(px[:-1]) + sum(px[1:])) / 7.0,            # 7 launches: read l-1, write l
+        "k_fast_cells": lambda calls: I * sum(px) + 4.0 * 8000 * I,                  # read pyramid once, write candidates
+        "k_octree": lambda calls: 4.0 * 8000 * I + 4.0 * kp_total,                   # read candidates, write selection
+        "k_orient": lambda calls: 961.0 * kp_total + 4.0 * kp_total,                 # 31x31 patch per keypoint
+        "k_gauss7": lambda calls: 2.0 * I * sum(px) / 8.0,                           # 8 launches: read + write a level
+        "k_brief": lambda calls: (1369.0 + 60.0) * kp_total,                         # 37x37 patch + 28+32 B out
+        "k_row_bucket": lambda calls: 28.0 * kp_total / 2 + 4.0 * kp_total / 2,
+        "k_match": lambda calls: 60.0 * kp_total + 8.0 * kp_total / 2,
+        "k_triangulate_matches": lambda calls: (56.0 + 25.0) * kp_total / 2,
+    }
+    dom_name, dom_ms = None, 0.0
+    kernels = {}
+    for name, (calls, total_ms) in kt.items():
+        kernels[name] = {"calls_per_step": calls / PROF_STEPS, "ms_per_step": total_ms / PROF_STEPS}
+        if total_ms > dom_ms:
+            dom_name, dom_ms = name, total_ms
+    dom_calls = kt[dom_name][0]
+    dom_avg_s = (dom_ms / dom_calls) * 1e-3
+    dom_bytes = algo.get(dom_name, lambda c: 0.0)(dom_calls)
+    achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_us": round(dom_avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(dom_bytes),
+                "note": "traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected offline: profiles/"}
+    # whole-pipeline figure: 12.0 MB algorithmic bytes per stereo pair
+    pipeline_gbs = 12.0e6 * value / world / 1e9
+
+    # ---------------- local BA (C3) ----------------
+    pr = make_ba_problem(P=10, L=4000, seed=1)
+    ba_kwargs = {}
+    if world > 1:
+        from ssvio_amd import dist_ba
+        pr_local = dist_ba.shard_problem(pr, rank, world)
+        ba_kwargs = dict(allreduce=dist_ba.make_allreduce_hook(dev), rank=rank, world_size=world)
+    else:
+        pr_local = pr
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            r = ba.ba_solve(ctx, pr_local, want_edges=False, **ba_kwargs)
+        barrier()
+        tb = time.perf_counter()
+        BA_REP = 5
+        n_it = 0
+        for _ in range(BA_REP):
+            r = ba.ba_solve(ctx, pr_local, want_edges=False, **ba_kwargs)
+            n_it += r["n_iters"]
+        barrier()
+        ba_elapsed = time.perf_counter() - tb
+    if world > 1:
+        t = torch.tensor([ba_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ba_elapsed = float(t.item())
+    ba_iters_s = n_it / ba_elapsed
+    ba_solve_ms = ba_elapsed / BA_REP * 1e3
+
+    # ---------------- CPU baseline (rank 0, N == 1 only) ----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        po.build()
+        ns = max(1, min(args.cpu_sample, B))
+        tc = time.perf_counter()
+        for i in range(ns):
+            L, R = host[i, 0], host[i, 1]
+            kL, dL = po.orb_extract(L); kR, dR = po.orb_extract(R)
+            idx, _ = po.stereo_match(kL, dL, kR, dR)
+            m = idx >= 0
+            uvL = np.stack([kL["x"][m], kL["y"][m]], 1).astype(np.float64)
+            uvR = np.stack([kR["x"][idx[m]], kR["y"][idx[m]]], 1).astype(np.float64)
+            po.triangulate(uvL, uvR, (718.856, 718.856, 607.1928, 185.2157), 386.1448 / 718.856)
+        cpu_t = time.perf_counter() - tc
+        cpu = {"value": round(ns / cpu_t, 3), "unit": "stereo frames/s", "cores": 1, "kind": "port",
+               "sample": f"{ns} of the benchmark's stereo pairs through the CPU oracle (scalar C++ restatement, "
+                         f"single thread; the reference's OpenCV path cannot be built: OpenCV absent)",
+               "host_cores_available": os.cpu_count()}
+        # BA: the reference's own g2o path when the compiled reference library travelled with the repo
+        tc = time.perf_counter()
+        if po.have_ref() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libssvio_ref.so")):
+            rr = po.ba_solve(pr, "ref", outer_rounds=1)
+            kind = "reference"
+        else:
+            rr = po.ba_solve(pr, "oracle", outer_rounds=1, jac_mode=1)
+            kind = "port"
+        ba_cpu_t = time.perf_counter() - tc
+        cpu["ba"] = {"value": round(len(rr["chi2"]) / ba_cpu_t, 2), "unit": "BA LM iterations/s", "kind": kind, "cores": 1,
+                     "sample": "one optimize(10) of the C3 graph (g2o numeric Jacobians, CSparse), single thread"}
+
+    if rank == 0:
+        out = {
+            "metric": "stereo frames/s (ORB extract + row-band match + triangulate) on 1241x376",
+            "value": round(value, 2), "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C2: 1241x376 synthetic stereo, 2000 ORB feats/img, 8 levels, extract+match+triangulate",
+                       "pairs_per_step_per_gpu": B, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
+                       "avg_keypoints_per_image": round(kp_total / I, 1),
+                       "avg_matches_per_pair": round(float(counts[:, 2].mean()), 1),
+                       "avg_triangulated_per_pair": round(float(counts[:, 3].mean()), 1)},
+            "roofline": roofline,
+            "pipeline_algorithmic_GBps_per_gpu": round(pipeline_gbs, 3),
+            "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
+            "ba": {"workload": "C3: local BA, 10 KF x 4000 landmarks x 20000 edges, analytic Jacobians, f64",
+                   "iters_per_s": round(ba_iters_s, 1), "ms_per_solve": round(ba_solve_ms, 3),
+                   "lm_iterations_per_solve": n_it // BA_REP,
+                   "sharding": f"landmarks over {world} GPUs + RCCL all-reduce" if world > 1 else "none",
+                   "includes": "host<->device transfer of the problem and the host LM control loop"},
+            "e2e_frames_per_s_with_one_local_BA_per_frame": round(1.0 / (1.0 / (value / world) + ba_solve_ms * 1e-3) * world, 2),
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

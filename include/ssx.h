@@ -64,6 +64,18 @@ SSX_API ssx_status ssx_ctx_synchronize(ssx_ctx* ctx);
 /* hipStream_t the ctx enqueues on (for callers that bracket calls with their own events). */
 SSX_API void* ssx_ctx_stream(ssx_ctx* ctx);
 
+/* Per-kernel GPU time, measured with HIP events recorded on the ctx stream around every kernel launch
+ * between ssx_profile_begin and ssx_profile_end (the counterpart of g2o's G2OBatchStatistics; bench.py uses it
+ * for the roofline of the dominant kernel).  Event pairs add a little launch overhead: time throughput with
+ * profiling off. */
+typedef struct {
+  char name[48];
+  int32_t calls;
+  double total_ms;
+} ssx_kernel_time;
+SSX_API ssx_status ssx_profile_begin(ssx_ctx* ctx);
+SSX_API ssx_status ssx_profile_end(ssx_ctx* ctx, ssx_kernel_time* out, int32_t cap, int32_t* n);
+
 /* ------------------------------------------------------------------------------------------------
  * Local bundle adjustment -- replaces the body of Backend::OptimizeActiveMap
  * (src/ssvio/backend.cpp:78-245): g2o BlockSolver_6_3 + LinearSolverCSparse + Levenberg-Marquardt

@@ -173,3 +173,19 @@ class StereoFrameOut(C.Structure):
     _fields_ = [("cap", C.c_int32), ("kpsL", C.c_void_p), ("kpsR", C.c_void_p), ("descL", u8_p), ("descR", u8_p),
                 ("nL", C.c_int32), ("nR", C.c_int32), ("match_idx", i32_p), ("match_dist", i32_p),
                 ("xyz", dbl_p), ("ok", u8_p), ("n_matched", C.c_int32), ("n_triangulated", C.c_int32)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("calls", C.c_int32), ("total_ms", C.c_double)]
+
+
+def profile_begin(ctx: "Context"):
+    ctx.check(ctx.lib.ssx_profile_begin(ctx.handle))
+
+
+def profile_end(ctx: "Context"):
+    """-> {kernel name: (calls, total_ms)} measured with HIP events on the ctx stream."""
+    arr = (KernelTime * 64)()
+    n = C.c_int32(0)
+    ctx.check(ctx.lib.ssx_profile_end(ctx.handle, arr, 64, C.byref(n)))
+    return {arr[i].name.decode(): (arr[i].calls, arr[i].total_ms) for i in range(n.value)}

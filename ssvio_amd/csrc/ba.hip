@@ -822,12 +822,12 @@ size_t schur_lds_bytes() { return sizeof(double) * (18 + 18 + 6 + 9 + 3) * CH + 
 ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, int jac, int cur)
 {
   if (d.nCh > 0) {
-    if (jac == SSX_JAC_NUMERIC_G2O) hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur);
-    else hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur);
+    if (jac == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
+    else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
   }
   const int n27 = d.nP * 27;
-  hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (n27 + CH - 1) / CH)), dim3(CH), 0, ctx->stream, d);
-  hipLaunchKernelGGL(k_maxdiag_pose, dim3(1), dim3(64), 0, ctx->stream, d);
+  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (n27 + CH - 1) / CH)), dim3(CH), 0, ctx->stream, d));
+  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_maxdiag_pose, dim3(1), dim3(64), 0, ctx->stream, d));
   SSX_HIP_TRY(ctx, hipGetLastError());
   return SSX_OK;
 }
@@ -962,12 +962,12 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
       bool lambda_bad = false;
       do {
         if (n > 0) {
-          hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, lambda);
-          hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + CH - 1) / CH), dim3(CH), 0, ctx->stream, d);
+          SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, lambda));
+          SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + CH - 1) / CH), dim3(CH), 0, ctx->stream, d));
         }
-        hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), lds_solve, ctx->stream, d, lambda, cur);
-        hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, lambda, cur);
-        hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d);
+        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), lds_solve, ctx->stream, d, lambda, cur));
+        SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, lambda, cur));
+        SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d));
         SSX_HIP_TRY(ctx, hipGetLastError());
         SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
         SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

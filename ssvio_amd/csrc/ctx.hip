@@ -50,6 +50,7 @@ void ssx_ctx_destroy(ssx_ctx* ctx)
   if (ctx->orb && ctx->orb_free) ctx->orb_free(ctx->orb);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -64,5 +65,43 @@ ssx_status ssx_ctx_synchronize(ssx_ctx* ctx)
 }
 
 void* ssx_ctx_stream(ssx_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+ssx_status ssx_profile_begin(ssx_ctx* ctx)
+{
+  if (!ctx) return SSX_ERR_INVALID_ARG;
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prof.on = true;
+  ctx->prof.used = 0;
+  ctx->prof.recs.clear();
+  return SSX_OK;
+}
+
+ssx_status ssx_profile_end(ssx_ctx* ctx, ssx_kernel_time* out, int32_t cap, int32_t* n)
+{
+  if (!ctx || !n) return SSX_ERR_INVALID_ARG;
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prof.on = false;
+  double total[KID_COUNT] = {0};
+  int calls[KID_COUNT] = {0};
+  for (const auto& r : ctx->prof.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total[r.id] += ms; calls[r.id]++; }
+  }
+  int k = 0;
+  for (int id = 0; id < KID_COUNT; ++id) {
+    if (!calls[id]) continue;
+    if (out && k < cap) {
+      memset(&out[k], 0, sizeof(out[k]));
+      strncpy(out[k].name, kSsxKernelNames[id], sizeof(out[k].name) - 1);
+      out[k].calls = calls[id];
+      out[k].total_ms = total[id];
+    }
+    ++k;
+  }
+  *n = k;
+  ctx->prof.recs.clear();
+  ctx->prof.used = 0;
+  return SSX_OK;
+}
 
 }  // extern "C"

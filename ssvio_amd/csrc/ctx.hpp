@@ -10,6 +10,20 @@
 
 #include "../../include/ssx.h"
 
+// Wrap a kernel launch: when profiling is on, bracket it with two HIP events on the ctx stream.
+#define SSX_PROF(ctx, kid, stmt)                                              \
+  do {                                                                        \
+    if ((ctx)->prof.on) {                                                     \
+      SsxProf::Rec _r{(kid), (ctx)->prof.get(), (ctx)->prof.get()};           \
+      (void)hipEventRecord(_r.a, (ctx)->stream);                              \
+      stmt;                                                                   \
+      (void)hipEventRecord(_r.b, (ctx)->stream);                              \
+      (ctx)->prof.recs.push_back(_r);                                         \
+    } else {                                                                  \
+      stmt;                                                                   \
+    }                                                                         \
+  } while (0)
+
 #define SSX_HIP_TRY(ctx, expr)                                                                  \
   do {                                                                                          \
     hipError_t _e = (expr);                                                                     \
@@ -62,6 +76,30 @@ struct Layout {
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; }
 };
 
+// ---- per-kernel timing with HIP events on the ctx stream (ssx_profile_begin / ssx_profile_end) ----
+enum SsxKernelId {
+  KID_BA_LINEARIZE = 0, KID_BA_REDUCE_LIN, KID_BA_SCHUR, KID_BA_REDUCE_SCHUR, KID_BA_SOLVE, KID_BA_BACKSUB,
+  KID_BA_REDUCE_TRIAL, KID_ORB_RESIZE, KID_ORB_FAST, KID_ORB_OCTREE, KID_ORB_ORIENT, KID_ORB_GAUSS, KID_ORB_BRIEF,
+  KID_ORB_MISC, KID_ST_BUCKET, KID_ST_MATCH, KID_ST_TRIANGULATE, KID_ST_MISC, KID_POSE_ONLY, KID_COUNT
+};
+static const char* const kSsxKernelNames[KID_COUNT] = {
+  "k_linearize", "k_reduce_lin", "k_schur", "k_reduce_schur", "k_solve", "k_backsub_residual", "k_reduce_trial",
+  "k_resize", "k_fast_cells", "k_octree", "k_orient", "k_gauss7", "k_brief", "orb_misc", "k_row_bucket", "k_match",
+  "k_triangulate_matches", "stereo_misc", "k_pose_only"};
+
+struct SsxProf {
+  bool on = false;
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  std::vector<Rec> recs;
+  hipEvent_t get()
+  {
+    if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+    return pool[used++];
+  }
+};
+
 struct BaWorkspace;   // ba.hip
 struct OrbWorkspace;  // orb.hip
 
@@ -76,6 +114,7 @@ struct ssx_ctx {
   void (*ba_free)(BaWorkspace*) = nullptr;    // set by the module that allocates the workspace
   void (*orb_free)(OrbWorkspace*) = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  SsxProf prof;
 
   void set_error(const char* fmt, ...)
   {

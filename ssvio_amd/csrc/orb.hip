@@ -650,11 +650,11 @@ ssx_status stage_level0(ssx_ctx* ctx, const uint8_t* imgs_dev, int stride, size_
   OrbWorkspace* ws = get_ws(ctx);
   const OrbDev& d = ws->dev;
   const dim3 grid((d.lvl_cols[0] + 255) / 256, d.lvl_rows[0], d.I);
-  hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, ctx->stream, imgs_dev, stride, img_bytes, d.pyr, d.pyr_bytes,
-                     d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0], 0, 0);
+  SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, ctx->stream, imgs_dev, stride, img_bytes, d.pyr, d.pyr_bytes,
+                     d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0], 0, 0));
   if (d.has_mask)
-    hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, ctx->stream, masks_dev, mask_stride, mask_bytes, d.maskpyr,
-                       d.pyr_bytes, d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0], 0, 0);
+    SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, ctx->stream, masks_dev, mask_stride, mask_bytes, d.maskpyr,
+                       d.pyr_bytes, d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0], 0, 0));
   SSX_HIP_TRY(ctx, hipGetLastError());
   return SSX_OK;
 }
@@ -668,28 +668,28 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   // pyramid (ComputePyramid): level l from level l-1
   for (int l = 1; l < d.nlevels; ++l) {
     const dim3 grid((d.lvl_cols[l] + 255) / 256, d.lvl_rows[l], d.I);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.pyr + d.lvl_off[l - 1], d.pyr + d.lvl_off[l], d.pyr_bytes,
-                       d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l]);
+    SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.pyr + d.lvl_off[l - 1], d.pyr + d.lvl_off[l], d.pyr_bytes,
+                       d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l]));
     if (d.has_mask)
-      hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.maskpyr + d.lvl_off[l - 1], d.maskpyr + d.lvl_off[l], d.pyr_bytes,
-                         d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l]);
+      SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.maskpyr + d.lvl_off[l - 1], d.maskpyr + d.lvl_off[l], d.pyr_bytes,
+                         d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l]));
   }
-  if (d.n_cells > 0) hipLaunchKernelGGL(k_fast_cells, dim3(d.n_cells, d.I), dim3(256), 0, s, d);
-  launch_octree(d, s);
+  if (d.n_cells > 0) SSX_PROF(ctx, KID_ORB_FAST, hipLaunchKernelGGL(k_fast_cells, dim3(d.n_cells, d.I), dim3(256), 0, s, d));
+  SSX_PROF(ctx, KID_ORB_OCTREE, launch_octree(d, s));
   if (d.detect_only) {
-    hipLaunchKernelGGL(k_finalize_detect, dim3((SEL_CAP + 255) / 256, d.I), dim3(256), 0, s, d);
+    SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_finalize_detect, dim3((SEL_CAP + 255) / 256, d.I), dim3(256), 0, s, d));
   } else {
     int maxfeat = 0;
     for (int l = 0; l < d.nlevels; ++l) maxfeat = std::max(maxfeat, d.feat[l] + 4);
     const dim3 kgrid((maxfeat + 3) / 4, d.nlevels, d.I);
-    hipLaunchKernelGGL(k_orient, kgrid, dim3(256), 0, s, d);
+    SSX_PROF(ctx, KID_ORB_ORIENT, hipLaunchKernelGGL(k_orient, kgrid, dim3(256), 0, s, d));
     for (int l = 0; l < d.nlevels; ++l) {
       const dim3 ggrid((d.lvl_cols[l] + GT_W - 1) / GT_W, (d.lvl_rows[l] + GT_H - 1) / GT_H, d.I);
-      hipLaunchKernelGGL(k_gauss7, ggrid, dim3(256), 0, s, d, l);
+      SSX_PROF(ctx, KID_ORB_GAUSS, hipLaunchKernelGGL(k_gauss7, ggrid, dim3(256), 0, s, d, l));
     }
-    hipLaunchKernelGGL(k_brief, kgrid, dim3(256), 0, s, d);
+    SSX_PROF(ctx, KID_ORB_BRIEF, hipLaunchKernelGGL(k_brief, kgrid, dim3(256), 0, s, d));
   }
-  hipLaunchKernelGGL(k_counts, dim3((d.I + 63) / 64), dim3(64), 0, s, d);
+  SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_counts, dim3((d.I + 63) / 64), dim3(64), 0, s, d));
   SSX_HIP_TRY(ctx, hipGetLastError());
   return SSX_OK;
 }

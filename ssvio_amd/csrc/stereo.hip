@@ -328,10 +328,10 @@ ssx_status make_match_dev(ssx_ctx* ctx, int pairs, const ssx_match_params& mp, c
 ssx_status launch_stereo(ssx_ctx* ctx, const MatchDev& m)
 {
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_row_bucket, dim3(m.pairs), dim3(1024), 0, s, m);
-  hipLaunchKernelGGL(k_match, dim3((m.out_cap + 3) / 4, m.pairs), dim3(256), 0, s, m);
-  hipLaunchKernelGGL(k_triangulate_matches, dim3((m.out_cap + 255) / 256, m.pairs), dim3(256), 0, s, m);
-  hipLaunchKernelGGL(k_pair_counts, dim3(m.pairs), dim3(256), 0, s, m);
+  SSX_PROF(ctx, KID_ST_BUCKET, hipLaunchKernelGGL(k_row_bucket, dim3(m.pairs), dim3(1024), 0, s, m));
+  SSX_PROF(ctx, KID_ST_MATCH, hipLaunchKernelGGL(k_match, dim3((m.out_cap + 3) / 4, m.pairs), dim3(256), 0, s, m));
+  SSX_PROF(ctx, KID_ST_TRIANGULATE, hipLaunchKernelGGL(k_triangulate_matches, dim3((m.out_cap + 255) / 256, m.pairs), dim3(256), 0, s, m));
+  SSX_PROF(ctx, KID_ST_MISC, hipLaunchKernelGGL(k_pair_counts, dim3(m.pairs), dim3(256), 0, s, m));
   SSX_HIP_TRY(ctx, hipGetLastError());
   return SSX_OK;
 }
@@ -414,8 +414,8 @@ ssx_status ssx_stereo_match(ssx_ctx* ctx, const ssx_keypoint* kL, const uint8_t*
   m.match_idx = (int*)(base + o_idx); m.match_dist = (int*)(base + o_dist);
   m.mp = *prm;
   fill_scale(m);
-  hipLaunchKernelGGL(k_row_bucket, dim3(1), dim3(1024), 0, ctx->stream, m);
-  hipLaunchKernelGGL(k_match, dim3((cap + 3) / 4, 1), dim3(256), 0, ctx->stream, m);
+  SSX_PROF(ctx, KID_ST_BUCKET, hipLaunchKernelGGL(k_row_bucket, dim3(1), dim3(1024), 0, ctx->stream, m));
+  SSX_PROF(ctx, KID_ST_MATCH, hipLaunchKernelGGL(k_match, dim3((cap + 3) / 4, 1), dim3(256), 0, ctx->stream, m));
   SSX_HIP_TRY(ctx, hipGetLastError());
   SSX_HIP_TRY(ctx, hipMemcpyAsync(match_idx, m.match_idx, sizeof(int) * nL, hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipMemcpyAsync(dist, m.match_dist, sizeof(int) * nL, hipMemcpyDeviceToHost, ctx->stream));
@@ -444,8 +444,8 @@ ssx_status ssx_bf_match(ssx_ctx* ctx, const uint8_t* dq, int32_t nq, const uint8
   if (nt) memcpy(hs + o_t, dt, (size_t)32 * nt);
   char* base = ws->input.as<char>();
   SSX_HIP_TRY(ctx, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_bf_match, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, (const uint8_t*)(base + o_q), nq,
-                     (const uint8_t*)(base + o_t), nt, (int*)(base + o_i), (int*)(base + o_d));
+  SSX_PROF(ctx, KID_ST_MISC, hipLaunchKernelGGL(k_bf_match, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, (const uint8_t*)(base + o_q), nq,
+                     (const uint8_t*)(base + o_t), nt, (int*)(base + o_i), (int*)(base + o_d)));
   SSX_HIP_TRY(ctx, hipGetLastError());
   SSX_HIP_TRY(ctx, hipMemcpyAsync(idx, base + o_i, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipMemcpyAsync(dist, base + o_d, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
@@ -476,8 +476,8 @@ ssx_status ssx_triangulate(ssx_ctx* ctx, int32_t n, const double* uvL, const dou
   MatchDev m{};
   m.has_T = T_wc ? 1 : 0;
   for (int i = 0; i < 7; ++i) m.T_wc[i] = T_wc ? T_wc[i] : (i == 3 ? 1.0 : 0.0);
-  hipLaunchKernelGGL(k_triangulate_uv, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, (const double*)(base + o_l),
-                     (const double*)(base + o_r), *rig, m, (double*)(base + o_x), (uint8_t*)(base + o_k));
+  SSX_PROF(ctx, KID_ST_MISC, hipLaunchKernelGGL(k_triangulate_uv, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, (const double*)(base + o_l),
+                     (const double*)(base + o_r), *rig, m, (double*)(base + o_x), (uint8_t*)(base + o_k)));
   SSX_HIP_TRY(ctx, hipGetLastError());
   SSX_HIP_TRY(ctx, hipMemcpyAsync(xyz_out, base + o_x, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipMemcpyAsync(ok_out, base + o_k, n, hipMemcpyDeviceToHost, ctx->stream));
