@@ -37,6 +37,9 @@ ssx_status ssx_ctx_create(const ssx_config* cfg, ssx_ctx** out)
   }
   (void)hipEventCreate(&c->ev0);
   (void)hipEventCreate(&c->ev1);
+  (void)hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   *out = c;
   return SSX_OK;
 }
@@ -50,6 +53,9 @@ void ssx_ctx_destroy(ssx_ctx* ctx)
   if (ctx->orb && ctx->orb_free) ctx->orb_free(ctx->orb);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

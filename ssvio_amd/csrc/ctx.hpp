@@ -24,6 +24,19 @@
     }                                                                         \
   } while (0)
 
+#define SSX_PROF_ON(ctx, strm, kid, stmt)                                     \
+  do {                                                                        \
+    if ((ctx)->prof.on) {                                                     \
+      SsxProf::Rec _r{(kid), (ctx)->prof.get(), (ctx)->prof.get()};           \
+      (void)hipEventRecord(_r.a, (strm));                                     \
+      stmt;                                                                   \
+      (void)hipEventRecord(_r.b, (strm));                                     \
+      (ctx)->prof.recs.push_back(_r);                                         \
+    } else {                                                                  \
+      stmt;                                                                   \
+    }                                                                         \
+  } while (0)
+
 #define SSX_HIP_TRY(ctx, expr)                                                                  \
   do {                                                                                          \
     hipError_t _e = (expr);                                                                     \
@@ -114,6 +127,8 @@ struct ssx_ctx {
   void (*ba_free)(BaWorkspace*) = nullptr;    // set by the module that allocates the workspace
   void (*orb_free)(OrbWorkspace*) = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t aux = nullptr;                 // second stream: independent stages overlap (blur || detect)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   SsxProf prof;
 
   void set_error(const char* fmt, ...)

@@ -45,15 +45,14 @@ __device__ __forceinline__ int cv_floor_f(float v) { int i = (int)v; return i - 
 
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base,
                                                 size_t img_stride_bytes, int srows, int scols, int spitch,
-                                                int drows, int dcols, int dpitch)
+                                                int drows, int dcols, int dpitch, double scale_x, double scale_y)
 {
+  // scale_x = 1. / ((double)dcols / scols) exactly as cv::resize forms it (computed once on the host)
   const int dx = blockIdx.x * 256 + threadIdx.x;
   const int dy = blockIdx.y;
   const uint8_t* src = src_base + (size_t)blockIdx.z * img_stride_bytes;
   uint8_t* dst = dst_base + (size_t)blockIdx.z * img_stride_bytes;
   if (dx >= dcols) return;
-  const double inv_scale_x = (double)dcols / scols, inv_scale_y = (double)drows / srows;
-  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
   float fx = (float)((dx + 0.5) * scale_x - 0.5);
   int sx = cv_floor_f(fx);
   fx -= sx;
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
 // ------------------------------------------------------------------------------------------------
 // A1+A2: grid FAST.  One workgroup per cell.
 // ------------------------------------------------------------------------------------------------
-constexpr int ROI_MAX = 72;
+constexpr int ROI_MAX = 72;   // largest supported cell ROI side
 
 __device__ __forceinline__ bool arc9(unsigned m)   // 9 contiguous set bits in a circular 16-bit mask
 {
@@ -141,105 +140,130 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int p, int t)
   return -b0 - 1;
 }
 
-// inclusive Hillis-Steele scan of 256 ints in LDS (all 256 threads call it)
-__device__ __forceinline__ void scan256(int* s)
+// ring pixel k of the Bresenham circle relative to c (LDS row pitch p)
+#define RING(k) ((int)c[c_ring_dx[k] + c_ring_dy[k] * p])
+
+// cheap necessary condition: an arc of 9 contiguous ring pixels contains at least 2 of the 4 compass pixels
+// (ring indices 0, 4, 8, 12), so a corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t.
+__device__ __forceinline__ bool fast_quick(const uint8_t* c, int p, int t)
 {
-  const int t = threadIdx.x;
-  for (int off = 1; off < 256; off <<= 1) {
-    const int v = (t >= off) ? s[t - off] : 0;
-    __syncthreads();
-    s[t] += v;
-    __syncthreads();
-  }
+  const int v = c[0];
+  const int lo = v - t, hi = v + t;
+  const int p0 = c[3 * p], p8 = c[-3 * p], p4 = c[3], p12 = c[-3];
+  const int nd = (p0 < lo) + (p8 < lo) + (p4 < lo) + (p12 < lo);
+  const int nb = (p0 > hi) + (p8 > hi) + (p4 > hi) + (p12 > hi);
+  return nd >= 2 || nb >= 2;
 }
 
+// ONE WAVE PER CELL (4 cells per 256-thread workgroup, no workgroup barrier anywhere):
+//   1. the ROI is staged in LDS with aligned dword loads (level pitch is a multiple of 128 bytes);
+//   2. every interior pixel takes the 4-load quick test; survivors are compacted with ballot/popcount;
+//   3. the compacted survivors take the full segment test + cornerScore (dense lanes);
+//   4. the corners (again a compacted list) take the 3x3 strict NMS, the mask test and an ORDER-PRESERVING
+//      compaction (ballot prefix inside a round; rounds walk the pixels in row-major order).
 __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o)
 {
-  __shared__ uint8_t sImg[ROI_MAX * ROI_MAX];
-  __shared__ uint8_t sScore[ROI_MAX * ROI_MAX];
-  __shared__ int sCnt[256];
-  const int cell = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cell = blockIdx.x * 4 + wave, img = blockIdx.y;
+  if (cell >= o.n_cells) return;
   const Cell c = o.cells[cell];
   const uint8_t* lvl = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[c.level];
   const int pitch = o.lvl_pitch[c.level];
   const int w = c.w, h = c.h;
-  // stage the ROI: consecutive threads read consecutive bytes of a row (coalesced row segments)
-  for (int i = t; i < w * h; i += 256) {
-    const int y = i / w, x = i - y * w;
-    sImg[i] = lvl[(size_t)(c.y0 + y) * pitch + (c.x0 + x)];
+  const int tx0 = c.x0 & ~3;                       // aligned tile origin
+  const int xoff = c.x0 - tx0;
+  const int tw = (xoff + w + 3) & ~3;              // LDS row pitch (bytes), multiple of 4
+  const int ndw = tw >> 2;
+  uint8_t* sImg = smem + (size_t)wave * o.fast_lds_per_wave;
+  uint8_t* sScore = sImg + o.fast_tile_bytes;
+  uint16_t* sList = reinterpret_cast<uint16_t*>(sScore + o.fast_tile_bytes);   // compacted pixel indices
+  for (int i = lane; i < h * ndw; i += 64) {
+    const int y = i / ndw, xd = i - y * ndw;
+    reinterpret_cast<uint32_t*>(sImg)[i] = *reinterpret_cast<const uint32_t*>(lvl + (size_t)(c.y0 + y) * pitch + tx0 + 4 * xd);
   }
-  const int iw = w - 6, ih = h - 6;            // cv::FAST ignores a 3-px border of the ROI
+  const int iw = w - 6, ih = h - 6;                // cv::FAST ignores a 3-px border of the ROI
   const int npx = (iw > 0 && ih > 0) ? iw * ih : 0;
-  const int chunk = (npx + 255) / 256;         // <= 18: interior pixels are dealt in row-major chunks
-  const int lo = min(t * chunk, npx), hi = min(lo + chunk, npx);
+  const float inv_iw = iw > 0 ? 1.0f / (float)iw : 0.f;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int* cell_count = o.cell_count + (size_t)img * o.n_cells + cell;
   uint32_t* cell_cand = o.cell_cand + ((size_t)img * o.n_cells + cell) * CELL_CAP;
-  unsigned long long flags = 0;
-  int mine = 0;
+  const uint8_t* mk = o.has_mask ? o.maskpyr + (size_t)img * o.pyr_bytes + o.lvl_off[c.level] : nullptr;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  int n_out = 0;
   for (int pass = 0; pass < 2; ++pass) {
     const int th = min(max(pass == 0 ? o.ini_th : o.min_th, 0), 255);
-    __syncthreads();
-    for (int i = t; i < w * h; i += 256) sScore[i] = 0;
-    __syncthreads();
-    for (int i = lo; i < hi; ++i) {
-      const int yy = i / iw;
-      const int y = 3 + yy, x = 3 + (i - yy * iw);
-      const int s = fast_score(&sImg[y * w + x], w, th);
-      // score buffer as OpenCV's: uchar score for corners, 0 elsewhere.  A corner whose score is 0 can never
-      // survive the strict '>' NMS, so "0" safely doubles as "not a corner".
-      if (s > 0) sScore[y * w + x] = (uint8_t)s;
-    }
-    __syncthreads();
-    flags = 0; mine = 0;
-    for (int i = lo; i < hi; ++i) {
-      const int yy = i / iw;
-      const int y = 3 + yy, x = 3 + (i - yy * iw);
-      const uint8_t* r = &sScore[y * w + x];
-      const int s = r[0];
-      if (s > r[1] && s > r[-1] && s > r[-w - 1] && s > r[-w] && s > r[-w + 1] && s > r[w - 1] && s > r[w] && s > r[w + 1]) {
-        flags |= 1ull << (i - lo);
-        ++mine;
+    for (int i = lane; i < h * ndw; i += 64) reinterpret_cast<uint32_t*>(sScore)[i] = 0;
+    // -- stage 1: quick test on every interior pixel, compaction of the survivors --
+    int n_surv = 0;
+    for (int base = 0; base < npx; base += 64) {
+      const int pxi = base + lane;
+      bool pass_q = false;
+      int off = 0;
+      if (pxi < npx) {
+        const int yy = (int)(((float)pxi + 0.5f) * inv_iw);
+        off = (3 + yy) * tw + xoff + 3 + (pxi - yy * iw);
+        pass_q = fast_quick(&sImg[off], tw, th);
       }
+      const unsigned long long bal = __ballot(pass_q);
+      if (pass_q) sList[n_surv + __popcll(bal & lt_mask)] = (uint16_t)off;
+      n_surv += __popcll(bal);
     }
-    sCnt[t] = mine;
-    __syncthreads();
-    scan256(sCnt);
-    if (sCnt[255] > 0) break;     // uniform: keypoints found at this threshold (orbextractor.cpp:803-808)
-  }
-  __syncthreads();
-  if (sCnt[255] == 0) { if (t == 0) *cell_count = 0; return; }
-  // the mask test comes AFTER the emptiness test (orbextractor.cpp:810-826) and is indexed with the UN-bordered
-  // cell coordinates (x + j*wCell, y + i*hCell) -- a quirk of the reference that is reproduced here
-  if (o.has_mask) {
-    const uint8_t* mk = o.maskpyr + (size_t)img * o.pyr_bytes + o.lvl_off[c.level];
-    int m2 = 0;
-    for (int i = lo; i < hi; ++i) {
-      if (!((flags >> (i - lo)) & 1)) continue;
-      const int yy = i / iw;
-      const int y = 3 + yy, x = 3 + (i - yy * iw);
-      if (mk[(size_t)(y + c.oy) * pitch + (x + c.ox)] == 0) flags &= ~(1ull << (i - lo));
-      else ++m2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // -- stage 2: full segment test + score on the survivors; corners compacted in place (order kept) --
+    int n_corner = 0;
+    for (int base = 0; base < n_surv; base += 64) {
+      const int k = base + lane;
+      int off = 0, sc = -1;
+      if (k < n_surv) {
+        off = sList[k];
+        sc = fast_score(&sImg[off], tw, th);
+      }
+      // OpenCV keeps the score as uchar; a corner with score 0 can never win the strict '>' NMS
+      const bool is_c = sc > 0;
+      if (is_c) sScore[off] = (uint8_t)sc;
+      const unsigned long long bal = __ballot(is_c);
+      __builtin_amdgcn_wave_barrier();   // all lanes have read sList[base..base+63] before it is overwritten
+      if (is_c) sList[n_corner + __popcll(bal & lt_mask)] = (uint16_t)off;   // n_corner + rank <= k: in-place safe
+      n_corner += __popcll(bal);
     }
-    mine = m2;
-    __syncthreads();
-    sCnt[t] = mine;
-    __syncthreads();
-    scan256(sCnt);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // -- stage 3: NMS (strict >), emptiness test BEFORE the mask (orbextractor.cpp:803-808), mask test at the
+    //    UN-bordered coordinates (orbextractor.cpp:816-823, reference quirk), ordered output --
+    int n_keep_pre = 0;
+    n_out = 0;
+    for (int base = 0; base < n_corner; base += 64) {
+      const int k = base + lane;
+      bool keep = false;
+      int off = 0;
+      if (k < n_corner) {
+        off = sList[k];
+        const uint8_t* r = &sScore[off];
+        const int sc = r[0];
+        keep = sc > r[1] && sc > r[-1] && sc > r[-tw - 1] && sc > r[-tw] && sc > r[-tw + 1] && sc > r[tw - 1] &&
+               sc > r[tw] && sc > r[tw + 1];
+      }
+      n_keep_pre += __popcll(__ballot(keep));
+      const int yl = off / tw, xl = off - yl * tw - xoff;           // ROI-local coordinates
+      if (keep && mk) keep = mk[(size_t)(yl + c.oy) * pitch + (xl + c.ox)] != 0;
+      const unsigned long long bal = __ballot(keep);
+      const int pos = n_out + __popcll(bal & lt_mask);
+      if (keep && pos < CELL_CAP)
+        cell_cand[pos] = (uint32_t)(xl + c.ox) | ((uint32_t)(yl + c.oy) << 12) | ((uint32_t)sScore[off] << 24);
+      n_out += __popcll(bal);
+    }
+    if (n_keep_pre > 0) break;      // keypoints found at this threshold: no retry (wave-uniform)
+    __builtin_amdgcn_wave_barrier();
   }
-  int pos = sCnt[t] - mine;   // exclusive prefix: row-major order is preserved
-  for (int i = lo; i < hi; ++i) {
-    if (!((flags >> (i - lo)) & 1)) continue;
-    const int yy = i / iw;
-    const int y = 3 + yy, x = 3 + (i - yy * iw);
-    if (pos < CELL_CAP)
-      cell_cand[pos] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)sScore[y * w + x] << 24);
-    ++pos;
-  }
-  if (t == 255) {
-    *cell_count = min(sCnt[255], CELL_CAP);
-    if (sCnt[255] > CELL_CAP) atomicOr(&o.status[img], 1);
+  if (lane == 0) {
+    *cell_count = min(n_out, CELL_CAP);
+    if (n_out > CELL_CAP) atomicOr(&o.status[img], 1);
   }
 }
+#undef RING
 
 // ------------------------------------------------------------------------------------------------
 // A7: cv::GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, 8-bit fixed point (row pass exact ints, column pass
@@ -252,41 +276,86 @@ __device__ __forceinline__ int reflect101(int i, int n)
   return i;
 }
 
-constexpr int GT_W = 64, GT_H = 16;
+constexpr int GT_W = 128, GT_H = 32;            // output tile
+constexpr int GT_PITCH = GT_W + 8;              // input tile pitch: 4 bytes of halo left, 4 right (3 needed)
 
-__global__ __launch_bounds__(256) void k_gauss7(OrbDev o, int level)
+// ONE launch for all levels and images: blockIdx.x walks the tiles of every level (o.gauss_tile0[]), blockIdx.y
+// is the image.  Input rows are fetched as aligned dwords (interior tiles) into LDS; the row pass produces four
+// Q8 sums per thread from three LDS dwords; the column pass reads ten int4 rows and stores one dword per row.
+__global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
 {
-  __shared__ uint8_t sIn[(GT_H + 6) * (GT_W + 6)];
-  __shared__ int sRow[(GT_H + 6) * GT_W];
-  const int img = blockIdx.z, t = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t sIn[(GT_H + 6) * GT_PITCH];
+  __shared__ __attribute__((aligned(16))) int sRow[(GT_H + 6) * GT_W];
+  const int img = blockIdx.y, t = threadIdx.x;
+  int level = 0;
+  while (level + 1 < o.nlevels && (int)blockIdx.x >= o.gauss_tile0[level + 1]) ++level;
+  const int tile = blockIdx.x - o.gauss_tile0[level];
   const int rows = o.lvl_rows[level], cols = o.lvl_cols[level], pitch = o.lvl_pitch[level];
+  const int tiles_x = (cols + GT_W - 1) / GT_W;
+  const int ty_ = tile / tiles_x, tx_ = tile - ty_ * tiles_x;
+  const int x0 = tx_ * GT_W, y0 = ty_ * GT_H;
   const uint8_t* src = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[level];
   uint8_t* dst = o.blur + (size_t)img * o.pyr_bytes + o.lvl_off[level];
-  const int x0 = blockIdx.x * GT_W, y0 = blockIdx.y * GT_H;
-  for (int i = t; i < (GT_H + 6) * (GT_W + 6); i += 256) {
-    const int ty = i / (GT_W + 6), tx = i - ty * (GT_W + 6);
-    const int y = reflect101(y0 + ty - 3, rows), x = reflect101(x0 + tx - 3, cols);
-    sIn[i] = src[(size_t)y * pitch + x];
+  constexpr int NDW = GT_PITCH / 4;   // 34 dwords per tile row
+  for (int i = t; i < (GT_H + 6) * NDW; i += 256) {
+    const int r = i / NDW, dwi = i - r * NDW;
+    const int gy = reflect101(y0 + r - 3, rows);
+    const int gx = x0 - 4 + 4 * dwi;
+    uint32_t v;
+    if (gx >= 0 && gx + 3 < cols) {
+      v = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
+    } else {
+      const uint8_t* row = src + (size_t)gy * pitch;
+      v = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
+          ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
+    }
+    reinterpret_cast<uint32_t*>(sIn)[i] = v;
   }
   __syncthreads();
-  for (int i = t; i < (GT_H + 6) * GT_W; i += 256) {
-    const int ty = i / GT_W, tx = i - ty * GT_W;
-    const uint8_t* r = &sIn[ty * (GT_W + 6) + tx];
-    int s = 0;
+  // row pass: thread -> (tile row r, group g of 4 output pixels); bytes 4g+1 .. 4g+10 of the tile row
+  for (int i = t; i < (GT_H + 6) * (GT_W / 4); i += 256) {
+    const int r = i / (GT_W / 4), g = i - r * (GT_W / 4);
+    const uint32_t* rowdw = reinterpret_cast<const uint32_t*>(sIn + r * GT_PITCH) + g;
+    const uint32_t d0 = rowdw[0], d1 = rowdw[1], d2 = rowdw[2];
+    int b[12];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) s += c_gauss[q] * r[q];
-    sRow[i] = s;
+    for (int k = 0; k < 4; ++k) { b[k] = (d0 >> (8 * k)) & 0xFF; b[4 + k] = (d1 >> (8 * k)) & 0xFF; b[8 + k] = (d2 >> (8 * k)) & 0xFF; }
+    int acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] = 0;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[j] += c_gauss[q] * b[1 + j + q];
+    }
+    *reinterpret_cast<int4*>(&sRow[r * GT_W + 4 * g]) = make_int4(acc[0], acc[1], acc[2], acc[3]);
   }
   __syncthreads();
-  for (int i = t; i < GT_H * GT_W; i += 256) {
-    const int ty = i / GT_W, tx = i - ty * GT_W;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= cols || y >= rows) continue;
-    int s = 0;
+  // column pass: thread -> 4 pixels x 4 rows
+  {
+    const int g = t & 31, rq = t >> 5;             // 32 groups x 8 row-quads
+    int4 rowv[10];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) s += c_gauss[q] * sRow[(ty + q) * GT_W + tx];
-    const int v = (s + (1 << 15)) >> 16;
-    dst[(size_t)y * pitch + x] = (uint8_t)min(max(v, 0), 255);
+    for (int k = 0; k < 10; ++k) rowv[k] = *reinterpret_cast<const int4*>(&sRow[(4 * rq + k) * GT_W + 4 * g]);
+    const int x = x0 + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + 4 * rq + j;
+      int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        a0 += c_gauss[q] * rowv[j + q].x; a1 += c_gauss[q] * rowv[j + q].y;
+        a2 += c_gauss[q] * rowv[j + q].z; a3 += c_gauss[q] * rowv[j + q].w;
+      }
+      // sums are non-negative, so only the upper clamp is needed.  Written with UNSIGNED shifts/min on purpose:
+      // hipcc (ROCm 7.2) fuses med3(ashr(x,16),0,255) pairs into v_ashr_pk_u8_i32 and then assumes the upper
+      // 16 bits of its result are zero, which they are not on gfx950 (byte 0 leaked into byte 2).
+      const uint32_t o0 = min(((uint32_t)a0 + (1u << 15)) >> 16, 255u);
+      const uint32_t o1 = min(((uint32_t)a1 + (1u << 15)) >> 16, 255u);
+      const uint32_t o2 = min(((uint32_t)a2 + (1u << 15)) >> 16, 255u);
+      const uint32_t o3 = min(((uint32_t)a3 + (1u << 15)) >> 16, 255u);
+      // the pitch is a multiple of the tile width: the dword store stays inside the row's padding
+      if (y < rows && x < pitch) *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+    }
   }
 }
 
@@ -595,6 +664,25 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
   d.n_cells = (int)cells.size();
   d.pyr_bytes = (off + 255) & ~size_t(255);
   d.out_cap = out_cap;
+  {
+    int tile = 16, npx = 1, t0 = 0;
+    for (const Cell& c : cells) {
+      const int tw = ((c.x0 & 3) + c.w + 3) & ~3;
+      tile = std::max(tile, tw * (int)c.h);
+      npx = std::max(npx, std::max(c.w - 6, 0) * std::max(c.h - 6, 0));
+    }
+    d.fast_tile_bytes = (tile + 15) & ~15;
+    d.fast_lds_per_wave = 2 * d.fast_tile_bytes + ((2 * npx + 15) & ~15);
+    for (int l = 0; l < nlevels; ++l) {
+      d.gauss_tile0[l] = t0;
+      t0 += ((d.lvl_cols[l] + GT_W - 1) / GT_W) * ((d.lvl_rows[l] + GT_H - 1) / GT_H);
+    }
+    for (int l = nlevels; l <= MAX_LEVELS; ++l) d.gauss_tile0[l] = t0;
+    for (int l = 1; l < nlevels; ++l) {   // cv::resize: inv_scale = dsize/ssize, scale = 1/inv_scale
+      d.rs_scale_x[l] = 1. / ((double)d.lvl_cols[l] / d.lvl_cols[l - 1]);
+      d.rs_scale_y[l] = 1. / ((double)d.lvl_rows[l] / d.lvl_rows[l - 1]);
+    }
+  }
   for (const Cell& c : cells)
     if (c.w > ROI_MAX || c.h > ROI_MAX) {
       ctx->set_error("ssx_orb: grid cell %dx%d exceeds the %d-px LDS tile", c.w, c.h, ROI_MAX);
@@ -669,12 +757,30 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   for (int l = 1; l < d.nlevels; ++l) {
     const dim3 grid((d.lvl_cols[l] + 255) / 256, d.lvl_rows[l], d.I);
     SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.pyr + d.lvl_off[l - 1], d.pyr + d.lvl_off[l], d.pyr_bytes,
-                       d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l]));
+                       d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l],
+                       d.rs_scale_x[l], d.rs_scale_y[l]));
     if (d.has_mask)
       SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.maskpyr + d.lvl_off[l - 1], d.maskpyr + d.lvl_off[l], d.pyr_bytes,
-                         d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l]));
+                         d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l],
+                         d.rs_scale_x[l], d.rs_scale_y[l]));
   }
-  if (d.n_cells > 0) SSX_PROF(ctx, KID_ORB_FAST, hipLaunchKernelGGL(k_fast_cells, dim3(d.n_cells, d.I), dim3(256), 0, s, d));
+  // the blur only depends on the pyramid: it runs on the auxiliary stream, concurrently with detection
+  // (HBM-streaming blur next to the latency-bound octree), and is joined before the descriptors.
+  const bool fork = !d.detect_only && ctx->aux != nullptr;
+  if (!d.detect_only) {
+    hipStream_t gs = fork ? ctx->aux : s;
+    if (fork) {
+      SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+      SSX_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    }
+    SSX_PROF_ON(ctx, gs, KID_ORB_GAUSS, hipLaunchKernelGGL(k_gauss7, dim3(d.gauss_tile0[d.nlevels], d.I), dim3(256), 0, gs, d));
+    if (fork) SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+  }
+  if (4 * (size_t)d.fast_lds_per_wave > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(4 * (size_t)d.fast_lds_per_wave));
+  if (d.n_cells > 0)
+    SSX_PROF(ctx, KID_ORB_FAST, hipLaunchKernelGGL(k_fast_cells, dim3((d.n_cells + 3) / 4, d.I), dim3(256), 4 * (size_t)d.fast_lds_per_wave, s, d));
   SSX_PROF(ctx, KID_ORB_OCTREE, launch_octree(d, s));
   if (d.detect_only) {
     SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_finalize_detect, dim3((SEL_CAP + 255) / 256, d.I), dim3(256), 0, s, d));
@@ -683,10 +789,7 @@ ssx_status run_pipeline(ssx_ctx* ctx)
     for (int l = 0; l < d.nlevels; ++l) maxfeat = std::max(maxfeat, d.feat[l] + 4);
     const dim3 kgrid((maxfeat + 3) / 4, d.nlevels, d.I);
     SSX_PROF(ctx, KID_ORB_ORIENT, hipLaunchKernelGGL(k_orient, kgrid, dim3(256), 0, s, d));
-    for (int l = 0; l < d.nlevels; ++l) {
-      const dim3 ggrid((d.lvl_cols[l] + GT_W - 1) / GT_W, (d.lvl_rows[l] + GT_H - 1) / GT_H, d.I);
-      SSX_PROF(ctx, KID_ORB_GAUSS, hipLaunchKernelGGL(k_gauss7, ggrid, dim3(256), 0, s, d, l));
-    }
+    if (fork) SSX_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     SSX_PROF(ctx, KID_ORB_BRIEF, hipLaunchKernelGGL(k_brief, kgrid, dim3(256), 0, s, d));
   }
   SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_counts, dim3((d.I + 63) / 64), dim3(64), 0, s, d));

@@ -68,6 +68,10 @@ struct OrbDev {
   int has_mask;
   int detect_only;               // ORBextractor::Detect: level 0 only, no orientation / descriptors
   int out_cap;                   // keypoints per image in the output arrays
+  int fast_tile_bytes;           // LDS bytes of one ROI tile (max over cells, pitch rounded to 4)
+  int fast_lds_per_wave;         // image tile + score tile + compaction list
+  int gauss_tile0[MAX_LEVELS + 1]; // first blur tile of each level (one launch covers all levels)
+  double rs_scale_x[MAX_LEVELS], rs_scale_y[MAX_LEVELS]; // cv::resize scale factors of level l (from l-1)
   // buffers
   const Cell* cells;
   uint8_t* pyr;                  // [I][pyr_bytes]
