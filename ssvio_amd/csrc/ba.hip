@@ -4,29 +4,38 @@
 // g2o's SparseOptimizer + BlockSolver<6,3> + OptimizationAlgorithmLevenberg over ssvio's
 // VertexPose / VertexXYZ / EdgeProjection (include/ssvio/g2otypes.hpp).  No g2o, no Eigen: the normal
 // equations are built, Schur-reduced, solved and applied by the kernels below; the host only runs the
-// LM accept/reject logic on a handful of scalars per trial.
+// LM accept/reject logic on a handful of scalars per trial (one stream synchronisation per LM trial).
 //
 // Data layout in HBM (one arena per ctx, grow-only):
 //   edges are SORTED BY LANDMARK (then by pose inside a landmark) on upload so that all observations of
 //   a landmark are contiguous; landmarks are grouped into CHUNKS of whole landmarks with <= 255 edges.
 //   One 256-thread workgroup (4 waves) owns one chunk in every per-edge / per-landmark kernel, so every
 //   per-landmark reduction (Hll, bl, Schur terms, back-substitution) happens in LDS without atomics.
-//   Per-edge arrays are structure-of-arrays (W[k][E], uv[2][E] ...) so that lane i touches element i:
-//   every global access of a wave is one contiguous 512-byte segment.
+//   Per-edge arrays are structure-of-arrays (W[k][E], uv[2][E] ...) so that lane i touches element i.
+//   Two small index lists per chunk are prepared on the host together with the sort:
+//     - the chunk's edges grouped by pose           (pose block accumulation walks only its own edges)
+//     - the chunk's (edge, edge) pairs grouped by reduced-system block (Schur accumulation likewise)
 //
 // Determinism: no floating-point atomics anywhere.  Cross-edge sums inside a chunk are done by
-// "owned entries" (each thread owns a few output scalars and adds the contributions in edge order);
-// cross-chunk sums are done by a reduction kernel that walks the per-chunk slabs in chunk order.
+// "owned entries" (each thread owns a few output scalars and adds its contributions in list order);
+// cross-chunk sums are done by reduction kernels with a fixed tree.  Two runs give identical bits.
 //
-// Kernels (small-pose path, free poses <= SSX_BA_SMALL_P; the local window of ssvio is 12):
+// Kernels (small-window path, free poses <= SSX_BA_SMALL_P = 16; the local window of ssvio is 12):
 //   k_linearize<JAC>      per LM iteration : residuals, Jacobians, Huber weights, W_e = Ji^T w Jj,
 //                                            Hll/bl per landmark, Hpp/bp slab per chunk, chi2 slab
-//   k_reduce_lin          per LM iteration : slabs -> Hpp, bp, chi2, max|diag|
+//   k_reduce_lin          per LM iteration : slabs -> Hpp, bp, chi2, max|diag| (+ lambda_0)
 //   k_schur               per LM trial     : (Hll+lambda I)^-1, W D^-1 W^T and W D^-1 bl slabs per chunk
 //   k_reduce_schur        per LM trial     : slabs -> dense reduced system S (without lambda), b_s
-//   k_solve               per LM trial     : one wave: (S + lambda I) x = b_s by LDS Cholesky, exp(x) * T
+//   k_solve               per LM trial     : (S + lambda I) x = b_s by LDL^T, register-tiled over 256 threads
+//                                            with the right-hand side carried as an extra row; exp(x) * T
 //   k_backsub_residual    per LM trial     : x_l = D^-1 (bl - W^T x_p), new points, new residuals, chi2 slab
 //   k_reduce_trial        per LM trial     : slabs -> tempChi, scale, outlier count
+//
+// Multi-GPU (landmark-sharded): every rank holds all poses and the edges of its
+// landmarks; three buffers are sum-all-reduced through the ssx_allreduce_fn hook (RCCL over xGMI when the
+// caller wires torch.distributed / rccl to it): [Hpp | bp | chi2 | per-rank max-diagonal slots] once per
+// iteration, [S | b_s] once per trial before the (replicated, deterministic) solve, [chi2', scale, #outliers]
+// once per trial after the residual pass.
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -41,9 +50,10 @@ namespace {
 using ssx::Cam;
 
 constexpr int CH = 256;            // threads per chunk workgroup
-constexpr int CH_E = 255;          // max edges per chunk (edge slot 0xFF is the 'no observation' marker)
+constexpr int CH_E = 255;          // max edges per chunk (chunk-local edge indices fit a byte)
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
+constexpr int NMAX = 6 * SSX_BA_SMALL_P;   // 96 unknowns of the reduced system
 
 // upper-triangular (r<=c) index tables of a 6x6 block
 __constant__ int8_t c_u6_r[UPPER6] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
@@ -51,7 +61,7 @@ __constant__ int8_t c_u6_c[UPPER6] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 
 
 struct BaDev {
   // problem (uploaded once per ssx_ba_solve)
-  int P, L, E, nP, nLm, nCh, nBlk;
+  int P, L, E, nP, nLm, nCh, nBlk, world, rank;
   const int* pose_free;     // P: free index or -1
   const uint8_t* lm_fixed;  // nLm (compact landmarks = landmarks that have edges)
   const int* lm_id;         // nLm -> original landmark
@@ -64,6 +74,11 @@ struct BaDev {
   const double* e_uv;       // [2][E]
   const int8_t* blk_pa;     // nBlk upper blocks (pa<=pb) of the reduced system
   const int8_t* blk_pb;
+  const uint8_t* porder;    // E: chunk-local edge indices grouped by free pose (fixed-pose edges last)
+  const uint16_t* pptr;     // nCh x (nP+1): segment of each pose inside the chunk's porder
+  const uint8_t* pair_a;    // nPairs: chunk-local leader edge a (pose pa)
+  const uint8_t* pair_b;    // nPairs: chunk-local leader edge b (pose pb)
+  const int* pair_ptr;      // nCh x (nBlk+1): absolute offsets into pair_a/pair_b
   Cam K;
   double ext[14];
   double huber_delta, chi2_th;
@@ -77,19 +92,20 @@ struct BaDev {
   double* Hll;              // [6][nLm]
   double* bl;               // [3][nLm]
   double* lin_slab;         // nCh x (nP*27 + 2)
-  double* Hpp;              // nP x 21
-  double* bp;               // nP x 6
+  double* Hpp;              // nP x 21   (this rank's part)
+  double* bp;               // nP x 6    (this rank's part)
+  double* iter_comm;        // [Hpp_g nP*21 | bp_g nP*6 | chi2 | maxdiag slots (world)]  all-reduced per iteration
   double* schur_slab;       // nCh x (nBlk*36 + nP*6)
-  double* S;                // n x n (n = 6 nP), without lambda
-  double* bs;               // n
+  double* trial_comm;       // [S n*n | bs n]   all-reduced per trial (n = 6 nP), S without lambda
   double* xp;               // n
   double* trial_slab;       // nCh x 3
-  double* scal;             // 16 scalars
+  double* scal_comm;        // [tempChi, scale_l, nout]  all-reduced per trial
+  double* scal;             // SC_N scalars
 };
 
 // scal[] slots
 enum { SC_CHI2_CUR = 0, SC_MAXDIAG = 1, SC_SOLVE_OK = 2, SC_SCALE_P = 3, SC_TEMP_CHI = 4, SC_SCALE_L = 5,
-       SC_NOUT = 6, SC_N = 16 };
+       SC_NOUT = 6, SC_LAMBDA = 7, SC_N = 16 };
 
 __device__ __forceinline__ double block_sum_256(double v, double* s)
 {
@@ -133,8 +149,9 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   __shared__ double sJi[12][CH];      // Jacobian wrt pose, [component][edge] (bank-conflict-free columns)
   __shared__ double sW1[CH], sR0[CH], sR1[CH];
   __shared__ double sL[9][CH];        // per-edge landmark contributions (6 Hll + 3 bl)
-  __shared__ int sPose[CH];
   __shared__ double sRed[CH];
+  __shared__ uint8_t sOrd[CH];
+  __shared__ uint16_t sPptr[SSX_BA_SMALL_P + 1];
 
   const int c = blockIdx.x, t = threadIdx.x;
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
@@ -144,7 +161,8 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   const double* point = d.point[cur];
 
   double rho0 = 0.0;
-  sPose[t] = -1;
+  if (t < ne) sOrd[t] = d.porder[e0 + t];
+  if (t <= d.nP) sPptr[t] = d.pptr[(size_t)c * (d.nP + 1) + t];
   if (t < ne) {
     const int e = e0 + t;
     const int p = d.e_pose[e];
@@ -177,7 +195,6 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
 #pragma unroll
       for (int b = 0; b < 3; ++b)
         d.W[(size_t)(a * 3 + b) * d.E + e] = both ? (Ji[a] * w * Jj[b] + Ji[6 + a] * w * Jj[3 + b]) : 0.0;
-    sPose[t] = pf;
 #pragma unroll
     for (int k = 0; k < 12; ++k) sJi[k][t] = Ji[k];
     sW1[t] = w; sR0[t] = r0; sR1[t] = r1;
@@ -208,19 +225,24 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
     maxd = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
   }
 
-  // pose blocks: owned entries, contributions added in edge order
+  // pose blocks: owned entries; each walks only the chunk's edges of ITS pose, in the host-prepared order
   double* slab = d.lin_slab + (size_t)c * (d.nP * 27 + 2);
   for (int idx = t; idx < d.nP * 27; idx += CH) {
     const int p = idx / 27, k = idx - p * 27;
+    const int s0 = sPptr[p], s1 = sPptr[p + 1];
     double acc = 0.0;
     if (k < UPPER6) {
       const int r = c_u6_r[k], cc = c_u6_c[k];
-      for (int j = 0; j < ne; ++j)
-        if (sPose[j] == p) acc += sJi[r][j] * sW1[j] * sJi[cc][j] + sJi[6 + r][j] * sW1[j] * sJi[6 + cc][j];
+      for (int s = s0; s < s1; ++s) {
+        const int j = sOrd[s];
+        acc += sJi[r][j] * sW1[j] * sJi[cc][j] + sJi[6 + r][j] * sW1[j] * sJi[6 + cc][j];
+      }
     } else {
       const int a = k - UPPER6;
-      for (int j = 0; j < ne; ++j)
-        if (sPose[j] == p) acc += sJi[a][j] * sR0[j] + sJi[6 + a][j] * sR1[j];
+      for (int s = s0; s < s1; ++s) {
+        const int j = sOrd[s];
+        acc += sJi[a][j] * sR0[j] + sJi[6 + a][j] * sR1[j];
+      }
     }
     slab[idx] = acc;
   }
@@ -232,47 +254,70 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   }
 }
 
-// slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|  (computeLambdaInit,
-// optimization_algorithm_levenberg.cpp:152-166, wants the max over pose AND landmark diagonals)
-__global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d)
+// slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|.  ONE workgroup of 1024 threads: entry e is summed by
+// 1 or 2 "lanes" striding over the chunks, combined in a fixed order (deterministic for a given nCh).
+// (computeLambdaInit, optimization_algorithm_levenberg.cpp:152-166, wants the max over pose AND landmark
+// diagonals; with several ranks the pose diagonals need the all-reduced Hpp, see k_lambda_init.)
+__global__ __launch_bounds__(1024) void k_reduce_lin(BaDev d)
 {
+  __shared__ double sAcc[1024];
+  const int t = threadIdx.x;
   const int n = d.nP * 27;
   const int stride = n + 2;
-  const int idx = blockIdx.x * CH + threadIdx.x;
-  if (idx < n) {
-    double acc = 0.0;
-    for (int c = 0; c < d.nCh; ++c) acc += d.lin_slab[(size_t)c * stride + idx];
-    const int p = idx / 27, k = idx - p * 27;
-    if (k < UPPER6) d.Hpp[p * UPPER6 + k] = acc;
-    else d.bp[p * 6 + (k - UPPER6)] = acc;
+  const int lanes = (n * 2 <= 1024) ? 2 : 1;
+  const int ent = t / lanes, ln = t - ent * lanes;
+  double acc = 0.0;
+  if (ent < n)
+    for (int c = ln; c < d.nCh; c += lanes) acc += d.lin_slab[(size_t)c * stride + ent];
+  sAcc[t] = acc;
+  __syncthreads();
+  if (ent < n && ln == 0) {
+    double v = sAcc[t];
+    if (lanes == 2) v += sAcc[t + 1];
+    const int p = ent / 27, k = ent - p * 27;
+    if (k < UPPER6) { d.Hpp[p * UPPER6 + k] = v; d.iter_comm[p * UPPER6 + k] = v; }
+    else { d.bp[p * 6 + (k - UPPER6)] = v; d.iter_comm[d.nP * UPPER6 + p * 6 + (k - UPPER6)] = v; }
   }
-  if (blockIdx.x == 0) {
-    __shared__ double sRed[CH];
-    double chi = 0.0, md = 0.0;
-    for (int c = threadIdx.x; c < d.nCh; c += CH) {
-      // per-thread partials are combined by the fixed tree below: deterministic for a given nCh
-      chi += d.lin_slab[(size_t)c * stride + n];
-      md = fmax(md, d.lin_slab[(size_t)c * stride + n + 1]);
-    }
-    chi = block_sum_256(chi, sRed);
-    md = block_max_256(md, sRed);
-    if (threadIdx.x == 0) {
-      d.scal[SC_CHI2_CUR] = chi;
-      d.scal[SC_MAXDIAG] = md;   // landmark part; the pose part is folded in by k_maxdiag_pose
-    }
+  __syncthreads();
+  // chi2 (sum) and landmark max-diagonal (max) over the chunks: fixed tree over 1024 lanes
+  double chi = 0.0, md = 0.0;
+  for (int c = t; c < d.nCh; c += 1024) {
+    chi += d.lin_slab[(size_t)c * stride + n];
+    md = fmax(md, d.lin_slab[(size_t)c * stride + n + 1]);
+  }
+  sAcc[t] = chi;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (t < o) sAcc[t] += sAcc[t + o]; __syncthreads(); }
+  const double chi_tot = sAcc[0];
+  __syncthreads();
+  sAcc[t] = md;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (t < o) sAcc[t] = fmax(sAcc[t], sAcc[t + o]); __syncthreads(); }
+  if (t == 0) {
+    double* tail = d.iter_comm + d.nP * 27;
+    tail[0] = chi_tot;
+    for (int r = 0; r < d.world; ++r) tail[1 + r] = (r == d.rank) ? sAcc[0] : 0.0;
   }
 }
 
-__global__ void k_maxdiag_pose(BaDev d)
+// after the (optional) all-reduce of iter_comm: chi2, max diagonal, and lambda_0 = 1e-5 * max on iteration 0
+__global__ void k_lambda_init(BaDev d, int first_iteration)
 {
-  // single thread: fold the pose-block diagonals into SC_MAXDIAG (nP <= 16)
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double m = d.scal[SC_MAXDIAG];
-    const int diag[6] = {0, 6, 11, 15, 18, 20};
-    for (int p = 0; p < d.nP; ++p)
-      for (int k = 0; k < 6; ++k) m = fmax(m, fabs(d.Hpp[p * UPPER6 + diag[k]]));
-    d.scal[SC_MAXDIAG] = m;
-  }
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double* tail = d.iter_comm + d.nP * 27;
+  double m = 0.0;
+  for (int r = 0; r < d.world; ++r) m = fmax(m, tail[1 + r]);
+  const int diag[6] = {0, 6, 11, 15, 18, 20};
+  for (int p = 0; p < d.nP; ++p)
+    for (int k = 0; k < 6; ++k) m = fmax(m, fabs(d.iter_comm[p * UPPER6 + diag[k]]));
+  d.scal[SC_CHI2_CUR] = tail[0];
+  d.scal[SC_MAXDIAG] = m;
+  if (first_iteration) d.scal[SC_LAMBDA] = 1e-5 * m;
+}
+
+__global__ void k_set_lambda(BaDev d, double lambda)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0) d.scal[SC_LAMBDA] = lambda;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,7 +325,7 @@ __global__ void k_maxdiag_pose(BaDev d)
 // restates the marginalisation loop of BlockSolver::solve (block_solver.hpp:342-393):
 //   Dinv = (Hll + lambda I)^-1 ; c_i += W_i Dinv bl ; S_ij -= (W_i Dinv) W_j^T  (upper blocks)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda)
+__global__ __launch_bounds__(CH) void k_schur(BaDev d)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* sW = reinterpret_cast<double*>(smem);            // [18][CH]
@@ -288,27 +333,31 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda)
   double* sC = sBD + 18 * CH;                              // [6][CH]
   double* sDinv = sC + 6 * CH;                             // [9][CH] per landmark
   double* sDb = sDinv + 9 * CH;                            // [3][CH]
-  uint8_t* sSlot = reinterpret_cast<uint8_t*>(sDb + 3 * CH);  // [nl][nP] -> edge slot or 0xFF
-  int* sLm = reinterpret_cast<int*>(sSlot + CH * SSX_BA_SMALL_P);  // [CH] local landmark of each edge
+  int* sLm = reinterpret_cast<int*>(sDb + 3 * CH);         // [CH] local landmark of each edge
+  uint8_t* sLeader = reinterpret_cast<uint8_t*>(sLm + CH); // [CH]
+  uint8_t* sOrd = sLeader + CH;                            // [CH]
+  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sOrd + CH);// [SSX_BA_SMALL_P + 1]
 
   const int c = blockIdx.x, t = threadIdx.x;
+  const double lambda = d.scal[SC_LAMBDA];
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
   const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
   const int ne = e1 - e0, nl = lm1 - lm0;
   const int nP = d.nP;
 
-  for (int i = t; i < nl * nP; i += CH) sSlot[i] = 0xFF;
-  int pf = -1;
   bool leader = false;
+  if (t < ne) sOrd[t] = d.porder[e0 + t];
+  if (t <= nP) sPptr[t] = d.pptr[(size_t)c * (nP + 1) + t];
   if (t < ne) {
     const int e = e0 + t;
 #pragma unroll
     for (int k = 0; k < 18; ++k) sW[k * CH + t] = d.W[(size_t)k * d.E + e];
     const int lc = d.e_lmc[e];
     sLm[t] = lc - lm0;
-    pf = d.pose_free[d.e_pose[e]];
+    const int pf = d.pose_free[d.e_pose[e]];
     leader = (pf >= 0) && !d.lm_fixed[lc] && !d.e_dup[e];
   }
+  sLeader[t] = leader ? 1 : 0;
   if (t < nl) {
     const int lc = lm0 + t;
     double D[6], Di[9];
@@ -325,13 +374,10 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda)
   __syncthreads();
   if (leader) {
     // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
-    const int e = e0 + t;
     for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j)
 #pragma unroll
       for (int k = 0; k < 18; ++k) sW[k * CH + t] += sW[k * CH + j];
-    (void)e;
     const int l = sLm[t];
-    sSlot[l * nP + pf] = (uint8_t)t;
     double Di[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) Di[k] = sDinv[k * CH + l];
@@ -345,128 +391,185 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda)
   }
   __syncthreads();
 
+  // owned entries of the reduced system: each walks the (edge a, edge b) pairs of ITS block, landmark order
   double* slab = d.schur_slab + (size_t)c * (d.nBlk * 36 + nP * 6);
   const int nS = d.nBlk * 36;
+  const int* pptr = d.pair_ptr + (size_t)c * (d.nBlk + 1);
   for (int idx = t; idx < nS; idx += CH) {
     const int blk = idx / 36, rc = idx - blk * 36;
     const int r = rc / 6, cc = rc - r * 6;
-    const int pa = d.blk_pa[blk], pb = d.blk_pb[blk];
+    const int q0 = pptr[blk], q1 = pptr[blk + 1];
     double acc = 0.0;
-    for (int l = 0; l < nl; ++l) {
-      const int ea = sSlot[l * nP + pa], eb = sSlot[l * nP + pb];
-      if (ea != 0xFF && eb != 0xFF)
-        acc += sBD[(r * 3) * CH + ea] * sW[(cc * 3) * CH + eb] + sBD[(r * 3 + 1) * CH + ea] * sW[(cc * 3 + 1) * CH + eb] +
-               sBD[(r * 3 + 2) * CH + ea] * sW[(cc * 3 + 2) * CH + eb];
+    for (int q = q0; q < q1; ++q) {
+      const int ea = d.pair_a[q], eb = d.pair_b[q];
+      acc += sBD[(r * 3) * CH + ea] * sW[(cc * 3) * CH + eb] + sBD[(r * 3 + 1) * CH + ea] * sW[(cc * 3 + 1) * CH + eb] +
+             sBD[(r * 3 + 2) * CH + ea] * sW[(cc * 3 + 2) * CH + eb];
     }
     slab[idx] = acc;
   }
   for (int idx = t; idx < nP * 6; idx += CH) {
     const int p = idx / 6, a = idx - p * 6;
     double acc = 0.0;
-    for (int l = 0; l < nl; ++l) {
-      const int ea = sSlot[l * nP + p];
-      if (ea != 0xFF) acc += sC[a * CH + ea];
+    for (int s = sPptr[p]; s < sPptr[p + 1]; ++s) {
+      const int j = sOrd[s];
+      if (sLeader[j]) acc += sC[a * CH + j];
     }
     slab[nS + idx] = acc;
   }
 }
 
-// slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c)
+// slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c).
+// 16 chunk-lanes per entry (16 entries per 256-thread workgroup), fixed tree: deterministic.
 __global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d)
 {
+  __shared__ double sAcc[CH];
   const int nS = d.nBlk * 36;
   const int stride = nS + d.nP * 6;
   const int n = 6 * d.nP;
-  const int idx = blockIdx.x * CH + threadIdx.x;
-  if (idx >= stride) return;
+  const int t = threadIdx.x;
+  const int ent = blockIdx.x * 16 + (t >> 4), ln = t & 15;
   double acc = 0.0;
-  for (int c = 0; c < d.nCh; ++c) acc += d.schur_slab[(size_t)c * stride + idx];
-  if (idx < nS) {
-    const int blk = idx / 36, rc = idx - blk * 36;
+  if (ent < stride)
+    for (int c = ln; c < d.nCh; c += 16) acc += d.schur_slab[(size_t)c * stride + ent];
+  sAcc[t] = acc;
+  __syncthreads();
+  for (int o = 8; o > 0; o >>= 1) { if (ln < o) sAcc[t] += sAcc[t + o]; __syncthreads(); }
+  if (ln != 0 || ent >= stride) return;
+  acc = sAcc[t];
+  double* S = d.trial_comm;
+  double* bs = d.trial_comm + (size_t)n * n;
+  if (ent < nS) {
+    const int blk = ent / 36, rc = ent - blk * 36;
     const int r = rc / 6, cc = rc - r * 6;
     const int pa = d.blk_pa[blk], pb = d.blk_pb[blk];
     double h = 0.0;
     if (pa == pb) {
       const int rr = r < cc ? r : cc, c2 = r < cc ? cc : r;
-      // index of (rr,c2) in the 21-entry upper layout
-      const int k = rr * 6 - (rr * (rr - 1)) / 2 + (c2 - rr);
+      const int k = rr * 6 - (rr * (rr - 1)) / 2 + (c2 - rr);   // index of (rr,c2) in the 21-entry upper layout
       h = d.Hpp[pa * UPPER6 + k];
     }
     const double v = h - acc;
-    d.S[(size_t)(6 * pa + r) * n + 6 * pb + cc] = v;
-    if (pa != pb) d.S[(size_t)(6 * pb + cc) * n + 6 * pa + r] = v;
+    S[(size_t)(6 * pa + r) * n + 6 * pb + cc] = v;
+    if (pa != pb) S[(size_t)(6 * pb + cc) * n + 6 * pa + r] = v;
   } else {
-    const int j = idx - nS;
-    d.bs[j] = d.bp[j] - acc;
+    const int j = ent - nS;
+    bs[j] = d.bp[j] - acc;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_solve: ONE wave.  (S + lambda I) x = bs by Cholesky in LDS (the role of LinearSolverCSparse::solve,
-// thirdparty/g2o/g2o/solvers/csparse/linear_solver_csparse.h:106-142: false when not SPD), then the pose
-// update T <- exp(x) T into the trial buffer (SparseOptimizer::update, sparse_optimizer.cpp:433-446) and
-// the pose part of computeScale (optimization_algorithm_levenberg.cpp:168-175).
+// k_solve: (S + lambda I) x = bs, the role of LinearSolverCSparse::solve
+// (thirdparty/g2o/g2o/solvers/csparse/linear_solver_csparse.h:106-142: false when not positive definite),
+// then the pose update T <- exp(x) T into the trial buffer (SparseOptimizer::update,
+// sparse_optimizer.cpp:433-446) and the pose part of computeScale (optimization_algorithm_levenberg.cpp:168-175).
+//
+// LDL^T, right-looking, register-tiled: the 256 threads form a 16x16 grid and thread (ty,tx) keeps the entries
+// (i,k) with i = ty (mod 16), k = tx (mod 16) of the matrix AUGMENTED with the right-hand side as row n, so the
+// elimination also performs the forward substitution (row n ends up holding w = D^-1 L^-1 b).  One barrier per
+// column (double-buffered column broadcast through LDS).  The backward substitution L^T x = w is done by ONE
+// wave with the running solution in registers and v_readlane broadcasts (no barrier in the dependent chain).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_solve(BaDev d, double lambda, int cur)
+__global__ __launch_bounds__(256) void k_solve(BaDev d, int cur)
 {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n = 6 * d.nP;
-  const int ld = n + 1;                 // +1 pad: column walks hit different banks
-  double* A = reinterpret_cast<double*>(smem);   // n x ld, lower triangle used
-  double* y = A + (size_t)n * ld;
+  __shared__ double sCol[2][NMAX + 8];
+  __shared__ double sL[NMAX * (NMAX + 1)];      // L (row-major, pitch n+1) for the backward substitution
+  __shared__ double sWv[NMAX + 8];
+  __shared__ double sX[NMAX + 8];
   __shared__ int sOk;
-  const int t = threadIdx.x;
-  for (int i = t; i < n * n; i += 64) {
-    const int r = i / n, c = i - r * n;
-    A[r * ld + c] = d.S[i] + (r == c ? lambda : 0.0);
-  }
+  const int n = 6 * d.nP;
+  const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+  const double lambda = d.scal[SC_LAMBDA];
+  const double* S = d.trial_comm;
+  const double* bs = d.trial_comm + (size_t)n * n;
+  constexpr int RA = NMAX / 16 + 1, RB = NMAX / 16;     // rows incl. the rhs row, columns
+  double R[RA][RB];
+#pragma unroll
+  for (int a = 0; a < RA; ++a)
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const int i = ty + 16 * a, k = tx + 16 * b;
+      double v = 0.0;
+      if (k < n) {
+        if (i < n) v = S[(size_t)i * n + k] + (i == k ? lambda : 0.0);
+        else if (i == n) v = bs[k];
+      }
+      R[a][b] = v;
+    }
   if (t == 0) sOk = 1;
   __syncthreads();
   for (int j = 0; j < n; ++j) {
-    // column j: A[j][j] = sqrt(A[j][j]); A[i][j] /= A[j][j]; trailing update
-    const double djj = A[j * ld + j];
-    if (!(djj > 0.0) || !isfinite(djj)) { if (t == 0) sOk = 0; break; }   // uniform across the wave
-    const double dj = sqrt(djj);
-    __syncthreads();
-    for (int i = j + t; i < n; i += 64) A[i * ld + j] = (i == j) ? dj : A[i * ld + j] / dj;
-    __syncthreads();
-    // A[i][k] -= A[i][j] * A[k][j]  for j < k <= i
-    const int m = n - j - 1;
-    for (int q = t; q < m * m; q += 64) {
-      const int i = j + 1 + q / m, k = j + 1 + (q - (q / m) * m);
-      if (k <= i) A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
+    double* col = sCol[j & 1];
+    const int bj = j >> 4;
+    if (tx == (j & 15)) {
+#pragma unroll
+      for (int a = 0; a < RA; ++a) {
+        const int i = ty + 16 * a;
+        if (i >= j && i <= n) {
+          double v = 0.0;
+#pragma unroll
+          for (int b = 0; b < RB; ++b) if (b == bj) v = R[a][b];
+          col[i] = v;
+        }
+      }
     }
     __syncthreads();
+    const double dj = col[j];
+    if (!(dj > 0.0) || !isfinite(dj)) { if (t == 0) sOk = 0; break; }   // uniform: every thread reads the same pivot
+    const double rinv = 1.0 / dj;
+#pragma unroll
+    for (int a = 0; a < RA; ++a) {
+      const int i = ty + 16 * a;
+      if (i > j && i <= n) {
+        const double li = col[i] * rinv;            // L[i][j]  (row n: w_j)
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          const int k = tx + 16 * b;
+          if (k > j && k <= i && k < n) R[a][b] -= li * col[k];
+          else if (k == j) R[a][b] = li;            // column j is final: keep L
+        }
+      }
+    }
   }
   __syncthreads();
   const int ok = sOk;
-  if (ok) {
-    // forward: L y = bs ; backward: L^T x = y    (sequential in i, lanes split the dot product)
-    for (int i = 0; i < n; ++i) {
-      double part = 0.0;
-      for (int k = t; k < i; k += 64) part += A[i * ld + k] * y[k];
+  // spill L and w to LDS for the backward substitution
+  const int ld = n + 1;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-      if (t == 0) y[i] = (d.bs[i] - part) / A[i * ld + i];
-      __syncthreads();
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double part = 0.0;
-      for (int k = i + 1 + t; k < n; k += 64) part += A[k * ld + i] * y[k];
+  for (int a = 0; a < RA; ++a)
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-      if (t == 0) y[i] = (y[i] - part) / A[i * ld + i];
-      __syncthreads();
+    for (int b = 0; b < RB; ++b) {
+      const int i = ty + 16 * a, k = tx + 16 * b;
+      if (k < n) {
+        if (i < n && k < i) sL[i * ld + k] = R[a][b];
+        else if (i == n) sWv[k] = R[a][b];
+      }
     }
-  } else {
-    for (int i = t; i < n; i += 64) y[i] = 0.0;
-    __syncthreads();
+  __syncthreads();
+  if (t < 64) {
+    // lane l holds x[l] and x[l + 64]
+    double x0 = (ok && t < n) ? sWv[t] : 0.0;
+    double x1 = (ok && t + 64 < n) ? sWv[t + 64] : 0.0;
+    if (ok) {
+      for (int i = n - 1; i > 0; --i) {
+        // broadcast the final x_i from its owner lane
+        const double src = (i >= 64) ? x1 : x0;
+        const int sl = i & 63;
+        const int lo = __builtin_amdgcn_readlane(__double2loint(src), sl);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(src), sl);
+        const double xi = __hiloint2double(hi, lo);
+        // x_k -= L[i][k] * x_i for k < i
+        if (t < i) x0 -= sL[i * ld + t] * xi;
+        if (t + 64 < i) x1 -= sL[i * ld + t + 64] * xi;
+      }
+    }
+    if (t < n) { sX[t] = x0; d.xp[t] = x0; }
+    if (t + 64 < n) { sX[t + 64] = x1; d.xp[t + 64] = x1; }
   }
-  for (int i = t; i < n; i += 64) d.xp[i] = y[i];
+  __syncthreads();
   // pose update into the trial buffer
   const double* src = d.pose[cur];
   double* dst = d.pose[cur ^ 1];
-  for (int p = t; p < d.P; p += 64) {
+  for (int p = t; p < d.P; p += 256) {
     const int pf = d.pose_free[p];
     double T[7], out[7];
 #pragma unroll
@@ -474,7 +577,7 @@ __global__ __launch_bounds__(64) void k_solve(BaDev d, double lambda, int cur)
     if (pf >= 0) {
       double dx[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) dx[k] = y[pf * 6 + k];
+      for (int k = 0; k < 6; ++k) dx[k] = sX[pf * 6 + k];
       ssx::pose_oplus(T, dx, out);
     } else {
 #pragma unroll
@@ -484,8 +587,9 @@ __global__ __launch_bounds__(64) void k_solve(BaDev d, double lambda, int cur)
     for (int k = 0; k < 7; ++k) dst[p * 7 + k] = out[k];
   }
   if (t == 0) {
+    const double* bp_g = d.iter_comm + d.nP * UPPER6;   // the (all-reduced) pose part of b
     double s = 0.0;
-    for (int j = 0; j < n; ++j) s += y[j] * (lambda * y[j] + d.bp[j]);
+    for (int j = 0; j < n; ++j) s += sX[j] * (lambda * sX[j] + bp_g[j]);
     d.scal[SC_SOLVE_OK] = ok ? 1.0 : 0.0;
     d.scal[SC_SCALE_P] = s;
   }
@@ -496,11 +600,12 @@ __global__ __launch_bounds__(64) void k_solve(BaDev d, double lambda, int cur)
 // residuals / robust chi2 of the TRIAL state (computeActiveErrors + activeRobustChi2,
 // sparse_optimizer.cpp:63-116).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, double lambda, int cur)
+__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur)
 {
   __shared__ double sPt[3][CH];
   __shared__ double sRed[CH];
   const int c = blockIdx.x, t = threadIdx.x;
+  const double lambda = d.scal[SC_LAMBDA];
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
   const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
   const int ne = e1 - e0, nl = lm1 - lm0;
@@ -582,18 +687,20 @@ __global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d)
   sl = block_sum_256(sl, sRed);
   no = block_sum_256(no, sRed);
   if (threadIdx.x == 0) {
-    d.scal[SC_TEMP_CHI] = chi;
-    d.scal[SC_SCALE_L] = sl;
-    d.scal[SC_NOUT] = no;
+    d.scal_comm[0] = chi;
+    d.scal_comm[1] = sl;
+    d.scal_comm[2] = no;
   }
 }
 
-// plain residual pass on the CURRENT state (used when iters == 0 and by ssx_ba_linearize)
-__global__ void k_copy_state(BaDev d, int from)
+// copy the (all-reduced) trial scalars next to the others so that ONE 64-byte download returns everything
+__global__ void k_publish_trial(BaDev d)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < d.P * 7) d.pose[from ^ 1][i] = d.pose[from][i];
-  if (i < d.L * 3) d.point[from ^ 1][i] = d.point[from][i];
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    d.scal[SC_TEMP_CHI] = d.scal_comm[0];
+    d.scal[SC_SCALE_L] = d.scal_comm[1];
+    d.scal[SC_NOUT] = d.scal_comm[2];
+  }
 }
 
 }  // namespace
@@ -620,8 +727,9 @@ namespace {
 
 struct HostPrep {
   int P, L, E, nP, nLm, nCh, nBlk;
-  std::vector<int> pose_free, lm_id, lm_ptr, ch_lm, e_pose, e_lmc, perm;
-  std::vector<uint8_t> lm_fixed, e_cam, e_dup;
+  std::vector<int> pose_free, lm_id, lm_ptr, ch_lm, e_pose, e_lmc, perm, pair_ptr;
+  std::vector<uint8_t> lm_fixed, e_cam, e_dup, porder, pair_a, pair_b;
+  std::vector<uint16_t> pptr;
   std::vector<double> e_uv;
   std::vector<int8_t> blk_pa, blk_pb;
 };
@@ -671,9 +779,13 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     for (int e = 0; e < E; ++e) h.perm[fill[pr->edge_point[e]]++] = e;
   }
   // inside a landmark: stable sort by pose so that duplicates of a (landmark,pose) pair are adjacent
-  for (int lc = 0; lc < h.nLm; ++lc)
-    std::stable_sort(h.perm.begin() + h.lm_ptr[lc], h.perm.begin() + h.lm_ptr[lc + 1],
-                     [&](int a, int b) { return pr->edge_pose[a] < pr->edge_pose[b]; });
+  for (int lc = 0; lc < h.nLm; ++lc) {
+    const int a = h.lm_ptr[lc], b = h.lm_ptr[lc + 1];
+    bool sorted = true;
+    for (int s = a + 1; s < b && sorted; ++s) sorted = pr->edge_pose[h.perm[s - 1]] <= pr->edge_pose[h.perm[s]];
+    if (!sorted)
+      std::stable_sort(h.perm.begin() + a, h.perm.begin() + b, [&](int x, int y) { return pr->edge_pose[x] < pr->edge_pose[y]; });
+  }
   h.e_pose.resize(E); h.e_lmc.resize(E); h.e_cam.resize(E); h.e_dup.assign(E, 0); h.e_uv.resize(2 * (size_t)E);
   for (int s = 0; s < E; ++s) {
     const int e = h.perm[s];
@@ -684,7 +796,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     h.e_uv[(size_t)E + s] = pr->edge_uv[2 * (size_t)e + 1];
     if (s > 0 && h.e_lmc[s] == h.e_lmc[s - 1] && h.e_pose[s] == h.e_pose[s - 1]) h.e_dup[s] = 1;
   }
-  // chunks of whole landmarks, <= CH edges and <= CH landmarks each
+  // chunks of whole landmarks, <= CH_E edges and <= CH landmarks each
   h.ch_lm.clear();
   h.ch_lm.push_back(0);
   int acc_e = 0, acc_l = 0;
@@ -704,22 +816,70 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     for (int a = 0; a < h.nP; ++a)
       for (int b = a; b < h.nP; ++b) { h.blk_pa.push_back((int8_t)a); h.blk_pb.push_back((int8_t)b); }
   h.nBlk = (int)h.blk_pa.size();
+  if (h.nP > SSX_BA_SMALL_P) return SSX_OK;   // caller reports "unsupported"
+  // per-chunk index lists: edges grouped by free pose; leader pairs grouped by reduced-system block
+  const int nP = h.nP, nBlk = h.nBlk;
+  h.porder.assign(E, 0);
+  h.pptr.assign((size_t)h.nCh * (nP + 1) + 1, 0);
+  h.pair_ptr.assign((size_t)h.nCh * (nBlk + 1) + 1, 0);
+  h.pair_a.clear(); h.pair_b.clear();
+  std::vector<int> blk_of((size_t)std::max(nP, 1) * std::max(nP, 1), -1);
+  for (int b = 0; b < nBlk; ++b) blk_of[(size_t)h.blk_pa[b] * nP + h.blk_pb[b]] = b;
+  std::vector<int> pc(nP + 1), bc(nBlk + 1);
+  std::vector<uint8_t> leaders;
+  for (int c = 0; c < h.nCh; ++c) {
+    const int lm0 = h.ch_lm[c], lm1 = h.ch_lm[c + 1];
+    const int e0 = h.lm_ptr[lm0], e1 = h.lm_ptr[lm1];
+    // --- by pose ---
+    std::fill(pc.begin(), pc.end(), 0);
+    for (int s = e0; s < e1; ++s) { const int pf = h.pose_free[h.e_pose[s]]; if (pf >= 0) pc[pf + 1]++; }
+    for (int p = 0; p < nP; ++p) pc[p + 1] += pc[p];
+    uint16_t* pp = &h.pptr[(size_t)c * (nP + 1)];
+    for (int p = 0; p <= nP; ++p) pp[p] = (uint16_t)pc[p];
+    int tail = pc[nP];
+    for (int s = e0; s < e1; ++s) {
+      const int pf = h.pose_free[h.e_pose[s]];
+      if (pf >= 0) h.porder[e0 + pc[pf]++] = (uint8_t)(s - e0);
+      else h.porder[e0 + tail++] = (uint8_t)(s - e0);
+    }
+    // --- pairs by block: two passes (count, fill) over the landmarks of the chunk ---
+    std::fill(bc.begin(), bc.end(), 0);
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int lc = lm0; lc < lm1; ++lc) {
+        if (h.lm_fixed[lc]) continue;
+        leaders.clear();
+        for (int s = h.lm_ptr[lc]; s < h.lm_ptr[lc + 1]; ++s)
+          if (h.pose_free[h.e_pose[s]] >= 0 && !h.e_dup[s]) leaders.push_back((uint8_t)(s - e0));
+        for (size_t i = 0; i < leaders.size(); ++i)
+          for (size_t j = i; j < leaders.size(); ++j) {
+            const int pa = h.pose_free[h.e_pose[e0 + leaders[i]]], pb = h.pose_free[h.e_pose[e0 + leaders[j]]];
+            const int b = blk_of[(size_t)pa * nP + pb];   // pa <= pb: edges of a landmark are sorted by pose
+            if (pass == 0) bc[b + 1]++;
+            else { const int q = bc[b]++; h.pair_a[q] = leaders[i]; h.pair_b[q] = leaders[j]; }
+          }
+      }
+      if (pass == 0) {
+        const int base = (int)h.pair_a.size();
+        bc[0] = base;
+        for (int b = 0; b < nBlk; ++b) bc[b + 1] += bc[b];
+        int* bp = &h.pair_ptr[(size_t)c * (nBlk + 1)];
+        for (int b = 0; b <= nBlk; ++b) bp[b] = bc[b];
+        h.pair_a.resize(bc[nBlk]); h.pair_b.resize(bc[nBlk]);
+      }
+    }
+  }
   return SSX_OK;
 }
 
-struct Upload {
-  BaDev d;
-  size_t bytes_total;
-};
-
 // carve the arena and upload the problem
 ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, double huber_delta, double chi2_th,
-                  BaDev& d)
+                  int world, int rank, BaDev& d)
 {
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
   const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm, nCh = h.nCh, nBlk = h.nBlk;
   const int n = 6 * nP;
+  const size_t nPairs = h.pair_a.size();
   Layout in;   // input blob (mirrored in pinned staging)
   const size_t o_pose_free = in.take(sizeof(int) * P);
   const size_t o_lm_fixed = in.take(nLm);
@@ -733,6 +893,11 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_e_uv = in.take(sizeof(double) * 2 * E);
   const size_t o_blk_pa = in.take(nBlk + 1);
   const size_t o_blk_pb = in.take(nBlk + 1);
+  const size_t o_porder = in.take(E + 1);
+  const size_t o_pptr = in.take(sizeof(uint16_t) * (h.pptr.size() + 1));
+  const size_t o_pair_a = in.take(nPairs + 1);
+  const size_t o_pair_b = in.take(nPairs + 1);
+  const size_t o_pair_ptr = in.take(sizeof(int) * (h.pair_ptr.size() + 1));
   const size_t o_pose0 = in.take(sizeof(double) * 7 * P);
   const size_t o_point0 = in.take(sizeof(double) * 3 * (L + 1));
   const size_t in_bytes = in.off;
@@ -747,11 +912,12 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_lin_slab = all.take(sizeof(double) * (size_t)(nCh + 1) * (nP * 27 + 2));
   const size_t o_Hpp = all.take(sizeof(double) * (nP + 1) * UPPER6);
   const size_t o_bp = all.take(sizeof(double) * (nP + 1) * 6);
+  const size_t o_iter = all.take(sizeof(double) * ((size_t)nP * 27 + 1 + world + 1));
   const size_t o_schur = all.take(sizeof(double) * (size_t)(nCh + 1) * (nBlk * 36 + nP * 6));
-  const size_t o_S = all.take(sizeof(double) * ((size_t)n * n + 1));
-  const size_t o_bs = all.take(sizeof(double) * (n + 1));
+  const size_t o_trial_comm = all.take(sizeof(double) * ((size_t)n * n + n + 1));
   const size_t o_xp = all.take(sizeof(double) * (n + 1));
   const size_t o_trial = all.take(sizeof(double) * 3 * (nCh + 1));
+  const size_t o_scal_comm = all.take(sizeof(double) * 4);
   const size_t o_scal = all.take(sizeof(double) * SC_N);
 
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -772,11 +938,18 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_e_cam, h.e_cam.data(), E);
     memcpy(hs + o_e_dup, h.e_dup.data(), E);
     memcpy(hs + o_e_uv, h.e_uv.data(), sizeof(double) * 2 * E);
+    if (!h.porder.empty()) memcpy(hs + o_porder, h.porder.data(), E);
   }
   if (nBlk) {
     memcpy(hs + o_blk_pa, h.blk_pa.data(), nBlk);
     memcpy(hs + o_blk_pb, h.blk_pb.data(), nBlk);
   }
+  if (!h.pptr.empty()) memcpy(hs + o_pptr, h.pptr.data(), sizeof(uint16_t) * h.pptr.size());
+  if (nPairs) {
+    memcpy(hs + o_pair_a, h.pair_a.data(), nPairs);
+    memcpy(hs + o_pair_b, h.pair_b.data(), nPairs);
+  }
+  if (!h.pair_ptr.empty()) memcpy(hs + o_pair_ptr, h.pair_ptr.data(), sizeof(int) * h.pair_ptr.size());
   memcpy(hs + o_pose0, pr->poses, sizeof(double) * 7 * P);
   if (L) memcpy(hs + o_point0, pr->points, sizeof(double) * 3 * L);
   char* base = ws->arena.as<char>();
@@ -786,7 +959,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   if (L)
     SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_point1, base + o_point0, sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, ctx->stream));
 
-  d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk;
+  d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
   d.pose_free = (const int*)(base + o_pose_free);
   d.lm_fixed = (const uint8_t*)(base + o_lm_fixed);
   d.lm_id = (const int*)(base + o_lm_id);
@@ -799,6 +972,11 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.e_uv = (const double*)(base + o_e_uv);
   d.blk_pa = (const int8_t*)(base + o_blk_pa);
   d.blk_pb = (const int8_t*)(base + o_blk_pb);
+  d.porder = (const uint8_t*)(base + o_porder);
+  d.pptr = (const uint16_t*)(base + o_pptr);
+  d.pair_a = (const uint8_t*)(base + o_pair_a);
+  d.pair_b = (const uint8_t*)(base + o_pair_b);
+  d.pair_ptr = (const int*)(base + o_pair_ptr);
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
@@ -810,24 +988,47 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.Hll = (double*)(base + o_Hll); d.bl = (double*)(base + o_bl);
   d.lin_slab = (double*)(base + o_lin_slab);
   d.Hpp = (double*)(base + o_Hpp); d.bp = (double*)(base + o_bp);
+  d.iter_comm = (double*)(base + o_iter);
   d.schur_slab = (double*)(base + o_schur);
-  d.S = (double*)(base + o_S); d.bs = (double*)(base + o_bs); d.xp = (double*)(base + o_xp);
+  d.trial_comm = (double*)(base + o_trial_comm);
+  d.xp = (double*)(base + o_xp);
   d.trial_slab = (double*)(base + o_trial);
+  d.scal_comm = (double*)(base + o_scal_comm);
   d.scal = (double*)(base + o_scal);
   return SSX_OK;
 }
 
-size_t schur_lds_bytes() { return sizeof(double) * (18 + 18 + 6 + 9 + 3) * CH + CH * SSX_BA_SMALL_P + sizeof(int) * CH; }
+size_t schur_lds_bytes()
+{
+  return sizeof(double) * (18 + 18 + 6 + 9 + 3) * CH + sizeof(int) * CH + 2 * CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) + 64;
+}
 
-ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, int jac, int cur)
+struct Comm {
+  ssx_allreduce_fn fn = nullptr;
+  void* user = nullptr;
+  int world = 1;
+};
+
+ssx_status allreduce(ssx_ctx* ctx, const Comm& cm, double* buf, size_t count)
+{
+  if (!cm.fn) return SSX_OK;
+  if (cm.fn(cm.user, buf, count, ctx->stream) != 0) {
+    ctx->set_error("ssx_ba: the all-reduce hook reported a failure");
+    return SSX_ERR_COMM;
+  }
+  return SSX_OK;
+}
+
+ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, const Comm& cm, int jac, int cur, int first_iteration)
 {
   if (d.nCh > 0) {
     if (jac == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
     else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
   }
-  const int n27 = d.nP * 27;
-  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (n27 + CH - 1) / CH)), dim3(CH), 0, ctx->stream, d));
-  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_maxdiag_pose, dim3(1), dim3(64), 0, ctx->stream, d));
+  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(1), dim3(1024), 0, ctx->stream, d));
+  ssx_status st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
+  if (st != SSX_OK) return st;
+  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_iteration));
   SSX_HIP_TRY(ctx, hipGetLastError());
   return SSX_OK;
 }
@@ -860,9 +1061,10 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
   if (st != SSX_OK) return st;
   if (h.nP > SSX_BA_SMALL_P) { ctx->set_error("ssx_ba_linearize: %d free poses > %d", h.nP, SSX_BA_SMALL_P); return SSX_ERR_UNSUPPORTED; }
   BaDev d;
-  st = upload(ctx, prob, h, huber_delta, 5.891, d);
+  st = upload(ctx, prob, h, huber_delta, 5.891, 1, 0, d);
   if (st != SSX_OK) return st;
-  st = launch_linearize(ctx, d, jac_mode, 0);
+  Comm cm;
+  st = launch_linearize(ctx, d, cm, jac_mode, 0, 1);
   if (st != SSX_OK) return st;
   const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm;
   std::vector<double> hHpp((size_t)nP * UPPER6 + 1), hbp((size_t)nP * 6 + 1), hHll((size_t)6 * nLm + 1), hbl((size_t)3 * nLm + 1),
@@ -923,21 +1125,26 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     ctx->set_error("ssx_ba_solve: %d free poses > %d (large-window path not built yet)", h.nP, SSX_BA_SMALL_P);
     return SSX_ERR_UNSUPPORTED;
   }
+  Comm cm;
+  // world_size 1 with a hook is allowed (the hook is then an identity): it exercises the collective plumbing
+  if (opt.allreduce && opt.world_size >= 1) { cm.fn = opt.allreduce; cm.user = opt.allreduce_user; cm.world = opt.world_size; }
+  if (cm.fn && (opt.rank < 0 || opt.rank >= cm.world || cm.world > 64)) {
+    ctx->set_error("ssx_ba_solve: invalid rank %d / world_size %d", opt.rank, cm.world);
+    return SSX_ERR_INVALID_ARG;
+  }
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   BaDev d;
-  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, d);
+  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d);
   if (st != SSX_OK) return st;
   BaWorkspace* ws = ctx->ba;
   double* hscal = ws->scal.as<double>();
   const int n = 6 * d.nP;
   const int nCh = d.nCh;
   const size_t lds_schur = schur_lds_bytes();
-  const size_t lds_solve = sizeof(double) * ((size_t)n * (n + 1) + n + 8);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     attr_set = true;
   }
   const int nSchurEntries = d.nBlk * 36 + d.nP * 6;
@@ -946,35 +1153,43 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   int cur = 0;                 // index of the accepted state buffer
   bool have_trial_err = false; // err_trial holds the errors of the last trial evaluated
   int round = 0;
-  const bool active = (d.nP + 0 > 0 || d.nLm > 0) && nCh > 0;
+  // with several ranks every rank must take part in every collective, even with an empty shard
+  const bool active = (nCh > 0) || cm.fn != nullptr;
+  double n_out_total = 0.0;
   while (round < opt.outer_rounds) {
     // ---- one g2o optimize(iters): OptimizationAlgorithmLevenberg::solve per iteration ----
     double lambda = -1.0, ni = 2.0;
     for (int it = 0; it < opt.iters && active; ++it) {
-      st = launch_linearize(ctx, d, opt.jac_mode, cur);
+      st = launch_linearize(ctx, d, cm, opt.jac_mode, cur, it == 0);
       if (st != SSX_OK) return st;
-      SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
-      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      double currentChi = hscal[SC_CHI2_CUR];
-      if (it == 0) { lambda = 1e-5 * hscal[SC_MAXDIAG]; ni = 2.0; }
-      double rho = 0.0, tempChi = currentChi;
+      double currentChi = 0.0, rho = 0.0, tempChi = 0.0;
       int qmax = 0;
       bool lambda_bad = false;
       do {
+        if (it > 0 || qmax > 0) SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_set_lambda, dim3(1), dim3(1), 0, ctx->stream, d, lambda));
         if (n > 0) {
-          SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, lambda));
-          SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + CH - 1) / CH), dim3(CH), 0, ctx->stream, d));
+          if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d));
+          SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
+          st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
+          if (st != SSX_OK) return st;
         }
-        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), lds_solve, ctx->stream, d, lambda, cur));
-        SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, lambda, cur));
+        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, ctx->stream, d, cur));
+        if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, cur));
         SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d));
+        st = allreduce(ctx, cm, d.scal_comm, 3);
+        if (st != SSX_OK) return st;
+        SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_publish_trial, dim3(1), dim3(1), 0, ctx->stream, d));
         SSX_HIP_TRY(ctx, hipGetLastError());
         SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the one host round trip of an LM trial
         have_trial_err = true;
+        if (qmax == 0) {
+          currentChi = hscal[SC_CHI2_CUR];
+          if (it == 0) { lambda = hscal[SC_LAMBDA]; ni = 2.0; }
+        }
         const bool ok2 = hscal[SC_SOLVE_OK] != 0.0;
         tempChi = hscal[SC_TEMP_CHI];
-        res->n_outliers = (int)hscal[SC_NOUT];
+        n_out_total = hscal[SC_NOUT];
         if (!ok2) tempChi = std::numeric_limits<double>::max();
         rho = currentChi - tempChi;
         double scale = hscal[SC_SCALE_P] + hscal[SC_SCALE_L];
@@ -1003,10 +1218,22 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
       if (qmax == 10 || rho == 0 || lambda_bad) break;
     }
     res->rounds++;
-    // outlier statistics of this round from the errors of the last evaluated trial (backend.cpp:181-194)
-    const int cnt_out = res->n_outliers, cnt_in = d.E - cnt_out;
-    res->n_inliers = cnt_in;
-    const double ratio = (d.E > 0) ? cnt_in / double(cnt_in + cnt_out) : 1.0;
+    // outlier statistics of this round from the errors of the last evaluated trial (backend.cpp:181-194);
+    // with several ranks n_out_total is already the global count: compare with the global edge count
+    double n_edges_total = (double)d.E;
+    if (cm.fn) {
+      double e_local = (double)d.E;
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(d.scal_comm, &e_local, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // e_local is a stack variable
+      st = allreduce(ctx, cm, d.scal_comm, 1);
+      if (st != SSX_OK) return st;
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(&n_edges_total, d.scal_comm, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const double cnt_out = n_out_total, cnt_in = n_edges_total - cnt_out;
+    res->n_outliers = (int)cnt_out;
+    res->n_inliers = (int)cnt_in;
+    const double ratio = (n_edges_total > 0) ? cnt_in / (cnt_in + cnt_out) : 1.0;
     if (ratio > opt.inlier_ratio) break;
     ++round;
   }
@@ -1021,7 +1248,8 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   const bool want_err = (res->edge_chi2 || res->edge_outlier) && d.E > 0;
   if (want_err) {
     if (!have_trial_err) {   // iters == 0: errors of the input state
-      st = launch_linearize(ctx, d, SSX_JAC_ANALYTIC, cur);
+      Comm none;
+      st = launch_linearize(ctx, d, none, SSX_JAC_ANALYTIC, cur, 0);
       if (st != SSX_OK) return st;
     }
     SSX_HIP_TRY(ctx, hipMemcpyAsync(h_err, have_trial_err ? d.err_trial : d.err_lin, sizeof(double) * 2 * (size_t)d.E,

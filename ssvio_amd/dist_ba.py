@@ -1,0 +1,54 @@
+"""Landmark-sharded multi-GPU bundle adjustment -- host-side plumbing.
+
+One process per GPU under torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).  Rank r owns the
+landmarks {l : l mod world == r} and ALL edges of those landmarks; every pose is replicated.  libssx.so sums three
+small buffers across ranks through the ssx_allreduce_fn hook (include/ssx.h); `make_allreduce_hook` wires that hook
+to torch.distributed.all_reduce on a zero-copy tensor view of the device buffer.  The ctx must run on torch's
+current stream (ssvio_amd.Context(device, stream=torch.cuda.current_stream().cuda_stream) inside a
+`with torch.cuda.stream(s)` block) so that the collective is ordered with the kernels.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_problem(pr: dict, rank: int, world: int) -> dict:
+    """The shard of `pr` (ssvio_amd.synth.make_ba_problem layout) owned by `rank`: landmarks l % world == rank,
+    re-indexed compactly, with all their edges; poses unchanged.  `lm_global` maps local -> global landmark ids."""
+    lm_global = np.nonzero(np.arange(pr["points"].shape[0]) % world == rank)[0]
+    remap = -np.ones(pr["points"].shape[0], dtype=np.int64)
+    remap[lm_global] = np.arange(len(lm_global))
+    keep = remap[pr["edge_point"]] >= 0
+    out = dict(pr)
+    out["L"] = int(len(lm_global))
+    out["points"] = np.ascontiguousarray(pr["points"][lm_global])
+    out["point_fixed"] = None if pr.get("point_fixed") is None else np.ascontiguousarray(pr["point_fixed"][lm_global])
+    out["edge_pose"] = np.ascontiguousarray(pr["edge_pose"][keep])
+    out["edge_point"] = np.ascontiguousarray(remap[pr["edge_point"][keep]].astype(np.int32))
+    out["edge_uv"] = np.ascontiguousarray(pr["edge_uv"][keep])
+    out["edge_cam"] = None if pr.get("edge_cam") is None else np.ascontiguousarray(pr["edge_cam"][keep])
+    out["E"] = int(keep.sum())
+    out["lm_global"] = lm_global
+    out["edge_global"] = np.nonzero(keep)[0]
+    return out
+
+
+def make_allreduce_hook(device, group=None):
+    """-> python callable (user, buf_dev, count, stream) -> 0 that sum-all-reduces `count` doubles in place."""
+    import torch
+    import torch.distributed as dist
+
+    class _Dev:   # zero-copy view of a raw device pointer
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+    def hook(user, buf, count, stream):
+        try:
+            t = torch.as_tensor(_Dev(buf, count), device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            print("ssvio_amd.dist_ba: all_reduce failed:", e, flush=True)
+            return 1
+
+    return hook

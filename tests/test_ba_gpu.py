@@ -118,3 +118,31 @@ def test_ba_errors(ctx):
     r = ba.ba_solve(ctx, empty)
     np.testing.assert_array_equal(r["poses"], pr["poses"])
     np.testing.assert_array_equal(r["points"], pr["points"])
+
+
+def test_allreduce_hook_world1_is_identity(ctx, po):
+    """single GPU, world_size 1: the RCCL hook path (torch.distributed nccl all_reduce on zero-copy views of the
+    library's device buffers, ctx on torch's current stream) must give exactly the plain result."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import ssvio_amd
+    from ssvio_amd import dist_ba
+    pr = make_ba_problem(P=10, L=600, seed=6)
+    plain = ba.ba_solve(ctx, pr)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29733")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        s = torch.cuda.Stream(device="cuda:0")
+        with torch.cuda.stream(s):
+            c2 = ssvio_amd.Context(0, stream=s.cuda_stream)
+            hooked = ba.ba_solve(c2, pr, allreduce=dist_ba.make_allreduce_hook(torch.device("cuda:0")), rank=0, world_size=1)
+            c2.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert np.array_equal(plain["poses"], hooked["poses"]) and np.array_equal(plain["points"], hooked["points"])
+    assert np.array_equal(plain["chi2"], hooked["chi2"]) and np.array_equal(plain["edge_chi2"], hooked["edge_chi2"])
