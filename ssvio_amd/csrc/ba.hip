@@ -50,10 +50,13 @@ namespace {
 using ssx::Cam;
 
 constexpr int CH = 256;            // threads per chunk workgroup
+constexpr int PW = CH + 1;         // padded LDS pitch (doubles) of [component][edge] tiles
 constexpr int CH_E = 255;          // max edges per chunk (chunk-local edge indices fit a byte)
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
 constexpr int NMAX = 6 * SSX_BA_SMALL_P;   // 96 unknowns of the reduced system
+constexpr int MAX_BLK = SSX_BA_SMALL_P * (SSX_BA_SMALL_P + 1) / 2;   // 136 upper blocks
+constexpr int MAX_PAIRS = CH_E * (SSX_BA_SMALL_P + 1) / 2 + 8;       // leader pairs of one chunk (sum k(k+1)/2, k <= 16)
 
 // upper-triangular (r<=c) index tables of a 6x6 block
 __constant__ int8_t c_u6_r[UPPER6] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
@@ -146,7 +149,7 @@ __device__ __forceinline__ double block_max_256(double v, double* s)
 template <int JAC>
 __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
 {
-  __shared__ double sJi[12][CH];      // Jacobian wrt pose, [component][edge] (bank-conflict-free columns)
+  __shared__ double sJi[12][CH + 1];  // Jacobian wrt pose, [component][edge]; odd pitch: rows land on different banks
   __shared__ double sW1[CH], sR0[CH], sR1[CH];
   __shared__ double sL[9][CH];        // per-edge landmark contributions (6 Hll + 3 bl)
   __shared__ double sRed[CH];
@@ -254,49 +257,43 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   }
 }
 
-// slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|.  ONE workgroup of 1024 threads: entry e is summed by
-// 1 or 2 "lanes" striding over the chunks, combined in a fixed order (deterministic for a given nCh).
+// slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|: 16 chunk-lanes per entry, 16 entries per 256-thread
+// workgroup, combined by a fixed tree (deterministic for a given nCh); workgroup 0 also reduces chi2 / max-diagonal.
 // (computeLambdaInit, optimization_algorithm_levenberg.cpp:152-166, wants the max over pose AND landmark
 // diagonals; with several ranks the pose diagonals need the all-reduced Hpp, see k_lambda_init.)
-__global__ __launch_bounds__(1024) void k_reduce_lin(BaDev d)
+__global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d)
 {
-  __shared__ double sAcc[1024];
+  __shared__ double sAcc[CH];
   const int t = threadIdx.x;
   const int n = d.nP * 27;
   const int stride = n + 2;
-  const int lanes = (n * 2 <= 1024) ? 2 : 1;
-  const int ent = t / lanes, ln = t - ent * lanes;
+  const int ent = blockIdx.x * 16 + (t >> 4), ln = t & 15;
   double acc = 0.0;
   if (ent < n)
-    for (int c = ln; c < d.nCh; c += lanes) acc += d.lin_slab[(size_t)c * stride + ent];
+    for (int c = ln; c < d.nCh; c += 16) acc += d.lin_slab[(size_t)c * stride + ent];
   sAcc[t] = acc;
   __syncthreads();
+  for (int o = 8; o > 0; o >>= 1) { if (ln < o) sAcc[t] += sAcc[t + o]; __syncthreads(); }
   if (ent < n && ln == 0) {
-    double v = sAcc[t];
-    if (lanes == 2) v += sAcc[t + 1];
+    const double v = sAcc[t];
     const int p = ent / 27, k = ent - p * 27;
     if (k < UPPER6) { d.Hpp[p * UPPER6 + k] = v; d.iter_comm[p * UPPER6 + k] = v; }
     else { d.bp[p * 6 + (k - UPPER6)] = v; d.iter_comm[d.nP * UPPER6 + p * 6 + (k - UPPER6)] = v; }
   }
+  if (blockIdx.x != 0) return;
   __syncthreads();
-  // chi2 (sum) and landmark max-diagonal (max) over the chunks: fixed tree over 1024 lanes
   double chi = 0.0, md = 0.0;
-  for (int c = t; c < d.nCh; c += 1024) {
+  for (int c = t; c < d.nCh; c += CH) {
     chi += d.lin_slab[(size_t)c * stride + n];
     md = fmax(md, d.lin_slab[(size_t)c * stride + n + 1]);
   }
-  sAcc[t] = chi;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) { if (t < o) sAcc[t] += sAcc[t + o]; __syncthreads(); }
-  const double chi_tot = sAcc[0];
-  __syncthreads();
-  sAcc[t] = md;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) { if (t < o) sAcc[t] = fmax(sAcc[t], sAcc[t + o]); __syncthreads(); }
+  chi = block_sum_256(chi, sAcc);
+  md = block_max_256(md, sAcc);
   if (t == 0) {
     double* tail = d.iter_comm + d.nP * 27;
-    tail[0] = chi_tot;
-    for (int r = 0; r < d.world; ++r) tail[1 + r] = (r == d.rank) ? sAcc[0] : 0.0;
+    tail[0] = chi;
+    for (int r = 0; r < d.world; ++r) tail[1 + r] = (r == d.rank) ? md : 0.0;
+    d.scal[SC_CHI2_CUR] = chi;     // final on a single GPU; k_lambda_init overwrites it after an all-reduce
   }
 }
 
@@ -325,21 +322,26 @@ __global__ void k_set_lambda(BaDev d, double lambda)
 // restates the marginalisation loop of BlockSolver::solve (block_solver.hpp:342-393):
 //   Dinv = (Hll + lambda I)^-1 ; c_i += W_i Dinv bl ; S_ij -= (W_i Dinv) W_j^T  (upper blocks)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CH) void k_schur(BaDev d)
+__global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int use_dev_lambda)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* sW = reinterpret_cast<double*>(smem);            // [18][CH]
-  double* sBD = sW + 18 * CH;                              // [18][CH]
-  double* sC = sBD + 18 * CH;                              // [6][CH]
-  double* sDinv = sC + 6 * CH;                             // [9][CH] per landmark
-  double* sDb = sDinv + 9 * CH;                            // [3][CH]
-  int* sLm = reinterpret_cast<int*>(sDb + 3 * CH);         // [CH] local landmark of each edge
+  // pitch PW = CH + 1 doubles: the owned-entry loops read [component][edge] with the component varying across
+  // lanes -- an even pitch would put all components on the same LDS bank
+  double* sW = reinterpret_cast<double*>(smem);            // [18][PW]
+  double* sBD = sW + 18 * PW;                              // [18][PW]
+  double* sC = sBD + 18 * PW;                              // [6][PW]
+  double* sDinv = sC + 6 * PW;                             // [9][PW] per landmark
+  double* sDb = sDinv + 9 * PW;                            // [3][PW]
+  int* sLm = reinterpret_cast<int*>(sDb + 3 * PW);         // [CH] local landmark of each edge
   uint8_t* sLeader = reinterpret_cast<uint8_t*>(sLm + CH); // [CH]
   uint8_t* sOrd = sLeader + CH;                            // [CH]
-  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sOrd + CH);// [SSX_BA_SMALL_P + 1]
+  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sOrd + CH);// [SSX_BA_SMALL_P + 2]
+  int* sBptr = reinterpret_cast<int*>(sPptr + SSX_BA_SMALL_P + 2);   // [MAX_BLK + 1] pair offsets of each block
+  uint8_t* sPa = reinterpret_cast<uint8_t*>(sBptr + MAX_BLK + 1);    // [MAX_PAIRS]
+  uint8_t* sPb = sPa + MAX_PAIRS;                                    // [MAX_PAIRS]
 
   const int c = blockIdx.x, t = threadIdx.x;
-  const double lambda = d.scal[SC_LAMBDA];
+  const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
   const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
   const int ne = e1 - e0, nl = lm1 - lm0;
@@ -348,10 +350,17 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d)
   bool leader = false;
   if (t < ne) sOrd[t] = d.porder[e0 + t];
   if (t <= nP) sPptr[t] = d.pptr[(size_t)c * (nP + 1) + t];
+  {
+    // the chunk's (edge a, edge b) pairs grouped by block: global -> LDS once, coalesced
+    const int* gp = d.pair_ptr + (size_t)c * (d.nBlk + 1);
+    const int q_base = gp[0], q_end = gp[d.nBlk];
+    for (int i = t; i <= d.nBlk; i += CH) sBptr[i] = gp[i] - q_base;
+    for (int q = t; q < q_end - q_base; q += CH) { sPa[q] = d.pair_a[q_base + q]; sPb[q] = d.pair_b[q_base + q]; }
+  }
   if (t < ne) {
     const int e = e0 + t;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) sW[k * CH + t] = d.W[(size_t)k * d.E + e];
+    for (int k = 0; k < 18; ++k) sW[k * PW + t] = d.W[(size_t)k * d.E + e];
     const int lc = d.e_lmc[e];
     sLm[t] = lc - lm0;
     const int pf = d.pose_free[d.e_pose[e]];
@@ -367,26 +376,26 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d)
     ssx::inv3_sym(D, Di);
     const double b0 = d.bl[lc], b1 = d.bl[(size_t)d.nLm + lc], b2 = d.bl[(size_t)2 * d.nLm + lc];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) sDinv[k * CH + t] = Di[k];
+    for (int k = 0; k < 9; ++k) sDinv[k * PW + t] = Di[k];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) sDb[r * CH + t] = Di[r * 3] * b0 + Di[r * 3 + 1] * b1 + Di[r * 3 + 2] * b2;
+    for (int r = 0; r < 3; ++r) sDb[r * PW + t] = Di[r * 3] * b0 + Di[r * 3 + 1] * b1 + Di[r * 3 + 2] * b2;
   }
   __syncthreads();
   if (leader) {
     // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
     for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j)
 #pragma unroll
-      for (int k = 0; k < 18; ++k) sW[k * CH + t] += sW[k * CH + j];
+      for (int k = 0; k < 18; ++k) sW[k * PW + t] += sW[k * PW + j];
     const int l = sLm[t];
     double Di[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Di[k] = sDinv[k * CH + l];
+    for (int k = 0; k < 9; ++k) Di[k] = sDinv[k * PW + l];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const double w0 = sW[(a * 3) * CH + t], w1 = sW[(a * 3 + 1) * CH + t], w2 = sW[(a * 3 + 2) * CH + t];
+      const double w0 = sW[(a * 3) * PW + t], w1 = sW[(a * 3 + 1) * PW + t], w2 = sW[(a * 3 + 2) * PW + t];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) sBD[(a * 3 + b) * CH + t] = w0 * Di[b] + w1 * Di[3 + b] + w2 * Di[6 + b];
-      sC[a * CH + t] = w0 * sDb[l] + w1 * sDb[CH + l] + w2 * sDb[2 * CH + l];
+      for (int b = 0; b < 3; ++b) sBD[(a * 3 + b) * PW + t] = w0 * Di[b] + w1 * Di[3 + b] + w2 * Di[6 + b];
+      sC[a * PW + t] = w0 * sDb[l] + w1 * sDb[PW + l] + w2 * sDb[2 * PW + l];
     }
   }
   __syncthreads();
@@ -394,16 +403,15 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d)
   // owned entries of the reduced system: each walks the (edge a, edge b) pairs of ITS block, landmark order
   double* slab = d.schur_slab + (size_t)c * (d.nBlk * 36 + nP * 6);
   const int nS = d.nBlk * 36;
-  const int* pptr = d.pair_ptr + (size_t)c * (d.nBlk + 1);
   for (int idx = t; idx < nS; idx += CH) {
     const int blk = idx / 36, rc = idx - blk * 36;
     const int r = rc / 6, cc = rc - r * 6;
-    const int q0 = pptr[blk], q1 = pptr[blk + 1];
+    const int q0 = sBptr[blk], q1 = sBptr[blk + 1];
     double acc = 0.0;
     for (int q = q0; q < q1; ++q) {
-      const int ea = d.pair_a[q], eb = d.pair_b[q];
-      acc += sBD[(r * 3) * CH + ea] * sW[(cc * 3) * CH + eb] + sBD[(r * 3 + 1) * CH + ea] * sW[(cc * 3 + 1) * CH + eb] +
-             sBD[(r * 3 + 2) * CH + ea] * sW[(cc * 3 + 2) * CH + eb];
+      const int ea = sPa[q], eb = sPb[q];
+      acc += sBD[(r * 3) * PW + ea] * sW[(cc * 3) * PW + eb] + sBD[(r * 3 + 1) * PW + ea] * sW[(cc * 3 + 1) * PW + eb] +
+             sBD[(r * 3 + 2) * PW + ea] * sW[(cc * 3 + 2) * PW + eb];
     }
     slab[idx] = acc;
   }
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d)
     double acc = 0.0;
     for (int s = sPptr[p]; s < sPptr[p + 1]; ++s) {
       const int j = sOrd[s];
-      if (sLeader[j]) acc += sC[a * CH + j];
+      if (sLeader[j]) acc += sC[a * PW + j];
     }
     slab[nS + idx] = acc;
   }
@@ -463,25 +471,31 @@ __global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d)
 // then the pose update T <- exp(x) T into the trial buffer (SparseOptimizer::update,
 // sparse_optimizer.cpp:433-446) and the pose part of computeScale (optimization_algorithm_levenberg.cpp:168-175).
 //
-// LDL^T, right-looking, register-tiled: the 256 threads form a 16x16 grid and thread (ty,tx) keeps the entries
-// (i,k) with i = ty (mod 16), k = tx (mod 16) of the matrix AUGMENTED with the right-hand side as row n, so the
-// elimination also performs the forward substitution (row n ends up holding w = D^-1 L^-1 b).  One barrier per
-// column (double-buffered column broadcast through LDS).  The backward substitution L^T x = w is done by ONE
-// wave with the running solution in registers and v_readlane broadcasts (no barrier in the dependent chain).
+// LDL^T, right-looking, BLOCKED by pose (6 columns per step), register-tiled: the 256 threads form a 16x16 grid
+// and thread (ty,tx) keeps the entries (i,k) with i = ty (mod 16), k = tx (mod 16) of the matrix AUGMENTED with
+// the right-hand side as row n, so the elimination also performs the forward substitution (row n ends up holding
+// w = D^-1 L^-1 b).  Per block step: the raw 6-column panel goes to LDS; every thread factors the 6x6 diagonal
+// block redundantly in registers (no communication), one thread per row solves its 6 panel entries; then every
+// thread applies the rank-6 update to its entries.  Two barriers per pose block (instead of one per column).
+// The backward substitution L^T x = w is done by ONE wave with the running solution in registers and
+// v_readlane broadcasts (no barrier in the dependent chain).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_solve(BaDev d, int cur)
+__global__ __launch_bounds__(256) void k_solve(BaDev d, int cur, double lambda_arg, int use_dev_lambda)
 {
-  __shared__ double sCol[2][NMAX + 8];
+  constexpr int BS = 6;
+  __shared__ double sPan[(NMAX + 2) * BS];      // raw panel rows j0..n
+  __shared__ double sLp[(NMAX + 2) * BS];       // L panel
+  __shared__ double sLD[(NMAX + 2) * BS];       // L panel times D
   __shared__ double sL[NMAX * (NMAX + 1)];      // L (row-major, pitch n+1) for the backward substitution
   __shared__ double sWv[NMAX + 8];
   __shared__ double sX[NMAX + 8];
-  __shared__ int sOk;
   const int n = 6 * d.nP;
   const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-  const double lambda = d.scal[SC_LAMBDA];
+  const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const double* S = d.trial_comm;
   const double* bs = d.trial_comm + (size_t)n * n;
   constexpr int RA = NMAX / 16 + 1, RB = NMAX / 16;     // rows incl. the rhs row, columns
+  const long long st0 = wall_clock64();
   double R[RA][RB];
 #pragma unroll
   for (int a = 0; a < RA; ++a)
@@ -495,43 +509,107 @@ __global__ __launch_bounds__(256) void k_solve(BaDev d, int cur)
       }
       R[a][b] = v;
     }
-  if (t == 0) sOk = 1;
-  __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    double* col = sCol[j & 1];
-    const int bj = j >> 4;
-    if (tx == (j & 15)) {
+  int ok = 1;
+  const long long st1 = wall_clock64();
+  for (int bstep = 0; bstep < d.nP; ++bstep) {
+    const int j0 = BS * bstep, j1 = j0 + BS;
+    // 1. publish the raw panel (lower part: i >= k) 
 #pragma unroll
-      for (int a = 0; a < RA; ++a) {
-        const int i = ty + 16 * a;
-        if (i >= j && i <= n) {
-          double v = 0.0;
+    for (int b = 0; b < RB; ++b) {
+      const int k = tx + 16 * b;
+      if (k >= j0 && k < j1) {
 #pragma unroll
-          for (int b = 0; b < RB; ++b) if (b == bj) v = R[a][b];
-          col[i] = v;
+        for (int a = 0; a < RA; ++a) {
+          const int i = ty + 16 * a;
+          if (i >= k && i <= n) sPan[i * BS + (k - j0)] = R[a][b];
         }
       }
     }
     __syncthreads();
-    const double dj = col[j];
-    if (!(dj > 0.0) || !isfinite(dj)) { if (t == 0) sOk = 0; break; }   // uniform: every thread reads the same pivot
-    const double rinv = 1.0 / dj;
+    // 2. factor the diagonal block (every thread, redundantly: identical arithmetic, identical result)
+    double Lb[BS][BS], D[BS], Dinv[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      double dc = sPan[(j0 + c) * BS + c];
+#pragma unroll
+      for (int m = 0; m < c; ++m) dc -= Lb[c][m] * Lb[c][m] * D[m];
+      D[c] = dc;
+      if (!(dc > 0.0) || !isfinite(dc)) ok = 0;
+      const double rinv = 1.0 / dc;
+      Dinv[c] = rinv;
+#pragma unroll
+      for (int r = c + 1; r < BS; ++r) {
+        double v = sPan[(j0 + r) * BS + c];
+#pragma unroll
+        for (int m = 0; m < c; ++m) v -= Lb[r][m] * Lb[c][m] * D[m];
+        Lb[r][c] = v * rinv;
+      }
+    }
+    if (!ok) break;      // uniform: every thread factored the same block
+    // one thread per row below the diagonal block (incl. the rhs row): its 6 entries of L
+    {
+      const int i = j1 + t;
+      if (i <= n) {
+        double l[BS];
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+          double v = sPan[i * BS + c];
+#pragma unroll
+          for (int m = 0; m < c; ++m) v -= l[m] * D[m] * Lb[c][m];
+          l[c] = v * Dinv[c];
+          sLp[i * BS + c] = l[c];
+          sLD[i * BS + c] = l[c] * D[c];
+        }
+      }
+    }
+    __syncthreads();
+    // 3. rank-6 update of the trailing entries; the panel columns become final (store L)
+    double lpk[RB][BS];      // L rows of this thread's columns, loaded once per block step
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const int k = tx + 16 * b;
+#pragma unroll
+      for (int c = 0; c < BS; ++c) lpk[b][c] = (k >= j1 && k < n) ? sLp[k * BS + c] : 0.0;
+    }
 #pragma unroll
     for (int a = 0; a < RA; ++a) {
       const int i = ty + 16 * a;
-      if (i > j && i <= n) {
-        const double li = col[i] * rinv;            // L[i][j]  (row n: w_j)
+      if (i < j0 || i > n) continue;
+      double ld[BS];
+      if (i >= j1) {
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-          const int k = tx + 16 * b;
-          if (k > j && k <= i && k < n) R[a][b] -= li * col[k];
-          else if (k == j) R[a][b] = li;            // column j is final: keep L
+        for (int c = 0; c < BS; ++c) ld[c] = sLD[i * BS + c];
+      }
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        const int k = tx + 16 * b;
+        if (k >= n) continue;
+        if (k >= j1) {
+          if (i >= j1 && k <= i) {
+            double acc = R[a][b];
+#pragma unroll
+            for (int c = 0; c < BS; ++c) acc -= ld[c] * lpk[b][c];
+            R[a][b] = acc;
+          }
+        } else if (k >= j0 && i > k) {
+          // final L entry of the panel
+          double v;
+          if (i >= j1) v = sLp[i * BS + (k - j0)];
+          else {
+            v = 0.0;
+#pragma unroll
+            for (int r = 1; r < BS; ++r)
+#pragma unroll
+              for (int c = 0; c < r; ++c)
+                if (r == i - j0 && c == k - j0) v = Lb[r][c];
+          }
+          R[a][b] = v;
         }
       }
     }
   }
   __syncthreads();
-  const int ok = sOk;
+  const long long st2 = wall_clock64();
   // spill L and w to LDS for the backward substitution
   const int ld = n + 1;
 #pragma unroll
@@ -566,6 +644,7 @@ __global__ __launch_bounds__(256) void k_solve(BaDev d, int cur)
     if (t + 64 < n) { sX[t + 64] = x1; d.xp[t + 64] = x1; }
   }
   __syncthreads();
+  const long long st3 = wall_clock64();
   // pose update into the trial buffer
   const double* src = d.pose[cur];
   double* dst = d.pose[cur ^ 1];
@@ -592,6 +671,9 @@ __global__ __launch_bounds__(256) void k_solve(BaDev d, int cur)
     for (int j = 0; j < n; ++j) s += sX[j] * (lambda * sX[j] + bp_g[j]);
     d.scal[SC_SOLVE_OK] = ok ? 1.0 : 0.0;
     d.scal[SC_SCALE_P] = s;
+    const long long st4 = wall_clock64();
+    // phase stamps (100 MHz wall clock ticks): load, factor, spill+backsub, pose update+scale
+    d.scal[8] = (double)(st1 - st0); d.scal[9] = (double)(st2 - st1); d.scal[10] = (double)(st3 - st2); d.scal[11] = (double)(st4 - st3);
   }
 }
 
@@ -600,12 +682,12 @@ __global__ __launch_bounds__(256) void k_solve(BaDev d, int cur)
 // residuals / robust chi2 of the TRIAL state (computeActiveErrors + activeRobustChi2,
 // sparse_optimizer.cpp:63-116).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur)
+__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, double lambda_arg, int use_dev_lambda)
 {
   __shared__ double sPt[3][CH];
   __shared__ double sRed[CH];
   const int c = blockIdx.x, t = threadIdx.x;
-  const double lambda = d.scal[SC_LAMBDA];
+  const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
   const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
   const int ne = e1 - e0, nl = lm1 - lm0;
@@ -690,6 +772,10 @@ __global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d)
     d.scal_comm[0] = chi;
     d.scal_comm[1] = sl;
     d.scal_comm[2] = no;
+    // single GPU: these are final (with a collective hook k_publish_trial copies the all-reduced values)
+    d.scal[SC_TEMP_CHI] = chi;
+    d.scal[SC_SCALE_L] = sl;
+    d.scal[SC_NOUT] = no;
   }
 }
 
@@ -1000,7 +1086,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
 
 size_t schur_lds_bytes()
 {
-  return sizeof(double) * (18 + 18 + 6 + 9 + 3) * CH + sizeof(int) * CH + 2 * CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) + 64;
+  return sizeof(double) * (18 + 18 + 6 + 9 + 3) * PW + sizeof(int) * CH + 2 * CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) +
+         sizeof(int) * (MAX_BLK + 1) + 2 * MAX_PAIRS + 64;
 }
 
 struct Comm {
@@ -1025,10 +1112,12 @@ ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, const Comm& cm, int ja
     if (jac == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
     else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
   }
-  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(1), dim3(1024), 0, ctx->stream, d));
+  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 15) / 16)), dim3(CH), 0, ctx->stream, d));
   ssx_status st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
   if (st != SSX_OK) return st;
-  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_iteration));
+  // lambda_0 (first iteration of a round) and, after a collective, the global chi2
+  if (first_iteration || cm.fn)
+    SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_iteration));
   SSX_HIP_TRY(ctx, hipGetLastError());
   return SSX_OK;
 }
@@ -1166,27 +1255,31 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
       int qmax = 0;
       bool lambda_bad = false;
       do {
-        if (it > 0 || qmax > 0) SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_set_lambda, dim3(1), dim3(1), 0, ctx->stream, d, lambda));
+        // lambda: known to the host except on the very first trial of a round, where k_lambda_init left it on the device
+        const int dev_lambda = (it == 0 && qmax == 0) ? 1 : 0;
         if (n > 0) {
-          if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d));
+          if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, lambda, dev_lambda));
           SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
           st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
           if (st != SSX_OK) return st;
         }
-        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, ctx->stream, d, cur));
-        if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, cur));
+        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, ctx->stream, d, cur, lambda, dev_lambda));
+        if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
         SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d));
-        st = allreduce(ctx, cm, d.scal_comm, 3);
-        if (st != SSX_OK) return st;
-        SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_publish_trial, dim3(1), dim3(1), 0, ctx->stream, d));
+        if (cm.fn) {
+          st = allreduce(ctx, cm, d.scal_comm, 3);
+          if (st != SSX_OK) return st;
+          SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_publish_trial, dim3(1), dim3(1), 0, ctx->stream, d));
+        }
         SSX_HIP_TRY(ctx, hipGetLastError());
-        SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 12, hipMemcpyDeviceToHost, ctx->stream));
         SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the one host round trip of an LM trial
         have_trial_err = true;
         if (qmax == 0) {
           currentChi = hscal[SC_CHI2_CUR];
           if (it == 0) { lambda = hscal[SC_LAMBDA]; ni = 2.0; }
         }
+        if (getenv("SSX_DEBUG_STAMPS")) fprintf(stderr, "k_solve ticks: load %.0f factor %.0f spill+backsub %.0f update %.0f | chi2cur %.6f maxdiag %.6e lambda_dev %.6e ok %.0f tempchi %.6f\n", hscal[8], hscal[9], hscal[10], hscal[11], hscal[0], hscal[1], hscal[7], hscal[2], hscal[4]);
         const bool ok2 = hscal[SC_SOLVE_OK] != 0.0;
         tempChi = hscal[SC_TEMP_CHI];
         n_out_total = hscal[SC_NOUT];
