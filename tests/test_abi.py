@@ -75,3 +75,30 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"#\s*include[^\n]*oracle|\bpyoracle\b|liboracle|from oracle|import oracle|libssvio_ref|dlopen", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_cpp_shim_compiles_and_links():
+    """include/ssx_shim.hpp (the C++ wrappers with the reference's method names) compiles against ssx.h and links
+    against libssx.so with plain g++ -- what a maintainer of ssvio would do."""
+    from ssvio_amd import build
+    lib = build.build()
+    src = r'''
+#include "ssx_shim.hpp"
+int main(int argc, char**) {
+  if (argc > 100) {   // never executed here (no GPU): only has to compile and link
+    ssx::Context ctx(0);
+    ssx::ORBextractor ex(ctx, 2000, 1.2f, 8, 20, 7);
+    std::vector<ssx_keypoint> k; std::vector<uint8_t> d;
+    ex.DetectAndCompute(nullptr, 0, 0, 0, nullptr, 0, k, d);
+    ssx::BundleAdjuster ba(ctx);
+    ssx_stereo_rig rig{718.856, 718.856, 607.1928, 185.2157, 0.537};
+    ssx::StereoFrontEnd fe(ctx, ex.params(), rig);
+  }
+  return ssx_version() == SSX_VERSION ? 0 : 1;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.cpp"), lib,
+                               "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+        assert subprocess.call([exe]) == 0
