@@ -153,6 +153,20 @@ SSX_API ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, do
 
 
 /* ------------------------------------------------------------------------------------------------
+ * Pose-only robust optimisation -- replaces the g2o part of FrontEnd::EstimateCurrentPose
+ * (src/ssvio/frontend.cpp:184-270): one VertexPose, EdgeProjectionPoseOnly per tracked map point
+ * (include/ssvio/g2otypes.hpp:67-110), Huber delta 1.0 (g2o default), `rounds` x optimize(`iters`) with
+ * chi2 > chi2_th => outlier after every round and the robust kernels dropped before the last round.
+ * The whole procedure (all rounds, iterations, LM trials) is ONE kernel launch.
+ *   pose_io: initial estimate in, result out;  xyz: M x 3 map points;  uv: M x 2 measured pixels (cv::Point2f
+ *   widened to double);  inlier_out[i] = 1 if the feature ends as inlier;  *n_inliers = features.size() - outliers.
+ *   Reference defaults: rounds 4, iters 10, chi2_th 5.991, huber_delta 1.0.
+ * ------------------------------------------------------------------------------------------------ */
+SSX_API ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const double* K4, int32_t M, const double* xyz,
+                                     const double* uv, int32_t rounds, int32_t iters, double chi2_th,
+                                     double huber_delta, uint8_t* inlier_out, int32_t* n_inliers);
+
+/* ------------------------------------------------------------------------------------------------
  * ORB extraction -- replaces the bodies of ssvio::ORBextractor::Detect / DetectAndCompute
  * (include/ssvio/orbextractor.hpp:50-59, src/ssvio/orbextractor.cpp:755-842, 687-753) and everything
  * they call: cv::FAST per grid cell, DistributeOctTree, ComputePyramid (cv::resize), IC_Angle
@@ -184,6 +198,14 @@ SSX_API ssx_status ssx_orb_detect(ssx_ctx* ctx, const uint8_t* img, int32_t stri
 SSX_API ssx_status ssx_orb_extract(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
                                    const uint8_t* mask, int32_t mask_stride, const ssx_orb_params* prm,
                                    int32_t cap, ssx_keypoint* kps_out, uint8_t* desc_out, int32_t* n);
+
+/* ORBextractor::ScreenAndComputeKPsParams + CalcDescriptors (orbextractor.hpp:54-55,69-71; the loop-closing use,
+ * src/ssvio/loopclosing.cpp:622-629): keypoints are GIVEN (level-0 position + octave); those at least 19 px inside
+ * their pyramid level that pass the FAST segment test at minThFAST are kept (input order), get angle / size, and
+ * are described on the blurred level.  kps_out / desc_out need capacity n_in. */
+SSX_API ssx_status ssx_orb_describe_at(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
+                                       const ssx_orb_params* prm, const ssx_keypoint* kps_in, int32_t n_in,
+                                       ssx_keypoint* kps_out, uint8_t* desc_out, int32_t* n);
 
 /* Parity / profiling hooks: copies of intermediate buffers of the LAST ssx_orb_extract / ssx_orb_detect /
  * ssx_stereo_* call on this ctx, image `image` of that call (0 = left / only image, 1 = right ...).

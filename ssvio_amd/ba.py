@@ -80,3 +80,19 @@ def ba_linearize(ctx: Context, pr, huber_delta=5.891, jac_mode=JAC_ANALYTIC):
                                        ptr(Hpp, dbl_p), ptr(bp, dbl_p), ptr(Hll, dbl_p), ptr(bl, dbl_p),
                                        ptr(Hpl, dbl_p), ptr(err, dbl_p), C.byref(chi)))
     return dict(Hpp=Hpp, bp=bp, Hll=Hll, bl=bl, Hpl=Hpl, err=err, chi2=chi.value)
+
+
+def pose_only_opt(ctx: Context, pose, K, xyz, uv, rounds=4, iters=10, chi2_th=5.991, huber_delta=1.0):
+    """FrontEnd::EstimateCurrentPose's optimisation (frontend.cpp:184-270) in one kernel launch.
+    -> dict(pose, inliers (uint8 per feature), n_inliers)."""
+    pose = np.ascontiguousarray(pose, dtype=np.float64).copy()
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+    M = xyz.shape[0]
+    inl = np.zeros(M, dtype=np.uint8)
+    n = C.c_int32(0)
+    ctx.check(ctx.lib.ssx_pose_only_opt(ctx.handle, ptr(pose, dbl_p), ptr(K, dbl_p), M, ptr(xyz, dbl_p), ptr(uv, dbl_p),
+                                        rounds, iters, C.c_double(chi2_th), C.c_double(huber_delta), ptr(inl, u8_p),
+                                        C.byref(n)))
+    return dict(pose=pose, inliers=inl, n_inliers=n.value)

@@ -51,6 +51,8 @@ void ssx_ctx_destroy(ssx_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ba && ctx->ba_free) ctx->ba_free(ctx->ba);
   if (ctx->orb && ctx->orb_free) ctx->orb_free(ctx->orb);
+  ctx->po_arena.release();
+  ctx->po_stage.release();
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }

@@ -130,6 +130,8 @@ struct ssx_ctx {
   hipStream_t aux = nullptr;                 // second stream: independent stages overlap (blur || detect)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   SsxProf prof;
+  DevBuf po_arena;                           // pose-only optimisation scratch
+  HostBuf po_stage;
 
   void set_error(const char* fmt, ...)
   {

@@ -520,6 +520,101 @@ __global__ __launch_bounds__(256) void k_brief(OrbDev o)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// A8: ORBextractor::ScreenAndComputeKPsParams (orbextractor.cpp:844-894) + CalcDescriptors (:943-991), the
+// loop-closing variant: keypoints GIVEN (position at level 0, octave), keep those that are >= 19 px inside their
+// level and pass the FAST segment test at minThFAST, then orientation + size + descriptor.  One wave per keypoint.
+// ------------------------------------------------------------------------------------------------
+struct DescribeAt {
+  const ssx_keypoint* in;   // n_in
+  ssx_keypoint* out;        // n_in (valid where keep)
+  uint8_t* desc;            // n_in x 32
+  uint8_t* keep;            // n_in
+  int n_in;
+};
+
+__global__ __launch_bounds__(256) void k_describe_at(OrbDev o, DescribeAt a)
+{
+  __shared__ uint8_t sPatch[4][BP * 40];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + wave;
+  bool active = k < a.n_in;
+  ssx_keypoint kp{};
+  int level = 0, cx = 0, cy = 0;
+  float sc = 1.f;
+  if (active) {
+    kp = a.in[k];
+    level = kp.octave;
+    active = level >= 0 && level < o.nlevels;
+  }
+  if (active) {
+    sc = o.scale[level];
+    kp.x = kp.x / sc; kp.y = kp.y / sc;                       // kps.pt /= scale
+    const int rows = o.lvl_rows[level], cols = o.lvl_cols[level];
+    active = (kp.y - EDGE_THRESHOLD >= 0 && kp.y + EDGE_THRESHOLD < rows && kp.x - EDGE_THRESHOLD >= 0 &&
+              kp.x + EDGE_THRESHOLD < cols);
+    cx = __float2int_rn(kp.x); cy = __float2int_rn(kp.y);     // cvRound
+  }
+  const uint8_t* lvl = o.pyr + o.lvl_off[level];
+  const int pitch = o.lvl_pitch[level];
+  if (active) active = fast_score(lvl + (size_t)cy * pitch + cx, pitch, min(max(o.min_th, 0), 255)) >= 0;   // isFastCorner
+  uint8_t* sp = sPatch[wave];
+  // orientation patch (raw level)
+  if (active)
+    for (int i = lane; i < 31 * 32; i += 64) {
+      const int r = i >> 5, cc = i & 31;
+      if (cc < 31) sp[i] = lvl[(size_t)(cy - 15 + r) * pitch + (cx - 15 + cc)];
+    }
+  __syncthreads();
+  float angle = 0.f;
+  if (active) {
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+      const int v = lane - 15;
+      const int dmax = c_umax[v < 0 ? -v : v];
+      int sum = 0;
+      for (int u = -dmax; u <= dmax; ++u) { const int val = sp[lane * 32 + (u + 15)]; m10 += u * val; sum += val; }
+      m01 = v * sum;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
+    angle = fast_atan2_deg((float)m01, (float)m10);
+  }
+  __syncthreads();
+  // CalcDescriptors: pt (already multiplied back by scale) is divided by scale AGAIN before describing
+  float ox = kp.x * sc, oy = kp.y * sc;                        // kps.pt *= scale  (the output coordinates)
+  const float dx = ox / sc, dy = oy / sc;
+  const int bx = __float2int_rn(dx), by = __float2int_rn(dy);
+  const uint8_t* blur = o.blur + o.lvl_off[level];
+  if (active)
+    for (int i = lane; i < BP * 40; i += 64) {
+      const int r = i / 40, cc = i - r * 40;
+      if (cc < BP) sp[i] = blur[(size_t)(by - BR + r) * pitch + (bx - BR + cc)];
+    }
+  __syncthreads();
+  if (!active) { if (k < a.n_in && lane == 0) a.keep[k] = 0; return; }
+  float ca, sb;
+  sincos_deg(angle, &ca, &sb);
+  unsigned long long words[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int8_t* tp = &c_pattern[(j * 64 + lane) * 4];
+    const float x0 = (float)tp[0], y0 = (float)tp[1], x1 = (float)tp[2], y1 = (float)tp[3];
+    const int r0 = __float2int_rn(x0 * sb + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sb);
+    const int r1 = __float2int_rn(x1 * sb + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sb);
+    words[j] = __ballot(sp[(r0 + BR) * 40 + (c0 + BR)] < sp[(r1 + BR) * 40 + (c1 + BR)]);
+  }
+  if (lane < 4) reinterpret_cast<unsigned long long*>(a.desc + (size_t)k * 32)[lane] = words[lane];
+  if (lane == 0) {
+    ssx_keypoint okp = kp;
+    okp.x = ox; okp.y = oy;
+    okp.angle = angle;
+    okp.size = 31 * sc;           // PATCH_SIZE * mvScaleFactor[level]  (float, :888)
+    a.out[k] = okp;
+    a.keep[k] = 1;
+  }
+}
+
 // ORBextractor::Detect output: octree selection of level 0 + border, size 7, angle -1, octave 0 (cv::FAST keypoints)
 __global__ __launch_bounds__(256) void k_finalize_detect(OrbDev o)
 {
@@ -889,6 +984,64 @@ ssx_status ssx_orb_extract(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int
   ssx_status st = run_host_image(ctx, img, stride, rows, cols, mask, mask_stride, *prm, false);
   if (st != SSX_OK) return st;
   return fetch_image_result(ctx, 0, cap, kps_out, desc_out, n);
+}
+
+ssx_status ssx_orb_describe_at(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
+                               const ssx_orb_params* prm, const ssx_keypoint* kps_in, int32_t n_in, ssx_keypoint* kps_out,
+                               uint8_t* desc_out, int32_t* n)
+{
+  if (!ctx || !prm || !n) return SSX_ERR_INVALID_ARG;
+  *n = 0;
+  if (!img || rows <= 0 || cols <= 0 || n_in <= 0 || !kps_in) return SSX_OK;   // LOG(ERROR) + return in the reference
+  ssx_status st = plan(ctx, rows, cols, 1, *prm, false, false);
+  if (st != SSX_OK) return st;
+  OrbWorkspace* ws = get_ws(ctx);
+  const OrbDev& d = ws->dev;
+  const size_t bytes = (size_t)rows * cols;
+  Layout lay;
+  const size_t o_img = lay.take(bytes);
+  const size_t o_in = lay.take(sizeof(ssx_keypoint) * (size_t)n_in);
+  const size_t in_bytes = lay.off;
+  const size_t o_out = lay.take(sizeof(ssx_keypoint) * (size_t)n_in);
+  const size_t o_desc = lay.take((size_t)32 * n_in);
+  const size_t o_keep = lay.take((size_t)n_in);
+  SSX_HIP_TRY(ctx, ws->input.reserve(lay.off));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(lay.off));
+  char* hs = ws->stage.as<char>();
+  for (int y = 0; y < rows; ++y) memcpy(hs + o_img + (size_t)y * cols, img + (size_t)y * stride, cols);
+  memcpy(hs + o_in, kps_in, sizeof(ssx_keypoint) * n_in);
+  char* base = ws->input.as<char>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  st = stage_level0(ctx, (const uint8_t*)(base + o_img), cols, bytes, nullptr, 0, 0);
+  if (st != SSX_OK) return st;
+  hipStream_t s = ctx->stream;
+  for (int l = 1; l < d.nlevels; ++l) {   // ComputePyramid(image), orbextractor.cpp:1012-1027
+    const dim3 grid((d.lvl_cols[l] + 255) / 256, d.lvl_rows[l], 1);
+    SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.pyr + d.lvl_off[l - 1], d.pyr + d.lvl_off[l], d.pyr_bytes,
+                       d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l],
+                       d.rs_scale_x[l], d.rs_scale_y[l]));
+  }
+  SSX_PROF(ctx, KID_ORB_GAUSS, hipLaunchKernelGGL(k_gauss7, dim3(d.gauss_tile0[d.nlevels], 1), dim3(256), 0, s, d));
+  DescribeAt a;
+  a.in = (const ssx_keypoint*)(base + o_in); a.out = (ssx_keypoint*)(base + o_out); a.desc = (uint8_t*)(base + o_desc);
+  a.keep = (uint8_t*)(base + o_keep); a.n_in = n_in;
+  SSX_PROF(ctx, KID_ORB_BRIEF, hipLaunchKernelGGL(k_describe_at, dim3((n_in + 3) / 4), dim3(256), 0, s, d, a));
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_out, base + o_out, lay.off - o_out, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  // order-preserving compaction of the kept keypoints (out_keypoints.push_back order, :893)
+  const ssx_keypoint* ok = (const ssx_keypoint*)(hs + o_out);
+  const uint8_t* od = (const uint8_t*)(hs + o_desc);
+  const uint8_t* keep = (const uint8_t*)(hs + o_keep);
+  int m = 0;
+  for (int i = 0; i < n_in; ++i) {
+    if (!keep[i]) continue;
+    if (kps_out) kps_out[m] = ok[i];
+    if (desc_out) memcpy(desc_out + (size_t)32 * m, od + (size_t)32 * i, 32);
+    ++m;
+  }
+  *n = m;
+  return SSX_OK;
 }
 
 ssx_status ssx_orb_stage_level(ssx_ctx* ctx, int32_t image, int32_t level, int32_t blurred, uint8_t* out,

@@ -63,6 +63,22 @@ class ORBextractor:
             ptr(desc, u8_p), C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def ScreenAndComputeKPsParams_CalcDescriptors(self, image, keypoints):
+        """ORBextractor::ScreenAndComputeKPsParams followed by CalcDescriptors (orbextractor.cpp:844-991), the
+        loop-closing use (loopclosing.cpp:622-629): -> (kept keypoints with angle/size, N x 32 descriptors)."""
+        image = np.asarray(image)
+        keypoints = np.ascontiguousarray(keypoints, dtype=KP_DTYPE)
+        if image.size == 0 or len(keypoints) == 0:
+            return np.zeros(0, dtype=KP_DTYPE), np.zeros((0, 32), np.uint8)
+        image = _img(image)
+        n_in = len(keypoints)
+        kps = np.zeros(n_in, dtype=KP_DTYPE); desc = np.zeros((n_in, 32), np.uint8)
+        n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_orb_describe_at(
+            self.ctx.handle, ptr(image, u8_p), image.strides[0], image.shape[0], image.shape[1], C.byref(self.prm),
+            keypoints.ctypes.data_as(C.c_void_p), n_in, kps.ctypes.data_as(C.c_void_p), ptr(desc, u8_p), C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
     # parity hooks ------------------------------------------------------------------------------
     def stage_level(self, level, blurred=False, image=0):
         r = C.c_int32(0); c = C.c_int32(0)

@@ -146,3 +146,35 @@ def test_allreduce_hook_world1_is_identity(ctx, po):
             dist.destroy_process_group()
     assert np.array_equal(plain["poses"], hooked["poses"]) and np.array_equal(plain["points"], hooked["points"])
     assert np.array_equal(plain["chi2"], hooked["chi2"]) and np.array_equal(plain["edge_chi2"], hooked["edge_chi2"])
+
+
+@pytest.mark.parametrize("name", ["po200", "po60"])
+def test_pose_only_matches_reference_golden_and_oracle(ctx, po, name):
+    """FrontEnd::EstimateCurrentPose (frontend.cpp:184-270): the one-launch kernel against the vectors produced by the
+    REAL reference (g2o + EdgeProjectionPoseOnly) and against the CPU oracle."""
+    import os
+    from ssvio_amd.synth import make_pose_only_problem
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz"))
+    M, seed, fg = [int(v) for v in G[f"{name}_cfg"]]
+    pp = make_pose_only_problem(M=M, seed=seed, frac_gross=fg / 100.0)
+    g = ba.pose_only_opt(ctx, pp["pose"], pp["K"], pp["xyz"], pp["uv"])
+    assert g["n_inliers"] == int(G[f"{name}_n"])
+    np.testing.assert_array_equal(g["inliers"], G[f"{name}_inliers"])
+    np.testing.assert_allclose(g["pose"], G[f"{name}_pose"], rtol=0, atol=1e-9)
+    o = po.pose_only(pp)
+    np.testing.assert_allclose(g["pose"], o["pose"], rtol=0, atol=2e-9)   # tree vs sequential f64 sums through 40 LM steps
+    np.testing.assert_array_equal(g["inliers"], o["inliers"])
+
+
+def test_pose_only_edge_cases(ctx, po):
+    from ssvio_amd.synth import make_pose_only_problem
+    pp = make_pose_only_problem(M=700, seed=11, frac_gross=0.3)        # more edges than threads; many outliers
+    g = ba.pose_only_opt(ctx, pp["pose"], pp["K"], pp["xyz"], pp["uv"])
+    o = po.pose_only(pp)
+    assert g["n_inliers"] == o["n_inliers"] and np.array_equal(g["inliers"], o["inliers"])
+    np.testing.assert_allclose(g["pose"], o["pose"], rtol=0, atol=2e-9)
+    assert np.abs(g["pose"] - pp["gt_pose"]).max() < 5e-3                 # recovers the true pose despite 30 % outliers
+    e = ba.pose_only_opt(ctx, pp["pose"], pp["K"], pp["xyz"][:0], pp["uv"][:0])
+    assert e["n_inliers"] == 0 and np.array_equal(e["pose"], pp["pose"])
+    z = ba.pose_only_opt(ctx, pp["pose"], pp["K"], pp["xyz"], pp["uv"], rounds=0)
+    assert np.array_equal(z["pose"], pp["pose"])

@@ -166,3 +166,24 @@ def test_stereo_batch_matches_single_frames(ctx, po):
         for key in ("dL", "dR", "match_idx", "match_dist", "ok"):
             assert np.array_equal(b[key], single[key])
         np.testing.assert_array_equal(b["xyz"], single["xyz"])
+
+
+def test_describe_at_bit_exact(ctx, po, pair_kitti):
+    """loop-closing descriptor path: every tracked feature is replicated over octaves 0..7 at the
+    same image location (loopclosing.cpp:607-619), screened and described (orbextractor.cpp:844-991)."""
+    L = pair_kitti[0]
+    base = po.orb_detect(L, prm=po.orb_params(nfeatures=300))
+    rep = np.zeros(len(base) * 8, dtype=po.KP_DTYPE)
+    for o in range(8):
+        rep[o::8] = base
+        rep["octave"][o::8] = o
+    rep = np.concatenate([rep, rep[:3]])
+    rep["octave"][-1] = 9                       # out-of-range octave: dropped
+    rep["x"][-2] = 5.0                          # too close to the border: dropped
+    ex = sorb.ORBextractor(ctx, nfeatures=2000)
+    gk, gd = ex.ScreenAndComputeKPsParams_CalcDescriptors(L, rep)
+    ok, od = po.orb_describe_at(L, rep, prm=po.orb_params(nfeatures=2000))
+    assert 0 < len(ok) < len(rep)
+    assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+    e_k, e_d = ex.ScreenAndComputeKPsParams_CalcDescriptors(L, rep[:0])
+    assert len(e_k) == 0 and e_d.shape == (0, 32)
