@@ -65,6 +65,8 @@ __constant__ int8_t c_u6_c[UPPER6] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 
 struct BaDev {
   // problem (uploaded once per ssx_ba_solve)
   int P, L, E, nP, nLm, nCh, nBlk, world, rank;
+  int big;                  // large-window path (free poses > SSX_BA_SMALL_P): pose blocks / Schur / solve in ba_big.inc
+  int lin_stride;           // doubles per chunk in lin_slab: nP*27 + 2 (small) or 2 (big)
   const int* pose_free;     // P: free index or -1
   const uint8_t* lm_fixed;  // nLm (compact landmarks = landmarks that have edges)
   const int* lm_id;         // nLm -> original landmark
@@ -164,8 +166,10 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   const double* point = d.point[cur];
 
   double rho0 = 0.0;
-  if (t < ne) sOrd[t] = d.porder[e0 + t];
-  if (t <= d.nP) sPptr[t] = d.pptr[(size_t)c * (d.nP + 1) + t];
+  if (!d.big) {
+    if (t < ne) sOrd[t] = d.porder[e0 + t];
+    if (t <= d.nP) sPptr[t] = d.pptr[(size_t)c * (d.nP + 1) + t];
+  }
   if (t < ne) {
     const int e = e0 + t;
     const int p = d.e_pose[e];
@@ -229,8 +233,9 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   }
 
   // pose blocks: owned entries; each walks only the chunk's edges of ITS pose, in the host-prepared order
-  double* slab = d.lin_slab + (size_t)c * (d.nP * 27 + 2);
-  for (int idx = t; idx < d.nP * 27; idx += CH) {
+  // (large windows build the pose blocks pose-major instead: k_pose_blocks)
+  double* slab = d.lin_slab + (size_t)c * d.lin_stride;
+  for (int idx = t; idx < (d.big ? 0 : d.nP * 27); idx += CH) {
     const int p = idx / 27, k = idx - p * 27;
     const int s0 = sPptr[p], s1 = sPptr[p + 1];
     double acc = 0.0;
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   const double chi = block_sum_256(rho0, sRed);
   const double md = block_max_256(maxd, sRed);
   if (t == 0) {
-    slab[d.nP * 27] = chi;
-    slab[d.nP * 27 + 1] = md;
+    slab[d.lin_stride - 2] = chi;
+    slab[d.lin_stride - 1] = md;
   }
 }
 
@@ -789,6 +794,8 @@ __global__ void k_publish_trial(BaDev d)
   }
 }
 
+#include "ba_big.inc"
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -818,6 +825,9 @@ struct HostPrep {
   std::vector<uint16_t> pptr;
   std::vector<double> e_uv;
   std::vector<int8_t> blk_pa, blk_pb;
+  // large-window path
+  bool big = false;
+  std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr, spair_a, spair_b;
 };
 
 ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
@@ -902,7 +912,57 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     for (int a = 0; a < h.nP; ++a)
       for (int b = a; b < h.nP; ++b) { h.blk_pa.push_back((int8_t)a); h.blk_pb.push_back((int8_t)b); }
   h.nBlk = (int)h.blk_pa.size();
-  if (h.nP > SSX_BA_SMALL_P) return SSX_OK;   // caller reports "unsupported"
+  h.big = h.nP > SSX_BA_SMALL_P;
+  if (h.big) {
+    const int nP = h.nP;
+    if (nP > 2048) { ctx->set_error("ssx_ba: %d free poses exceed the supported 2048", nP); return SSX_ERR_UNSUPPORTED; }
+    // pose-major edge list (free poses)
+    h.pe_ptr.assign(nP + 1, 0);
+    for (int s = 0; s < E; ++s) { const int pf = h.pose_free[h.e_pose[s]]; if (pf >= 0) h.pe_ptr[pf + 1]++; }
+    for (int p = 0; p < nP; ++p) h.pe_ptr[p + 1] += h.pe_ptr[p];
+    h.pe_edge.assign(std::max(h.pe_ptr[nP], 1), 0);
+    {
+      std::vector<int> fill(h.pe_ptr.begin(), h.pe_ptr.end() - 1);
+      for (int s = 0; s < E; ++s) { const int pf = h.pose_free[h.e_pose[s]]; if (pf >= 0) h.pe_edge[fill[pf]++] = s; }
+    }
+    // non-zero upper blocks of the reduced system (co-visibility) and the (leader, leader) pairs feeding each
+    std::vector<int> blk_id((size_t)nP * nP, -1);
+    h.sblk_pa.clear(); h.sblk_pb.clear();
+    for (int p = 0; p < nP; ++p) { blk_id[(size_t)p * nP + p] = p; h.sblk_pa.push_back(p); h.sblk_pb.push_back(p); }
+    std::vector<int> cntb;
+    std::vector<int> leaders;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int lc = 0; lc < h.nLm; ++lc) {
+        if (h.lm_fixed[lc]) continue;
+        leaders.clear();
+        for (int s = h.lm_ptr[lc]; s < h.lm_ptr[lc + 1]; ++s)
+          if (h.pose_free[h.e_pose[s]] >= 0 && !h.e_dup[s]) leaders.push_back(s);
+        for (size_t i = 0; i < leaders.size(); ++i)
+          for (size_t j = i; j < leaders.size(); ++j) {
+            const int pa = h.pose_free[h.e_pose[leaders[i]]], pb = h.pose_free[h.e_pose[leaders[j]]];
+            int& id = blk_id[(size_t)pa * nP + pb];
+            if (pass == 0) {
+              if (id < 0) { id = (int)h.sblk_pa.size(); h.sblk_pa.push_back(pa); h.sblk_pb.push_back(pb); }
+              if ((int)cntb.size() <= id) cntb.resize(id + 1, 0);
+              cntb[id]++;
+            } else {
+              const int q = cntb[id]++;
+              h.spair_a[q] = leaders[i]; h.spair_b[q] = leaders[j];
+            }
+          }
+      }
+      if (pass == 0) {
+        const int nb = (int)h.sblk_pa.size();
+        cntb.resize(nb, 0);
+        h.spair_ptr.assign(nb + 1, 0);
+        for (int b = 0; b < nb; ++b) h.spair_ptr[b + 1] = h.spair_ptr[b] + cntb[b];
+        h.spair_a.assign(std::max(h.spair_ptr[nb], 1), 0); h.spair_b.assign(std::max(h.spair_ptr[nb], 1), 0);
+        for (int b = 0; b < nb; ++b) cntb[b] = h.spair_ptr[b];
+      }
+    }
+    h.nBlk = 0;
+    return SSX_OK;
+  }
   // per-chunk index lists: edges grouped by free pose; leader pairs grouped by reduced-system block
   const int nP = h.nP, nBlk = h.nBlk;
   h.porder.assign(E, 0);
@@ -959,13 +1019,17 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
 
 // carve the arena and upload the problem
 ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, double huber_delta, double chi2_th,
-                  int world, int rank, BaDev& d)
+                  int world, int rank, BaDev& d, BigDev& bd)
 {
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
   const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm, nCh = h.nCh, nBlk = h.nBlk;
   const int n = 6 * nP;
   const size_t nPairs = h.pair_a.size();
+  const bool big = h.big;
+  const int lin_stride = big ? 2 : nP * 27 + 2;
+  const int n_pad = big ? ((n + NB - 1) / NB) * NB : 0;
+  const size_t nBlkS = h.sblk_pa.size(), nSPairs = big ? (size_t)h.spair_ptr.back() : 0;
   Layout in;   // input blob (mirrored in pinned staging)
   const size_t o_pose_free = in.take(sizeof(int) * P);
   const size_t o_lm_fixed = in.take(nLm);
@@ -984,6 +1048,13 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_pair_a = in.take(nPairs + 1);
   const size_t o_pair_b = in.take(nPairs + 1);
   const size_t o_pair_ptr = in.take(sizeof(int) * (h.pair_ptr.size() + 1));
+  const size_t o_pe_ptr = in.take(sizeof(int) * (h.pe_ptr.size() + 1));
+  const size_t o_pe_edge = in.take(sizeof(int) * (h.pe_edge.size() + 1));
+  const size_t o_sblk_pa = in.take(sizeof(int) * (nBlkS + 1));
+  const size_t o_sblk_pb = in.take(sizeof(int) * (nBlkS + 1));
+  const size_t o_spair_ptr = in.take(sizeof(int) * (h.spair_ptr.size() + 1));
+  const size_t o_spair_a = in.take(sizeof(int) * (nSPairs + 1));
+  const size_t o_spair_b = in.take(sizeof(int) * (nSPairs + 1));
   const size_t o_pose0 = in.take(sizeof(double) * 7 * P);
   const size_t o_point0 = in.take(sizeof(double) * 3 * (L + 1));
   const size_t in_bytes = in.off;
@@ -995,12 +1066,18 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_err_trial = all.take(sizeof(double) * 2 * (size_t)E);
   const size_t o_Hll = all.take(sizeof(double) * 6 * (size_t)nLm);
   const size_t o_bl = all.take(sizeof(double) * 3 * (size_t)nLm);
-  const size_t o_lin_slab = all.take(sizeof(double) * (size_t)(nCh + 1) * (nP * 27 + 2));
+  const size_t o_lin_slab = all.take(sizeof(double) * (size_t)(nCh + 1) * lin_stride);
   const size_t o_Hpp = all.take(sizeof(double) * (nP + 1) * UPPER6);
   const size_t o_bp = all.take(sizeof(double) * (nP + 1) * 6);
   const size_t o_iter = all.take(sizeof(double) * ((size_t)nP * 27 + 1 + world + 1));
-  const size_t o_schur = all.take(sizeof(double) * (size_t)(nCh + 1) * (nBlk * 36 + nP * 6));
-  const size_t o_trial_comm = all.take(sizeof(double) * ((size_t)n * n + n + 1));
+  const size_t o_schur = all.take(big ? 256 : sizeof(double) * (size_t)(nCh + 1) * (nBlk * 36 + nP * 6));
+  const size_t o_trial_comm = all.take(big ? 256 : sizeof(double) * ((size_t)n * n + n + 1));
+  const size_t o_BDa = all.take(big ? sizeof(double) * 18 * (size_t)(E + 1) : 256);
+  const size_t o_Wma = all.take(big ? sizeof(double) * 18 * (size_t)(E + 1) : 256);
+  const size_t o_Cv = all.take(big ? sizeof(double) * 6 * (size_t)(E + 1) : 256);
+  const size_t o_S = all.take(big ? sizeof(double) * (size_t)(n_pad + NB) * n_pad : 256);
+  const size_t o_x = all.take(sizeof(double) * (n_pad + 8));
+  const size_t o_scale_part = all.take(sizeof(double) * 64);
   const size_t o_xp = all.take(sizeof(double) * (n + 1));
   const size_t o_trial = all.take(sizeof(double) * 3 * (nCh + 1));
   const size_t o_scal_comm = all.take(sizeof(double) * 4);
@@ -1036,6 +1113,15 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_pair_b, h.pair_b.data(), nPairs);
   }
   if (!h.pair_ptr.empty()) memcpy(hs + o_pair_ptr, h.pair_ptr.data(), sizeof(int) * h.pair_ptr.size());
+  if (big) {
+    memcpy(hs + o_pe_ptr, h.pe_ptr.data(), sizeof(int) * h.pe_ptr.size());
+    memcpy(hs + o_pe_edge, h.pe_edge.data(), sizeof(int) * h.pe_edge.size());
+    memcpy(hs + o_sblk_pa, h.sblk_pa.data(), sizeof(int) * nBlkS);
+    memcpy(hs + o_sblk_pb, h.sblk_pb.data(), sizeof(int) * nBlkS);
+    memcpy(hs + o_spair_ptr, h.spair_ptr.data(), sizeof(int) * h.spair_ptr.size());
+    memcpy(hs + o_spair_a, h.spair_a.data(), sizeof(int) * h.spair_a.size());
+    memcpy(hs + o_spair_b, h.spair_b.data(), sizeof(int) * h.spair_b.size());
+  }
   memcpy(hs + o_pose0, pr->poses, sizeof(double) * 7 * P);
   if (L) memcpy(hs + o_point0, pr->points, sizeof(double) * 3 * L);
   char* base = ws->arena.as<char>();
@@ -1046,6 +1132,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_point1, base + o_point0, sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, ctx->stream));
 
   d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
+  d.big = big ? 1 : 0; d.lin_stride = lin_stride;
   d.pose_free = (const int*)(base + o_pose_free);
   d.lm_fixed = (const uint8_t*)(base + o_lm_fixed);
   d.lm_id = (const int*)(base + o_lm_id);
@@ -1081,6 +1168,15 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.trial_slab = (double*)(base + o_trial);
   d.scal_comm = (double*)(base + o_scal_comm);
   d.scal = (double*)(base + o_scal);
+  bd = BigDev{};
+  if (big) {
+    bd.n = n; bd.n_pad = n_pad; bd.ld = n_pad; bd.T = n_pad / NB; bd.nBlkS = (int)nBlkS;
+    bd.pe_ptr = (const int*)(base + o_pe_ptr); bd.pe_edge = (const int*)(base + o_pe_edge);
+    bd.sblk_pa = (const int*)(base + o_sblk_pa); bd.sblk_pb = (const int*)(base + o_sblk_pb);
+    bd.spair_ptr = (const int*)(base + o_spair_ptr); bd.spair_a = (const int*)(base + o_spair_a); bd.spair_b = (const int*)(base + o_spair_b);
+    bd.BDa = (double*)(base + o_BDa); bd.Wma = (double*)(base + o_Wma); bd.Cv = (double*)(base + o_Cv);
+    bd.S = (double*)(base + o_S); bd.x = (double*)(base + o_x); bd.scale_part = (double*)(base + o_scale_part);
+  }
   return SSX_OK;
 }
 
@@ -1106,12 +1202,17 @@ ssx_status allreduce(ssx_ctx* ctx, const Comm& cm, double* buf, size_t count)
   return SSX_OK;
 }
 
-ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, const Comm& cm, int jac, int cur, int first_iteration)
+ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, const BigDev& bd, const Comm& cm, int jac, int cur, int first_iteration)
 {
   if (d.nCh > 0) {
     if (jac == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
     else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
   }
+  if (d.big) {
+    if (jac == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_pose_blocks<SSX_JAC_NUMERIC_G2O>, dim3(d.nP), dim3(CH), 0, ctx->stream, d, bd, cur));
+    else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_pose_blocks<SSX_JAC_ANALYTIC>, dim3(d.nP), dim3(CH), 0, ctx->stream, d, bd, cur));
+    SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_big, dim3(1), dim3(CH), 0, ctx->stream, d));
+  } else
   SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 15) / 16)), dim3(CH), 0, ctx->stream, d));
   ssx_status st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
   if (st != SSX_OK) return st;
@@ -1148,12 +1249,12 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
   HostPrep h;
   ssx_status st = prepare(ctx, prob, h);
   if (st != SSX_OK) return st;
-  if (h.nP > SSX_BA_SMALL_P) { ctx->set_error("ssx_ba_linearize: %d free poses > %d", h.nP, SSX_BA_SMALL_P); return SSX_ERR_UNSUPPORTED; }
   BaDev d;
-  st = upload(ctx, prob, h, huber_delta, 5.891, 1, 0, d);
+  BigDev bd;
+  st = upload(ctx, prob, h, huber_delta, 5.891, 1, 0, d, bd);
   if (st != SSX_OK) return st;
   Comm cm;
-  st = launch_linearize(ctx, d, cm, jac_mode, 0, 1);
+  st = launch_linearize(ctx, d, bd, cm, jac_mode, 0, 1);
   if (st != SSX_OK) return st;
   const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm;
   std::vector<double> hHpp((size_t)nP * UPPER6 + 1), hbp((size_t)nP * 6 + 1), hHll((size_t)6 * nLm + 1), hbl((size_t)3 * nLm + 1),
@@ -1210,10 +1311,6 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   HostPrep h;
   ssx_status st = prepare(ctx, prob, h);
   if (st != SSX_OK) return st;
-  if (h.nP > SSX_BA_SMALL_P) {
-    ctx->set_error("ssx_ba_solve: %d free poses > %d (large-window path not built yet)", h.nP, SSX_BA_SMALL_P);
-    return SSX_ERR_UNSUPPORTED;
-  }
   Comm cm;
   // world_size 1 with a hook is allowed (the hook is then an identity): it exercises the collective plumbing
   if (opt.allreduce && opt.world_size >= 1) { cm.fn = opt.allreduce; cm.user = opt.allreduce_user; cm.world = opt.world_size; }
@@ -1224,18 +1321,47 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   BaDev d;
-  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d);
+  BigDev bd;
+  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd);
   if (st != SSX_OK) return st;
   BaWorkspace* ws = ctx->ba;
   double* hscal = ws->scal.as<double>();
   const int n = 6 * d.nP;
   const int nCh = d.nCh;
   const size_t lds_schur = schur_lds_bytes();
+  const size_t lds_prep = sizeof(double) * (18 + 9 + 3) * PW + 64;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
     attr_set = true;
   }
+  // large windows: Schur blocks -> dense S (+ rhs row) -> all-reduce -> blocked Cholesky (MFMA) -> back-substitution
+  auto big_trial = [&](double lambda, int dev_lambda, int cur_) -> ssx_status {
+    hipStream_t s = ctx->stream;
+    SSX_HIP_TRY(ctx, hipMemsetAsync(bd.S, 0, sizeof(double) * (size_t)(bd.n_pad + 1) * bd.ld, s));
+    if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_prep, dim3(nCh), dim3(CH), lds_prep, s, d, bd, lambda, dev_lambda));
+    SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_blocks, dim3((bd.nBlkS + 3) / 4), dim3(CH), 0, s, d, bd));
+    SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_bs, dim3(d.nP), dim3(CH), 0, s, d, bd));
+    ssx_status st2 = allreduce(ctx, cm, bd.S, (size_t)(bd.n_pad + 1) * bd.ld);
+    if (st2 != SSX_OK) return st2;
+    SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_add_lambda, dim3((bd.n + 255) / 256), dim3(256), 0, s, d, bd, lambda, dev_lambda));
+    for (int kb = 0; kb < bd.T; ++kb) {
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(CH), 0, s, d, bd, kb));
+      const int rows_below = bd.n_pad - (kb + 1) * NB + 1;   // + the rhs row
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_trsm64, dim3((rows_below + CH - 1) / CH), dim3(CH), 0, s, bd, kb));
+      const int tiles = bd.T - kb - 1;
+      if (tiles > 0) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_syrk64, dim3(tiles, tiles + 1), dim3(CH), 0, s, bd, kb));
+    }
+    for (int kb = bd.T - 1; kb >= 0; --kb) {
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_trsvT64, dim3(1), dim3(64), 0, s, bd, kb));
+      if (kb > 0) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_gemvT64, dim3((kb * NB + CH - 1) / CH), dim3(CH), 0, s, bd, kb));
+    }
+    const int nparts = std::min(32, (d.P + CH - 1) / CH);
+    SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_pose_update_big, dim3(nparts), dim3(CH), 0, s, d, bd, cur_, lambda, dev_lambda));
+    SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_scale_finish, dim3(1), dim3(64), 0, s, d, bd, nparts));
+    return SSX_OK;
+  };
   const int nSchurEntries = d.nBlk * 36 + d.nP * 6;
 
   res->rounds = 0; res->n_iters = 0; res->n_inliers = 0; res->n_outliers = 0;
@@ -1249,7 +1375,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     // ---- one g2o optimize(iters): OptimizationAlgorithmLevenberg::solve per iteration ----
     double lambda = -1.0, ni = 2.0;
     for (int it = 0; it < opt.iters && active; ++it) {
-      st = launch_linearize(ctx, d, cm, opt.jac_mode, cur, it == 0);
+      st = launch_linearize(ctx, d, bd, cm, opt.jac_mode, cur, it == 0);
       if (st != SSX_OK) return st;
       double currentChi = 0.0, rho = 0.0, tempChi = 0.0;
       int qmax = 0;
@@ -1257,6 +1383,10 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
       do {
         // lambda: known to the host except on the very first trial of a round, where k_lambda_init left it on the device
         const int dev_lambda = (it == 0 && qmax == 0) ? 1 : 0;
+        if (d.big) {
+          st = big_trial(lambda, dev_lambda, cur);
+          if (st != SSX_OK) return st;
+        } else {
         if (n > 0) {
           if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, lambda, dev_lambda));
           SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
@@ -1264,6 +1394,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
           if (st != SSX_OK) return st;
         }
         SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, ctx->stream, d, cur, lambda, dev_lambda));
+        }
         if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
         SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d));
         if (cm.fn) {
@@ -1342,7 +1473,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   if (want_err) {
     if (!have_trial_err) {   // iters == 0: errors of the input state
       Comm none;
-      st = launch_linearize(ctx, d, none, SSX_JAC_ANALYTIC, cur, 0);
+      st = launch_linearize(ctx, d, bd, none, SSX_JAC_ANALYTIC, cur, 0);
       if (st != SSX_OK) return st;
     }
     SSX_HIP_TRY(ctx, hipMemcpyAsync(h_err, have_trial_err ? d.err_trial : d.err_lin, sizeof(double) * 2 * (size_t)d.E,
