@@ -6,8 +6,8 @@
 // order of the keypoints inside every node and (c) the processing order of the "largest first" phase.  All
 // three are reproduced with flat arrays and prefix sums (tools/octree_model.py is the executable statement
 // of this formulation, checked against the sequential oracle):
-//   * every node owns a contiguous range of keys[]; a division is a STABLE 4-way partition of that range,
-//     computed for all divided nodes at once from one packed (4 x 16 bit) exclusive scan over the key array;
+//   * every node owns a contiguous range of the key array; a division is a STABLE 4-way partition of that range,
+//     computed for all divided nodes at once from one packed (4 x 16 bit) exclusive scan over the key positions;
 //   * the node table is kept IN LIST ORDER: after a round the children of the i-th processed node sit at
 //     [T - P_i - cc_i, T - P_i) in quadrant order 4,3,2,1 (push_front semantics) and the untouched nodes follow
 //     in their old relative order;
@@ -15,6 +15,12 @@
 //     cuts the list at the first prefix that reaches N nodes.
 // Tie-break of equal sizes: creation order (the reference compares heap pointers, orbextractor.cpp:486, which is
 // not reproducible); identical to the oracle.
+//
+// Memory: per key only two u32 streams exist (packed candidate x|y|score, and key|node); the quadrant of every key
+// lives in LDS for the duration of a round; each thread walks a contiguous run of key positions, so the node
+// record is re-read only when the run crosses a node boundary.  (Round 1 kept a 64-bit scan value, separate key /
+// node-id arrays and unpacked coordinates per key in global memory: rocprof showed 400 MB of L2<->HBM traffic per
+// launch for 1.3 MB of algorithmic bytes.)
 #include "orb_ws.hpp"
 
 namespace ssxorb {
@@ -26,10 +32,10 @@ constexpr int T = OCT_THREADS;
 constexpr int NW = T / 64;
 
 struct Oct {
-  uint16_t *cx, *cy; uint8_t* cr;
-  uint16_t* keys[2]; uint16_t* nat[2];
-  u64* E;
+  uint32_t* pk;            // packed candidates
+  uint32_t* kn[2];         // key | node << 16
   OctNode* nodes[2];
+  u64* eb;                 // packed scan value at the first key of each node
   uint16_t *proc, *expa, *expb, *newpos;
   u64 *c4, *kid4;
   uint32_t *ccp, *exp, *sortk;
@@ -38,13 +44,10 @@ struct Oct {
 __device__ __forceinline__ Oct carve(uint8_t* base)
 {
   Oct o;
-  o.cx = (uint16_t*)(base + OctLayout::candx);
-  o.cy = (uint16_t*)(base + OctLayout::candy);
-  o.cr = (uint8_t*)(base + OctLayout::candr);
-  o.keys[0] = (uint16_t*)(base + OctLayout::keys); o.keys[1] = o.keys[0] + CAND_CAP;
-  o.nat[0] = (uint16_t*)(base + OctLayout::nodeat); o.nat[1] = o.nat[0] + CAND_CAP;
-  o.E = (u64*)(base + OctLayout::escan);
+  o.pk = (uint32_t*)(base + OctLayout::candpk);
+  o.kn[0] = (uint32_t*)(base + OctLayout::keynode); o.kn[1] = o.kn[0] + CAND_CAP;
   o.nodes[0] = (OctNode*)(base + OctLayout::nodes); o.nodes[1] = o.nodes[0] + NODE_CAP;
+  o.eb = (u64*)(base + OctLayout::ebeg);
   o.proc = (uint16_t*)(base + OctLayout::proc);
   o.expa = (uint16_t*)(base + OctLayout::expa);
   o.expb = (uint16_t*)(base + OctLayout::expb);
@@ -91,6 +94,9 @@ __device__ __forceinline__ int quadrant(int x, int y, const OctNode& n)
 }
 
 __device__ __forceinline__ unsigned f16(u64 v, int q) { return (unsigned)((v >> (16 * q)) & 0xFFFFu); }
+__device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xFFF); }
+__device__ __forceinline__ int pk_y(uint32_t p) { return (int)((p >> 12) & 0xFFF); }
+__device__ __forceinline__ int pk_r(uint32_t p) { return (int)(p >> 24); }
 
 }  // namespace
 
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   __shared__ u64 s_w64[NW + 1];
   __shared__ uint32_t s_w32[NW + 1];
   __shared__ uint32_t s_sort[4096];
+  __shared__ uint8_t s_q[CAND_CAP];     // quadrant of every key position in the current round (4 = node not divided)
   __shared__ int s_i[8];
   const int level = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
   if (d.detect_only && level > 0) return;
@@ -121,12 +128,8 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
     uint32_t pos = block_excl_scan<uint32_t>(mine, s_w32, total);
     for (int c = lo; c < hi; ++c) {
       const int n = ccount[c];
-      for (int k = 0; k < n; ++k, ++pos) {
-        if (pos < (uint32_t)CAND_CAP) {
-          const uint32_t p = ccand[(size_t)c * CELL_CAP + k];
-          o.cx[pos] = (uint16_t)(p & 0xFFF); o.cy[pos] = (uint16_t)((p >> 12) & 0xFFF); o.cr[pos] = (uint8_t)(p >> 24);
-        }
-      }
+      for (int k = 0; k < n; ++k, ++pos)
+        if (pos < (uint32_t)CAND_CAP) o.pk[pos] = ccand[(size_t)c * CELL_CAP + k];
     }
     M = (int)min(total, (uint32_t)CAND_CAP);
     if (t == 0) {
@@ -150,22 +153,20 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   int cur = 0;
   int nNodes = 0;
   {
+    // root of every candidate once (s_q doubles as scratch), then one stable pass per root
+    for (int p = klo; p < khi; ++p) {
+      int rt = (int)((float)pk_x(o.pk[p]) / hX);
+      s_q[p] = (uint8_t)(rt >= nIni ? nIni - 1 : rt);
+    }
     int base = 0;
     for (int r = 0; r < nIni; ++r) {
       uint32_t mine = 0;
-      for (int p = klo; p < khi; ++p) {
-        int rt = (int)((float)o.cx[p] / hX);
-        if (rt >= nIni) rt = nIni - 1;
-        mine += (rt == r);
-      }
+      for (int p = klo; p < khi; ++p) mine += (s_q[p] == r);
       uint32_t total;
       uint32_t pos = block_excl_scan<uint32_t>(mine, s_w32, total);
       if (total > 0) {
-        for (int p = klo; p < khi; ++p) {
-          int rt = (int)((float)o.cx[p] / hX);
-          if (rt >= nIni) rt = nIni - 1;
-          if (rt == r) { o.keys[cur][base + pos] = (uint16_t)p; o.nat[cur][base + pos] = (uint16_t)nNodes; ++pos; }
-        }
+        for (int p = klo; p < khi; ++p)
+          if (s_q[p] == r) { o.kn[cur][base + pos] = (uint32_t)p | ((uint32_t)nNodes << 16); ++pos; }
         if (t == 0) {
           OctNode n;
           n.b = (uint16_t)base; n.e = (uint16_t)(base + total);
@@ -190,6 +191,8 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   while (!finish && ++guard < 256) {
     OctNode* nd = o.nodes[cur];
     OctNode* nn = o.nodes[cur ^ 1];
+    const uint32_t* kn = o.kn[cur];
+    uint32_t* kn_next = o.kn[cur ^ 1];
     const int prevSize = nNodes;
     const int nchunk = (nNodes + T - 1) / T;
     const int nlo = min(t * nchunk, nNodes), nhi = min(nlo + nchunk, nNodes);
@@ -233,32 +236,47 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
       m = nExp;
     }
     __syncthreads();
-    // ---------------- packed exclusive scan of quadrant indicators over the key array ----------------
+    // ---------------- quadrant of every key (LDS) + packed exclusive scan over the key positions ----------------
+    u64 my_prefix;
+    u64 Etotal;
     {
       u64 mine = 0;
+      int cn = -1;
+      OctNode x{};
       for (int p = klo; p < khi; ++p) {
-        const OctNode& x = nd[o.nat[cur][p]];
-        if (x.div) { const int k = o.keys[cur][p]; mine += 1ull << (16 * quadrant(o.cx[k], o.cy[k], x)); }
+        const uint32_t v = kn[p];
+        const int node = (int)(v >> 16);
+        if (node != cn) { cn = node; x = nd[node]; }
+        int q = 4;
+        if (x.div) { const uint32_t c = o.pk[v & 0xFFFFu]; q = quadrant(pk_x(c), pk_y(c), x); mine += 1ull << (16 * q); }
+        s_q[p] = (uint8_t)q;
       }
-      u64 total;
-      u64 run = block_excl_scan<u64>(mine, s_w64, total);
+      my_prefix = block_excl_scan<u64>(mine, s_w64, Etotal);
+      // scan value at the first key of every node (the stable rank of a key = running value - value at node start)
+      u64 run = my_prefix;
+      cn = -1;
       for (int p = klo; p < khi; ++p) {
-        o.E[p] = run;
-        const OctNode& x = nd[o.nat[cur][p]];
-        if (x.div) { const int k = o.keys[cur][p]; run += 1ull << (16 * quadrant(o.cx[k], o.cy[k], x)); }
+        const int node = (int)(kn[p] >> 16);
+        if (node != cn) { cn = node; if (nd[node].b == p) o.eb[node] = run; }
+        const int q = s_q[p];
+        if (q < 4) run += 1ull << (16 * q);
       }
-      if (t == T - 1 || khi == M) o.E[M] = total;
     }
     __syncthreads();
+    // quadrant counts of node x = E(x.e) - E(x.b), with E(pos) the scan value at the node that starts at pos
+    auto E_at = [&](int pos) -> u64 { return pos >= M ? Etotal : o.eb[kn[pos] >> 16]; };
     // ---------------- quadrant counts / child counts per processed node ----------------
     const int pchunk = (m + T - 1) / T;
     int plo = min(t * pchunk, m), phi = min(plo + pchunk, m);
+    for (int i = plo; i < phi; ++i) {
+      const OctNode& x = nd[o.proc[i]];
+      o.c4[i] = E_at(x.e) - o.eb[o.proc[i]];
+    }
     if (phase == 2) {
       // cut the list at the first prefix that brings the node count to >= N (orbextractor.cpp:487-539)
       uint32_t mine = 0;
       for (int i = plo; i < phi; ++i) {
-        const OctNode& x = nd[o.proc[i]];
-        const u64 c = o.E[x.e] - o.E[x.b];
+        const u64 c = o.c4[i];
         const int cc = (f16(c, 0) > 0) + (f16(c, 1) > 0) + (f16(c, 2) > 0) + (f16(c, 3) > 0);
         mine += (uint32_t)(cc - 1);
       }
@@ -267,8 +285,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
       if (t == 0) s_i[0] = m;
       __syncthreads();
       for (int i = plo; i < phi; ++i) {
-        const OctNode& x = nd[o.proc[i]];
-        const u64 c = o.E[x.e] - o.E[x.b];
+        const u64 c = o.c4[i];
         const int cc = (f16(c, 0) > 0) + (f16(c, 1) > 0) + (f16(c, 2) > 0) + (f16(c, 3) > 0);
         const uint32_t before = run;
         run += (uint32_t)(cc - 1);
@@ -287,9 +304,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
     {
       uint32_t mine_cc = 0, mine_ex = 0;
       for (int i = plo; i < phi; ++i) {
-        const OctNode& x = nd[o.proc[i]];
-        const u64 c = o.E[x.e] - o.E[x.b];
-        o.c4[i] = c;
+        const u64 c = o.c4[i];
         for (int q = 0; q < 4; ++q) { mine_cc += f16(c, q) > 0; mine_ex += f16(c, q) > 1; }
       }
       uint32_t run_cc = block_excl_scan<uint32_t>(mine_cc, s_w32, Tchild);
@@ -342,23 +357,31 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
       if (!nd[j].div) { OctNode x = nd[j]; x.pidx = 0; nn[o.newpos[j]] = x; }
     __syncthreads();
     // ---------------- move the keys (stable partition) ----------------
-    for (int p = klo; p < khi; ++p) {
-      const int j = o.nat[cur][p];
-      const OctNode& x = nd[j];
-      const uint16_t key = o.keys[cur][p];
-      if (x.div) {
-        const int i = x.pidx;
-        const u64 c = o.c4[i];
-        const int q = quadrant(o.cx[key], o.cy[key], x);
-        int before = 0;
-        for (int qq = 0; qq < q; ++qq) before += (int)f16(c, qq);
-        const int rank = (int)f16(o.E[p], q) - (int)f16(o.E[x.b], q);
-        const int dest = x.b + before + rank;
-        o.keys[cur ^ 1][dest] = key;
-        o.nat[cur ^ 1][dest] = (uint16_t)f16(o.kid4[i], q);
-      } else {
-        o.keys[cur ^ 1][p] = key;
-        o.nat[cur ^ 1][p] = o.newpos[j];
+    {
+      u64 run = my_prefix;
+      int cn = -1;
+      OctNode x{};
+      u64 c = 0, kid = 0, ebn = 0;
+      uint32_t np = 0;
+      for (int p = klo; p < khi; ++p) {
+        const uint32_t v = kn[p];
+        const int node = (int)(v >> 16);
+        if (node != cn) {
+          cn = node; x = nd[node];
+          if (x.div) { c = o.c4[x.pidx]; kid = o.kid4[x.pidx]; ebn = o.eb[node]; }
+          else np = o.newpos[node];
+        }
+        const int q = s_q[p];
+        if (q < 4 && x.div) {
+          int before = 0;
+          for (int qq = 0; qq < q; ++qq) before += (int)f16(c, qq);
+          const int rank = (int)f16(run, q) - (int)f16(ebn, q);
+          kn_next[x.b + before + rank] = (v & 0xFFFFu) | ((uint32_t)f16(kid, q) << 16);
+        } else {
+          kn_next[p] = (v & 0xFFFFu) | (np << 16);
+        }
+        // keys of phase-2 candidates that were cut from this round still sit in the scan: keep `run` in step
+        if (q < 4) run += 1ull << (16 * q);
       }
     }
     __syncthreads();
@@ -374,15 +397,16 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   // ---- best response per node, first wins ties (orbextractor.cpp:549-565), in list order ----
   {
     const OctNode* nd = o.nodes[cur];
+    const uint32_t* kn = o.kn[cur];
     const int nOut = min(nNodes, SEL_CAP);
     for (int j = t; j < nOut; j += T) {
       const OctNode x = nd[j];
-      int best = o.keys[cur][x.b];
+      uint32_t best = o.pk[kn[x.b] & 0xFFFFu];
       for (int p = x.b + 1; p < x.e; ++p) {
-        const int k = o.keys[cur][p];
-        if (o.cr[k] > o.cr[best]) best = k;
+        const uint32_t c = o.pk[kn[p] & 0xFFFFu];
+        if (pk_r(c) > pk_r(best)) best = c;
       }
-      sel[j] = (uint32_t)o.cx[best] | ((uint32_t)o.cy[best] << 12) | ((uint32_t)o.cr[best] << 24);
+      sel[j] = best;
     }
     if (t == 0) {
       *sel_count = nOut;

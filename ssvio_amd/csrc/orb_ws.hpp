@@ -24,16 +24,15 @@ struct Cell {
   int16_t level, pad;
 };
 
-// per (image, level) octree scratch, laid out at fixed byte offsets inside one block of OCT_BYTES
+// per (image, level) octree scratch, laid out at fixed byte offsets inside one block of OctLayout::total bytes.
+// Per-KEY data are two u32 streams only (packed candidate, key|node); everything else is per node / per processed node,
+// so the footprint a workgroup actually touches (~12 B per candidate + ~50 B per node) stays L2-resident.
 struct OctLayout {
-  static constexpr size_t candx = 0;                                        // u16[CAND_CAP]
-  static constexpr size_t candy = candx + 2 * CAND_CAP;                     // u16[CAND_CAP]
-  static constexpr size_t candr = candy + 2 * CAND_CAP;                     // u8 [CAND_CAP]
-  static constexpr size_t keys = candr + CAND_CAP;                          // u16[2][CAND_CAP]
-  static constexpr size_t nodeat = keys + 4 * CAND_CAP;                     // u16[2][CAND_CAP]
-  static constexpr size_t escan = nodeat + 4 * CAND_CAP;                    // u64[CAND_CAP+8]
-  static constexpr size_t nodes = escan + 8 * (CAND_CAP + 8);               // Node[2][NODE_CAP] (16 B each)
-  static constexpr size_t proc = nodes + 2 * 16 * (size_t)NODE_CAP;         // u16[NODE_CAP]
+  static constexpr size_t candpk = 0;                                       // u32[CAND_CAP]  x | y<<12 | score<<24
+  static constexpr size_t keynode = candpk + 4 * (size_t)CAND_CAP;          // u32[2][CAND_CAP] key | node<<16 (ping-pong)
+  static constexpr size_t nodes = keynode + 8 * (size_t)CAND_CAP;           // OctNode[2][NODE_CAP] (16 B each)
+  static constexpr size_t ebeg = nodes + 2 * 16 * (size_t)NODE_CAP;         // u64[NODE_CAP] packed scan value at a node's first key
+  static constexpr size_t proc = ebeg + 8 * (size_t)NODE_CAP;               // u16[NODE_CAP]
   static constexpr size_t expa = proc + 2 * NODE_CAP;                       // u16[NODE_CAP]
   static constexpr size_t expb = expa + 2 * NODE_CAP;                       // u16[NODE_CAP]
   static constexpr size_t c4 = expb + 2 * NODE_CAP;                         // u64[NODE_CAP] quadrant counts per proc
