@@ -116,9 +116,8 @@ def main():
         "k_resize": lambda calls: I * (sum(px[:-1]) + sum(px[1:])) / 7.0,            # 7 launches: read l-1, write l
         "k_fast_cells": lambda calls: I * sum(px) + 4.0 * 8000 * I,                  # read pyramid once, write candidates
         "k_octree": lambda calls: 4.0 * 8000 * I + 4.0 * kp_total,                   # read candidates, write selection
-        "k_orient": lambda calls: 961.0 * kp_total + 4.0 * kp_total,                 # 31x31 patch per keypoint
         "k_gauss7": lambda calls: 2.0 * I * sum(px) / 8.0,                           # 8 launches: read + write a level
-        "k_brief": lambda calls: (1369.0 + 60.0) * kp_total,                         # 37x37 patch + 28+32 B out
+        "k_orient_brief": lambda calls: (961.0 + 1369.0 + 60.0) * kp_total,          # 31x31 + 37x37 patches, 28+32 B out
         "k_row_bucket": lambda calls: 28.0 * kp_total / 2 + 4.0 * kp_total / 2,
         "k_match": lambda calls: 60.0 * kp_total + 8.0 * kp_total / 2,
         "k_triangulate_matches": lambda calls: (56.0 + 25.0) * kp_total / 2,

@@ -97,7 +97,7 @@ enum SsxKernelId {
 };
 static const char* const kSsxKernelNames[KID_COUNT] = {
   "k_linearize", "k_reduce_lin", "k_schur", "k_reduce_schur", "k_solve", "k_backsub_residual", "k_reduce_trial",
-  "k_resize", "k_fast_cells", "k_octree", "k_orient", "k_gauss7", "k_brief", "orb_misc", "k_row_bucket", "k_match",
+  "k_resize", "k_fast_cells", "k_octree", "k_orient", "k_gauss7", "k_orient_brief", "orb_misc", "k_row_bucket", "k_match",
   "k_triangulate_matches", "stereo_misc", "k_pose_only"};
 
 struct SsxProf {

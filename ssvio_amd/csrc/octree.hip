@@ -107,7 +107,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   __shared__ uint32_t s_sort[4096];
   __shared__ uint8_t s_q[CAND_CAP];     // quadrant of every key position in the current round (4 = node not divided)
   __shared__ int s_i[8];
-  const int level = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+  const int img = blockIdx.x, level = blockIdx.y, t = threadIdx.x;   // see launch_octree for the order
   if (d.detect_only && level > 0) return;
   const int il = img * d.nlevels + level;
   Oct o = carve(d.oct + (size_t)il * OctLayout::total);
@@ -417,7 +417,10 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
 
 void launch_octree(const OrbDev& o, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_octree, dim3(o.detect_only ? 1 : o.nlevels, o.I), dim3(OCT_THREADS), 0, s, o);
+  // image-major grid: workgroups are dealt round-robin to the 8 XCDs, so with the level as the fastest index
+  // (8 levels) every level-0 workgroup - the long one - would land on the same XCD.  Level-major order starts
+  // all level-0 workgroups first and spreads them over the whole chip.
+  hipLaunchKernelGGL(k_octree, dim3(o.I, o.detect_only ? 1 : o.nlevels), dim3(OCT_THREADS), 0, s, o);
 }
 
 }  // namespace ssxorb

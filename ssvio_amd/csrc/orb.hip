@@ -9,15 +9,16 @@
 // Everything is batched over I images (a stereo pair is I = 2; ssx_stereo_batch_dev runs I = 2 x pairs):
 // blockIdx.z (or the leading grid dimension) is the image, so one launch sequence serves the whole batch.
 //
-//   k_resize         level l from level l-1, one thread per destination pixel, fixed-point bilinear (A5)
+//   k_resize         level l from level l-1, host-tabulated indices/weights, 4 pixels per thread           (A5)
 //   k_fast_cells     ONE WORKGROUP PER GRID CELL: ROI (<= 72x72 bytes) staged in LDS from coalesced row reads,
 //                    segment test + cornerScore at iniThFAST, fallback to minThFAST when the cell is empty,
 //                    3x3 NMS inside the cell, mask test, ordered (row-major) compaction                     (A1+A2)
 //   k_octree         ONE WORKGROUP PER (image, level): data-parallel DistributeOctTree (A3); the formulation is
 //                    tools/octree_model.py -- stable 4-way partitions by packed prefix sums, list order by scans
-//   k_orient         one wave per keypoint: 31x31 patch in LDS, integer moments, fastAtan2 polynomial        (A6)
-//   k_gauss7         separable 7x7 sigma=2 in Q8 fixed point, 64x16 tiles with 3-px halo in LDS             (A7)
-//   k_brief          one wave per keypoint: 37x37 blurred patch in LDS, 4 tests per lane, ballot-packed      (A7)
+//   k_gauss7         separable 7x7 sigma=2 in Q8 fixed point, 128x32 tiles with halo in LDS                  (A7)
+//   k_orient_brief   one wave per output keypoint: raw 31x31 + blurred 37x37 patches staged in LDS as aligned
+//                    dwords; integer moments + fastAtan2 polynomial (A6), then the steered BRIEF tests, 4 per
+//                    lane, ballot-packed (A7), and the keypoint record
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -41,53 +42,78 @@ __constant__ int c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 
 // ------------------------------------------------------------------------------------------------
 // A5: cv::resize INTER_LINEAR 8UC1 (11-bit coefficients, vertical ((b*(S>>4))>>16 ... +2)>>2)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+// The source indices and the two 11-bit weights of a destination column depend on the column only (rows likewise),
+// so plan() tabulates them once per level on the host with the exact float sequence of cv::resize.  One thread =
+// 4 destination pixels of one row = one QUAD row of the column table (ResizeQuad): the 8 source bytes starting at
+// s0 (ONE unaligned 8-byte load per source row) hold every left/right neighbour of the quad, two v_perm_b32 with
+// the tabulated selectors gather them, then the integer blend and one aligned dword store.  A 64x4 block covers
+// 256 columns x 4 rows.  WIDE8 = false (a level whose quads span more than 8 source bytes, scale factor > 2)
+// falls back to byte loads.
+struct ResizeQuad {          // 32 bytes
+  uint32_t s0;               // first source column of the quad
+  uint32_t sel0, sel1;       // byte k: (sx[k] - s0), (sx1[k] - s0)      (v_perm selectors when all <= 7)
+  uint32_t pad;
+  uint32_t w[4];             // a0 | a1 << 16 per destination column (0 for columns past dcols)
+};
 
+template <bool WIDE8>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base,
-                                                size_t img_stride_bytes, int srows, int scols, int spitch,
-                                                int drows, int dcols, int dpitch, double scale_x, double scale_y)
+                                                size_t img_stride_bytes, int spitch, int drows, int dcols, int dpitch,
+                                                const ResizeQuad* __restrict__ xtab, const uint2* __restrict__ ytab)
 {
-  // scale_x = 1. / ((double)dcols / scols) exactly as cv::resize forms it (computed once on the host)
-  const int dx = blockIdx.x * 256 + threadIdx.x;
-  const int dy = blockIdx.y;
+  const int q = blockIdx.x * 64 + threadIdx.x;      // quad of destination columns
+  const int dy = blockIdx.y * 4 + threadIdx.y;
+  if (dy >= drows || 4 * q >= dcols) return;
   const uint8_t* src = src_base + (size_t)blockIdx.z * img_stride_bytes;
   uint8_t* dst = dst_base + (size_t)blockIdx.z * img_stride_bytes;
-  if (dx >= dcols) return;
-  float fx = (float)((dx + 0.5) * scale_x - 0.5);
-  int sx = cv_floor_f(fx);
-  fx -= sx;
-  if (sx < 0) { fx = 0; sx = 0; }
-  const bool tail = (sx + 1 >= scols);   // dx >= xmax
-  if (sx >= scols - 1) { fx = 0; sx = scols - 1; }
-  const int a0 = __float2int_rn((1.f - fx) * 2048), a1 = __float2int_rn(fx * 2048);
-  float fy = (float)((dy + 0.5) * scale_y - 0.5);
-  int sy = cv_floor_f(fy);
-  fy -= sy;
-  const int b0 = __float2int_rn((1.f - fy) * 2048), b1 = __float2int_rn(fy * 2048);
-  const int sy0 = sy < 0 ? 0 : (sy < srows ? sy : srows - 1);
-  const int sy1 = (sy + 1) < 0 ? 0 : ((sy + 1) < srows ? (sy + 1) : srows - 1);
-  const uint8_t* r0 = src + (size_t)sy0 * spitch;
-  const uint8_t* r1 = src + (size_t)sy1 * spitch;
-  int S0, S1;
-  if (!tail) {
-    S0 = r0[sx] * a0 + r0[sx + 1] * a1;
-    S1 = r1[sx] * a0 + r1[sx + 1] * a1;
+  const uint2 yt = ytab[dy];
+  const uint4 ta = reinterpret_cast<const uint4*>(xtab)[2 * q], tw = reinterpret_cast<const uint4*>(xtab)[2 * q + 1];
+  const uint8_t* r0 = src + (size_t)(yt.x & 0xFFFFu) * spitch + ta.x;
+  const uint8_t* r1 = src + (size_t)(yt.x >> 16) * spitch + ta.x;
+  const int b0 = (int)(yt.y & 0xFFFFu), b1 = (int)(yt.y >> 16);
+  uint32_t p00, p01, p10, p11;       // row 0 left / right neighbours, row 1 left / right (4 bytes each)
+  if (WIDE8) {
+    uint2 w0, w1;
+    __builtin_memcpy(&w0, r0, 8);
+    __builtin_memcpy(&w1, r1, 8);
+    p00 = __builtin_amdgcn_perm(w0.y, w0.x, ta.y); p01 = __builtin_amdgcn_perm(w0.y, w0.x, ta.z);
+    p10 = __builtin_amdgcn_perm(w1.y, w1.x, ta.y); p11 = __builtin_amdgcn_perm(w1.y, w1.x, ta.z);
   } else {
-    S0 = r0[sx] * 2048;
-    S1 = r1[sx] * 2048;
+    p00 = p01 = p10 = p11 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int o0 = (ta.y >> (8 * k)) & 0xFF, o1 = (ta.z >> (8 * k)) & 0xFF;
+      p00 |= (uint32_t)r0[o0] << (8 * k); p01 |= (uint32_t)r0[o1] << (8 * k);
+      p10 |= (uint32_t)r1[o0] << (8 * k); p11 |= (uint32_t)r1[o1] << (8 * k);
+    }
   }
-  dst[(size_t)dy * dpitch + dx] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+  const uint32_t wa[4] = {tw.x, tw.y, tw.z, tw.w};
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int a0 = (int)(wa[k] & 0xFFFFu), a1 = (int)(wa[k] >> 16);
+    const int S0 = (int)((p00 >> (8 * k)) & 0xFF) * a0 + (int)((p01 >> (8 * k)) & 0xFF) * a1;
+    const int S1 = (int)((p10 >> (8 * k)) & 0xFF) * a0 + (int)((p11 >> (8 * k)) & 0xFF) * a1;
+    const uint32_t v = (uint32_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+    out |= (v & 0xFFu) << (8 * k);
+  }
+  *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + 4 * q) = out;
 }
 
-// copy a pitched host-layout image into level 0 of the pyramid (pitch change) and optionally fill a constant
+// copy a pitched host-layout image into level 0 of the pyramid (pitch change): 8 destination bytes per thread
+// (the source rows of a 1241-px image are not dword aligned, the destination rows always are)
 __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__ in, int in_stride, size_t in_img_bytes,
                                                      uint8_t* __restrict__ dst_base, size_t img_stride_bytes,
-                                                     int rows, int cols, int dpitch, int fill, int fill_value)
+                                                     int rows, int cols, int dpitch)
 {
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= cols) return;
-  uint8_t* dst = dst_base + (size_t)blockIdx.z * img_stride_bytes;
-  dst[(size_t)y * dpitch + x] = fill ? (uint8_t)fill_value : in[(size_t)blockIdx.z * in_img_bytes + (size_t)y * in_stride + x];
+  const int x = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  const uint8_t* srow = in + (size_t)blockIdx.z * in_img_bytes + (size_t)y * in_stride;
+  uint32_t w[2] = {0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (x + k < cols) w[k >> 2] |= (uint32_t)srow[x + k] << (8 * (k & 3));
+  *reinterpret_cast<uint2*>(dst_base + (size_t)blockIdx.z * img_stride_bytes + (size_t)y * dpitch + x) = make_uint2(w[0], w[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -105,39 +131,53 @@ __device__ __forceinline__ bool arc9(unsigned m)   // 9 contiguous set bits in a
   return (r & 0xFFFFu) != 0;
 }
 
-// segment test + cornerScore<16> (OpenCV) for the pixel at LDS address c (row pitch p): returns -1 when the
-// pixel is not a FAST-9 corner at threshold t, else the score (largest threshold that still passes, minus 1... i.e.
-// -b0-1 of OpenCV's cornerScore) which is >= t-1 and <= 254.
+// segment test + cornerScore<16> (OpenCV) for the pixel at address c (row pitch p): returns -1 when the pixel is
+// not a FAST-9 corner at threshold t, else OpenCV's cornerScore (the largest threshold at which the pixel is still
+// a corner), which is >= t and <= 254.
+//
+// With d[k] = v - ring[k], a0 = max over the 16 arcs of (min of d over the 9-arc) and b0 = min over arcs of (max
+// over the arc): the pixel is a dark corner at t iff a0 > t and a bright one iff b0 < -t, and cornerScore is
+// max(a0, -b0) - 1 once both are clamped at t - so the segment test needs no bit masks, it falls out of the
+// score.  The ring is held as 8 packed i16 pairs (d[k], d[k+8]); every sliding-window min/max then runs on
+// v_pk_min_i16 / v_pk_max_i16 and the "+8" rotations are half swaps (op_sel, free).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 hswap(s16x2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
 __device__ __forceinline__ int fast_score(const uint8_t* c, int p, int t)
 {
-  const int v = c[0];
-  int d[16];
-  unsigned dark = 0, bright = 0;
+  const short v = (short)c[0];
+  s16x2 D[12];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int r = c[c_ring_dx[k] + c_ring_dy[k] * p];
-    d[k] = v - r;
-    dark |= (unsigned)(r < v - t) << k;
-    bright |= (unsigned)(r > v + t) << k;
+  for (int k = 0; k < 8; ++k) {
+    const short r0 = (short)c[c_ring_dx[k] + c_ring_dy[k] * p];
+    const short r1 = (short)c[c_ring_dx[k + 8] + c_ring_dy[k + 8] * p];
+    D[k] = s16x2{v, v} - s16x2{r0, r1};
   }
-  if (!arc9(dark) && !arc9(bright)) return -1;
-  // sliding-window (9) min / max over the circular ring by doubling: 2, 4, 8, then +1
-  int mn[16], mx[16];
+  // index j >= 8 of any packed array is the half swap of index j - 8
+  s16x2 mn[12], mx[12];
+  D[8] = hswap(D[0]);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
-  int mn4[16], mx4[16];
+  for (int k = 0; k < 8; ++k) { mn[k] = pmin(D[k], D[k + 1]); mx[k] = pmax(D[k], D[k + 1]); }
+  mn[8] = hswap(mn[0]); mn[9] = hswap(mn[1]); mx[8] = hswap(mx[0]); mx[9] = hswap(mx[1]);
+  s16x2 mn4[12], mx4[12];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
-  int a0 = t, bmin = 255;
+  for (int k = 0; k < 8; ++k) { mn4[k] = pmin(mn[k], mn[k + 2]); mx4[k] = pmax(mx[k], mx[k + 2]); }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int m8 = min(mn4[k], mn4[(k + 4) & 15]);
-    const int x8 = max(mx4[k], mx4[(k + 4) & 15]);
-    a0 = max(a0, min(m8, d[(k + 8) & 15]));
-    bmin = min(bmin, max(x8, d[(k + 8) & 15]));
+  for (int k = 0; k < 4; ++k) { mn4[8 + k] = hswap(mn4[k]); mx4[8 + k] = hswap(mx4[k]); }
+  s16x2 a0 = s16x2{(short)t, (short)t}, b0 = s16x2{255, 255};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const s16x2 m8 = pmin(mn4[k], mn4[k + 4]);      // min of d over k .. k+7 (and k+8 .. k+15)
+    const s16x2 x8 = pmax(mx4[k], mx4[k + 4]);
+    const s16x2 d8 = hswap(D[k]);                   // d[k+8], d[k+16]
+    a0 = pmax(a0, pmin(m8, d8));
+    b0 = pmin(b0, pmax(x8, d8));
   }
-  const int b0 = min(-a0, bmin);
-  return -b0 - 1;
+  const int a = max((int)a0.x, (int)a0.y), b = min((int)b0.x, (int)b0.y);
+  const int sc = max(a, -b) - 1;                    // == -min(-a, b) - 1 of OpenCV with a0 seeded at t
+  return sc >= t ? sc : -1;
 }
 
 // ring pixel k of the Bresenham circle relative to c (LDS row pitch p)
@@ -178,8 +218,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o)
   uint8_t* sImg = smem + (size_t)wave * o.fast_lds_per_wave;
   uint8_t* sScore = sImg + o.fast_tile_bytes;
   uint16_t* sList = reinterpret_cast<uint16_t*>(sScore + o.fast_tile_bytes);   // compacted pixel indices
+  const float inv_ndw = 1.0f / (float)ndw;
   for (int i = lane; i < h * ndw; i += 64) {
-    const int y = i / ndw, xd = i - y * ndw;
+    const int y = (int)(((float)i + 0.5f) * inv_ndw), xd = i - y * ndw;   // exact: i < 1368, ndw <= 19
     reinterpret_cast<uint32_t*>(sImg)[i] = *reinterpret_cast<const uint32_t*>(lvl + (size_t)(c.y0 + y) * pitch + tx0 + 4 * xd);
   }
   const int iw = w - 6, ih = h - 6;                // cv::FAST ignores a 3-px border of the ROI
@@ -383,44 +424,51 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
   return a;
 }
 
-__global__ __launch_bounds__(256) void k_orient(OrbDev o)
+// Stage ROWS patch rows as NDW ALIGNED dwords each (level pitches and offsets are multiples of 128 bytes), starting
+// at the dword that holds column x0 of row y0; returns x0 & 3, the byte offset of x0 inside each staged row.
+// (MUL, SH): i / NDW == (i * MUL) >> SH over the index range used.
+template <int ROWS, int NDW, int MUL, int SH>
+__device__ __forceinline__ int stage_patch(uint32_t* sp, const uint8_t* src, int pitch, int x0, int y0, int lane)
 {
-  __shared__ uint8_t sPatch[4][31 * 32];
-  const int level = blockIdx.y, img = blockIdx.z;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int il = img * o.nlevels + level;
-  const int n = o.sel_count[il];
-  const int k = blockIdx.x * 4 + wave;
-  const bool active = k < n;
-  const uint32_t p = active ? o.sel[(size_t)il * SEL_CAP + k] : 0u;
-  const int minB = EDGE_THRESHOLD - 3;
-  const int cx = (int)(p & 0xFFF) + minB, cy = (int)((p >> 12) & 0xFFF) + minB;   // cvRound of integral coords
-  const uint8_t* src = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[level];
-  const int pitch = o.lvl_pitch[level];
-  uint8_t* sp = sPatch[wave];
-  // stage the 31x31 patch: each iteration the wave reads two 31-byte row segments
-  if (active)
-    for (int i = lane; i < 31 * 32; i += 64) {
-      const int r = i >> 5, cc = i & 31;
-      if (cc < 31) sp[i] = src[(size_t)(cy - 15 + r) * pitch + (cx - 15 + cc)];
+  const int ax = x0 & ~3;
+  const uint8_t* base = src + (size_t)y0 * pitch + ax;
+#pragma unroll
+  for (int i0 = 0; i0 < ROWS * NDW; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < ROWS * NDW) {
+      const int r = (i * MUL) >> SH, d = i - r * NDW;
+      sp[i] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * d);
     }
-  __syncthreads();
-  if (!active) return;
+  }
+  return x0 - ax;
+}
+
+constexpr int OP_NDW = 9;            // orientation patch: 31 rows x 9 dwords (31 bytes + <= 3 bytes of alignment)
+constexpr int BP = 37, BR = 18;      // blurred patch side / radius: |rotated pattern point| <= 18.4 -> rounds to <= 18
+constexpr int BP_NDW = 10;           // 37 bytes + <= 3 bytes of alignment
+constexpr int PATCH_LDS_DW = 31 * OP_NDW + BP * BP_NDW;   // both patches of one keypoint
+
+// IC_Angle (orbextractor.cpp:25-44): integer moments of the circular patch; two lanes per row (u < 0 | u >= 0)
+__device__ __forceinline__ float ic_angle(const uint8_t* sp, int off, int lane)
+{
   int m10 = 0, m01 = 0;
-  if (lane < 31) {
-    const int v = lane - 15;
+  if (lane < 62) {
+    const int row = lane >> 1, half = lane & 1;
+    const int v = row - 15;
     const int dmax = c_umax[v < 0 ? -v : v];
+    const uint8_t* rp = sp + row * (4 * OP_NDW) + off + 15;
+    const int u0 = half ? 0 : -dmax, u1 = half ? dmax : -1;
     int sum = 0;
-    for (int u = -dmax; u <= dmax; ++u) {
-      const int val = sp[lane * 32 + (u + 15)];
+    for (int u = u0; u <= u1; ++u) {
+      const int val = rp[u];
       m10 += u * val;
       sum += val;
     }
     m01 = v * sum;
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
-  if (lane == 0) o.sel_angle[(size_t)il * SEL_CAP + k] = fast_atan2_deg((float)m01, (float)m10);
+  for (int o2 = 32; o2 > 0; o2 >>= 1) { m10 += __shfl_xor(m10, o2); m01 += __shfl_xor(m01, o2); }
+  return fast_atan2_deg((float)m01, (float)m10);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -459,49 +507,53 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float* c, float* s)
   *s = (float)so;
 }
 
-constexpr int BP = 37, BR = 18;   // blurred patch side / radius: |rotated pattern point| <= 18.4 -> rounds to <= 18
-
-__global__ __launch_bounds__(256) void k_brief(OrbDev o)
+// steered BRIEF: lane l evaluates tests l, 64+l, 128+l, 192+l on the staged blurred patch (byte offset `off` in
+// each row of 4 * BP_NDW bytes); the four ballots ARE the descriptor's four 64-bit words (bit i = test i).
+__device__ __forceinline__ void brief_words(const uint8_t* sp, int off, float angle, int lane, unsigned long long words[4])
 {
-  __shared__ uint8_t sPatch[4][BP * 40];
-  const int level = blockIdx.y, img = blockIdx.z;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int il = img * o.nlevels + level;
-  const int n = o.sel_count[il];
-  const int k = blockIdx.x * 4 + wave;
-  // output slot: levels are concatenated in order (orbextractor.cpp:722-752)
-  int base = 0;
-  for (int l = 0; l < level; ++l) base += o.sel_count[img * o.nlevels + l];
-  const int slot = base + k;
-  const bool active = (k < n) && (slot < o.out_cap);
-  if (k < n && slot >= o.out_cap && lane == 0) atomicOr(&o.status[img], 4);
-  const uint32_t p = active ? o.sel[(size_t)il * SEL_CAP + k] : 0u;
-  const int minB = EDGE_THRESHOLD - 3;
-  const int cx = (int)(p & 0xFFF) + minB, cy = (int)((p >> 12) & 0xFFF) + minB;
-  const float angle = active ? o.sel_angle[(size_t)il * SEL_CAP + k] : 0.f;
-  const uint8_t* src = o.blur + (size_t)img * o.pyr_bytes + o.lvl_off[level];
-  const int pitch = o.lvl_pitch[level];
-  uint8_t* sp = sPatch[wave];
-  if (active)
-    for (int i = lane; i < BP * 40; i += 64) {
-      const int r = i / 40, cc = i - r * 40;
-      if (cc < BP) sp[i] = src[(size_t)(cy - BR + r) * pitch + (cx - BR + cc)];
-    }
-  __syncthreads();
-  if (!active) return;
   float a, b;
   sincos_deg(angle, &a, &b);
-  unsigned long long words[4];
+  const uint8_t* c = sp + BR * (4 * BP_NDW) + BR + off;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int8_t* tp = &c_pattern[(j * 64 + lane) * 4];
     const float x0 = (float)tp[0], y0 = (float)tp[1], x1 = (float)tp[2], y1 = (float)tp[3];
     const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
     const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
-    const int t0 = sp[(r0 + BR) * 40 + (c0 + BR)];
-    const int t1 = sp[(r1 + BR) * 40 + (c1 + BR)];
+    const int t0 = c[r0 * (4 * BP_NDW) + c0];
+    const int t1 = c[r1 * (4 * BP_NDW) + c1];
     words[j] = __ballot(t0 < t1);
   }
+}
+
+// One wave per OUTPUT SLOT (levels concatenated in order, orbextractor.cpp:722-752): orientation from the raw
+// 31x31 patch, descriptor from the blurred 37x37 patch, keypoint record.  No workgroup barrier: a wave owns its
+// LDS patches.
+__global__ __launch_bounds__(256) void k_orient_brief(OrbDev o)
+{
+  __shared__ uint32_t sPatch[4][PATCH_LDS_DW];
+  const int img = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + wave;
+  int level = 0, base = 0, n = o.sel_count[img * o.nlevels];
+  while (level + 1 < o.nlevels && slot >= base + n) { base += n; ++level; n = o.sel_count[img * o.nlevels + level]; }
+  const int k = slot - base;
+  if (k >= n) return;                                   // past the last level's keypoints (wave-uniform)
+  if (slot >= o.out_cap) { if (lane == 0) atomicOr(&o.status[img], 4); return; }
+  const int il = img * o.nlevels + level;
+  const uint32_t p = o.sel[(size_t)il * SEL_CAP + k];
+  const int minB = EDGE_THRESHOLD - 3;
+  const int cx = (int)(p & 0xFFF) + minB, cy = (int)((p >> 12) & 0xFFF) + minB;   // cvRound of integral coords
+  const size_t lvl = (size_t)img * o.pyr_bytes + o.lvl_off[level];
+  const int pitch = o.lvl_pitch[level];
+  uint32_t* sp = sPatch[wave];
+  const int off_o = stage_patch<31, OP_NDW, 57, 9>(sp, o.pyr + lvl, pitch, cx - 15, cy - 15, lane);
+  const int off_b = stage_patch<BP, BP_NDW, 205, 11>(sp + 31 * OP_NDW, o.blur + lvl, pitch, cx - BR, cy - BR, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const float angle = ic_angle(reinterpret_cast<const uint8_t*>(sp), off_o, lane);
+  unsigned long long words[4];
+  brief_words(reinterpret_cast<const uint8_t*>(sp + 31 * OP_NDW), off_b, angle, lane, words);
   if (lane < 4) {
     unsigned long long* dd = reinterpret_cast<unsigned long long*>(o.out_desc + ((size_t)img * o.out_cap + slot) * 32);
     dd[lane] = words[lane];
@@ -535,7 +587,7 @@ struct DescribeAt {
 
 __global__ __launch_bounds__(256) void k_describe_at(OrbDev o, DescribeAt a)
 {
-  __shared__ uint8_t sPatch[4][BP * 40];
+  __shared__ uint32_t sPatch[4][PATCH_LDS_DW];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + wave;
   bool active = k < a.n_in;
@@ -558,52 +610,24 @@ __global__ __launch_bounds__(256) void k_describe_at(OrbDev o, DescribeAt a)
   const uint8_t* lvl = o.pyr + o.lvl_off[level];
   const int pitch = o.lvl_pitch[level];
   if (active) active = fast_score(lvl + (size_t)cy * pitch + cx, pitch, min(max(o.min_th, 0), 255)) >= 0;   // isFastCorner
-  uint8_t* sp = sPatch[wave];
+  uint32_t* sp = sPatch[wave];
   // orientation patch (raw level)
-  if (active)
-    for (int i = lane; i < 31 * 32; i += 64) {
-      const int r = i >> 5, cc = i & 31;
-      if (cc < 31) sp[i] = lvl[(size_t)(cy - 15 + r) * pitch + (cx - 15 + cc)];
-    }
+  int off_o = 0;
+  if (active) off_o = stage_patch<31, OP_NDW, 57, 9>(sp, lvl, pitch, cx - 15, cy - 15, lane);
   __syncthreads();
   float angle = 0.f;
-  if (active) {
-    int m10 = 0, m01 = 0;
-    if (lane < 31) {
-      const int v = lane - 15;
-      const int dmax = c_umax[v < 0 ? -v : v];
-      int sum = 0;
-      for (int u = -dmax; u <= dmax; ++u) { const int val = sp[lane * 32 + (u + 15)]; m10 += u * val; sum += val; }
-      m01 = v * sum;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
-    angle = fast_atan2_deg((float)m01, (float)m10);
-  }
-  __syncthreads();
+  if (active) angle = ic_angle(reinterpret_cast<const uint8_t*>(sp), off_o, lane);
   // CalcDescriptors: pt (already multiplied back by scale) is divided by scale AGAIN before describing
   float ox = kp.x * sc, oy = kp.y * sc;                        // kps.pt *= scale  (the output coordinates)
   const float dx = ox / sc, dy = oy / sc;
   const int bx = __float2int_rn(dx), by = __float2int_rn(dy);
   const uint8_t* blur = o.blur + o.lvl_off[level];
-  if (active)
-    for (int i = lane; i < BP * 40; i += 64) {
-      const int r = i / 40, cc = i - r * 40;
-      if (cc < BP) sp[i] = blur[(size_t)(by - BR + r) * pitch + (bx - BR + cc)];
-    }
+  int off_b = 0;
+  if (active) off_b = stage_patch<BP, BP_NDW, 205, 11>(sp + 31 * OP_NDW, blur, pitch, bx - BR, by - BR, lane);
   __syncthreads();
   if (!active) { if (k < a.n_in && lane == 0) a.keep[k] = 0; return; }
-  float ca, sb;
-  sincos_deg(angle, &ca, &sb);
   unsigned long long words[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int8_t* tp = &c_pattern[(j * 64 + lane) * 4];
-    const float x0 = (float)tp[0], y0 = (float)tp[1], x1 = (float)tp[2], y1 = (float)tp[3];
-    const int r0 = __float2int_rn(x0 * sb + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sb);
-    const int r1 = __float2int_rn(x1 * sb + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sb);
-    words[j] = __ballot(sp[(r0 + BR) * 40 + (c0 + BR)] < sp[(r1 + BR) * 40 + (c1 + BR)]);
-  }
+  brief_words(reinterpret_cast<const uint8_t*>(sp + 31 * OP_NDW), off_b, angle, lane, words);
   if (lane < 4) reinterpret_cast<unsigned long long*>(a.desc + (size_t)k * 32)[lane] = words[lane];
   if (lane == 0) {
     ssx_keypoint okp = kp;
@@ -773,9 +797,49 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
       t0 += ((d.lvl_cols[l] + GT_W - 1) / GT_W) * ((d.lvl_rows[l] + GT_H - 1) / GT_H);
     }
     for (int l = nlevels; l <= MAX_LEVELS; ++l) d.gauss_tile0[l] = t0;
-    for (int l = 1; l < nlevels; ++l) {   // cv::resize: inv_scale = dsize/ssize, scale = 1/inv_scale
-      d.rs_scale_x[l] = 1. / ((double)d.lvl_cols[l] / d.lvl_cols[l - 1]);
-      d.rs_scale_y[l] = 1. / ((double)d.lvl_rows[l] / d.lvl_rows[l - 1]);
+  }
+  // cv::resize INTER_LINEAR tables (resize.cpp: inv_scale = dsize/ssize, scale = 1/inv_scale; fx = (dx+0.5)*scale-0.5
+  // in float, sx = floor, clamps, cvRound of the weights * 2048): one (index, weight) pair row per destination
+  // column / row of every level.  Column tables are padded to a multiple of 4 with zero rows.
+  std::vector<ResizeQuad> xtab;
+  std::vector<uint2> ytab;
+  for (int l = 1; l < nlevels; ++l) {
+    const int scols = d.lvl_cols[l - 1], srows = d.lvl_rows[l - 1], dcols = d.lvl_cols[l], drows = d.lvl_rows[l];
+    const double scale_x = 1. / ((double)dcols / scols), scale_y = 1. / ((double)drows / srows);
+    d.rs_xoff[l] = (int)xtab.size();
+    d.rs_yoff[l] = (int)ytab.size();
+    d.rs_wide8[l] = 1;
+    for (int q = 0; 4 * q < dcols; ++q) {
+      ResizeQuad rq{};
+      for (int k = 0; k < 4 && 4 * q + k < dcols; ++k) {
+        const int dx = 4 * q + k;
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= scols - 1) { fx = 0; sx = scols - 1; }       // dx >= xmax: the right neighbour gets weight 0
+        const int a0 = h_round((1.f - fx) * 2048), a1 = h_round(fx * 2048);
+        const int sx1 = std::min(sx + 1, scols - 1);
+        if (k == 0) rq.s0 = (uint32_t)sx;
+        const int o0 = sx - (int)rq.s0, o1 = sx1 - (int)rq.s0;
+        if (o1 > 7) d.rs_wide8[l] = 0;
+        if (o1 > 255) {
+          ctx->set_error("ssx_orb: pyramid scale factor %g is too large for the resize tables", (double)prm.scale_factor);
+          return SSX_ERR_UNSUPPORTED;
+        }
+        rq.sel0 |= (uint32_t)o0 << (8 * k);
+        rq.sel1 |= (uint32_t)o1 << (8 * k);
+        rq.w[k] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+      }
+      xtab.push_back(rq);
+    }
+    for (int dy = 0; dy < drows; ++dy) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      const int sy = (int)std::floor(fy);
+      fy -= sy;
+      const int b0 = h_round((1.f - fy) * 2048), b1 = h_round(fy * 2048);
+      const int sy0 = std::min(std::max(sy, 0), srows - 1), sy1 = std::min(std::max(sy + 1, 0), srows - 1);
+      ytab.push_back(make_uint2((uint32_t)sy0 | ((uint32_t)sy1 << 16), (uint32_t)b0 | ((uint32_t)b1 << 16)));
     }
   }
   for (const Cell& c : cells)
@@ -785,6 +849,8 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
     }
   Layout lay;
   const size_t o_cells = lay.take(sizeof(Cell) * std::max<size_t>(cells.size(), 1));
+  const size_t o_xtab = lay.take(sizeof(ResizeQuad) * std::max<size_t>(xtab.size(), 1));
+  const size_t o_ytab = lay.take(sizeof(uint2) * std::max<size_t>(ytab.size(), 4));
   const size_t o_pyr = lay.take(d.pyr_bytes * I);
   const size_t o_mask = lay.take(has_mask ? d.pyr_bytes * I : 256);
   const size_t o_blur = lay.take(d.pyr_bytes * I);
@@ -802,6 +868,8 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
   SSX_HIP_TRY(ctx, ws->arena.reserve(lay.off));
   char* base = ws->arena.as<char>();
   d.cells = (const Cell*)(base + o_cells);
+  d.rs_xtab = (const ResizeQuad*)(base + o_xtab);
+  d.rs_ytab = (const uint2*)(base + o_ytab);
   d.pyr = (uint8_t*)(base + o_pyr);
   d.maskpyr = (uint8_t*)(base + o_mask);
   d.blur = (uint8_t*)(base + o_blur);
@@ -818,7 +886,11 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
   d.out_n = (int*)(base + o_n);
   if (!cells.empty())
     SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_cells, cells.data(), sizeof(Cell) * cells.size(), hipMemcpyHostToDevice, ctx->stream));
-  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `cells` is a pageable temporary
+  if (!xtab.empty()) {
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_xtab, xtab.data(), sizeof(ResizeQuad) * xtab.size(), hipMemcpyHostToDevice, ctx->stream));
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_ytab, ytab.data(), sizeof(uint2) * ytab.size(), hipMemcpyHostToDevice, ctx->stream));
+  }
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `cells` and the tables are pageable temporaries
   ws->dev = d;
   ws->rows = rows; ws->cols = cols; ws->I = I; ws->nlevels = nlevels; ws->nfeatures = prm.nfeatures;
   ws->ini_th = prm.ini_th_fast; ws->min_th = prm.min_th_fast; ws->has_mask = has_mask; ws->detect_only = detect_only;
@@ -827,17 +899,31 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
   return SSX_OK;
 }
 
+// pyramid (ComputePyramid, orbextractor.cpp:993-1027): level l from level l-1, images (and masks) of the batch
+static void launch_pyramid(ssx_ctx* ctx, const OrbDev& d, hipStream_t s, int images)
+{
+  for (int l = 1; l < d.nlevels; ++l) {
+    const dim3 grid((d.lvl_cols[l] + 255) / 256, (d.lvl_rows[l] + 3) / 4, images);
+    auto kern = d.rs_wide8[l] ? k_resize<true> : k_resize<false>;
+    for (int m = 0; m < (d.has_mask ? 2 : 1); ++m) {
+      uint8_t* pyr = m ? d.maskpyr : d.pyr;
+      SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(kern, grid, dim3(64, 4), 0, s, pyr + d.lvl_off[l - 1], pyr + d.lvl_off[l], d.pyr_bytes,
+                         d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l], d.rs_xtab + d.rs_xoff[l], d.rs_ytab + d.rs_yoff[l]));
+    }
+  }
+}
+
 ssx_status stage_level0(ssx_ctx* ctx, const uint8_t* imgs_dev, int stride, size_t img_bytes, const uint8_t* masks_dev,
                         int mask_stride, size_t mask_bytes)
 {
   OrbWorkspace* ws = get_ws(ctx);
   const OrbDev& d = ws->dev;
-  const dim3 grid((d.lvl_cols[0] + 255) / 256, d.lvl_rows[0], d.I);
-  SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, ctx->stream, imgs_dev, stride, img_bytes, d.pyr, d.pyr_bytes,
-                     d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0], 0, 0));
+  const dim3 grid((d.lvl_cols[0] + 511) / 512, (d.lvl_rows[0] + 3) / 4, d.I);
+  SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_copy_level0, grid, dim3(64, 4), 0, ctx->stream, imgs_dev, stride, img_bytes, d.pyr, d.pyr_bytes,
+                     d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0]));
   if (d.has_mask)
-    SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, ctx->stream, masks_dev, mask_stride, mask_bytes, d.maskpyr,
-                       d.pyr_bytes, d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0], 0, 0));
+    SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_copy_level0, grid, dim3(64, 4), 0, ctx->stream, masks_dev, mask_stride, mask_bytes, d.maskpyr,
+                       d.pyr_bytes, d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0]));
   SSX_HIP_TRY(ctx, hipGetLastError());
   return SSX_OK;
 }
@@ -848,17 +934,7 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   const OrbDev& d = ws->dev;
   hipStream_t s = ctx->stream;
   SSX_HIP_TRY(ctx, hipMemsetAsync(d.status, 0, sizeof(int) * d.I, s));
-  // pyramid (ComputePyramid): level l from level l-1
-  for (int l = 1; l < d.nlevels; ++l) {
-    const dim3 grid((d.lvl_cols[l] + 255) / 256, d.lvl_rows[l], d.I);
-    SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.pyr + d.lvl_off[l - 1], d.pyr + d.lvl_off[l], d.pyr_bytes,
-                       d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l],
-                       d.rs_scale_x[l], d.rs_scale_y[l]));
-    if (d.has_mask)
-      SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.maskpyr + d.lvl_off[l - 1], d.maskpyr + d.lvl_off[l], d.pyr_bytes,
-                         d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l],
-                         d.rs_scale_x[l], d.rs_scale_y[l]));
-  }
+  launch_pyramid(ctx, d, s, d.I);
   // the blur only depends on the pyramid: it runs on the auxiliary stream, concurrently with detection
   // (HBM-streaming blur next to the latency-bound octree), and is joined before the descriptors.
   const bool fork = !d.detect_only && ctx->aux != nullptr;
@@ -880,12 +956,10 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   if (d.detect_only) {
     SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_finalize_detect, dim3((SEL_CAP + 255) / 256, d.I), dim3(256), 0, s, d));
   } else {
-    int maxfeat = 0;
-    for (int l = 0; l < d.nlevels; ++l) maxfeat = std::max(maxfeat, d.feat[l] + 4);
-    const dim3 kgrid((maxfeat + 3) / 4, d.nlevels, d.I);
-    SSX_PROF(ctx, KID_ORB_ORIENT, hipLaunchKernelGGL(k_orient, kgrid, dim3(256), 0, s, d));
+    // one wave per output slot; a keypoint past out_cap raises the capacity flag from the first wave beyond it
+    const dim3 kgrid((d.out_cap + 4 + 3) / 4, d.I);
     if (fork) SSX_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-    SSX_PROF(ctx, KID_ORB_BRIEF, hipLaunchKernelGGL(k_brief, kgrid, dim3(256), 0, s, d));
+    SSX_PROF(ctx, KID_ORB_BRIEF, hipLaunchKernelGGL(k_orient_brief, kgrid, dim3(256), 0, s, d));
   }
   SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_counts, dim3((d.I + 63) / 64), dim3(64), 0, s, d));
   SSX_HIP_TRY(ctx, hipGetLastError());
@@ -1015,12 +1089,7 @@ ssx_status ssx_orb_describe_at(ssx_ctx* ctx, const uint8_t* img, int32_t stride,
   st = stage_level0(ctx, (const uint8_t*)(base + o_img), cols, bytes, nullptr, 0, 0);
   if (st != SSX_OK) return st;
   hipStream_t s = ctx->stream;
-  for (int l = 1; l < d.nlevels; ++l) {   // ComputePyramid(image), orbextractor.cpp:1012-1027
-    const dim3 grid((d.lvl_cols[l] + 255) / 256, d.lvl_rows[l], 1);
-    SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, d.pyr + d.lvl_off[l - 1], d.pyr + d.lvl_off[l], d.pyr_bytes,
-                       d.lvl_rows[l - 1], d.lvl_cols[l - 1], d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l],
-                       d.rs_scale_x[l], d.rs_scale_y[l]));
-  }
+  launch_pyramid(ctx, d, s, 1);           // ComputePyramid(image), orbextractor.cpp:1012-1027
   SSX_PROF(ctx, KID_ORB_GAUSS, hipLaunchKernelGGL(k_gauss7, dim3(d.gauss_tile0[d.nlevels], 1), dim3(256), 0, s, d));
   DescribeAt a;
   a.in = (const ssx_keypoint*)(base + o_in); a.out = (ssx_keypoint*)(base + o_out); a.desc = (uint8_t*)(base + o_desc);

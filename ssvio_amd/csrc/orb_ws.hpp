@@ -52,6 +52,8 @@ struct OctNode {      // 16 bytes
   uint8_t div;        // marked for division in the current round
 };
 
+struct ResizeQuad;
+
 struct OrbDev {
   // geometry
   int I;                         // images in the batch
@@ -70,9 +72,12 @@ struct OrbDev {
   int fast_tile_bytes;           // LDS bytes of one ROI tile (max over cells, pitch rounded to 4)
   int fast_lds_per_wave;         // image tile + score tile + compaction list
   int gauss_tile0[MAX_LEVELS + 1]; // first blur tile of each level (one launch covers all levels)
-  double rs_scale_x[MAX_LEVELS], rs_scale_y[MAX_LEVELS]; // cv::resize scale factors of level l (from l-1)
+  int rs_xoff[MAX_LEVELS], rs_yoff[MAX_LEVELS];   // first row of level l in the cv::resize tables below
+  int rs_wide8[MAX_LEVELS];      // every quad of the level reads <= 8 consecutive source bytes
   // buffers
   const Cell* cells;
+  const ResizeQuad* rs_xtab;     // per quad of destination columns (levels concatenated), see k_resize
+  const uint2* rs_ytab;          // per destination row:    sy0 | sy1<<16, b0 | b1<<16
   uint8_t* pyr;                  // [I][pyr_bytes]
   uint8_t* maskpyr;              // [I][pyr_bytes] (only when has_mask)
   uint8_t* blur;                 // [I][pyr_bytes]
