@@ -2,25 +2,34 @@
 //
 // Replaces ORBextractor::DistributeOctTree + ExtractorNode::DivideNode
 // (/root/reference/src/ssvio/orbextractor.cpp:340-568, 282-338).  The reference walks a std::list and splits
-// nodes one at a time; the selection it produces depends only on (a) the order of the list, (b) the insertion
-// order of the keypoints inside every node and (c) the processing order of the "largest first" phase.  All
-// three are reproduced with flat arrays and prefix sums (tools/octree_model.py is the executable statement
-// of this formulation, checked against the sequential oracle):
-//   * every node owns a contiguous range of the key array; a division is a STABLE 4-way partition of that range,
-//     computed for all divided nodes at once from one packed (4 x 16 bit) exclusive scan over the key positions;
-//   * the node table is kept IN LIST ORDER: after a round the children of the i-th processed node sit at
-//     [T - P_i - cc_i, T - P_i) in quadrant order 4,3,2,1 (push_front semantics) and the untouched nodes follow
-//     in their old relative order;
-//   * phase 2 sorts the expandable nodes by (size, creation index) descending with an LDS bitonic sort and
-//     cuts the list at the first prefix that reaches N nodes.
-// Tie-break of equal sizes: creation order (the reference compares heap pointers, orbextractor.cpp:486, which is
-// not reproducible); identical to the oracle.
+// nodes one at a time, moving the keypoints of a node into its children.  What it SELECTS depends only on
+//   (a) the order of the node list,
+//   (b) how many keypoints every node holds (bNoMore, "expandable", the largest-first order of phase 2), and
+//   (c) inside a node, the keypoint with the largest response, the FIRST such keypoint in the node's vector.
+// A node's vector is always in the original candidate order (the root assignment and every DivideNode are stable),
+// so (c) is "largest response, then smallest candidate index", and the keypoints never have to move:
+//   * every thread owns up to 16 CONSECUTIVE candidates, kept in LDS in a conflict-free [slot][thread] layout
+//     (packed x|y|score and the id of the node they are in);
+//   * a round = one pass over the keys that adds the quadrant of every key of a divided node to that node's packed
+//     4 x 16-bit counter (64-bit LDS atomics, one per run of equal nodes in a thread's keys), node-level
+//     bookkeeping, and a second pass that renames each key's node id to the child (or to the survivor's new
+//     position);
+//   * the node table (boxes, counts, processing list, child ids, expandable lists) lives in LDS, IN LIST ORDER:
+//     after a round the children of the i-th processed node sit at [T - P_i - cc_i, T - P_i) in quadrant order
+//     4,3,2,1 (push_front semantics) and the untouched nodes follow in their old relative order
+//     (tools/octree_model.py is the executable statement of this bookkeeping, checked against the sequential
+//     oracle);
+//   * phase 2 orders the expandable nodes by (size, creation index) descending by counting ranks, and cuts the
+//     list at the first prefix that reaches N nodes;
+//   * the winner of every final node is one LDS atomicMax on (response << 14 | 16383 - candidate index).
+// Tie-break of equal sizes in phase 2: creation order (the reference compares heap pointers,
+// orbextractor.cpp:486, which is not reproducible); identical to the oracle.
 //
-// Memory: per key only two u32 streams exist (packed candidate x|y|score, and key|node); the quadrant of every key
-// lives in LDS for the duration of a round; each thread walks a contiguous run of key positions, so the node
-// record is re-read only when the run crosses a node boundary.  (Round 1 kept a 64-bit scan value, separate key /
-// node-id arrays and unpacked coordinates per key in global memory: rocprof showed 400 MB of L2<->HBM traffic per
-// launch for 1.3 MB of algorithmic bytes.)
+// History: v1 kept per-key 64-bit scan values and unpacked coordinates in global memory (rocprof: 400 MB of
+// L2<->HBM traffic per launch for 1.3 MB of algorithmic bytes); v2 packed the per-key streams but still moved the
+// keys with a stable partition every round through global memory (~150 us per level-0 workgroup, bound by ~30
+// barriers and a dozen dependent global round trips per round).  This version touches global memory twice: the
+// cell lists in, the selection out.
 #include "orb_ws.hpp"
 
 namespace ssxorb {
@@ -30,112 +39,136 @@ namespace {
 typedef unsigned long long u64;
 constexpr int T = OCT_THREADS;
 constexpr int NW = T / 64;
+constexpr int KPT = CAND_CAP / T;          // candidates per thread (registers)
+constexpr unsigned NONE = 0xFFFFu;
+static_assert(KPT * 2 <= 32, "quadrants of a thread's keys are packed 2 bits each in one 32-bit register");
 
-struct Oct {
-  uint32_t* pk;            // packed candidates
-  uint32_t* kn[2];         // key | node << 16
-  OctNode* nodes[2];
-  u64* eb;                 // packed scan value at the first key of each node
-  uint16_t *proc, *expa, *expb, *newpos;
-  u64 *c4, *kid4;
-  uint32_t *ccp, *exp, *sortk;
+struct Box { int16_t ulx, uly, brx, bry; };   // node corners (UL, BR), relative to the level's border
+
+// node-level arrays, LN entries each (OCT_NODE_BYTES per entry): LDS, or global scratch for very large budgets
+struct Tab {
+  u64* c4;            // per PROCESSED node: 4 x 16-bit quadrant counts
+  u64* kid4;          // per processed node: 4 x 16-bit child ids (new list positions)
+  Box* box;           // per node, [2][LN] (ping-pong over rounds; indexed, never selected by pointer, so the
+                      // compiler keeps the LDS address space and emits ds_ instead of flat_ instructions)
+  uint32_t* key;      // phase-2 sort keys; reused for the per-node winner at the end
+  uint16_t* cnt;      // keypoints per node, [2][LN]
+  uint16_t* pidx;     // per node: index in the processing list of this round, NONE = not divided
+  uint16_t* newpos;   // per surviving node: position in the new list
+  uint16_t* proc;     // processing list -> node
+  uint16_t* exp;      // expandable children (count > 1) in creation order, [2][LN]
 };
 
-__device__ __forceinline__ Oct carve(uint8_t* base)
+__device__ __forceinline__ Tab carve(uint8_t* base, int LN)
 {
-  Oct o;
-  o.pk = (uint32_t*)(base + OctLayout::candpk);
-  o.kn[0] = (uint32_t*)(base + OctLayout::keynode); o.kn[1] = o.kn[0] + CAND_CAP;
-  o.nodes[0] = (OctNode*)(base + OctLayout::nodes); o.nodes[1] = o.nodes[0] + NODE_CAP;
-  o.eb = (u64*)(base + OctLayout::ebeg);
-  o.proc = (uint16_t*)(base + OctLayout::proc);
-  o.expa = (uint16_t*)(base + OctLayout::expa);
-  o.expb = (uint16_t*)(base + OctLayout::expb);
-  o.c4 = (u64*)(base + OctLayout::c4);
-  o.kid4 = (u64*)(base + OctLayout::kid4);
-  o.ccp = (uint32_t*)(base + OctLayout::ccp);
-  o.exp = (uint32_t*)(base + OctLayout::exp_);
-  o.newpos = (uint16_t*)(base + OctLayout::newpos);
-  o.sortk = (uint32_t*)(base + OctLayout::sortk);
+  Tab o;
+  const size_t n = (size_t)LN;
+  o.c4 = (u64*)base;
+  o.kid4 = o.c4 + n;
+  o.box = (Box*)(o.kid4 + n);
+  o.key = (uint32_t*)(o.box + 2 * n);
+  o.cnt = (uint16_t*)(o.key + n);
+  o.pidx = o.cnt + 2 * n;
+  o.newpos = o.pidx + n;
+  o.proc = o.newpos + n;
+  o.exp = o.proc + n;
   return o;
 }
+static_assert(OCT_NODE_BYTES == 8 + 8 + 16 + 4 + 4 + 2 + 2 + 2 + 4, "Tab layout and OCT_NODE_BYTES disagree");
 
-// block-wide exclusive scan of one value per thread (thread order); total returned to every thread.
-template <class V>
-__device__ __forceinline__ V block_excl_scan(V v, V* s_wave /*[NW+1]*/, V& total)
+// block-wide exclusive scan of one packed value per thread (thread order); total returned to every thread.
+// ONE barrier: the wave totals go to s_w[par] and every thread adds up the waves before its own; par alternates,
+// so a buffer is rewritten only after the barrier of the following call.
+__device__ __forceinline__ u64 block_scan(u64 v, u64 (*s_w)[NW], int& par, u64& total)
 {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  V inc = v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u64 inc = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const V up = __shfl_up(inc, o);
+    const u64 up = __shfl_up(inc, o);
     if (lane >= o) inc += up;
   }
-  if (lane == 63) s_wave[wave] = inc;
+  if (lane == 63) s_w[par][wave] = inc;
   __syncthreads();
-  if (t == 0) {
-    V run = 0;
-    for (int w = 0; w < NW; ++w) { const V x = s_wave[w]; s_wave[w] = run; run += x; }
-    s_wave[NW] = run;
+  u64 before = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const u64 x = s_w[par][w];
+    tot += x;
+    if (w < wave) before += x;
   }
-  __syncthreads();
-  const V res = s_wave[wave] + (inc - v);
-  total = s_wave[NW];
-  __syncthreads();
-  return res;
+  par ^= 1;
+  total = tot;
+  return before + (inc - v);
 }
 
-__device__ __forceinline__ int quadrant(int x, int y, const OctNode& n)
+__device__ __forceinline__ int quadrant(int x, int y, const Box& n)
 {
-  // DivideNode: halfX = ceil((UR.x - UL.x) / 2), children split at UL + half (orbextractor.cpp:285-327)
-  const int mx = n.ulx + (int)ceilf((float)(n.brx - n.ulx) / 2);
-  const int my = n.uly + (int)ceilf((float)(n.bry - n.uly) / 2);
+  // DivideNode: halfX = ceil((UR.x - UL.x) / 2), children split at UL + half (orbextractor.cpp:285-327);
+  // ceil(w / 2.f) == (w + 1) >> 1 for the non-negative integer widths that occur
+  const int mx = n.ulx + ((n.brx - n.ulx + 1) >> 1);
+  const int my = n.uly + ((n.bry - n.uly + 1) >> 1);
   return (x < mx) ? ((y < my) ? 0 : 2) : ((y < my) ? 1 : 3);
 }
 
 __device__ __forceinline__ unsigned f16(u64 v, int q) { return (unsigned)((v >> (16 * q)) & 0xFFFFu); }
 __device__ __forceinline__ int pk_x(uint32_t p) { return (int)(p & 0xFFF); }
 __device__ __forceinline__ int pk_y(uint32_t p) { return (int)((p >> 12) & 0xFFF); }
-__device__ __forceinline__ int pk_r(uint32_t p) { return (int)(p >> 24); }
+__device__ __forceinline__ uint32_t pk_r(uint32_t p) { return p >> 24; }
+__device__ __forceinline__ int nonzero4(u64 c) { return (f16(c, 0) > 0) + (f16(c, 1) > 0) + (f16(c, 2) > 0) + (f16(c, 3) > 0); }
+__device__ __forceinline__ int above1_4(u64 c) { return (f16(c, 0) > 1) + (f16(c, 1) > 1) + (f16(c, 2) > 1) + (f16(c, 3) > 1); }
 
-}  // namespace
-
+// GLOBAL_TAB = false: node tables in dynamic LDS (OCT_NODE_BYTES * LN bytes); true: in the global scratch block
+template <bool GLOBAL_TAB>
 __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
 {
-  __shared__ u64 s_w64[NW + 1];
-  __shared__ uint32_t s_w32[NW + 1];
-  __shared__ uint32_t s_sort[4096];
-  __shared__ uint8_t s_q[CAND_CAP];     // quadrant of every key position in the current round (4 = node not divided)
-  __shared__ int s_i[8];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ u64 s_w[2][NW];
+  __shared__ int s_root[64], s_rootpos[64];
+  __shared__ int s_i[2];
   const int img = blockIdx.x, level = blockIdx.y, t = threadIdx.x;   // see launch_octree for the order
+  const int lane = t & 63;
   if (d.detect_only && level > 0) return;
   const int il = img * d.nlevels + level;
-  Oct o = carve(d.oct + (size_t)il * OctLayout::total);
+  const int LN = d.oct_ln;
+  Tab tb;
+  uint32_t* s_cellpos;                                                 // [cells of the level + 1], dynamic LDS
+  if constexpr (GLOBAL_TAB) {
+    tb = carve(d.oct + (size_t)il * d.oct_stride, LN);
+    s_cellpos = reinterpret_cast<uint32_t*>(smem);
+  } else {
+    tb = carve(smem, LN);
+    s_cellpos = reinterpret_cast<uint32_t*>(smem + (((size_t)OCT_NODE_BYTES * LN + 15) & ~size_t(15)));
+  }
+  // per-key state, slot k of thread t at [k * T + t]
+  uint32_t* s_kpk = s_cellpos + ((d.oct_max_cells + 1 + 3) & ~3);       // [CAND_CAP] x | y << 12 | score << 24
+  uint16_t* s_kn = reinterpret_cast<uint16_t*>(s_kpk + CAND_CAP);        // [CAND_CAP] node of the key
   const int N = d.feat[level];
   const int cell0 = d.lvl_cell0[level], cell1 = d.lvl_cell0[level + 1];
   const int ncell = cell1 - cell0;
   const int* ccount = d.cell_count + (size_t)img * d.n_cells + cell0;
-  const uint32_t* ccand = d.cell_cand + ((size_t)img * d.n_cells + cell0) * CELL_CAP;
+  const uint32_t* __restrict__ ccand = d.cell_cand + ((size_t)img * d.n_cells + cell0) * CELL_CAP;
+  int par = 0;
 
   // ---- gather the candidates of this level in reference order (cell-row-major, row-major inside a cell) ----
+  // s_cellpos[c] = index of cell c's first candidate in reference order; the candidates themselves stay where
+  // k_fast_cells wrote them and are read straight into registers below.
   int M;
   {
     const int chunk = (ncell + T - 1) / T;
     const int lo = min(t * chunk, ncell), hi = min(lo + chunk, ncell);
-    uint32_t mine = 0;
-    for (int c = lo; c < hi; ++c) mine += (uint32_t)ccount[c];
-    uint32_t total;
-    uint32_t pos = block_excl_scan<uint32_t>(mine, s_w32, total);
-    for (int c = lo; c < hi; ++c) {
-      const int n = ccount[c];
-      for (int k = 0; k < n; ++k, ++pos)
-        if (pos < (uint32_t)CAND_CAP) o.pk[pos] = ccand[(size_t)c * CELL_CAP + k];
-    }
-    M = (int)min(total, (uint32_t)CAND_CAP);
+    u64 mine = 0;
+    for (int c = lo; c < hi; ++c) mine += (u64)ccount[c];
+    u64 total;
+    uint32_t pos = (uint32_t)block_scan(mine, s_w, par, total);
+    for (int c = lo; c < hi; ++c) { s_cellpos[c] = pos; pos += (uint32_t)ccount[c]; }
     if (t == 0) {
+      s_cellpos[ncell] = (uint32_t)total;
       d.lvl_ncand[il] = (int)total;
-      if (total > (uint32_t)CAND_CAP) atomicOr(&d.status[img], 1);
+      if (total > (u64)CAND_CAP) atomicOr(&d.status[img], 1);
     }
+    M = (int)min(total, (u64)CAND_CAP);
+    if (t < 64) s_root[t] = 0;
   }
   __syncthreads();
   int* sel_count = d.sel_count + il;
@@ -148,247 +181,215 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   const int nIni = (int)roundf((float)(maxX - minX) / (float)(maxY - minY));
   if (nIni < 1 || nIni > 64) { if (t == 0) *sel_count = 0; return; }
   const float hX = (float)(maxX - minX) / (float)nIni;
+  // my candidates: the CONTIGUOUS range [p0, p0 + nk) of the reference order.  Neighbouring candidates mostly sit
+  // in the same node, so a thread folds runs of equal targets in registers and issues one LDS atomic per run
+  // (one atomic per key made every round LDS-atomic bound: ~4 clocks per conflicting lane, 13 us per round).
   const int kchunk = (M + T - 1) / T;
-  const int klo = min(t * kchunk, M), khi = min(klo + kchunk, M);
-  int cur = 0;
-  int nNodes = 0;
+  const int p0 = min(t * kchunk, M);
+  const int nk = min(kchunk, M - p0);
   {
-    // root of every candidate once (s_q doubles as scratch), then one stable pass per root
-    for (int p = klo; p < khi; ++p) {
-      int rt = (int)((float)pk_x(o.pk[p]) / hX);
-      s_q[p] = (uint8_t)(rt >= nIni ? nIni - 1 : rt);
+    // cell of p0 by binary search, then walk (empty cells are skipped)
+    int c = 0, off = 0, cend = 0;
+    if (nk > 0) {
+      int lo = 0, hi = ncell;                          // invariant: s_cellpos[lo] <= p0 < s_cellpos[hi]
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cellpos[mid] <= (uint32_t)p0) lo = mid; else hi = mid; }
+      c = lo;
+      off = p0 - (int)s_cellpos[c];
+      cend = (int)(s_cellpos[c + 1] - s_cellpos[c]);
     }
-    int base = 0;
-    for (int r = 0; r < nIni; ++r) {
-      uint32_t mine = 0;
-      for (int p = klo; p < khi; ++p) mine += (s_q[p] == r);
-      uint32_t total;
-      uint32_t pos = block_excl_scan<uint32_t>(mine, s_w32, total);
-      if (total > 0) {
-        for (int p = klo; p < khi; ++p)
-          if (s_q[p] == r) { o.kn[cur][base + pos] = (uint32_t)p | ((uint32_t)nNodes << 16); ++pos; }
-        if (t == 0) {
-          OctNode n;
-          n.b = (uint16_t)base; n.e = (uint16_t)(base + total);
-          n.ulx = (int16_t)(int)(hX * (float)r); n.uly = 0;
-          n.brx = (int16_t)(int)(hX * (float)(r + 1)); n.bry = (int16_t)(maxY - minY);
-          n.pidx = 0; n.no_more = (total == 1); n.div = 0;
-          o.nodes[cur][nNodes] = n;
-        }
-        ++nNodes;
-        base += (int)total;
+    int run_root = -1, run_n = 0;
+    for (int k = 0; k < nk; ++k) {
+      while (off >= cend) { ++c; off = 0; cend = (int)(s_cellpos[c + 1] - s_cellpos[c]); }
+      const uint32_t v = ccand[(size_t)c * CELL_CAP + off];
+      ++off;
+      s_kpk[k * T + t] = v;
+      const int rt = (int)((float)pk_x(v) / hX);
+      const int root = rt >= nIni ? nIni - 1 : rt;
+      s_kn[k * T + t] = (uint16_t)root;
+      if (root != run_root) {
+        if (run_n > 0) atomicAdd(&s_root[run_root], run_n);
+        run_root = root; run_n = 0;
       }
-      __syncthreads();
+      ++run_n;
     }
+    if (run_n > 0) atomicAdd(&s_root[run_root], run_n);
   }
+  __syncthreads();
+  if (t < 64) {
+    // the list keeps the non-empty roots in creation order
+    const int c = t < nIni ? s_root[t] : 0;
+    const u64 bal = __ballot(c > 0);
+    const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+    s_rootpos[t] = pos;
+    if (c > 0) {
+      Box b;
+      b.ulx = (int16_t)(int)(hX * (float)t); b.uly = 0;
+      b.brx = (int16_t)(int)(hX * (float)(t + 1)); b.bry = (int16_t)(maxY - minY);
+      tb.box[pos] = b;
+      tb.cnt[pos] = (uint16_t)c;
+    }
+    if (t == 0) s_i[0] = __popcll(bal);
+  }
+  __syncthreads();
+  int nNodes = s_i[0];
+  for (int k = 0; k < nk; ++k) s_kn[k * T + t] = (uint16_t)s_rootpos[s_kn[k * T + t]];
 
-  uint16_t* exp_cur = o.expa;
-  uint16_t* exp_nxt = o.expb;
-  int nExp = 0;
+  int cur = 0, ecur = 0, nExp = 0, phase = 1, guard = 0;
   bool finish = false;
-  int phase = 1;
-  int guard = 0;
   while (!finish && ++guard < 256) {
-    OctNode* nd = o.nodes[cur];
-    OctNode* nn = o.nodes[cur ^ 1];
-    const uint32_t* kn = o.kn[cur];
-    uint32_t* kn_next = o.kn[cur ^ 1];
+    const Box* bx = tb.box + cur * LN;
+    const uint16_t* ct = tb.cnt + cur * LN;
+    Box* nbx = tb.box + (cur ^ 1) * LN;
+    uint16_t* nct = tb.cnt + (cur ^ 1) * LN;
+    const uint16_t* exp_cur = tb.exp + ecur * LN;
+    uint16_t* exp_nxt = tb.exp + (ecur ^ 1) * LN;
     const int prevSize = nNodes;
     const int nchunk = (nNodes + T - 1) / T;
     const int nlo = min(t * nchunk, nNodes), nhi = min(nlo + nchunk, nNodes);
     int m = 0;   // length of the processing list
     // ---------------- build the processing list ----------------
     if (phase == 1) {
-      uint32_t mine = 0;
-      for (int j = nlo; j < nhi; ++j) mine += !nd[j].no_more;
-      uint32_t total;
-      uint32_t pos = block_excl_scan<uint32_t>(mine, s_w32, total);
-      for (int j = nlo; j < nhi; ++j)
-        if (!nd[j].no_more) { o.proc[pos] = (uint16_t)j; nd[j].pidx = (uint16_t)pos; nd[j].div = 1; ++pos; }
+      u64 mine = 0;
+      for (int j = nlo; j < nhi; ++j) mine += ct[j] > 1;   // !bNoMore
+      u64 total;
+      uint32_t pos = (uint32_t)block_scan(mine, s_w, par, total);
+      for (int j = nlo; j < nhi; ++j) {
+        if (ct[j] > 1) { tb.proc[pos] = (uint16_t)j; tb.pidx[j] = (uint16_t)pos; tb.c4[pos] = 0; ++pos; }
+        else tb.pidx[j] = (uint16_t)NONE;
+      }
       m = (int)total;
     } else {
-      // sort the expandable nodes by (size, creation index) descending: key = size << 16 | index
-      int n2 = 1;
-      while (n2 < nExp) n2 <<= 1;
-      uint32_t* sk = (n2 <= 4096) ? s_sort : o.sortk;
-      for (int i = t; i < n2; i += T) {
-        uint32_t key = 0;
-        if (i < nExp) { const OctNode& x = nd[exp_cur[i]]; key = ((uint32_t)(x.e - x.b) << 16) | (uint32_t)i; }
-        sk[i] = key;
-      }
+      // expandable nodes by (size, creation index) descending: key = size << 16 | index, rank by counting
+      // (keys are unique and non-zero; the array is padded with zeros to a multiple of 4 for 16-byte reads)
+      const int nExp4 = (nExp + 3) & ~3;
+      for (int i = t; i < nExp4; i += T) tb.key[i] = i < nExp ? (((uint32_t)ct[exp_cur[i]] << 16) | (uint32_t)i) : 0u;
+      for (int j = nlo; j < nhi; ++j) tb.pidx[j] = (uint16_t)NONE;
       __syncthreads();
-      for (int k = 2; k <= n2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          for (int i = t; i < n2; i += T) {
-            const int l = i ^ j;
-            if (l > i) {
-              const uint32_t a = sk[i], b = sk[l];
-              const bool desc = ((i & k) == 0);
-              if (desc ? (a < b) : (a > b)) { sk[i] = b; sk[l] = a; }
-            }
-          }
-          __syncthreads();
-        }
       for (int i = t; i < nExp; i += T) {
-        const int j = exp_cur[sk[i] & 0xFFFFu];
-        o.proc[i] = (uint16_t)j; nd[j].pidx = (uint16_t)i; nd[j].div = 1;
+        const uint32_t ki = tb.key[i];
+        int rank = 0;
+#pragma unroll 4
+        for (int l = 0; l < nExp4; l += 4) {
+          const uint4 kk = *reinterpret_cast<const uint4*>(&tb.key[l]);
+          rank += (kk.x > ki) + (kk.y > ki) + (kk.z > ki) + (kk.w > ki);
+        }
+        const int j = exp_cur[i];
+        tb.proc[rank] = (uint16_t)j; tb.pidx[j] = (uint16_t)rank; tb.c4[rank] = 0;
       }
       m = nExp;
     }
     __syncthreads();
-    // ---------------- quadrant of every key (LDS) + packed exclusive scan over the key positions ----------------
-    u64 my_prefix;
-    u64 Etotal;
+    // ---------------- key pass 1: quadrant counts of the divided nodes ----------------
+    uint32_t kq = 0;
     {
-      u64 mine = 0;
-      int cn = -1;
-      OctNode x{};
-      for (int p = klo; p < khi; ++p) {
-        const uint32_t v = kn[p];
-        const int node = (int)(v >> 16);
-        if (node != cn) { cn = node; x = nd[node]; }
-        int q = 4;
-        if (x.div) { const uint32_t c = o.pk[v & 0xFFFFu]; q = quadrant(pk_x(c), pk_y(c), x); mine += 1ull << (16 * q); }
-        s_q[p] = (uint8_t)q;
+      unsigned run_pi = NONE;
+      u64 run_c = 0;
+      for (int k = 0; k < nk; ++k) {
+        const int j = s_kn[k * T + t];
+        const uint32_t v = s_kpk[k * T + t];
+        const unsigned pi = tb.pidx[j];
+        const int q = quadrant(pk_x(v), pk_y(v), bx[j]);
+        kq |= (uint32_t)q << (2 * k);
+        if (pi != run_pi) {
+          if (run_pi != NONE) atomicAdd(&tb.c4[run_pi], run_c);
+          run_pi = pi; run_c = 0;
+        }
+        run_c += 1ull << (16 * q);
       }
-      my_prefix = block_excl_scan<u64>(mine, s_w64, Etotal);
-      // scan value at the first key of every node (the stable rank of a key = running value - value at node start)
-      u64 run = my_prefix;
-      cn = -1;
-      for (int p = klo; p < khi; ++p) {
-        const int node = (int)(kn[p] >> 16);
-        if (node != cn) { cn = node; if (nd[node].b == p) o.eb[node] = run; }
-        const int q = s_q[p];
-        if (q < 4) run += 1ull << (16 * q);
-      }
+      if (run_pi != NONE) atomicAdd(&tb.c4[run_pi], run_c);
     }
     __syncthreads();
-    // quadrant counts of node x = E(x.e) - E(x.b), with E(pos) the scan value at the node that starts at pos
-    auto E_at = [&](int pos) -> u64 { return pos >= M ? Etotal : o.eb[kn[pos] >> 16]; };
-    // ---------------- quadrant counts / child counts per processed node ----------------
-    const int pchunk = (m + T - 1) / T;
+    int pchunk = (m + T - 1) / T;
     int plo = min(t * pchunk, m), phi = min(plo + pchunk, m);
-    for (int i = plo; i < phi; ++i) {
-      const OctNode& x = nd[o.proc[i]];
-      o.c4[i] = E_at(x.e) - o.eb[o.proc[i]];
-    }
     if (phase == 2) {
       // cut the list at the first prefix that brings the node count to >= N (orbextractor.cpp:487-539)
-      uint32_t mine = 0;
-      for (int i = plo; i < phi; ++i) {
-        const u64 c = o.c4[i];
-        const int cc = (f16(c, 0) > 0) + (f16(c, 1) > 0) + (f16(c, 2) > 0) + (f16(c, 3) > 0);
-        mine += (uint32_t)(cc - 1);
-      }
-      uint32_t total;
-      uint32_t run = block_excl_scan<uint32_t>(mine, s_w32, total);
+      u64 mine = 0;
+      for (int i = plo; i < phi; ++i) mine += (u64)(nonzero4(tb.c4[i]) - 1);
+      u64 total;
+      uint32_t run = (uint32_t)block_scan(mine, s_w, par, total);
       if (t == 0) s_i[0] = m;
       __syncthreads();
       for (int i = plo; i < phi; ++i) {
-        const u64 c = o.c4[i];
-        const int cc = (f16(c, 0) > 0) + (f16(c, 1) > 0) + (f16(c, 2) > 0) + (f16(c, 3) > 0);
         const uint32_t before = run;
-        run += (uint32_t)(cc - 1);
+        run += (uint32_t)(nonzero4(tb.c4[i]) - 1);
         // first index whose inclusive prefix reaches N: size0 + before < N <= size0 + run
         if ((int)(nNodes + before) < N && (int)(nNodes + run) >= N) s_i[0] = i + 1;
       }
       __syncthreads();
       const int mt = s_i[0];
-      for (int i = mt + t; i < m; i += T) nd[o.proc[i]].div = 0;   // not processed in this round
+      for (int i = mt + t; i < m; i += T) tb.pidx[tb.proc[i]] = (uint16_t)NONE;   // not processed in this round
       m = mt;
       __syncthreads();
-      const int pc2 = (m + T - 1) / T;
-      plo = min(t * pc2, m); phi = min(plo + pc2, m);
+      pchunk = (m + T - 1) / T;
+      plo = min(t * pchunk, m); phi = min(plo + pchunk, m);
     }
+    // ---------------- one packed scan: children (bits 0-15), expandable children (16-31), survivors (32-47) ----
     uint32_t Tchild, EXtot, Kkeep;
+    uint32_t run_cc, run_ex, run_k;
     {
-      uint32_t mine_cc = 0, mine_ex = 0;
+      u64 mine = 0;
       for (int i = plo; i < phi; ++i) {
-        const u64 c = o.c4[i];
-        for (int q = 0; q < 4; ++q) { mine_cc += f16(c, q) > 0; mine_ex += f16(c, q) > 1; }
+        const u64 c = tb.c4[i];
+        mine += (u64)nonzero4(c) | ((u64)above1_4(c) << 16);
       }
-      uint32_t run_cc = block_excl_scan<uint32_t>(mine_cc, s_w32, Tchild);
-      uint32_t run_ex = block_excl_scan<uint32_t>(mine_ex, s_w32, EXtot);
-      for (int i = plo; i < phi; ++i) {
-        const u64 c = o.c4[i];
-        o.ccp[i] = run_cc; o.exp[i] = run_ex;
-        for (int q = 0; q < 4; ++q) { run_cc += f16(c, q) > 0; run_ex += f16(c, q) > 1; }
-      }
-      uint32_t mine_k = 0;
-      for (int j = nlo; j < nhi; ++j) mine_k += !nd[j].div;
-      uint32_t run_k = block_excl_scan<uint32_t>(mine_k, s_w32, Kkeep);
-      for (int j = nlo; j < nhi; ++j)
-        if (!nd[j].div) { o.newpos[j] = (uint16_t)min(Tchild + run_k, (uint32_t)(NODE_CAP - 1)); ++run_k; }
+      for (int j = nlo; j < nhi; ++j) mine += (u64)(tb.pidx[j] == NONE) << 32;
+      u64 total;
+      const u64 run = block_scan(mine, s_w, par, total);
+      Tchild = (uint32_t)(total & 0xFFFFu); EXtot = (uint32_t)((total >> 16) & 0xFFFFu); Kkeep = (uint32_t)((total >> 32) & 0xFFFFu);
+      run_cc = (uint32_t)(run & 0xFFFFu); run_ex = (uint32_t)((run >> 16) & 0xFFFFu); run_k = (uint32_t)((run >> 32) & 0xFFFFu);
     }
     const int nNew = (int)(Tchild + Kkeep);
-    if (nNew > NODE_CAP) {
+    if (nNew > LN) {
       if (t == 0) atomicOr(&d.status[img], 2);
       break;
     }
-    __syncthreads();
     // ---------------- create the children (list order = push_front order) and move the survivors ----------------
     for (int i = plo; i < phi; ++i) {
-      const OctNode x = nd[o.proc[i]];
-      const u64 c = o.c4[i];
-      const int cc = (f16(c, 0) > 0) + (f16(c, 1) > 0) + (f16(c, 2) > 0) + (f16(c, 3) > 0);
-      const int mx = x.ulx + (int)ceilf((float)(x.brx - x.ulx) / 2);
-      const int my = x.uly + (int)ceilf((float)(x.bry - x.uly) / 2);
-      const int first = (int)Tchild - (int)o.ccp[i] - cc;   // block of this node's children in the new list
-      int off = x.b, above = cc, ex = (int)o.exp[i];
+      const int j = tb.proc[i];
+      const Box x = bx[j];
+      const u64 c = tb.c4[i];
+      const int cc = nonzero4(c);
+      const int mx = x.ulx + ((x.brx - x.ulx + 1) >> 1);
+      const int my = x.uly + ((x.bry - x.uly + 1) >> 1);
+      const int first = (int)Tchild - (int)run_cc - cc;   // block of this node's children in the new list
+      int above = cc;
       u64 kid = 0;
       for (int q = 0; q < 4; ++q) {
         const int n = (int)f16(c, q);
         if (n == 0) continue;
         --above;                      // children with a larger quadrant index come first (push_front)
         const int id = first + above;
-        OctNode ch;
-        ch.b = (uint16_t)off; ch.e = (uint16_t)(off + n);
+        Box ch;
         ch.ulx = (int16_t)((q & 1) ? mx : x.ulx); ch.brx = (int16_t)((q & 1) ? x.brx : mx);
         ch.uly = (int16_t)((q & 2) ? my : x.uly); ch.bry = (int16_t)((q & 2) ? x.bry : my);
-        ch.pidx = 0; ch.no_more = (n == 1); ch.div = 0;
-        nn[id] = ch;
+        nbx[id] = ch;
+        nct[id] = (uint16_t)n;
         kid |= (u64)id << (16 * q);
-        if (n > 1) exp_nxt[ex++] = (uint16_t)id;
-        off += n;
+        if (n > 1) exp_nxt[run_ex++] = (uint16_t)id;
       }
-      o.kid4[i] = kid;
+      tb.kid4[i] = kid;
+      run_cc += (uint32_t)cc;
     }
     for (int j = nlo; j < nhi; ++j)
-      if (!nd[j].div) { OctNode x = nd[j]; x.pidx = 0; nn[o.newpos[j]] = x; }
-    __syncthreads();
-    // ---------------- move the keys (stable partition) ----------------
-    {
-      u64 run = my_prefix;
-      int cn = -1;
-      OctNode x{};
-      u64 c = 0, kid = 0, ebn = 0;
-      uint32_t np = 0;
-      for (int p = klo; p < khi; ++p) {
-        const uint32_t v = kn[p];
-        const int node = (int)(v >> 16);
-        if (node != cn) {
-          cn = node; x = nd[node];
-          if (x.div) { c = o.c4[x.pidx]; kid = o.kid4[x.pidx]; ebn = o.eb[node]; }
-          else np = o.newpos[node];
-        }
-        const int q = s_q[p];
-        if (q < 4 && x.div) {
-          int before = 0;
-          for (int qq = 0; qq < q; ++qq) before += (int)f16(c, qq);
-          const int rank = (int)f16(run, q) - (int)f16(ebn, q);
-          kn_next[x.b + before + rank] = (v & 0xFFFFu) | ((uint32_t)f16(kid, q) << 16);
-        } else {
-          kn_next[p] = (v & 0xFFFFu) | (np << 16);
-        }
-        // keys of phase-2 candidates that were cut from this round still sit in the scan: keep `run` in step
-        if (q < 4) run += 1ull << (16 * q);
+      if (tb.pidx[j] == NONE) {
+        const uint32_t np = Tchild + run_k++;
+        tb.newpos[j] = (uint16_t)np;
+        nbx[np] = bx[j];
+        nct[np] = ct[j];
       }
+    __syncthreads();
+    // ---------------- key pass 2: rename every key's node ----------------
+    for (int k = 0; k < nk; ++k) {
+      const int j = s_kn[k * T + t];
+      const unsigned pi = tb.pidx[j];
+      const int q = (int)((kq >> (2 * k)) & 3);
+      s_kn[k * T + t] = (pi != NONE) ? (uint16_t)f16(tb.kid4[pi], q) : tb.newpos[j];
     }
     __syncthreads();
     cur ^= 1;
+    ecur ^= 1;
     nNodes = nNew;
     nExp = (int)EXtot;
-    { uint16_t* tmp = exp_cur; exp_cur = exp_nxt; exp_nxt = tmp; }
     // ---------------- termination (orbextractor.cpp:472-476, 541-543) ----------------
     if (nNodes >= N || nNodes == prevSize) finish = true;
     else if (phase == 1 && nNodes + 3 * nExp > N) phase = 2;
@@ -396,17 +397,29 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   __syncthreads();
   // ---- best response per node, first wins ties (orbextractor.cpp:549-565), in list order ----
   {
-    const OctNode* nd = o.nodes[cur];
-    const uint32_t* kn = o.kn[cur];
-    const int nOut = min(nNodes, SEL_CAP);
-    for (int j = t; j < nOut; j += T) {
-      const OctNode x = nd[j];
-      uint32_t best = o.pk[kn[x.b] & 0xFFFFu];
-      for (int p = x.b + 1; p < x.e; ++p) {
-        const uint32_t c = o.pk[kn[p] & 0xFFFFu];
-        if (pk_r(c) > pk_r(best)) best = c;
+    uint32_t* best = tb.key;
+    for (int j = t; j < nNodes; j += T) best[j] = 0;
+    __syncthreads();
+    {
+      int run_j = -1;
+      uint32_t run_best = 0;
+      for (int k = 0; k < nk; ++k) {
+        const int j = s_kn[k * T + t];
+        const uint32_t v = (pk_r(s_kpk[k * T + t]) << 14) | (uint32_t)(0x3FFF - (p0 + k));
+        if (j != run_j) {
+          if (run_j >= 0) atomicMax(&best[run_j], run_best);
+          run_j = j; run_best = 0;
+        }
+        run_best = max(run_best, v);
       }
-      sel[j] = best;
+      if (run_j >= 0) atomicMax(&best[run_j], run_best);
+    }
+    __syncthreads();
+    const int nOut = min(nNodes, SEL_CAP);
+    for (int k = 0; k < nk; ++k) {
+      const int j = s_kn[k * T + t];
+      const uint32_t c = s_kpk[k * T + t];
+      if (j < nOut && best[j] == ((pk_r(c) << 14) | (uint32_t)(0x3FFF - (p0 + k)))) sel[j] = c;
     }
     if (t == 0) {
       *sel_count = nOut;
@@ -415,12 +428,20 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   }
 }
 
+}  // namespace
+
 void launch_octree(const OrbDev& o, hipStream_t s)
 {
   // image-major grid: workgroups are dealt round-robin to the 8 XCDs, so with the level as the fastest index
   // (8 levels) every level-0 workgroup - the long one - would land on the same XCD.  Level-major order starts
   // all level-0 workgroups first and spreads them over the whole chip.
-  hipLaunchKernelGGL(k_octree, dim3(o.I, o.detect_only ? 1 : o.nlevels), dim3(OCT_THREADS), 0, s, o);
+  const dim3 grid(o.I, o.detect_only ? 1 : o.nlevels);
+  const size_t tab = o.oct_global_tab ? 0 : (((size_t)OCT_NODE_BYTES * o.oct_ln + 15) & ~size_t(15));
+  const size_t lds = tab + 4 * (size_t)((o.oct_max_cells + 1 + 3) & ~3) + 6 * (size_t)CAND_CAP;
+  auto kern = o.oct_global_tab ? k_octree<true> : k_octree<false>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(OCT_THREADS), lds, s, o);
 }
 
 }  // namespace ssxorb

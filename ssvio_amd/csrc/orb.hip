@@ -773,7 +773,7 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
     d.lvl_cell0[l] = (int)cells.size();
     make_cells(d.lvl_rows[l], d.lvl_cols[l], l, cells);
     out_cap += d.feat[l] + 4;
-    if (d.feat[l] * 4 + 8 > NODE_CAP) {
+    if (d.feat[l] + 8 > SEL_CAP) {
       ctx->set_error("ssx_orb: %d features on level %d exceed the octree node capacity", d.feat[l], l);
       return SSX_ERR_UNSUPPORTED;
     }
@@ -783,6 +783,21 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
   d.n_cells = (int)cells.size();
   d.pyr_bytes = (off + 255) & ~size_t(255);
   d.out_cap = out_cap;
+  {
+    // octree node-table capacity: a round of phase 1 never ends above N nodes (it is only entered while
+    // size + 3 * expandable <= N) except the first one (<= 4 * nIni <= 256), phase 2 stops within N + 2
+    int maxN = 256;
+    for (int l = 0; l < (detect_only ? 1 : nlevels); ++l) maxN = std::max(maxN, d.feat[l]);
+    d.oct_ln = (maxN + 8 + 7) & ~7;
+    d.oct_max_cells = 1;
+    for (int l = 0; l < nlevels; ++l) d.oct_max_cells = std::max(d.oct_max_cells, d.lvl_cell0[l + 1] - d.lvl_cell0[l]);
+    if (4 * (size_t)(d.oct_max_cells + 8) + 6 * (size_t)CAND_CAP > (size_t)OCT_LDS_BUDGET) {
+      ctx->set_error("ssx_orb: %d grid cells on one level exceed the octree workgroup's LDS", d.oct_max_cells);
+      return SSX_ERR_UNSUPPORTED;
+    }
+    d.oct_global_tab = (size_t)OCT_NODE_BYTES * d.oct_ln + 4 * (size_t)(d.oct_max_cells + 8) + 6 * (size_t)CAND_CAP > (size_t)OCT_LDS_BUDGET;
+    d.oct_stride = d.oct_global_tab ? (((size_t)OCT_NODE_BYTES * d.oct_ln + 255) & ~size_t(255)) : 0;
+  }
   {
     int tile = 16, npx = 1, t0 = 0;
     for (const Cell& c : cells) {
@@ -856,7 +871,7 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
   const size_t o_blur = lay.take(d.pyr_bytes * I);
   const size_t o_ccount = lay.take(sizeof(int) * (size_t)I * std::max(d.n_cells, 1));
   const size_t o_ccand = lay.take(sizeof(uint32_t) * (size_t)I * std::max(d.n_cells, 1) * CELL_CAP);
-  const size_t o_oct = lay.take(OctLayout::total * (size_t)I * nlevels);
+  const size_t o_oct = lay.take(std::max<size_t>(d.oct_stride * (size_t)I * nlevels, 256));
   const size_t o_ncand = lay.take(sizeof(int) * (size_t)I * nlevels);
   const size_t o_selc = lay.take(sizeof(int) * (size_t)I * nlevels);
   const size_t o_sel = lay.take(sizeof(uint32_t) * (size_t)I * nlevels * SEL_CAP);

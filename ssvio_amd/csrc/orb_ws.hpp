@@ -12,7 +12,6 @@ namespace ssxorb {
 constexpr int MAX_LEVELS = 8;
 constexpr int CELL_CAP = 256;      // candidates kept per grid cell (31x32 interior: NMS leaves < 250)
 constexpr int CAND_CAP = 16384;    // candidates per (image, level) fed to the octree
-constexpr int NODE_CAP = 16384;    // octree nodes alive per (image, level)  (>= 4 x per-level budget + 4)
 constexpr int SEL_CAP = 4096;      // selected keypoints per (image, level)
 constexpr int EDGE_THRESHOLD = 19; // orbextractor.cpp:13
 constexpr int OCT_THREADS = 1024;
@@ -24,33 +23,10 @@ struct Cell {
   int16_t level, pad;
 };
 
-// per (image, level) octree scratch, laid out at fixed byte offsets inside one block of OctLayout::total bytes.
-// Per-KEY data are two u32 streams only (packed candidate, key|node); everything else is per node / per processed node,
-// so the footprint a workgroup actually touches (~12 B per candidate + ~50 B per node) stays L2-resident.
-struct OctLayout {
-  static constexpr size_t candpk = 0;                                       // u32[CAND_CAP]  x | y<<12 | score<<24
-  static constexpr size_t keynode = candpk + 4 * (size_t)CAND_CAP;          // u32[2][CAND_CAP] key | node<<16 (ping-pong)
-  static constexpr size_t nodes = keynode + 8 * (size_t)CAND_CAP;           // OctNode[2][NODE_CAP] (16 B each)
-  static constexpr size_t ebeg = nodes + 2 * 16 * (size_t)NODE_CAP;         // u64[NODE_CAP] packed scan value at a node's first key
-  static constexpr size_t proc = ebeg + 8 * (size_t)NODE_CAP;               // u16[NODE_CAP]
-  static constexpr size_t expa = proc + 2 * NODE_CAP;                       // u16[NODE_CAP]
-  static constexpr size_t expb = expa + 2 * NODE_CAP;                       // u16[NODE_CAP]
-  static constexpr size_t c4 = expb + 2 * NODE_CAP;                         // u64[NODE_CAP] quadrant counts per proc
-  static constexpr size_t kid4 = c4 + 8 * (size_t)NODE_CAP;                 // u64[NODE_CAP] child ids per proc
-  static constexpr size_t ccp = kid4 + 8 * (size_t)NODE_CAP;                // u32[NODE_CAP] scan of child counts
-  static constexpr size_t exp_ = ccp + 4 * (size_t)NODE_CAP;                // u32[NODE_CAP] scan of expandable counts
-  static constexpr size_t newpos = exp_ + 4 * (size_t)NODE_CAP;             // u16[NODE_CAP] survivors' new id
-  static constexpr size_t sortk = newpos + 2 * NODE_CAP;                    // u32[NODE_CAP] phase-2 sort keys
-  static constexpr size_t total = ((sortk + 4 * (size_t)NODE_CAP) + 255) & ~size_t(255);
-};
-
-struct OctNode {      // 16 bytes
-  uint16_t b, e;      // key range [b, e)
-  int16_t ulx, uly, brx, bry;
-  uint16_t pidx;      // index in the processing list of the current round
-  uint8_t no_more;    // bNoMore
-  uint8_t div;        // marked for division in the current round
-};
+// octree (octree.hip): OCT_NODE_BYTES per node-table entry; the tables live in LDS, or in a per (image, level) global
+// scratch block when the per-level budget is too large for LDS (OrbDev::oct_global_tab).
+constexpr int OCT_NODE_BYTES = 50;
+constexpr int OCT_LDS_BUDGET = 158 * 1024;   // dynamic LDS the octree workgroup may ask for (160 KB per CU, ~1 KB static)
 
 struct ResizeQuad;
 
@@ -83,7 +59,11 @@ struct OrbDev {
   uint8_t* blur;                 // [I][pyr_bytes]
   int* cell_count;               // [I][n_cells]
   uint32_t* cell_cand;           // [I][n_cells][CELL_CAP]   x | y<<12 | score<<24 (relative to the 16-px border)
-  uint8_t* oct;                  // [I][nlevels][OctLayout::total]
+  uint8_t* oct;                  // [I][nlevels][oct_stride] (only with oct_global_tab)
+  size_t oct_stride;
+  int oct_max_cells;             // most grid cells on one level (cell-prefix array in LDS)
+  int oct_ln;                    // node-table capacity: max(N, 256) + 8 over the levels (N = per-level budget)
+  int oct_global_tab;            // node tables in global scratch (budgets too large for LDS)
   int* lvl_ncand;                // [I][nlevels]
   int* sel_count;                // [I][nlevels]
   uint32_t* sel;                 // [I][nlevels][SEL_CAP] packed like cell_cand

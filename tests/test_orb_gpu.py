@@ -45,9 +45,10 @@ def test_grid_fast_candidates_bit_exact(ctx, po, pair_kitti, pair_small):
         assert len(g) == len(o) and g.tobytes() == o.tobytes()
 
 
-@pytest.mark.parametrize("nfeat", [100, 300, 2000])
+@pytest.mark.parametrize("nfeat", [100, 300, 2000, 3600])
 def test_detect_bit_exact(ctx, po, pair_kitti, nfeat):
-    """ORBextractor::Detect with the reference's three budgets (kitti_00.yaml:37-39 and the C2 setting)."""
+    """ORBextractor::Detect with the reference's three budgets (kitti_00.yaml:37-39 and the C2 setting); 3600 is
+    past the LDS node-table budget of the octree kernel and takes its global-scratch variant."""
     L = pair_kitti[0]
     g = sorb.ORBextractor(ctx, nfeatures=nfeat).Detect(L)
     o = po.orb_detect(L, prm=po.orb_params(nfeatures=nfeat))
