@@ -161,30 +161,64 @@ __global__ __launch_bounds__(256) void k_bf_match(const uint8_t* dq, int nq, con
   }
 }
 
-// ---- 4x4 SVD by one-sided Jacobi, everything in registers (loops fully unrolled: static indices) ----
-__device__ __forceinline__ void jacobi_pair(double* U, double* V, int p, int q, bool& rotated)
+// ---- 4x4 SVD by one-sided (Hestenes) Jacobi, everything in registers (loops fully unrolled: static indices) ----
+// frontend.cpp:458-465 / algorithm.hpp:23-45 take the right singular vector of the smallest singular value from
+// Eigen::JacobiSVD; any convergent Jacobi ordering gives it to ~1e-15 relative.  This one is laid out for the
+// latency of ONE thread (a stereo frame has ~1000 matches: the kernel is a few hundred waves, all latency):
+//   * round-robin ordering {(0,1),(2,3)}, {(0,2),(1,3)}, {(0,3),(1,2)}: the two rotations of a round touch disjoint
+//     columns, so their dependent sqrt/div chains interleave;
+//   * t = 2g / (d + sign(d) * hypot(d, 2g)), c = rsqrt(1 + t^2): three slow fp64 operations per rotation instead of
+//     the textbook five (zeta, sqrt, 1/x, sqrt, 1/x);
+//   * explicit fma (the file is compiled with -ffp-contract=off for the float code that must match the CPU bit
+//     for bit; this routine is compared at 1e-9 relative, see tests);
+//   * a sweep whose largest |g| / sqrt(a b) was below 1e-8 ends the iteration: Jacobi converges quadratically, so
+//     the off-diagonal mass after it is at rounding level and the usual extra "nothing rotated" sweep is skipped.
+__device__ __forceinline__ void jacobi_moments(const double* U, int p, int q, double& a, double& b, double& g)
 {
-  double alpha = 0, beta = 0, gamma = 0;
+  a = U[p] * U[p]; b = U[q] * U[q]; g = U[p] * U[q];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    alpha += U[r * 4 + p] * U[r * 4 + p];
-    beta += U[r * 4 + q] * U[r * 4 + q];
-    gamma += U[r * 4 + p] * U[r * 4 + q];
+  for (int r = 1; r < 4; ++r) {
+    a = fma(U[r * 4 + p], U[r * 4 + p], a);
+    b = fma(U[r * 4 + q], U[r * 4 + q], b);
+    g = fma(U[r * 4 + p], U[r * 4 + q], g);
   }
-  if (fabs(gamma) <= 1e-15 * sqrt(alpha * beta) || gamma == 0.0) return;
-  rotated = true;
-  const double zeta = (beta - alpha) / (2.0 * gamma);
-  const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+}
+
+__device__ __forceinline__ void jacobi_rotation(double a, double b, double g, double& c, double& s, bool& big)
+{
+  const double g2 = g * g, ab = a * b;
+  const bool on = g2 > 1e-30 * ab;            // |g| > 1e-15 sqrt(a b)
+  big = big || (g2 > 1e-16 * ab);
+  const double d = b - a, tg = g + g;
+  const double h = sqrt(fma(d, d, tg * tg));
+  const double t = tg / (d + copysign(h, d));
+  const double cc = rsqrt(fma(t, t, 1.0));
+  c = on ? cc : 1.0;
+  s = on ? cc * t : 0.0;
+}
+
+__device__ __forceinline__ void jacobi_apply(double* U, double* V, int p, int q, double c, double s)
+{
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const double up = U[r * 4 + p], uq = U[r * 4 + q];
-    U[r * 4 + p] = c * up - s * uq;
-    U[r * 4 + q] = s * up + c * uq;
+    U[r * 4 + p] = fma(c, up, -(s * uq));
+    U[r * 4 + q] = fma(s, up, c * uq);
     const double vp = V[r * 4 + p], vq = V[r * 4 + q];
-    V[r * 4 + p] = c * vp - s * vq;
-    V[r * 4 + q] = s * vp + c * vq;
+    V[r * 4 + p] = fma(c, vp, -(s * vq));
+    V[r * 4 + q] = fma(s, vp, c * vq);
   }
+}
+
+__device__ __forceinline__ void jacobi_round(double* U, double* V, int p0, int q0, int p1, int q1, bool& big)
+{
+  double a0, b0, g0, a1, b1, g1, c0, s0, c1, s1;
+  jacobi_moments(U, p0, q0, a0, b0, g0);
+  jacobi_moments(U, p1, q1, a1, b1, g1);
+  jacobi_rotation(a0, b0, g0, c0, s0, big);
+  jacobi_rotation(a1, b1, g1, c1, s1, big);
+  jacobi_apply(U, V, p0, q0, c0, s0);
+  jacobi_apply(U, V, p1, q1, c1, s1);
 }
 
 __device__ __forceinline__ void triangulate_one(double uL, double vL, double uR, double vR, const ssx_stereo_rig& rig,
@@ -196,18 +230,19 @@ __device__ __forceinline__ void triangulate_one(double uL, double vL, double uR,
   double U[16] = {-1, 0, x1, 0, 0, -1, y1, 0, -1, 0, x2, x2 * 0.0 - tx, 0, -1, y2, y2 * 0.0 - 0.0};
   double V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (int sweep = 0; sweep < 30; ++sweep) {
-    bool rotated = false;
-    jacobi_pair(U, V, 0, 1, rotated); jacobi_pair(U, V, 0, 2, rotated); jacobi_pair(U, V, 0, 3, rotated);
-    jacobi_pair(U, V, 1, 2, rotated); jacobi_pair(U, V, 1, 3, rotated); jacobi_pair(U, V, 2, 3, rotated);
-    if (!rotated) break;
+    bool big = false;
+    jacobi_round(U, V, 0, 1, 2, 3, big);
+    jacobi_round(U, V, 0, 2, 1, 3, big);
+    jacobi_round(U, V, 0, 3, 1, 2, big);
+    if (!big) break;
   }
-  double n[4];
+  double n[4];   // SQUARED singular values
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    double s = 0;
+    double s = U[c] * U[c];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s += U[r * 4 + c] * U[r * 4 + c];
-    n[c] = sqrt(s);
+    for (int r = 1; r < 4; ++r) s = fma(U[r * 4 + c], U[r * 4 + c], s);
+    n[c] = s;
   }
   // smallest and second smallest singular value, ties resolved like the oracle's stable descending sort:
   // ord = [0,1,2,3]; swap when n[ord[j]] > n[ord[i]] (j > i)
@@ -227,9 +262,10 @@ __device__ __forceinline__ void triangulate_one(double uL, double vL, double uR,
     if (c == cmin) { vx = V[0 * 4 + c]; vy = V[1 * 4 + c]; vz = V[2 * 4 + c]; vw = V[3 * 4 + c]; smin = n[c]; }
     if (c == c2) s2 = n[c];
   }
-  double p[3] = {vx / vw, vy / vw, vz / vw};
-  const double ratio = smin / s2;
-  *ok = ((ratio < 1e-2) && (p[2] > 0)) ? 1 : 0;
+  const double iw = 1.0 / vw;
+  double p[3] = {vx * iw, vy * iw, vz * iw};
+  // sigma3 / sigma2 < 1e-2 on the squared values (algorithm.hpp:38)
+  *ok = ((smin < 1e-4 * s2) && (p[2] > 0)) ? 1 : 0;
   if (T_wc) {
     const double qx = T_wc[0], qy = T_wc[1], qz = T_wc[2], qw = T_wc[3];
     double ux = qy * p[2] - qz * p[1], uy = qz * p[0] - qx * p[2], uz = qx * p[1] - qy * p[0];

@@ -116,12 +116,17 @@ def test_triangulate_matches_oracle_and_reference_golden(ctx, po):
     np.testing.assert_array_equal(ok, G["tri_ok"])                      # vs the REAL reference function
     m = G["tri_ok"].astype(bool)
     np.testing.assert_allclose(xyz[m], G["tri_xyz"][m], rtol=1e-9)
+    # The device routine is a latency-oriented Jacobi (round-robin pair order, fma, early exit) and the oracle the
+    # plain cyclic one: same singular vector, different rounding.  Tolerance 1e-9 relative / 1e-9 m absolute, five
+    # orders tighter than the 1e-4 residual bound of the north star.
     o = po.triangulate(G["tri_uvL"], G["tri_uvR"], KITTI_K, KITTI_BASELINE)
-    np.testing.assert_allclose(xyz, o["xyz"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(ok, o["ok"])
+    print("triangulate max |dev - oracle| =", np.abs(xyz - o["xyz"]).max())
+    np.testing.assert_allclose(xyz, o["xyz"], rtol=1e-9, atol=1e-9)
     T = np.array([0.01, -0.02, 0.03, 0.9993, 1.0, -2.0, 0.5]); T[:4] /= np.linalg.norm(T[:4])
     xyz2, _ = sorb.triangulate(ctx, G["tri_uvL"], G["tri_uvR"], T_wc=T)
     o2 = po.triangulate(G["tri_uvL"], G["tri_uvR"], KITTI_K, KITTI_BASELINE, T_wc=T)
-    np.testing.assert_allclose(xyz2, o2["xyz"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(xyz2, o2["xyz"], rtol=1e-9, atol=1e-9)
 
 
 def test_stereo_frame_end_to_end(ctx, po, pair_kitti):
@@ -138,7 +143,7 @@ def test_stereo_frame_end_to_end(ctx, po, pair_kitti):
     uvR = np.stack([kR["x"][oi[m]], kR["y"][oi[m]]], 1).astype(np.float64)
     t = po.triangulate(uvL, uvR, KITTI_K, KITTI_BASELINE)
     np.testing.assert_array_equal(r["ok"][m], t["ok"])
-    np.testing.assert_allclose(r["xyz"][m], t["xyz"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(r["xyz"][m], t["xyz"], rtol=1e-9, atol=1e-9)
     assert r["n_matched"] == int(m.sum()) and r["n_triangulated"] == int(t["ok"].sum())
     # sanity against the synthetic ground truth: depth = bf / disparity
     good = m & (r["ok"] == 1)
