@@ -321,12 +321,26 @@ constexpr int GT_W = 128, GT_H = 32;            // output tile
 constexpr int GT_PITCH = GT_W + 8;              // input tile pitch: 4 bytes of halo left, 4 right (3 needed)
 
 // ONE launch for all levels and images: blockIdx.x walks the tiles of every level (o.gauss_tile0[]), blockIdx.y
-// is the image.  Input rows are fetched as aligned dwords (interior tiles) into LDS; the row pass produces four
-// Q8 sums per thread from three LDS dwords; the column pass reads ten int4 rows and stores one dword per row.
+// is the image.  Input rows are fetched as aligned dwords into LDS (interior tiles take a branch-free path).
+//   row pass     thread = (row PAIR, quad of 4 pixels): a pixel's 7 taps are two v_dot4_u32_u8 on byte windows cut
+//                with v_alignbyte from three LDS dwords; the sums (<= 255 * 257, exact) of the two rows are packed
+//                as u16 pairs, one int4 store per quad;
+//   column pass  thread = 4 pixels x 4 rows: five int4 loads give the ten input rows as vertical u16 pairs, and
+//                every output pixel is four v_dot2_u32_u16 (the weight pairs depend on the row parity), seeded
+//                with the 2^15 rounding term.
+// The fixed-point result is exact integer arithmetic, so the evaluation order is free (OpenCV: row sums exact,
+// column pass (sum + 2^15) >> 16, saturate).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t pair, uint32_t w, uint32_t acc)
+{
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, w), acc, false);
+}
+
 __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
 {
   __shared__ __attribute__((aligned(16))) uint8_t sIn[(GT_H + 6) * GT_PITCH];
-  __shared__ __attribute__((aligned(16))) int sRow[(GT_H + 6) * GT_W];
+  __shared__ __attribute__((aligned(16))) uint32_t sRowP[(GT_H + 6) / 2 * GT_W];   // [row pair][x]: sum(2rp) | sum(2rp+1) << 16
+  static_assert((GT_H + 6) % 2 == 0, "rows are processed in pairs");
   const int img = blockIdx.y, t = threadIdx.x;
   int level = 0;
   while (level + 1 < o.nlevels && (int)blockIdx.x >= o.gauss_tile0[level + 1]) ++level;
@@ -338,64 +352,87 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
   const uint8_t* src = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[level];
   uint8_t* dst = o.blur + (size_t)img * o.pyr_bytes + o.lvl_off[level];
   constexpr int NDW = GT_PITCH / 4;   // 34 dwords per tile row
-  for (int i = t; i < (GT_H + 6) * NDW; i += 256) {
-    const int r = i / NDW, dwi = i - r * NDW;
-    const int gy = reflect101(y0 + r - 3, rows);
-    const int gx = x0 - 4 + 4 * dwi;
-    uint32_t v;
-    if (gx >= 0 && gx + 3 < cols) {
-      v = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
-    } else {
-      const uint8_t* row = src + (size_t)gy * pitch;
-      v = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
-          ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
+  const bool interior = y0 >= 3 && y0 + GT_H + 3 <= rows && x0 >= 4 && x0 + GT_W + 4 <= cols;   // block-uniform
+  if (interior) {
+    const uint8_t* base = src + (size_t)(y0 - 3) * pitch + (x0 - 4);
+    for (int i = t; i < (GT_H + 6) * NDW; i += 256) {
+      const int r = i / NDW, dwi = i - r * NDW;
+      reinterpret_cast<uint32_t*>(sIn)[i] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * dwi);
     }
-    reinterpret_cast<uint32_t*>(sIn)[i] = v;
+  } else {
+    for (int i = t; i < (GT_H + 6) * NDW; i += 256) {
+      const int r = i / NDW, dwi = i - r * NDW;
+      const int gy = reflect101(y0 + r - 3, rows);
+      const int gx = x0 - 4 + 4 * dwi;
+      uint32_t v;
+      if (gx >= 0 && gx + 3 < cols) {
+        v = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
+      } else {
+        const uint8_t* row = src + (size_t)gy * pitch;
+        v = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
+            ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
+      }
+      reinterpret_cast<uint32_t*>(sIn)[i] = v;
+    }
   }
   __syncthreads();
-  // row pass: thread -> (tile row r, group g of 4 output pixels); bytes 4g+1 .. 4g+10 of the tile row
-  for (int i = t; i < (GT_H + 6) * (GT_W / 4); i += 256) {
-    const int r = i / (GT_W / 4), g = i - r * (GT_W / 4);
-    const uint32_t* rowdw = reinterpret_cast<const uint32_t*>(sIn + r * GT_PITCH) + g;
-    const uint32_t d0 = rowdw[0], d1 = rowdw[1], d2 = rowdw[2];
-    int b[12];
+  // row pass: tile column x sits at byte x + 4 of a tile row, so the taps of pixels 4g .. 4g+3 are bytes
+  // 4g+1 .. 4g+10 = bytes 1 .. 10 of the dwords g, g+1, g+2
+  constexpr uint32_t W_LO = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3
+  constexpr uint32_t W_HI = 49u | (34u << 8) | (18u << 16);                  // taps 4..6 (+ a zero weight)
+  for (int i = t; i < (GT_H + 6) / 2 * (GT_W / 4); i += 256) {
+    const int rp = i / (GT_W / 4), g = i - rp * (GT_W / 4);
+    uint32_t sum[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { b[k] = (d0 >> (8 * k)) & 0xFF; b[4 + k] = (d1 >> (8 * k)) & 0xFF; b[8 + k] = (d2 >> (8 * k)) & 0xFF; }
-    int acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[j] = 0;
-#pragma unroll
-      for (int q = 0; q < 7; ++q) acc[j] += c_gauss[q] * b[1 + j + q];
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t* rowdw = reinterpret_cast<const uint32_t*>(sIn + (2 * rp + h) * GT_PITCH) + g;
+      const uint32_t d0 = rowdw[0], d1 = rowdw[1], d2 = rowdw[2];
+      sum[h][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), W_LO, 0u, false);
+      sum[h][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), W_HI, sum[h][0], false);
+      sum[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), W_LO, 0u, false);
+      sum[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), W_HI, sum[h][1], false);
+      sum[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), W_LO, 0u, false);
+      sum[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), W_HI, sum[h][2], false);
+      sum[h][3] = __builtin_amdgcn_udot4(d1, W_LO, 0u, false);
+      sum[h][3] = __builtin_amdgcn_udot4(d2, W_HI, sum[h][3], false);
     }
-    *reinterpret_cast<int4*>(&sRow[r * GT_W + 4 * g]) = make_int4(acc[0], acc[1], acc[2], acc[3]);
+    uint4 pk;
+    pk.x = sum[0][0] | (sum[1][0] << 16); pk.y = sum[0][1] | (sum[1][1] << 16);
+    pk.z = sum[0][2] | (sum[1][2] << 16); pk.w = sum[0][3] | (sum[1][3] << 16);
+    *reinterpret_cast<uint4*>(&sRowP[rp * GT_W + 4 * g]) = pk;
   }
   __syncthreads();
-  // column pass: thread -> 4 pixels x 4 rows
+  // column pass: thread -> 4 pixels x 4 rows (output rows 4rq .. 4rq+3 need tile rows 4rq .. 4rq+9 = pairs 2rq .. 2rq+4)
   {
     const int g = t & 31, rq = t >> 5;             // 32 groups x 8 row-quads
-    int4 rowv[10];
+    uint4 P[5];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) rowv[k] = *reinterpret_cast<const int4*>(&sRow[(4 * rq + k) * GT_W + 4 * g]);
+    for (int k = 0; k < 5; ++k) P[k] = *reinterpret_cast<const uint4*>(&sRowP[(2 * rq + k) * GT_W + 4 * g]);
+    // weights of the vertical pairs: an even output row starts on a pair, an odd one in the middle of a pair
+    constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
+    constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
     const int x = x0 + 4 * g;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int y = y0 + 4 * rq + j;
-      int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      const int k0 = j >> 1;
+      const bool odd = j & 1;
+      const uint32_t w0 = odd ? O0 : E0, w1 = odd ? O1 : E1, w2 = odd ? O2 : E2, w3 = odd ? O3 : E3;
+      uint32_t a[4];
+      const uint32_t p0[4] = {P[k0].x, P[k0].y, P[k0].z, P[k0].w}, p1[4] = {P[k0 + 1].x, P[k0 + 1].y, P[k0 + 1].z, P[k0 + 1].w};
+      const uint32_t p2[4] = {P[k0 + 2].x, P[k0 + 2].y, P[k0 + 2].z, P[k0 + 2].w}, p3[4] = {P[k0 + 3].x, P[k0 + 3].y, P[k0 + 3].z, P[k0 + 3].w};
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        a0 += c_gauss[q] * rowv[j + q].x; a1 += c_gauss[q] * rowv[j + q].y;
-        a2 += c_gauss[q] * rowv[j + q].z; a3 += c_gauss[q] * rowv[j + q].w;
+      for (int c = 0; c < 4; ++c) {
+        uint32_t acc = udot2(p0[c], w0, 1u << 15);
+        acc = udot2(p1[c], w1, acc);
+        acc = udot2(p2[c], w2, acc);
+        acc = udot2(p3[c], w3, acc);
+        // unsigned shift/min on purpose: hipcc (ROCm 7.2) fuses med3(ashr(x,16),0,255) pairs into v_ashr_pk_u8_i32
+        // and then assumes the upper 16 bits of its result are zero, which they are not on gfx950
+        a[c] = min(acc >> 16, 255u);
       }
-      // sums are non-negative, so only the upper clamp is needed.  Written with UNSIGNED shifts/min on purpose:
-      // hipcc (ROCm 7.2) fuses med3(ashr(x,16),0,255) pairs into v_ashr_pk_u8_i32 and then assumes the upper
-      // 16 bits of its result are zero, which they are not on gfx950 (byte 0 leaked into byte 2).
-      const uint32_t o0 = min(((uint32_t)a0 + (1u << 15)) >> 16, 255u);
-      const uint32_t o1 = min(((uint32_t)a1 + (1u << 15)) >> 16, 255u);
-      const uint32_t o2 = min(((uint32_t)a2 + (1u << 15)) >> 16, 255u);
-      const uint32_t o3 = min(((uint32_t)a3 + (1u << 15)) >> 16, 255u);
       // the pitch is a multiple of the tile width: the dword store stays inside the row's padding
-      if (y < rows && x < pitch) *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+      if (y < rows && x < pitch) *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x) = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
     }
   }
 }
