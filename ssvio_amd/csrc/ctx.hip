@@ -37,9 +37,19 @@ ssx_status ssx_ctx_create(const ssx_config* cfg, ssx_ctx** out)
   }
   (void)hipEventCreate(&c->ev0);
   (void)hipEventCreate(&c->ev1);
-  (void)hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+  {
+    // the auxiliary stream carries work that fills the gaps of the main stream's dependent chain: lowest priority
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, least) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+    }
+  }
   (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming);
   *out = c;
   return SSX_OK;
 }
@@ -58,6 +68,8 @@ void ssx_ctx_destroy(ssx_ctx* ctx)
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_pyr) (void)hipEventDestroy(ctx->ev_pyr);
+  if (ctx->ev_fast0) (void)hipEventDestroy(ctx->ev_fast0);
   for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

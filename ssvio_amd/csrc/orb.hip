@@ -201,12 +201,12 @@ __device__ __forceinline__ bool fast_quick(const uint8_t* c, int p, int t)
 //   3. the compacted survivors take the full segment test + cornerScore (dense lanes);
 //   4. the corners (again a compacted list) take the 3x3 strict NMS, the mask test and an ORDER-PRESERVING
 //      compaction (ballot prefix inside a round; rounds walk the pixels in row-major order).
-__global__ __launch_bounds__(256) void k_fast_cells(OrbDev o)
+__global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, int cell_end)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cell = blockIdx.x * 4 + wave, img = blockIdx.y;
-  if (cell >= o.n_cells) return;
+  const int cell = cell_begin + blockIdx.x * 4 + wave, img = blockIdx.y;
+  if (cell >= cell_end) return;
   const Cell c = o.cells[cell];
   const uint8_t* lvl = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[c.level];
   const int pitch = o.lvl_pitch[c.level];
@@ -986,24 +986,37 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   const OrbDev& d = ws->dev;
   hipStream_t s = ctx->stream;
   SSX_HIP_TRY(ctx, hipMemsetAsync(d.status, 0, sizeof(int) * d.I, s));
-  launch_pyramid(ctx, d, s, d.I);
-  // the blur only depends on the pyramid: it runs on the auxiliary stream, concurrently with detection
-  // (HBM-streaming blur next to the latency-bound octree), and is joined before the descriptors.
-  const bool fork = !d.detect_only && ctx->aux != nullptr;
-  if (!d.detect_only) {
-    hipStream_t gs = fork ? ctx->aux : s;
-    if (fork) {
-      SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
-      SSX_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    }
-    SSX_PROF_ON(ctx, gs, KID_ORB_GAUSS, hipLaunchKernelGGL(k_gauss7, dim3(d.gauss_tile0[d.nlevels], d.I), dim3(256), 0, gs, d));
-    if (fork) SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
-  }
   if (4 * (size_t)d.fast_lds_per_wave > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(4 * (size_t)d.fast_lds_per_wave));
-  if (d.n_cells > 0)
-    SSX_PROF(ctx, KID_ORB_FAST, hipLaunchKernelGGL(k_fast_cells, dim3((d.n_cells + 3) / 4, d.I), dim3(256), 4 * (size_t)d.fast_lds_per_wave, s, d));
+  auto launch_fast = [&](hipStream_t st, int c0, int c1) {
+    if (c1 > c0)
+      SSX_PROF_ON(ctx, st, KID_ORB_FAST, hipLaunchKernelGGL(k_fast_cells, dim3((c1 - c0 + 3) / 4, d.I), dim3(256),
+                                                            4 * (size_t)d.fast_lds_per_wave, st, d, c0, c1));
+  };
+  // Two streams.  The pyramid is a chain of seven dependent, mostly small launches that leaves the chip idle, so
+  // level 0 of the detection (a third of the cells) runs beside it on the auxiliary stream; the blur only needs
+  // the pyramid and runs beside the detection of the upper levels and the octree.  Joined before the octree
+  // (level-0 candidates) and before the descriptors (blur).
+  const bool fork = !d.detect_only && ctx->aux != nullptr;
+  if (fork) {
+    SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+    SSX_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    launch_fast(ctx->aux, 0, d.lvl_cell0[1]);
+    SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_fast0, ctx->aux));
+    launch_pyramid(ctx, d, s, d.I);
+    SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_pyr, s));
+    SSX_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_pyr, 0));
+    SSX_PROF_ON(ctx, ctx->aux, KID_ORB_GAUSS, hipLaunchKernelGGL(k_gauss7, dim3(d.gauss_tile0[d.nlevels], d.I), dim3(256), 0, ctx->aux, d));
+    SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    launch_fast(s, d.lvl_cell0[1], d.n_cells);
+    SSX_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_fast0, 0));
+  } else {
+    launch_pyramid(ctx, d, s, d.I);
+    if (!d.detect_only)
+      SSX_PROF(ctx, KID_ORB_GAUSS, hipLaunchKernelGGL(k_gauss7, dim3(d.gauss_tile0[d.nlevels], d.I), dim3(256), 0, s, d));
+    launch_fast(s, 0, d.n_cells);
+  }
   SSX_PROF(ctx, KID_ORB_OCTREE, launch_octree(d, s));
   if (d.detect_only) {
     SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_finalize_detect, dim3((SEL_CAP + 255) / 256, d.I), dim3(256), 0, s, d));
