@@ -109,18 +109,19 @@ def main():
     kt = _lib.profile_end(ctx)
     px = level_pixels(KITTI_H, KITTI_W)
     I = 2 * B
-    n_cand = None
-    # algorithmic bytes one LAUNCH of each kernel must move (per image x I images)
+    # algorithmic bytes every kernel must move per STEP (SURVEY.md section 8-D per-image figures x I images); a
+    # kernel launched several times per step (k_resize: 7 levels, k_fast_cells: level 0 | levels 1..7) gets the
+    # per-launch average
     kp_total = int(counts[:, 0].sum() + counts[:, 1].sum())
-    algo = {
-        "k_resize": lambda calls: I * (sum(px[:-1]) + sum(px[1:])) / 7.0,            # 7 launches: read l-1, write l
-        "k_fast_cells": lambda calls: I * sum(px) + 4.0 * 8000 * I,                  # read pyramid once, write candidates
-        "k_octree": lambda calls: 4.0 * 8000 * I + 4.0 * kp_total,                   # read candidates, write selection
-        "k_gauss7": lambda calls: 2.0 * I * sum(px) / 8.0,                           # 8 launches: read + write a level
-        "k_orient_brief": lambda calls: (961.0 + 1369.0 + 60.0) * kp_total,          # 31x31 + 37x37 patches, 28+32 B out
-        "k_row_bucket": lambda calls: 28.0 * kp_total / 2 + 4.0 * kp_total / 2,
-        "k_match": lambda calls: 60.0 * kp_total + 8.0 * kp_total / 2,
-        "k_triangulate_matches": lambda calls: (56.0 + 25.0) * kp_total / 2,
+    algo_step = {
+        "k_resize": I * (sum(px[:-1]) + sum(px[1:])),                 # read level l-1, write level l
+        "k_fast_cells": I * sum(px) + 4.0 * 8000 * I,                 # read the pyramid once, write the candidates
+        "k_octree": 4.0 * 8000 * I + 4.0 * kp_total,                  # read candidates, write the selection
+        "k_gauss7": 2.0 * I * sum(px),                                # read + write the pyramid
+        "k_orient_brief": (961.0 + 1369.0 + 60.0) * kp_total,         # 31x31 + 37x37 patches, 28+32 B out
+        "k_row_bucket": 28.0 * kp_total / 2 + 4.0 * kp_total / 2,
+        "k_match": 60.0 * kp_total + 8.0 * kp_total / 2,
+        "k_triangulate_matches": (56.0 + 25.0) * kp_total / 2,
     }
     dom_name, dom_ms = None, 0.0
     kernels = {}
@@ -130,12 +131,26 @@ def main():
             dom_name, dom_ms = name, total_ms
     dom_calls = kt[dom_name][0]
     dom_avg_s = (dom_ms / dom_calls) * 1e-3
-    dom_bytes = algo.get(dom_name, lambda c: 0.0)(dom_calls)
+    dom_bytes = algo_step.get(dom_name, 0.0) / (dom_calls / PROF_STEPS)
     achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    # HBM traffic per launch from the committed PMC passes (tools/collect_profiles.sh: separate FETCH_SIZE /
+    # WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes); only valid for the batch it was taken at
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        if pt.get("pairs_per_step") == B and world == 1:
+            key = [k for k in pt["bytes_per_launch"] if k.split("<")[0] == dom_name]
+            if key:
+                traffic, traffic_src = int(pt["bytes_per_launch"][key[0]]), pt.get("source")
+    except (OSError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "avg_launch_us": round(dom_avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(dom_bytes),
-                "note": "traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected offline: profiles/"}
+                "launches_per_step": dom_calls / PROF_STEPS,
+                "note": "the dominant kernel (grid FAST) is bound by integer VALU issue, not by HBM: see DESIGN.md section 5; "
+                        "traffic = PMC bytes per launch from " + (traffic_src or "profiles/ (not available for this batch size)")}
     # whole-pipeline figure: 12.0 MB algorithmic bytes per stereo pair
     pipeline_gbs = 12.0e6 * value / world / 1e9
 

@@ -1,0 +1,68 @@
+"""Turn gpurun_out/prof/<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/<round>/.
+
+    python tools/summarize_profiles.py <tag> <round-dir> <name>
+
+writes <name>_kernel_stats.csv (rocprofv3 --stats table, kernel names shortened), <name>_pmc_hbm.md, <name>.json
+(the bench line) and refreshes profiles/pmc_traffic.json, which bench.py reads for roofline.traffic.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+tag, rdir, name = sys.argv[1], sys.argv[2], sys.argv[3]
+src = os.path.join("gpurun_out", "prof", tag)
+os.makedirs(rdir, exist_ok=True)
+
+
+def short(n):
+    m = re.search(r"(k_\w+(?:<[^>]*>)?|__amd_rocclr_\w+)", n)
+    return m.group(1) if m else n[:48]
+
+
+# 1. kernel stats
+f = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")))[-1]
+rows = list(csv.DictReader(open(f)))
+with open(os.path.join(rdir, name + "_kernel_stats.csv"), "w") as o:
+    o.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent\n")
+    for r in rows:
+        o.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.1f},{r['MinNs']},{r['MaxNs']},{r['Percentage']}\n")
+avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+
+
+# 2. PMC
+def pmc(sub, counter):
+    f = sorted(glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")))[-1]
+    tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        tot[k] += float(r["Counter_Value"])
+        cnt[k] += 1
+    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
+
+
+fe, wr = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+traffic = {}
+with open(os.path.join(rdir, name + "_pmc_hbm.md"), "w") as o:
+    o.write("# PMC memory-side counters of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` (16 pairs/step), MI355X\n\n"
+            "Two separate `rocprofv3 --pmc <counter> --kernel-trace` passes (FETCH_SIZE, WRITE_SIZE), averaged per launch.\n"
+            "Raw counter units are KB.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts\n"
+            "half of the bytes of a wide read stream: `traffic` = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes).  The counters sit\n"
+            "between L2 and the fabric, so reads served by L2 / MALL never show up and small kernels read ~0.\n\n"
+            "| kernel | launches | avg us (stats pass) | FETCH_SIZE KB | WRITE_SIZE KB | traffic MB/launch |\n|---|---|---|---|---|---|\n")
+    for k in sorted(fe, key=lambda k: -(2 * fe[k][0] + wr.get(k, (0, 0))[0])):
+        w = wr.get(k, (0.0, 0))[0]
+        t = (2 * fe[k][0] + w) * 1024.0
+        traffic[k] = t
+        o.write(f"| {k} | {fe[k][1]} | {avg_ns.get(k, 0) / 1e3:.1f} | {fe[k][0]:.1f} | {w:.1f} | {t / 1e6:.2f} |\n")
+bj = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+json.dump(bj, open(os.path.join(rdir, name + ".json"), "w"), indent=1)
+json.dump({"source": f"{rdir}/{name}_pmc_hbm.md", "pairs_per_step": bj["config"]["pairs_per_step_per_gpu"],
+           "bytes_per_launch": {k: round(v) for k, v in traffic.items()}},
+          open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(rdir, name + "_pmc_hbm.md")).read())
