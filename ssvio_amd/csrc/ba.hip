@@ -1077,6 +1077,9 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_Cv = all.take(big ? sizeof(double) * 6 * (size_t)(E + 1) : 256);
   const size_t o_S = all.take(big ? sizeof(double) * (size_t)(n_pad + NB) * n_pad : 256);
   const size_t o_x = all.take(sizeof(double) * (n_pad + 8));
+  const size_t o_Ld = all.take(sizeof(double) * NB * NB);
+  const size_t o_invd = all.take(sizeof(double) * (n_pad + 8));
+  const size_t o_Ninv = all.take(sizeof(double) * 4 * 256);
   const size_t o_scale_part = all.take(sizeof(double) * 64);
   const size_t o_xp = all.take(sizeof(double) * (n + 1));
   const size_t o_trial = all.take(sizeof(double) * 3 * (nCh + 1));
@@ -1175,7 +1178,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     bd.sblk_pa = (const int*)(base + o_sblk_pa); bd.sblk_pb = (const int*)(base + o_sblk_pb);
     bd.spair_ptr = (const int*)(base + o_spair_ptr); bd.spair_a = (const int*)(base + o_spair_a); bd.spair_b = (const int*)(base + o_spair_b);
     bd.BDa = (double*)(base + o_BDa); bd.Wma = (double*)(base + o_Wma); bd.Cv = (double*)(base + o_Cv);
-    bd.S = (double*)(base + o_S); bd.x = (double*)(base + o_x); bd.scale_part = (double*)(base + o_scale_part);
+    bd.S = (double*)(base + o_S); bd.x = (double*)(base + o_x); bd.Ld = (double*)(base + o_Ld); bd.invd = (double*)(base + o_invd); bd.Ninv = (double*)(base + o_Ninv); bd.scale_part = (double*)(base + o_scale_part);
   }
   return SSX_OK;
 }
@@ -1348,15 +1351,12 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_add_lambda, dim3((bd.n + 255) / 256), dim3(256), 0, s, d, bd, lambda, dev_lambda));
     for (int kb = 0; kb < bd.T; ++kb) {
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(CH), 0, s, d, bd, kb));
-      const int rows_below = bd.n_pad - (kb + 1) * NB + 1;   // + the rhs row
-      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_trsm64, dim3((rows_below + CH - 1) / CH), dim3(CH), 0, s, bd, kb));
+      // row tiles kb+1 .. T-1 and the rhs row tile
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_trsm64, dim3(bd.T - kb), dim3(CH), 0, s, bd, kb));
       const int tiles = bd.T - kb - 1;
       if (tiles > 0) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_syrk64, dim3(tiles, tiles + 1), dim3(CH), 0, s, bd, kb));
     }
-    for (int kb = bd.T - 1; kb >= 0; --kb) {
-      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_trsvT64, dim3(1), dim3(64), 0, s, bd, kb));
-      if (kb > 0) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_gemvT64, dim3((kb * NB + CH - 1) / CH), dim3(CH), 0, s, bd, kb));
-    }
+    SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(1024), 0, s, bd));
     const int nparts = std::min(32, (d.P + CH - 1) / CH);
     SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_pose_update_big, dim3(nparts), dim3(CH), 0, s, d, bd, cur_, lambda, dev_lambda));
     SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_scale_finish, dim3(1), dim3(64), 0, s, d, bd, nparts));
