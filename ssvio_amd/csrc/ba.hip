@@ -805,6 +805,8 @@ struct BaWorkspace {
   DevBuf arena;      // everything on the device
   HostBuf stage;     // pinned upload / download staging
   HostBuf scal;      // pinned scalars read back per trial
+  DevBuf tiles;      // large windows: tile-sparsity lists of the factor
+  HostBuf tiles_h;
 };
 
 static void ssx_ba_workspace_free(BaWorkspace* w)
@@ -813,6 +815,8 @@ static void ssx_ba_workspace_free(BaWorkspace* w)
   w->arena.release();
   w->stage.release();
   w->scal.release();
+  w->tiles.release();
+  w->tiles_h.release();
   delete w;
 }
 
@@ -1339,6 +1343,71 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
     attr_set = true;
   }
+  // large windows: which 64x64 tiles of the factor can be non-zero.  The local co-visibility gives the tiles of this
+  // rank's share of S; the union over the ranks (one small all-reduce of the T x T indicator) is the pattern of
+  // the reduced system, and a symbolic elimination at tile level adds the fill.  A sliding window / odometry chain
+  // gives a block-banded S: the panels then touch a handful of tiles instead of (T-k)^2 / 2.
+  std::vector<int> tl_row_cnt, tl_pair_cnt;
+  if (d.big) {
+    const int T = bd.T;
+    SSX_HIP_TRY(ctx, ws->tiles_h.reserve(sizeof(double) * (size_t)T * T + 64));
+    double* hp = ws->tiles_h.as<double>();
+    std::fill(hp, hp + (size_t)T * T, 0.0);
+    for (size_t q = 0; q < h.sblk_pa.size(); ++q) {
+      const int pa = h.sblk_pa[q], pb = h.sblk_pb[q];
+      for (int ta = (6 * pa) / NB; ta <= (6 * pa + 5) / NB; ++ta)
+        for (int tb = (6 * pb) / NB; tb <= (6 * pb + 5) / NB; ++tb)
+          hp[(size_t)std::max(ta, tb) * T + std::min(ta, tb)] = 1.0;
+    }
+    if (cm.fn) {
+      SSX_HIP_TRY(ctx, ws->tiles.reserve(sizeof(double) * (size_t)T * T + 64));
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->tiles.p, hp, sizeof(double) * (size_t)T * T, hipMemcpyHostToDevice, ctx->stream));
+      st = allreduce(ctx, cm, ws->tiles.as<double>(), (size_t)T * T);
+      if (st != SSX_OK) return st;
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(hp, ws->tiles.p, sizeof(double) * (size_t)T * T, hipMemcpyDeviceToHost, ctx->stream));
+      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<uint8_t> pat((size_t)T * T, 0);
+    for (size_t i = 0; i < (size_t)T * T; ++i) pat[i] = hp[i] != 0.0;
+    std::vector<int> row_ptr(T + 1, 0), rows, pair_ptr(T + 1, 0), pair_bi, pair_bj, col_ptr(T + 1, 0), cols;
+    std::vector<int> R;
+    for (int k = 0; k < T; ++k) {
+      R.clear();
+      for (int i = k + 1; i < T; ++i) if (pat[(size_t)i * T + k]) R.push_back(i);
+      for (size_t a = 0; a < R.size(); ++a)
+        for (size_t c = 0; c <= a; ++c) pat[(size_t)R[a] * T + R[c]] = 1;       // fill
+      R.push_back(T);                                                             // the rhs row tile
+      for (int i : R) rows.push_back(i);
+      row_ptr[k + 1] = (int)rows.size();
+      for (size_t a = 0; a < R.size(); ++a)
+        for (size_t c = 0; c <= a; ++c)
+          if (R[c] != T) { pair_bi.push_back(R[a]); pair_bj.push_back(R[c]); }
+      pair_ptr[k + 1] = (int)pair_bi.size();
+    }
+    for (int k = 0; k < T; ++k) {
+      for (int j = 0; j < k; ++j) if (pat[(size_t)k * T + j]) cols.push_back(j);
+      col_ptr[k + 1] = (int)cols.size();
+    }
+    tl_row_cnt.resize(T); tl_pair_cnt.resize(T);
+    for (int k = 0; k < T; ++k) { tl_row_cnt[k] = row_ptr[k + 1] - row_ptr[k]; tl_pair_cnt[k] = pair_ptr[k + 1] - pair_ptr[k]; }
+    Layout tl;
+    const size_t o_rp = tl.take(sizeof(int) * (T + 1)), o_r = tl.take(sizeof(int) * (rows.size() + 1));
+    const size_t o_pp = tl.take(sizeof(int) * (T + 1)), o_pbi = tl.take(sizeof(int) * (pair_bi.size() + 1));
+    const size_t o_pbj = tl.take(sizeof(int) * (pair_bj.size() + 1));
+    const size_t o_cp = tl.take(sizeof(int) * (T + 1)), o_c = tl.take(sizeof(int) * (cols.size() + 1));
+    SSX_HIP_TRY(ctx, ws->tiles_h.reserve(tl.off));
+    SSX_HIP_TRY(ctx, ws->tiles.reserve(tl.off));
+    char* th = ws->tiles_h.as<char>();
+    memcpy(th + o_rp, row_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_r, rows.data(), sizeof(int) * rows.size());
+    memcpy(th + o_pp, pair_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_pbi, pair_bi.data(), sizeof(int) * pair_bi.size());
+    memcpy(th + o_pbj, pair_bj.data(), sizeof(int) * pair_bj.size());
+    memcpy(th + o_cp, col_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_c, cols.data(), sizeof(int) * cols.size());
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->tiles.p, th, tl.off, hipMemcpyHostToDevice, ctx->stream));
+    const char* tb = ws->tiles.as<char>();
+    bd.tl_row_ptr = (const int*)(tb + o_rp); bd.tl_rows = (const int*)(tb + o_r);
+    bd.tl_pair_ptr = (const int*)(tb + o_pp); bd.tl_pair_bi = (const int*)(tb + o_pbi); bd.tl_pair_bj = (const int*)(tb + o_pbj);
+    bd.tl_col_ptr = (const int*)(tb + o_cp); bd.tl_cols = (const int*)(tb + o_c);
+  }
   // large windows: Schur blocks -> dense S (+ rhs row) -> all-reduce -> blocked Cholesky (MFMA) -> back-substitution
   auto big_trial = [&](double lambda, int dev_lambda, int cur_) -> ssx_status {
     hipStream_t s = ctx->stream;
@@ -1351,10 +1420,9 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_add_lambda, dim3((bd.n + 255) / 256), dim3(256), 0, s, d, bd, lambda, dev_lambda));
     for (int kb = 0; kb < bd.T; ++kb) {
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(CH), 0, s, d, bd, kb));
-      // row tiles kb+1 .. T-1 and the rhs row tile
-      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_trsm64, dim3(bd.T - kb), dim3(CH), 0, s, bd, kb));
-      const int tiles = bd.T - kb - 1;
-      if (tiles > 0) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_syrk64, dim3(tiles, tiles + 1), dim3(CH), 0, s, bd, kb));
+      // the structurally non-zero row tiles below the panel (always the rhs row tile), then their pairs
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_trsm64, dim3(tl_row_cnt[kb]), dim3(CH), 0, s, bd, kb));
+      if (tl_pair_cnt[kb] > 0) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_syrk64, dim3(tl_pair_cnt[kb]), dim3(CH), 0, s, bd, kb));
     }
     SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(1024), 0, s, bd));
     const int nparts = std::min(32, (d.P + CH - 1) / CH);
