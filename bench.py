@@ -134,7 +134,8 @@ def main():
     dom_bytes = algo_step.get(dom_name, 0.0) / (dom_calls / PROF_STEPS)
     achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     # HBM traffic per launch from the committed PMC passes (tools/collect_profiles.sh: separate FETCH_SIZE /
-    # WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes); only valid for the batch it was taken at
+    # WRITE_SIZE runs; no 16 B/lane streams here, so no FETCH doubling, see the header of the .md); only valid for
+    # the batch size it was taken at
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -149,7 +150,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "avg_launch_us": round(dom_avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(dom_bytes),
                 "launches_per_step": dom_calls / PROF_STEPS,
-                "note": "the dominant kernel (grid FAST) is bound by integer VALU issue, not by HBM: see DESIGN.md section 5; "
+                "note": "the dominant kernel (grid FAST) is bound by integer VALU issue, not by HBM: see DESIGN.md section 4; "
                         "traffic = PMC bytes per launch from " + (traffic_src or "profiles/ (not available for this batch size)")}
     # whole-pipeline figure: 12.0 MB algorithmic bytes per stereo pair
     pipeline_gbs = 12.0e6 * value / world / 1e9
@@ -181,6 +182,36 @@ def main():
         ba_elapsed = float(t.item())
     ba_iters_s = n_it / ba_elapsed
     ba_solve_ms = ba_elapsed / BA_REP * 1e3
+
+    # ---------------- global BA (C4 shape), WEAK scaling over the GPUs ----------------
+    # 500 keyframes on a loop, 10 000 landmarks PER GPU (6 observations each): at 8 GPUs this is BASELINE
+    # configs[3] exactly (80 000 landmarks, 480 000 edges).  Landmarks are sharded, the 3000 x 3000 reduced system
+    # is all-reduced (non-zero tiles only) and solved redundantly on every rank.
+    C4_LM_PER_GPU = 10000
+    pr4 = make_ba_problem(P=500, L=C4_LM_PER_GPU * world, obs_per_lm=6, seed=4, loop=True, fix_first_pose=True)
+    pr4_local = dist_ba.shard_problem(pr4, rank, world) if world > 1 else pr4
+    with torch.cuda.stream(stream):
+        r4 = ba.ba_solve(ctx, pr4_local, outer_rounds=1, iters=10, want_edges=False, **ba_kwargs)
+        barrier()
+        tb = time.perf_counter()
+        C4_REP = 2
+        n_it4 = 0
+        for _ in range(C4_REP):
+            r4 = ba.ba_solve(ctx, pr4_local, outer_rounds=1, iters=10, want_edges=False, **ba_kwargs)
+            n_it4 += r4["n_iters"]
+        barrier()
+        c4_elapsed = time.perf_counter() - tb
+    if world > 1:
+        t = torch.tensor([c4_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c4_elapsed = float(t.item())
+    c4 = {"workload": f"C4 shape: 500 KF on a loop x {C4_LM_PER_GPU * world} landmarks x {int(pr4['E'])} edges "
+                      f"({C4_LM_PER_GPU} landmarks per GPU, weak scaling), analytic Jacobians, f64",
+          "iters_per_s": round(n_it4 / c4_elapsed, 2),
+          "edge_iters_per_s": round(float(pr4["E"]) * n_it4 / c4_elapsed, 1),
+          "ms_per_lm_iteration": round(c4_elapsed / max(n_it4, 1) * 1e3, 3),
+          "chi2_first_last": [float(r4["chi2"][0]), float(r4["chi2"][-1])],
+          "sharding": f"landmarks over {world} GPUs + RCCL all-reduce of the non-zero 64x64 tiles" if world > 1 else "none"}
 
     # ---------------- CPU baseline (rank 0, N == 1 only) ----------------
     cpu = None
@@ -233,6 +264,7 @@ def main():
                    "lm_iterations_per_solve": n_it // BA_REP,
                    "sharding": f"landmarks over {world} GPUs + RCCL all-reduce" if world > 1 else "none",
                    "includes": "host<->device transfer of the problem and the host LM control loop"},
+            "ba_c4": c4,
             "e2e_frames_per_s_with_one_local_BA_per_frame": round(1.0 / (1.0 / (value / world) + ba_solve_ms * 1e-3) * world, 2),
             "cpu_baseline": cpu,
         }

@@ -1369,6 +1369,10 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     }
     std::vector<uint8_t> pat((size_t)T * T, 0);
     for (size_t i = 0; i < (size_t)T * T; ++i) pat[i] = hp[i] != 0.0;
+    std::vector<int> init_bi, init_bj;
+    for (int i = 0; i < T; ++i)
+      for (int j = 0; j <= i; ++j)
+        if (pat[(size_t)i * T + j] || i == j) { init_bi.push_back(i); init_bj.push_back(j); }
     std::vector<int> row_ptr(T + 1, 0), rows, pair_ptr(T + 1, 0), pair_bi, pair_bj, col_ptr(T + 1, 0), cols;
     std::vector<int> R;
     for (int k = 0; k < T; ++k) {
@@ -1395,15 +1399,22 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     const size_t o_pp = tl.take(sizeof(int) * (T + 1)), o_pbi = tl.take(sizeof(int) * (pair_bi.size() + 1));
     const size_t o_pbj = tl.take(sizeof(int) * (pair_bj.size() + 1));
     const size_t o_cp = tl.take(sizeof(int) * (T + 1)), o_c = tl.take(sizeof(int) * (cols.size() + 1));
-    SSX_HIP_TRY(ctx, ws->tiles_h.reserve(tl.off));
+    const size_t o_ibi = tl.take(sizeof(int) * (init_bi.size() + 1)), o_ibj = tl.take(sizeof(int) * (init_bj.size() + 1));
+    const size_t tl_lists = tl.off;
+    const size_t o_spack = tl.take(cm.fn ? sizeof(double) * (init_bi.size() * (size_t)NB_TILE + bd.n_pad + 8) : 256);
+    SSX_HIP_TRY(ctx, ws->tiles_h.reserve(tl_lists));
     SSX_HIP_TRY(ctx, ws->tiles.reserve(tl.off));
     char* th = ws->tiles_h.as<char>();
     memcpy(th + o_rp, row_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_r, rows.data(), sizeof(int) * rows.size());
     memcpy(th + o_pp, pair_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_pbi, pair_bi.data(), sizeof(int) * pair_bi.size());
     memcpy(th + o_pbj, pair_bj.data(), sizeof(int) * pair_bj.size());
     memcpy(th + o_cp, col_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_c, cols.data(), sizeof(int) * cols.size());
-    SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->tiles.p, th, tl.off, hipMemcpyHostToDevice, ctx->stream));
-    const char* tb = ws->tiles.as<char>();
+    memcpy(th + o_ibi, init_bi.data(), sizeof(int) * init_bi.size()); memcpy(th + o_ibj, init_bj.data(), sizeof(int) * init_bj.size());
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->tiles.p, th, tl_lists, hipMemcpyHostToDevice, ctx->stream));
+    char* tb = ws->tiles.as<char>();
+    bd.n_init = (int)init_bi.size();
+    bd.tl_init_bi = (const int*)(tb + o_ibi); bd.tl_init_bj = (const int*)(tb + o_ibj);
+    bd.Spack = (double*)(tb + o_spack);
     bd.tl_row_ptr = (const int*)(tb + o_rp); bd.tl_rows = (const int*)(tb + o_r);
     bd.tl_pair_ptr = (const int*)(tb + o_pp); bd.tl_pair_bi = (const int*)(tb + o_pbi); bd.tl_pair_bj = (const int*)(tb + o_pbj);
     bd.tl_col_ptr = (const int*)(tb + o_cp); bd.tl_cols = (const int*)(tb + o_c);
@@ -1415,8 +1426,13 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_prep, dim3(nCh), dim3(CH), lds_prep, s, d, bd, lambda, dev_lambda));
     SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_blocks, dim3((bd.nBlkS + 3) / 4), dim3(CH), 0, s, d, bd));
     SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_bs, dim3(d.nP), dim3(CH), 0, s, d, bd));
-    ssx_status st2 = allreduce(ctx, cm, bd.S, (size_t)(bd.n_pad + 1) * bd.ld);
-    if (st2 != SSX_OK) return st2;
+    if (cm.fn) {
+      // exchange the non-zero tiles and the rhs row only
+      hipLaunchKernelGGL(k_pack_tiles, dim3(bd.n_init + 1), dim3(CH), 0, s, bd, 0);
+      ssx_status st2 = allreduce(ctx, cm, bd.Spack, (size_t)bd.n_init * NB_TILE + bd.n_pad);
+      if (st2 != SSX_OK) return st2;
+      hipLaunchKernelGGL(k_pack_tiles, dim3(bd.n_init + 1), dim3(CH), 0, s, bd, 1);
+    }
     SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_add_lambda, dim3((bd.n + 255) / 256), dim3(256), 0, s, d, bd, lambda, dev_lambda));
     for (int kb = 0; kb < bd.T; ++kb) {
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(CH), 0, s, d, bd, kb));

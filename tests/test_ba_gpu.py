@@ -130,6 +130,9 @@ def test_allreduce_hook_world1_is_identity(ctx, po):
     from ssvio_amd import dist_ba
     pr = make_ba_problem(P=10, L=600, seed=6)
     plain = ba.ba_solve(ctx, pr)
+    # the large-window path exchanges packed non-zero tiles of the reduced system (+ the tile pattern itself)
+    pr_big = make_ba_problem(P=40, L=1500, obs_per_lm=5, seed=9, loop=False, fix_first_pose=True)
+    plain_big = ba.ba_solve(ctx, pr_big, outer_rounds=1, iters=5)
     created = False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29733")
@@ -139,13 +142,16 @@ def test_allreduce_hook_world1_is_identity(ctx, po):
         s = torch.cuda.Stream(device="cuda:0")
         with torch.cuda.stream(s):
             c2 = ssvio_amd.Context(0, stream=s.cuda_stream)
-            hooked = ba.ba_solve(c2, pr, allreduce=dist_ba.make_allreduce_hook(torch.device("cuda:0")), rank=0, world_size=1)
+            hook = dist_ba.make_allreduce_hook(torch.device("cuda:0"))
+            hooked = ba.ba_solve(c2, pr, allreduce=hook, rank=0, world_size=1)
+            hooked_big = ba.ba_solve(c2, pr_big, outer_rounds=1, iters=5, allreduce=hook, rank=0, world_size=1)
             c2.close()
     finally:
         if created:
             dist.destroy_process_group()
     assert np.array_equal(plain["poses"], hooked["poses"]) and np.array_equal(plain["points"], hooked["points"])
     assert np.array_equal(plain["chi2"], hooked["chi2"]) and np.array_equal(plain["edge_chi2"], hooked["edge_chi2"])
+    assert np.array_equal(plain_big["poses"], hooked_big["poses"]) and np.array_equal(plain_big["chi2"], hooked_big["chi2"])
 
 
 @pytest.mark.parametrize("name", ["po200", "po60"])
