@@ -141,6 +141,8 @@ __device__ __forceinline__ bool arc9(unsigned m)   // 9 contiguous set bits in a
 // score.  The ring is held as 8 packed i16 pairs (d[k], d[k+8]); every sliding-window min/max then runs on
 // v_pk_min_i16 / v_pk_max_i16 and the "+8" rotations are half swaps (op_sel, free).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 __device__ __forceinline__ s16x2 hswap(s16x2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 __device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
@@ -180,24 +182,11 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int p, int t)
   return sc >= t ? sc : -1;
 }
 
-// ring pixel k of the Bresenham circle relative to c (LDS row pitch p)
-#define RING(k) ((int)c[c_ring_dx[k] + c_ring_dy[k] * p])
-
-// cheap necessary condition: an arc of 9 contiguous ring pixels contains at least 2 of the 4 compass pixels
-// (ring indices 0, 4, 8, 12), so a corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t.
-__device__ __forceinline__ bool fast_quick(const uint8_t* c, int p, int t)
-{
-  const int v = c[0];
-  const int lo = v - t, hi = v + t;
-  const int p0 = c[3 * p], p8 = c[-3 * p], p4 = c[3], p12 = c[-3];
-  const int nd = (p0 < lo) + (p8 < lo) + (p4 < lo) + (p12 < lo);
-  const int nb = (p0 > hi) + (p8 > hi) + (p4 > hi) + (p12 > hi);
-  return nd >= 2 || nb >= 2;
-}
-
 // ONE WAVE PER CELL (4 cells per 256-thread workgroup, no workgroup barrier anywhere):
 //   1. the ROI is staged in LDS with aligned dword loads (level pitch is a multiple of 128 bytes);
-//   2. every interior pixel takes the 4-load quick test; survivors are compacted with ballot/popcount;
+//   2. every interior pixel takes the quick test (an arc of 9 contiguous ring pixels contains at least 2 of the 4
+//      compass pixels, so a corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t), four pixels per
+//      lane on packed u16 pairs; survivors are compacted with ballot/popcount;
 //   3. the compacted survivors take the full segment test + cornerScore (dense lanes);
 //   4. the corners (again a compacted list) take the 3x3 strict NMS, the mask test and an ORDER-PRESERVING
 //      compaction (ballot prefix inside a round; rounds walk the pixels in row-major order).
@@ -205,7 +194,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cell = cell_begin + blockIdx.x * 4 + wave, img = blockIdx.y;
+  const int cell = cell_begin + blockIdx.x * (blockDim.x >> 6) + wave, img = blockIdx.y;   // 1..4 cells per workgroup
   if (cell >= cell_end) return;
   const Cell c = o.cells[cell];
   const uint8_t* lvl = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[c.level];
@@ -224,8 +213,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
     reinterpret_cast<uint32_t*>(sImg)[i] = *reinterpret_cast<const uint32_t*>(lvl + (size_t)(c.y0 + y) * pitch + tx0 + 4 * xd);
   }
   const int iw = w - 6, ih = h - 6;                // cv::FAST ignores a 3-px border of the ROI
-  const int npx = (iw > 0 && ih > 0) ? iw * ih : 0;
-  const float inv_iw = iw > 0 ? 1.0f / (float)iw : 0.f;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int* cell_count = o.cell_count + (size_t)img * o.n_cells + cell;
   uint32_t* cell_cand = o.cell_cand + ((size_t)img * o.n_cells + cell) * CELL_CAP;
@@ -236,23 +223,67 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
   for (int pass = 0; pass < 2; ++pass) {
     const int th = min(max(pass == 0 ? o.ini_th : o.min_th, 0), 255);
     for (int i = lane; i < h * ndw; i += 64) reinterpret_cast<uint32_t*>(sScore)[i] = 0;
-    // -- stage 1: quick test on every interior pixel, compaction of the survivors --
+    // -- stage 1: quick test on every interior pixel, FOUR pixels of one row per lane, compaction of the
+    //    survivors in row-major order.  Five aligned LDS dwords (centre row x4-4, x4, x4+4; rows y-3 and y+3 at x4)
+    //    hold the centre and the four compass pixels of the quad; as u16 pairs (pixels 0|2 and 1|3) the second
+    //    smallest / second largest compass pixel come from a 4-input min/max network on v_pk_min/max_u16, and
+    //    "two compass pixels darker than v-t" is  sat(sat(v-t) - second_smallest) != 0.
     int n_surv = 0;
-    for (int base = 0; base < npx; base += 64) {
-      const int pxi = base + lane;
-      bool pass_q = false;
-      int off = 0;
-      if (pxi < npx) {
-        const int yy = (int)(((float)pxi + 0.5f) * inv_iw);
-        off = (3 + yy) * tw + xoff + 3 + (pxi - yy * iw);
-        pass_q = fast_quick(&sImg[off], tw, th);
+    {
+      const int xs = xoff + 3, xe = xs + iw;            // interior columns of the tile
+      const int qx0 = xs & ~3;
+      const int nq = (iw > 0 && ih > 0) ? ((xe - qx0 + 3) >> 2) : 0;   // quads per interior row
+      const int nitems = nq * max(ih, 0);
+      const float inv_nq = nq > 0 ? 1.0f / (float)nq : 0.f;
+      const uint32_t t2 = (uint32_t)th | ((uint32_t)th << 16);
+      const uint32_t* dw = reinterpret_cast<const uint32_t*>(sImg);
+      for (int base = 0; base < nitems; base += 64) {
+        const int item = base + lane;
+        const bool in = item < nitems;
+        const int it = in ? item : 0;
+        const int yy = (int)(((float)it + 0.5f) * inv_nq);
+        const int x4 = qx0 + 4 * (it - yy * nq);
+        const int y = 3 + yy;
+        const int ci = y * ndw + (x4 >> 2);
+        const uint32_t C0 = dw[ci - 1], C1 = dw[ci], C2 = dw[ci + 1], Tp = dw[ci - 3 * ndw], Bt = dw[ci + 3 * ndw];
+        const uint32_t Lf = __builtin_amdgcn_alignbyte(C1, C0, 1);     // pixels x-3 of the quad
+        const uint32_t Rt = __builtin_amdgcn_alignbyte(C2, C1, 3);     // pixels x+3
+        uint32_t flag[2];
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {                            // pixels 0|2, then 1|3
+          const int sh = 8 * par;
+          const u16x2 v = as_u16x2((C1 >> sh) & 0x00FF00FFu), tp = as_u16x2((Tp >> sh) & 0x00FF00FFu);
+          const u16x2 bt = as_u16x2((Bt >> sh) & 0x00FF00FFu), lf = as_u16x2((Lf >> sh) & 0x00FF00FFu);
+          const u16x2 rt = as_u16x2((Rt >> sh) & 0x00FF00FFu);
+          const u16x2 a = __builtin_elementwise_min(tp, bt), bmx = __builtin_elementwise_max(tp, bt);
+          const u16x2 c2 = __builtin_elementwise_min(lf, rt), d2 = __builtin_elementwise_max(lf, rt);
+          const u16x2 m1 = __builtin_elementwise_max(a, c2), m2 = __builtin_elementwise_min(bmx, d2);
+          const u16x2 s2 = __builtin_elementwise_min(m1, m2), s3 = __builtin_elementwise_max(m1, m2);
+          const u16x2 lo = __builtin_elementwise_sub_sat(v, as_u16x2(t2)), hi = v + as_u16x2(t2);
+          const u16x2 f = __builtin_elementwise_sub_sat(lo, s2) | __builtin_elementwise_sub_sat(s3, hi);
+          flag[par] = __builtin_bit_cast(uint32_t, f);
+        }
+        bool fk[4];
+        fk[0] = (flag[0] & 0xFFFFu) != 0; fk[1] = (flag[1] & 0xFFFFu) != 0;
+        fk[2] = (flag[0] >> 16) != 0;     fk[3] = (flag[1] >> 16) != 0;
+        int before = n_surv, mine = 0, total = 0;
+        unsigned long long bal[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          fk[k] = fk[k] && in && (x4 + k >= xs) && (x4 + k < xe);
+          bal[k] = __ballot(fk[k]);
+          before += __popcll(bal[k] & lt_mask);
+          total += __popcll(bal[k]);
+        }
+        const int off0 = y * tw + x4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (fk[k]) sList[before + mine] = (uint16_t)(off0 + k);
+          mine += fk[k];
+        }
+        n_surv += total;
       }
-      const unsigned long long bal = __ballot(pass_q);
-      if (pass_q) sList[n_surv + __popcll(bal & lt_mask)] = (uint16_t)off;
-      n_surv += __popcll(bal);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
     // -- stage 2: full segment test + score on the survivors; corners compacted in place (order kept) --
     int n_corner = 0;
     for (int base = 0; base < n_surv; base += 64) {
@@ -304,7 +335,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
     if (n_out > CELL_CAP) atomicOr(&o.status[img], 1);
   }
 }
-#undef RING
 
 // ------------------------------------------------------------------------------------------------
 // A7: cv::GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, 8-bit fixed point (row pass exact ints, column pass
@@ -330,7 +360,6 @@ constexpr int GT_PITCH = GT_W + 8;              // input tile pitch: 4 bytes of 
 //                with the 2^15 rounding term.
 // The fixed-point result is exact integer arithmetic, so the evaluation order is free (OpenCV: row sums exact,
 // column pass (sum + 2^15) >> 16, saturate).
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t udot2(uint32_t pair, uint32_t w, uint32_t acc)
 {
   return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, w), acc, false);
@@ -986,13 +1015,14 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   const OrbDev& d = ws->dev;
   hipStream_t s = ctx->stream;
   SSX_HIP_TRY(ctx, hipMemsetAsync(d.status, 0, sizeof(int) * d.I, s));
-  if (4 * (size_t)d.fast_lds_per_wave > 48 * 1024)
+  constexpr int FAST_WPW = 4;   // cells (waves) per workgroup; 1, 2 and 4 measure the same end to end
+  if (FAST_WPW * (size_t)d.fast_lds_per_wave > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(4 * (size_t)d.fast_lds_per_wave));
+                              (int)(FAST_WPW * (size_t)d.fast_lds_per_wave));
   auto launch_fast = [&](hipStream_t st, int c0, int c1) {
     if (c1 > c0)
-      SSX_PROF_ON(ctx, st, KID_ORB_FAST, hipLaunchKernelGGL(k_fast_cells, dim3((c1 - c0 + 3) / 4, d.I), dim3(256),
-                                                            4 * (size_t)d.fast_lds_per_wave, st, d, c0, c1));
+      SSX_PROF_ON(ctx, st, KID_ORB_FAST, hipLaunchKernelGGL(k_fast_cells, dim3((c1 - c0 + FAST_WPW - 1) / FAST_WPW, d.I), dim3(64 * FAST_WPW),
+                                                            FAST_WPW * (size_t)d.fast_lds_per_wave, st, d, c0, c1));
   };
   // Two streams.  The pyramid is a chain of seven dependent, mostly small launches that leaves the chip idle, so
   // level 0 of the detection (a third of the cells) runs beside it on the auxiliary stream; the blur only needs
