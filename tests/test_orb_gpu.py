@@ -193,3 +193,54 @@ def test_describe_at_bit_exact(ctx, po, pair_kitti):
     assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
     e_k, e_d = ex.ScreenAndComputeKPsParams_CalcDescriptors(L, rep[:0])
     assert len(e_k) == 0 and e_d.shape == (0, 32)
+
+
+@pytest.mark.parametrize("scale,nlevels,nfeat", [(1.5, 4, 400), (2.0, 3, 300), (2.3, 3, 300), (1.1, 6, 500)])
+def test_extract_other_pyramids_bit_exact(ctx, po, pair_small, pair_kitti, scale, nlevels, nfeat):
+    """other scale factors / level counts than the yaml defaults: the resize tables (incl. the byte-load fallback of
+    k_resize for quads spanning more than 8 source bytes, scale > 2), the per-level budgets and the cell grids"""
+    for img in (pair_small[0], pair_kitti[1][40:300, 100:900]):
+        ex = sorb.ORBextractor(ctx, nfeatures=nfeat, scaleFactor=scale, nlevels=nlevels)
+        gk, gd = ex.DetectAndCompute(np.ascontiguousarray(img))
+        ok, od = po.orb_extract(np.ascontiguousarray(img), prm=po.orb_params(nfeatures=nfeat, scale_factor=scale, nlevels=nlevels))
+        assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+
+
+def test_low_contrast_cells_fall_back_to_min_threshold(ctx, po, pair_small):
+    """cells without a corner at iniThFAST are re-run at minThFAST (orbextractor.cpp:598-606): a low-contrast
+    image makes most cells take the second pass, a high iniThFAST all of them"""
+    L = pair_small[0]
+    soft = (L.astype(np.float32) * 0.22 + 90).astype(np.uint8)
+    for img, ini, mn in ((soft, 20, 7), (L, 120, 7), (L, 20, 20), (soft, 7, 3)):
+        ex = sorb.ORBextractor(ctx, nfeatures=300, nlevels=4, iniThFAST=ini, minThFAST=mn)
+        gk, gd = ex.DetectAndCompute(img)
+        ok, od = po.orb_extract(img, prm=po.orb_params(nfeatures=300, nlevels=4, ini_th=ini, min_th=mn))
+        assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+        gdet = ex.Detect(img)
+        odet = po.orb_detect(img, prm=po.orb_params(nfeatures=300, nlevels=4, ini_th=ini, min_th=mn))
+        assert gdet.tobytes() == odet.tobytes()
+
+
+def test_matcher_and_triangulation_edge_cases(ctx, po, pair_small):
+    """no keypoints on one side, a single keypoint, everything out of the row band"""
+    L, R = pair_small[0], pair_small[1]
+    kL, dL = po.orb_extract(L, prm=po.orb_params(nfeatures=300, nlevels=4))
+    kR, dR = po.orb_extract(R, prm=po.orb_params(nfeatures=300, nlevels=4))
+    empty_k, empty_d = kR[:0], dR[:0]
+    for a, b, c, d in ((kL, dL, empty_k, empty_d), (empty_k, empty_d, kR, dR), (kL[:1], dL[:1], kR, dR), (kL, dL, kR[:1], dR[:1])):
+        gi, gd = sorb.stereo_match(ctx, a, b, c, d)
+        oi, od = po.stereo_match(a, b, c, d)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    far = kR.copy(); far["y"] += 500.0                      # no right keypoint inside any left keypoint's band
+    gi, gd = sorb.stereo_match(ctx, kL, dL, far, dR)
+    oi, od = po.stereo_match(kL, dL, far, dR)
+    assert np.array_equal(gi, oi) and (gi < 0).all()
+    xyz, ok = sorb.triangulate(ctx, np.zeros((0, 2)), np.zeros((0, 2)))
+    assert xyz.shape == (0, 3) and ok.shape == (0,)
+    # zero and negative disparity: behind / at infinity -> rejected like the oracle
+    uvL = np.array([[300.0, 100.0], [300.0, 100.0], [10.0, 20.0]]); uvR = np.array([[300.0, 100.0], [310.0, 100.0], [9.0, 21.5]])
+    xyz, ok = sorb.triangulate(ctx, uvL, uvR)
+    o = po.triangulate(uvL, uvR, KITTI_K, KITTI_BASELINE)
+    assert np.array_equal(ok, o["ok"])
+    m = o["ok"].astype(bool)
+    np.testing.assert_allclose(xyz[m], o["xyz"][m], rtol=1e-9, atol=1e-9)
