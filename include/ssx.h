@@ -287,6 +287,40 @@ SSX_API ssx_status ssx_stereo_batch_fetch(ssx_ctx* ctx, int32_t pair, ssx_stereo
  * download (bench.py brackets a run of these with HIP events). */
 SSX_API ssx_status ssx_stereo_batch_enqueue(ssx_ctx* ctx);
 
+/* ------------------------------------------------------------------------------------------------
+ * N1: pyramidal Lucas-Kanade tracking.
+ * Replaces the two cv::calcOpticalFlowPyrLK calls of the reference front-end:
+ *   FrontEnd::TrackLastFrame        /root/reference/src/ssvio/frontend.cpp:130-182 (call at :156-166)
+ *   FrontEnd::FindFeaturesInRight   /root/reference/src/ssvio/frontend.cpp:346-428 (call at :374-384)
+ * both with cv::Size(11,11), maxLevel 3, TermCriteria(COUNT+EPS, 30, 0.01), OPTFLOW_USE_INITIAL_FLOW.
+ * Semantics of OpenCV 3.x calcOpticalFlowPyrLK: buildOpticalFlowPyramid (pyrDown, REFLECT_101 border, the pyramid
+ * stops before a level not larger than the window), Scharr derivatives, 14-bit bilinear weights, status = 0 when
+ * the window leaves the image or the smaller eigenvalue of the normal matrix falls below the threshold, err =
+ * mean absolute patch difference / 32 at level 0.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ssx_lk_params {
+  int32_t win;                /* winSize (square, odd, 3..15): 11 */
+  int32_t max_level;          /* maxLevel: 3 */
+  int32_t max_iters;          /* TermCriteria COUNT: 30 */
+  double eps;                 /* TermCriteria EPS: 0.01 (compared squared against |delta|^2) */
+  float min_eig_threshold;    /* minEigThreshold: 1e-4 */
+  int32_t use_initial_flow;   /* OPTFLOW_USE_INITIAL_FLOW: next_pts holds the initial guesses */
+} ssx_lk_params;
+SSX_API void ssx_lk_default_params(ssx_lk_params* p);
+/* prev / next: host images rows x cols (8-bit, strides in bytes); prev_pts: n x 2 floats (x, y); next_pts: n x 2
+ * floats, in (initial guess when use_initial_flow) and out; status: n bytes; err: n floats or NULL;
+ * top_level (optional): the top pyramid level actually used. */
+SSX_API ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const uint8_t* next,
+                                int32_t next_stride, int32_t rows, int32_t cols, int32_t n, const float* prev_pts,
+                                float* next_pts, uint8_t* status, float* err, const ssx_lk_params* prm,
+                                int32_t* top_level);
+/* Test access to the pyramids (which = 0 previous, 1 next) and the Scharr images (int16 dx, dy interleaved) of
+ * the last ssx_lk_track call. */
+SSX_API ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level, uint8_t* out, int32_t out_cap,
+                                      int32_t* rows, int32_t* cols);
+SSX_API ssx_status ssx_lk_stage_deriv(ssx_ctx* ctx, int32_t level, int16_t* out, int32_t out_cap, int32_t* rows,
+                                      int32_t* cols);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 //   ssx::triangulation           ssvio::triangulation (include/ssvio/algorithm.hpp:23-25) for the stereo rig
 //   ssx::BundleAdjuster          the optimisation of Backend::OptimizeActiveMap (src/ssvio/backend.cpp:78-245)
 //   ssx::StereoFrontEnd          DetectFeatures + FindFeaturesInRight + triangulation in one device-resident call
+//   ssx::calcOpticalFlowPyrLK    cv::calcOpticalFlowPyrLK as frontend.cpp:156-166 / :374-384 call it
 #pragma once
 #include <cstdint>
 #include <stdexcept>
@@ -175,5 +176,24 @@ class StereoFrontEnd {
   ssx_orb_params orb_;
   ssx_stereo_rig rig_;
 };
+
+// cv::calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, status, err, Size(win, win), maxLevel,
+//                          TermCriteria(COUNT+EPS, maxCount, epsilon), OPTFLOW_USE_INITIAL_FLOW)
+// with cv::Point2f passed as interleaved floats (same layout).  nextPts must hold the initial guesses (as both call
+// sites of the reference prepare them); status / err are resized.
+inline void calcOpticalFlowPyrLK(Context& ctx, const uint8_t* prevImg, int prevStep, const uint8_t* nextImg, int nextStep,
+                                 int rows, int cols, const std::vector<float>& prevPts, std::vector<float>& nextPts,
+                                 std::vector<uint8_t>& status, std::vector<float>& err, int win = 11, int maxLevel = 3,
+                                 int maxCount = 30, double epsilon = 0.01, bool useInitialFlow = true)
+{
+  if (prevPts.size() != nextPts.size() || (prevPts.size() & 1)) throw std::invalid_argument("calcOpticalFlowPyrLK: point vectors");
+  const int n = (int)(prevPts.size() / 2);
+  status.assign(n, 0); err.assign(n, 0.f);
+  ssx_lk_params p;
+  ssx_lk_default_params(&p);
+  p.win = win; p.max_level = maxLevel; p.max_iters = maxCount; p.eps = epsilon; p.use_initial_flow = useInitialFlow ? 1 : 0;
+  ctx.check(ssx_lk_track(ctx.get(), prevImg, prevStep, nextImg, nextStep, rows, cols, n, prevPts.data(), nextPts.data(),
+                         status.data(), err.data(), &p, nullptr));
+}
 
 }  // namespace ssx

@@ -373,3 +373,44 @@ def bf_match(dq, dt):
     idx = np.zeros(len(dq), np.int32); dist = np.zeros(len(dq), np.int32)
     oracle_lib().orc_bf_match(_p(dq, u8_p), len(dq), _p(dt, u8_p), len(dt), _p(idx, i32_p), _p(dist, i32_p))
     return idx, dist
+
+
+# ---------------- pyramidal LK (N1) ----------------
+class LkParams(C.Structure):
+    _fields_ = [("win", C.c_int), ("max_level", C.c_int), ("max_iters", C.c_int), ("eps", C.c_double),
+                ("min_eig_threshold", C.c_float), ("use_initial_flow", C.c_int)]
+
+
+def lk_params(win=11, max_level=3, max_iters=30, eps=0.01, min_eig_threshold=1e-4, use_initial_flow=1):
+    return LkParams(win, max_level, max_iters, eps, min_eig_threshold, use_initial_flow)
+
+
+def lk_pyr_down(img):
+    img = _img(img)
+    out = np.zeros(((img.shape[0] + 1) // 2, (img.shape[1] + 1) // 2), np.uint8)
+    oracle_lib().orc_lk_pyr_down(_p(img, u8_p), img.strides[0], img.shape[0], img.shape[1], _p(out, u8_p), out.strides[0])
+    return out
+
+
+def lk_scharr(img):
+    img = _img(img)
+    out = np.zeros((img.shape[0], img.shape[1], 2), np.int16)
+    oracle_lib().orc_lk_scharr(_p(img, u8_p), img.strides[0], img.shape[0], img.shape[1], out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def lk_track(prev, nxt, prev_pts, next_pts_init=None, prm=None):
+    """cv::calcOpticalFlowPyrLK as frontend.cpp:156-166 / 374-384 call it; returns (next_pts, status, err, top_level)."""
+    prev = _img(prev); nxt = _img(nxt)
+    assert prev.shape == nxt.shape
+    prm = prm or lk_params()
+    pp = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+    npts = (pp.copy() if next_pts_init is None else np.ascontiguousarray(next_pts_init, dtype=np.float32).reshape(-1, 2).copy())
+    n = len(pp)
+    status = np.zeros(n, np.uint8); err = np.zeros(n, np.float32)
+    f32_p = C.POINTER(C.c_float)
+    lib = oracle_lib()
+    lib.orc_lk_track.restype = C.c_int
+    top = lib.orc_lk_track(_p(prev, u8_p), prev.strides[0], _p(nxt, u8_p), nxt.strides[0], prev.shape[0], prev.shape[1], n,
+                           _p(pp, f32_p), _p(npts, f32_p), _p(status, u8_p), _p(err, f32_p), C.byref(prm))
+    return npts, status, err, top

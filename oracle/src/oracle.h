@@ -122,6 +122,22 @@ void orc_stereo_match(const orc_keypoint* kL, const uint8_t* dL, int nL, const o
 /* BruteForce-Hamming match() + the loopclosing.cpp:111-120 filter (N2 semantic source) */
 void orc_bf_match(const uint8_t* dq, int nq, const uint8_t* dt, int nt, int32_t* idx, int32_t* dist);
 
+/* ---------------- Pyramidal Lucas-Kanade tracker (N1: frontend.cpp:156-166, 374-384; OpenCV calcOpticalFlowPyrLK) -- */
+typedef struct {
+  int win;                  /* winSize 11 */
+  int max_level;            /* 3 */
+  int max_iters;            /* TermCriteria COUNT 30 */
+  double eps;               /* TermCriteria EPS 0.01 (squared internally) */
+  float min_eig_threshold;  /* 1e-4 */
+  int use_initial_flow;     /* OPTFLOW_USE_INITIAL_FLOW */
+} orc_lk_params;
+void orc_lk_default_params(orc_lk_params* p);
+void orc_lk_pyr_down(const uint8_t* src, int sstride, int rows, int cols, uint8_t* dst, int dstride);
+void orc_lk_scharr(const uint8_t* src, int sstride, int rows, int cols, int16_t* dxy);
+/* returns the top pyramid level used; next_pts in/out, status/err out (err may be NULL) */
+int orc_lk_track(const uint8_t* prev, int pstride, const uint8_t* next, int nstride, int rows, int cols, int n,
+                 const float* prev_pts, float* next_pts, uint8_t* status, float* err, const orc_lk_params* prm);
+
 #ifdef __cplusplus
 }
 #endif

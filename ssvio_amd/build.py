@@ -26,6 +26,7 @@ COMMON = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno
 PER_FILE = {
     "orb.hip": ["-ffp-contract=off"],
     "stereo.hip": ["-ffp-contract=off"],
+    "lk.hip": ["-ffp-contract=off"],
 }
 
 

@@ -61,6 +61,7 @@ void ssx_ctx_destroy(ssx_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ba && ctx->ba_free) ctx->ba_free(ctx->ba);
   if (ctx->orb && ctx->orb_free) ctx->orb_free(ctx->orb);
+  if (ctx->lk && ctx->lk_free) ctx->lk_free(ctx->lk);
   ctx->po_arena.release();
   ctx->po_stage.release();
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

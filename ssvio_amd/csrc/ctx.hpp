@@ -126,6 +126,8 @@ struct ssx_ctx {
   OrbWorkspace* orb = nullptr;
   void (*ba_free)(BaWorkspace*) = nullptr;    // set by the module that allocates the workspace
   void (*orb_free)(OrbWorkspace*) = nullptr;
+  void* lk = nullptr;                        // lk.hip workspace
+  void (*lk_free)(void*) = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t aux = nullptr;                 // second stream: independent stages overlap (blur || detect)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pyr = nullptr, ev_fast0 = nullptr;

@@ -1,0 +1,427 @@
+// ssvio_amd/csrc/lk.hip -- pyramidal Lucas-Kanade tracker on gfx950.
+//
+// Replaces the two cv::calcOpticalFlowPyrLK calls of the reference front-end
+// (/root/reference/src/ssvio/frontend.cpp:156-166 TrackLastFrame, :374-384 FindFeaturesInRight; 11x11 window,
+// maxLevel 3, TermCriteria(COUNT+EPS, 30, 0.01), OPTFLOW_USE_INITIAL_FLOW).  The arithmetic is the fixed-point
+// scheme of OpenCV 3.x lkpyramid.cpp (14-bit bilinear weights, Scharr derivatives in int16, patch values scaled
+// by 32) with ONE documented difference, shared with the CPU oracle (oracle/src/lk_oracle.cpp): the 2x2 normal
+// matrix and the mismatch vector are sums of integer products and are accumulated EXACTLY in 64-bit integers (then
+// converted to float once) instead of in float -- the result does not depend on the order of the parallel
+// reduction, so the device is bit-identical to the CPU restatement.
+//
+//   k_lk_pad_level0   image -> level 0 with a BORDER_REFLECT_101 border of win+1 pixels (what
+//                     buildOpticalFlowPyramid's copyMakeBorder produces), pitch a multiple of 64
+//   k_lk_pyr_down     level l-1 -> level l (+ border): 5x5 binomial, (sum + 128) >> 8, one thread per padded pixel
+//   k_lk_scharr       Scharr dx|dy packed as int16x2 per pixel, ZERO border (BORDER_CONSTANT, as calcOpticalFlowPyrLK)
+//   k_lk_track        ONE WAVE PER POINT, all pyramid levels inside the kernel: lane l owns window pixels l and
+//                     l + 64 (121 of 128 slots for 11x11); the template patch and its derivatives stay in
+//                     registers; every iteration is 2 x 4 bilinear taps per lane, one 64-bit wave reduction of
+//                     the mismatch vector (xor butterfly), and the 2x2 solve done redundantly by every lane.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+constexpr int LK_MAX_LEVELS = 8;
+constexpr int LK_MAX_WIN = 15;          // win * win <= 4 slots x 64 lanes would allow 16; 15 keeps the border small
+
+struct LkDev {
+  int levels;                            // pyramid levels built (top level = levels - 1)
+  int win, pad;                          // window side, border = win + 1
+  int rows[LK_MAX_LEVELS], cols[LK_MAX_LEVELS], pitch[LK_MAX_LEVELS];
+  size_t off[LK_MAX_LEVELS];             // byte offset of a padded level inside one image pyramid
+  size_t doff[LK_MAX_LEVELS];            // int32 offset of a padded derivative level
+  uint8_t* pyr[2];                       // [0] previous image, [1] next image
+  uint32_t* deriv;                       // previous image: dx | dy << 16 (int16 each), same padded geometry
+  // tracking
+  int n, max_iters, use_initial_flow;
+  double eps2;
+  float min_eig;
+  const float* prev_pts;
+  float* next_pts;
+  uint8_t* status;
+  float* err;
+};
+
+struct LkWorkspace {
+  DevBuf arena, io;
+  HostBuf stage;
+  LkDev dev{};
+  int rows = 0, cols = 0, win = 0, max_level = -1;
+  bool planned = false;
+};
+
+void lk_ws_free(LkWorkspace* w)
+{
+  if (!w) return;
+  w->arena.release(); w->io.release(); w->stage.release();
+  delete w;
+}
+
+LkWorkspace* lk_ws(ssx_ctx* ctx)
+{
+  if (!ctx->lk) { ctx->lk = new LkWorkspace(); ctx->lk_free = reinterpret_cast<void (*)(void*)>(lk_ws_free); }
+  return static_cast<LkWorkspace*>(ctx->lk);
+}
+
+__device__ __forceinline__ int refl101(int i, int n)
+{
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * n - 2 - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void k_lk_pad_level0(const uint8_t* __restrict__ img, int stride, LkDev d, int which)
+{
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;      // padded coordinates
+  const int pw = d.cols[0] + 2 * d.pad;
+  if (x >= pw) return;
+  const int sy = refl101(y - d.pad, d.rows[0]), sx = refl101(x - d.pad, d.cols[0]);
+  d.pyr[which][d.off[0] + (size_t)y * d.pitch[0] + x] = img[(size_t)sy * stride + sx];
+}
+
+// pyrDown (imgproc/pyramids.cpp, 8u): separable 1-4-6-4-1, (sum + 128) >> 8, BORDER_REFLECT_101; the padded
+// border of the source level already holds the reflected pixels.  Border pixels of the destination are the
+// reflected destination pixels, computed redundantly.
+__global__ __launch_bounds__(256) void k_lk_pyr_down(LkDev d, int which, int level)
+{
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  const int pw = d.cols[level] + 2 * d.pad;
+  if (x >= pw) return;
+  const int dy = refl101(y - d.pad, d.rows[level]), dx = refl101(x - d.pad, d.cols[level]);
+  const uint8_t* s = d.pyr[which] + d.off[level - 1];
+  const int sp = d.pitch[level - 1];
+  const int w[5] = {1, 4, 6, 4, 1};
+  int sum = 0;
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky) {
+    const uint8_t* row = s + (size_t)(2 * dy + ky - 2 + d.pad) * sp + (2 * dx - 2 + d.pad);
+    int r = 0;
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) r += w[kx] * row[kx];
+    sum += w[ky] * r;
+  }
+  d.pyr[which][d.off[level] + (size_t)y * d.pitch[level] + x] = (uint8_t)((sum + 128) >> 8);
+}
+
+// calcSharrDeriv (video/lkpyramid.cpp): dx = [3 10 3]^T (x) [-1 0 1], dy = [-1 0 1]^T (x) [3 10 3]; rows and
+// columns reflect (101) at the image edge = the padded border; the derivative image itself has a zero border.
+__global__ __launch_bounds__(256) void k_lk_scharr(LkDev d, int level)
+{
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;      // padded coordinates
+  const int pw = d.cols[level] + 2 * d.pad;
+  if (x >= pw) return;
+  const int iy = y - d.pad, ix = x - d.pad;
+  uint32_t out = 0;
+  if (iy >= 0 && iy < d.rows[level] && ix >= 0 && ix < d.cols[level]) {
+    const uint8_t* c = d.pyr[0] + d.off[level] + (size_t)y * d.pitch[level] + x;
+    const int p = d.pitch[level];
+    const int a00 = c[-p - 1], a01 = c[-p], a02 = c[-p + 1], a10 = c[-1], a12 = c[1], a20 = c[p - 1], a21 = c[p], a22 = c[p + 1];
+    const int gx = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
+    const int gy = ((a20 - a00) + (a22 - a02)) * 3 + (a21 - a01) * 10;
+    out = ((uint32_t)gx & 0xFFFFu) | ((uint32_t)gy << 16);
+  }
+  d.deriv[d.doff[level] + (size_t)y * d.pitch[level] + x] = out;
+}
+
+__device__ __forceinline__ long long wave_sum(long long v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int cv_floor(float v) { int i = (int)v; return i - (i > v); }
+__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+
+struct Weights { int w00, w01, w10, w11; };
+__device__ __forceinline__ Weights bilinear(float a, float b)
+{
+  Weights w;
+  w.w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << 14));
+  w.w01 = __float2int_rn(a * (1.f - b) * (float)(1 << 14));
+  w.w10 = __float2int_rn((1.f - a) * b * (float)(1 << 14));
+  w.w11 = (1 << 14) - w.w00 - w.w01 - w.w10;
+  return w;
+}
+
+constexpr int SLOTS = 4;     // window pixels per lane (win <= 15 -> 225 <= 256)
+
+__global__ __launch_bounds__(256) void k_lk_track(LkDev d)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= d.n) return;
+  const int win = d.win, nwin = win * win, pad = d.pad;
+  const float half = (float)(win - 1) * 0.5f;
+  int wy[SLOTS], wx[SLOTS];
+  bool on[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int idx = lane + 64 * s;
+    on[s] = idx < nwin;
+    wy[s] = on[s] ? idx / win : 0;
+    wx[s] = on[s] ? idx - wy[s] * win : 0;
+  }
+  const float ppx = d.prev_pts[2 * i], ppy = d.prev_pts[2 * i + 1];
+  float outx = d.next_pts[2 * i], outy = d.next_pts[2 * i + 1];       // nextPts[ptidx] as the levels go by
+  int status = 1;
+  float errv = 0.f;
+  const int top = d.levels - 1;
+  for (int level = top; level >= 0; --level) {
+    const uint8_t* I = d.pyr[0] + d.off[level];
+    const uint8_t* J = d.pyr[1] + d.off[level];
+    const uint32_t* G = d.deriv + d.doff[level];
+    const int pitch = d.pitch[level], rows = d.rows[level], cols = d.cols[level];
+    const float sc = (float)(1. / (double)(1 << level));
+    float px = ppx * sc, py = ppy * sc;
+    float nx, ny;
+    if (level == top) {
+      if (d.use_initial_flow) { nx = outx * sc; ny = outy * sc; }
+      else { nx = px; ny = py; }
+    } else { nx = outx * 2.f; ny = outy * 2.f; }
+    outx = nx; outy = ny;
+    px -= half; py -= half;
+    const int ipx = cv_floor(px), ipy = cv_floor(py);
+    if (ipx < -win || ipx >= cols || ipy < -win || ipy >= rows) {
+      if (level == 0) { status = 0; errv = 0.f; }
+      continue;
+    }
+    Weights w = bilinear(px - (float)ipx, py - (float)ipy);
+    int Iw[SLOTS], Ix[SLOTS], Iy[SLOTS];
+    long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      Iw[s] = 0; Ix[s] = 0; Iy[s] = 0;
+      if (on[s]) {
+        const size_t o = (size_t)(wy[s] + ipy + pad) * pitch + (wx[s] + ipx + pad);
+        const uint8_t* p = I + o;
+        Iw[s] = (int)(short)descale(p[0] * w.w00 + p[1] * w.w01 + p[pitch] * w.w10 + p[pitch + 1] * w.w11, 14 - 5);
+        const uint32_t g00 = G[o], g01 = G[o + 1], g10 = G[o + pitch], g11 = G[o + pitch + 1];
+        Ix[s] = (int)(short)descale((int)(short)(g00 & 0xFFFF) * w.w00 + (int)(short)(g01 & 0xFFFF) * w.w01 +
+                                    (int)(short)(g10 & 0xFFFF) * w.w10 + (int)(short)(g11 & 0xFFFF) * w.w11, 14);
+        Iy[s] = (int)(short)descale(((int)g00 >> 16) * w.w00 + ((int)g01 >> 16) * w.w01 + ((int)g10 >> 16) * w.w10 +
+                                    ((int)g11 >> 16) * w.w11, 14);
+        sA11 += (long long)Ix[s] * Ix[s]; sA12 += (long long)Ix[s] * Iy[s]; sA22 += (long long)Iy[s] * Iy[s];
+      }
+    }
+    sA11 = wave_sum(sA11); sA12 = wave_sum(sA12); sA22 = wave_sum(sA22);
+    const float FLT_SCALE = 1.f / (float)(1 << 20);
+    const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+    if (minEig < d.min_eig || D < 1.1920928955078125e-7f) {
+      if (level == 0) status = 0;
+      continue;
+    }
+    D = 1.f / D;
+    nx -= half; ny -= half;
+    float pdx = 0.f, pdy = 0.f;
+    for (int j = 0; j < d.max_iters; ++j) {
+      const int inx = cv_floor(nx), iny = cv_floor(ny);
+      if (inx < -win || inx >= cols || iny < -win || iny >= rows) {
+        if (level == 0) status = 0;
+        break;
+      }
+      w = bilinear(nx - (float)inx, ny - (float)iny);
+      long long sb1 = 0, sb2 = 0;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (on[s]) {
+          const uint8_t* p = J + (size_t)(wy[s] + iny + pad) * pitch + (wx[s] + inx + pad);
+          const int diff = descale(p[0] * w.w00 + p[1] * w.w01 + p[pitch] * w.w10 + p[pitch + 1] * w.w11, 14 - 5) - Iw[s];
+          sb1 += (long long)diff * Ix[s]; sb2 += (long long)diff * Iy[s];
+        }
+      sb1 = wave_sum(sb1); sb2 = wave_sum(sb2);
+      const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+      const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+      nx += dx; ny += dy;
+      outx = nx + half; outy = ny + half;
+      if ((double)dx * (double)dx + (double)dy * (double)dy <= d.eps2) break;
+      if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+        outx -= dx * 0.5f; outy -= dy * 0.5f;
+        break;
+      }
+      pdx = dx; pdy = dy;
+    }
+    if (status && level == 0) {
+      const float ex = outx - half, ey = outy - half;
+      const int inx = cv_floor(ex), iny = cv_floor(ey);
+      if (inx < -win || inx >= cols || iny < -win || iny >= rows) { status = 0; continue; }
+      w = bilinear(ex - (float)inx, ey - (float)iny);
+      long long e = 0;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (on[s]) {
+          const uint8_t* p = J + (size_t)(wy[s] + iny + pad) * pitch + (wx[s] + inx + pad);
+          const int diff = descale(p[0] * w.w00 + p[1] * w.w01 + p[pitch] * w.w10 + p[pitch + 1] * w.w11, 14 - 5) - Iw[s];
+          e += diff < 0 ? -diff : diff;
+        }
+      e = wave_sum(e);
+      errv = (float)e * (1.f / (float)(32 * win * win));
+    }
+  }
+  if (lane == 0) {
+    d.next_pts[2 * i] = outx; d.next_pts[2 * i + 1] = outy;
+    d.status[i] = (uint8_t)status;
+    if (d.err) d.err[i] = errv;
+  }
+}
+
+ssx_status lk_plan(ssx_ctx* ctx, int rows, int cols, const ssx_lk_params& prm)
+{
+  LkWorkspace* ws = lk_ws(ctx);
+  if (prm.win < 3 || prm.win > LK_MAX_WIN || (prm.win & 1) == 0 || prm.max_level < 0 || prm.max_level >= LK_MAX_LEVELS) {
+    ctx->set_error("ssx_lk: unsupported window %d (odd, 3..%d) or max_level %d (0..%d)", prm.win, LK_MAX_WIN, prm.max_level, LK_MAX_LEVELS - 1);
+    return SSX_ERR_INVALID_ARG;
+  }
+  if (rows < 2 || cols < 2 || rows > 8192 || cols > 8192) {
+    ctx->set_error("ssx_lk: image %dx%d outside the supported range", cols, rows);
+    return SSX_ERR_INVALID_ARG;
+  }
+  if (ws->planned && ws->rows == rows && ws->cols == cols && ws->win == prm.win && ws->max_level == prm.max_level) return SSX_OK;
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  LkDev d{};
+  d.win = prm.win; d.pad = prm.win + 1;
+  // buildOpticalFlowPyramid: a level not larger than the window ends the pyramid
+  d.levels = 1;
+  d.rows[0] = rows; d.cols[0] = cols;
+  for (int l = 1; l <= prm.max_level; ++l) {
+    const int w = (d.cols[l - 1] + 1) / 2, h = (d.rows[l - 1] + 1) / 2;
+    if (w <= prm.win || h <= prm.win) break;
+    d.rows[l] = h; d.cols[l] = w; d.levels = l + 1;
+  }
+  size_t off = 0, doff = 0;
+  for (int l = 0; l < d.levels; ++l) {
+    d.pitch[l] = (d.cols[l] + 2 * d.pad + 63) & ~63;
+    d.off[l] = off; d.doff[l] = doff;
+    off += (size_t)d.pitch[l] * (d.rows[l] + 2 * d.pad) + 64;
+    doff += (size_t)d.pitch[l] * (d.rows[l] + 2 * d.pad) + 64;
+  }
+  const size_t pyr_bytes = (off + 255) & ~size_t(255);
+  Layout lay;
+  const size_t o_p0 = lay.take(pyr_bytes), o_p1 = lay.take(pyr_bytes), o_g = lay.take(sizeof(uint32_t) * doff);
+  SSX_HIP_TRY(ctx, ws->arena.reserve(lay.off));
+  char* base = ws->arena.as<char>();
+  d.pyr[0] = (uint8_t*)(base + o_p0); d.pyr[1] = (uint8_t*)(base + o_p1); d.deriv = (uint32_t*)(base + o_g);
+  ws->dev = d;
+  ws->rows = rows; ws->cols = cols; ws->win = prm.win; ws->max_level = prm.max_level;
+  ws->planned = true;
+  return SSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ssx_lk_default_params(ssx_lk_params* p)
+{
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->win = 11; p->max_level = 3; p->max_iters = 30; p->eps = 0.01; p->min_eig_threshold = 1e-4f; p->use_initial_flow = 1;
+}
+
+ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const uint8_t* next, int32_t next_stride,
+                        int32_t rows, int32_t cols, int32_t n, const float* prev_pts, float* next_pts, uint8_t* status,
+                        float* err, const ssx_lk_params* prm_in, int32_t* top_level)
+{
+  if (!ctx || !prev || !next || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return SSX_ERR_INVALID_ARG;
+  ssx_lk_params prm;
+  if (prm_in) prm = *prm_in; else ssx_lk_default_params(&prm);
+  if (prev_stride < cols || next_stride < cols) { ctx->set_error("ssx_lk: stride smaller than the image width"); return SSX_ERR_INVALID_ARG; }
+  ssx_status st = lk_plan(ctx, rows, cols, prm);
+  if (st != SSX_OK) return st;
+  LkWorkspace* ws = lk_ws(ctx);
+  LkDev d = ws->dev;
+  hipStream_t s = ctx->stream;
+  // inputs: two images + points through pinned staging
+  const size_t img_bytes = (size_t)rows * cols;
+  Layout io;
+  const size_t o_i0 = io.take(img_bytes), o_i1 = io.take(img_bytes);
+  const size_t o_pp = io.take(sizeof(float) * 2 * (size_t)std::max(n, 1));
+  const size_t o_np = io.take(sizeof(float) * 2 * (size_t)std::max(n, 1));
+  const size_t in_bytes = io.off;
+  const size_t o_st = io.take((size_t)std::max(n, 1));
+  const size_t o_er = io.take(sizeof(float) * (size_t)std::max(n, 1));
+  SSX_HIP_TRY(ctx, ws->io.reserve(io.off));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(io.off));
+  char* hs = ws->stage.as<char>();
+  for (int y = 0; y < rows; ++y) {
+    memcpy(hs + o_i0 + (size_t)y * cols, prev + (size_t)y * prev_stride, cols);
+    memcpy(hs + o_i1 + (size_t)y * cols, next + (size_t)y * next_stride, cols);
+  }
+  if (n > 0) { memcpy(hs + o_pp, prev_pts, sizeof(float) * 2 * n); memcpy(hs + o_np, next_pts, sizeof(float) * 2 * n); }
+  char* db = ws->io.as<char>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(db, hs, in_bytes, hipMemcpyHostToDevice, s));
+  for (int which = 0; which < 2; ++which) {
+    const dim3 g0((d.cols[0] + 2 * d.pad + 255) / 256, d.rows[0] + 2 * d.pad);
+    hipLaunchKernelGGL(k_lk_pad_level0, g0, dim3(256), 0, s, (const uint8_t*)(db + (which ? o_i1 : o_i0)), cols, d, which);
+    for (int l = 1; l < d.levels; ++l) {
+      const dim3 g((d.cols[l] + 2 * d.pad + 255) / 256, d.rows[l] + 2 * d.pad);
+      hipLaunchKernelGGL(k_lk_pyr_down, g, dim3(256), 0, s, d, which, l);
+    }
+  }
+  for (int l = 0; l < d.levels; ++l) {
+    const dim3 g((d.cols[l] + 2 * d.pad + 255) / 256, d.rows[l] + 2 * d.pad);
+    hipLaunchKernelGGL(k_lk_scharr, g, dim3(256), 0, s, d, l);
+  }
+  if (n > 0) {
+    d.n = n;
+    d.max_iters = std::min(std::max(prm.max_iters, 0), 100);          // TermCriteria clamps of calcOpticalFlowPyrLK
+    const double e = std::min(std::max(prm.eps, 0.), 10.);
+    d.eps2 = e * e;
+    d.min_eig = prm.min_eig_threshold;
+    d.use_initial_flow = prm.use_initial_flow;
+    d.prev_pts = (const float*)(db + o_pp); d.next_pts = (float*)(db + o_np);
+    d.status = (uint8_t*)(db + o_st); d.err = (float*)(db + o_er);
+    hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, s, d);
+    SSX_HIP_TRY(ctx, hipGetLastError());
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_np, db + o_np, io.off - o_np, hipMemcpyDeviceToHost, s));
+  }
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (n > 0) {
+    memcpy(next_pts, hs + o_np, sizeof(float) * 2 * n);
+    memcpy(status, hs + o_st, (size_t)n);
+    if (err) memcpy(err, hs + o_er, sizeof(float) * n);
+  }
+  if (top_level) *top_level = d.levels - 1;
+  return SSX_OK;
+}
+
+// test / debug access to the pyramid and derivative images of the last ssx_lk_track call
+ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level, uint8_t* out, int32_t out_cap, int32_t* rows, int32_t* cols)
+{
+  if (!ctx || !ctx->lk || !rows || !cols) return SSX_ERR_INVALID_ARG;
+  LkWorkspace* ws = static_cast<LkWorkspace*>(ctx->lk);
+  if (!ws->planned || which < 0 || which > 1 || level < 0 || level >= ws->dev.levels) return SSX_ERR_INVALID_ARG;
+  const LkDev& d = ws->dev;
+  *rows = d.rows[level]; *cols = d.cols[level];
+  if (!out) return SSX_OK;
+  if (out_cap < d.rows[level] * d.cols[level]) return SSX_ERR_CAPACITY;
+  const uint8_t* src = d.pyr[which] + d.off[level] + (size_t)d.pad * d.pitch[level] + d.pad;
+  SSX_HIP_TRY(ctx, hipMemcpy2DAsync(out, d.cols[level], src, d.pitch[level], d.cols[level], d.rows[level], hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SSX_OK;
+}
+
+ssx_status ssx_lk_stage_deriv(ssx_ctx* ctx, int32_t level, int16_t* out, int32_t out_cap, int32_t* rows, int32_t* cols)
+{
+  if (!ctx || !ctx->lk || !rows || !cols) return SSX_ERR_INVALID_ARG;
+  LkWorkspace* ws = static_cast<LkWorkspace*>(ctx->lk);
+  if (!ws->planned || level < 0 || level >= ws->dev.levels) return SSX_ERR_INVALID_ARG;
+  const LkDev& d = ws->dev;
+  *rows = d.rows[level]; *cols = d.cols[level];
+  if (!out) return SSX_OK;
+  if (out_cap < 2 * d.rows[level] * d.cols[level]) return SSX_ERR_CAPACITY;
+  const uint32_t* src = d.deriv + d.doff[level] + (size_t)d.pad * d.pitch[level] + d.pad;
+  SSX_HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)d.cols[level] * 4, src, (size_t)d.pitch[level] * 4, (size_t)d.cols[level] * 4, d.rows[level],
+                                    hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Pyramidal Lucas-Kanade tracking: the host-side mirror of the two
+cv::calcOpticalFlowPyrLK calls of the reference front-end (frontend.cpp:156-166 and :374-384)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import Context
+
+
+class LkParams(C.Structure):
+    _fields_ = [("win", C.c_int32), ("max_level", C.c_int32), ("max_iters", C.c_int32), ("eps", C.c_double),
+                ("min_eig_threshold", C.c_float), ("use_initial_flow", C.c_int32)]
+
+
+u8_p = C.POINTER(C.c_ubyte)
+f32_p = C.POINTER(C.c_float)
+
+
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 2
+    return a
+
+
+def calcOpticalFlowPyrLK(ctx: Context, prev, nxt, prev_pts, next_pts=None, winSize=11, maxLevel=3, maxCount=30,
+                         epsilon=0.01, minEigThreshold=1e-4):
+    """cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(win, win), maxLevel,
+    TermCriteria(COUNT+EPS, maxCount, epsilon), next_pts is None ? 0 : OPTFLOW_USE_INITIAL_FLOW, minEigThreshold).
+    Returns (next_pts [n,2] f32, status [n] u8, err [n] f32, top_level)."""
+    prev = _img(prev); nxt = _img(nxt)
+    if prev.shape != nxt.shape:
+        raise ValueError("calcOpticalFlowPyrLK: the two images must have the same size")
+    pp = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+    use_init = next_pts is not None
+    npts = np.ascontiguousarray(next_pts, dtype=np.float32).reshape(-1, 2).copy() if use_init else pp.copy()
+    if len(npts) != len(pp):
+        raise ValueError("calcOpticalFlowPyrLK: prev_pts and next_pts differ in length")
+    n = len(pp)
+    status = np.zeros(n, np.uint8); err = np.zeros(n, np.float32)
+    prm = LkParams(int(winSize), int(maxLevel), int(maxCount), float(epsilon), float(minEigThreshold), int(use_init))
+    top = C.c_int32(0)
+    lib = ctx.lib
+    lib.ssx_lk_track.restype = C.c_int
+    ctx.check(lib.ssx_lk_track(ctx.handle, prev.ctypes.data_as(u8_p), prev.strides[0], nxt.ctypes.data_as(u8_p), nxt.strides[0],
+                               prev.shape[0], prev.shape[1], n, pp.ctypes.data_as(f32_p), npts.ctypes.data_as(f32_p),
+                               status.ctypes.data_as(u8_p), err.ctypes.data_as(f32_p), C.byref(prm), C.byref(top)))
+    return npts, status, err, top.value
+
+
+def stage_level(ctx: Context, which, level):
+    r = C.c_int32(0); c = C.c_int32(0)
+    ctx.check(ctx.lib.ssx_lk_stage_level(ctx.handle, which, level, None, 0, C.byref(r), C.byref(c)))
+    out = np.zeros((r.value, c.value), np.uint8)
+    ctx.check(ctx.lib.ssx_lk_stage_level(ctx.handle, which, level, out.ctypes.data_as(u8_p), out.size, C.byref(r), C.byref(c)))
+    return out
+
+
+def stage_deriv(ctx: Context, level):
+    r = C.c_int32(0); c = C.c_int32(0)
+    ctx.check(ctx.lib.ssx_lk_stage_deriv(ctx.handle, level, None, 0, C.byref(r), C.byref(c)))
+    out = np.zeros((r.value, c.value, 2), np.int16)
+    ctx.check(ctx.lib.ssx_lk_stage_deriv(ctx.handle, level, out.ctypes.data_as(C.c_void_p), out.size, C.byref(r), C.byref(c)))
+    return out

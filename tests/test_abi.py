@@ -50,6 +50,8 @@ def test_struct_layout_matches_ctypes():
                              "ssx_match_params": "MatchParams", "ssx_stereo_rig": "StereoRig"}[extra], None)
         if cls is not None and extra in open(HDR).read():
             names[extra] = cls
+    from ssvio_amd import lk
+    names["ssx_lk_params"] = lk.LkParams
     prog = '#include <stdio.h>\n#include "ssx.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:

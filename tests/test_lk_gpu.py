@@ -1,0 +1,95 @@
+"""GPU parity of the pyramidal LK tracker (N1) against the CPU oracle: BIT-EXACT pyramids, Scharr images, tracked
+positions (f32 bit patterns), status flags and errors -- the normal matrix / mismatch sums are exact integers on
+both sides, every float operation is the same IEEE operation in the same order.  (The oracle itself is "parity
+unpinned vs OpenCV": tests/test_oracle_lk.py.)"""
+import numpy as np
+import pytest
+
+from ssvio_amd import lk
+from ssvio_amd.synth import make_stereo_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kitti():
+    return make_stereo_pair(seed=0)
+
+
+def _points(po, img, n=400):
+    k, _ = po.orb_extract(img, prm=po.orb_params(nfeatures=n, nlevels=1))
+    return np.stack([k["x"], k["y"]], 1).astype(np.float32)
+
+
+def _same(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_pyramid_and_scharr_bit_exact(ctx, po, kitti):
+    L, R, _ = kitti
+    pts = _points(po, L, 50)
+    lk.calcOpticalFlowPyrLK(ctx, L, R, pts, pts)
+    prev, nxt = L, R
+    for level in range(4):
+        if level > 0:
+            prev, nxt = po.lk_pyr_down(prev), po.lk_pyr_down(nxt)
+        assert np.array_equal(lk.stage_level(ctx, 0, level), prev), f"prev pyramid level {level}"
+        assert np.array_equal(lk.stage_level(ctx, 1, level), nxt), f"next pyramid level {level}"
+        assert np.array_equal(lk.stage_deriv(ctx, level), po.lk_scharr(prev)), f"Scharr level {level}"
+
+
+def test_stereo_tracking_with_initial_flow_bit_exact(ctx, po, kitti):
+    """FindFeaturesInRight (frontend.cpp:374-384): left -> right, initial guess = the left position"""
+    L, R, disp = kitti
+    pts = _points(po, L, 1500)
+    g = lk.calcOpticalFlowPyrLK(ctx, L, R, pts, pts)
+    o = po.lk_track(L, R, pts, pts)
+    assert g[3] == o[3] == 3
+    assert _same(g[1], o[1]) and _same(g[0], o[0]) and _same(g[2], o[2])
+    ok = g[1] > 0
+    d = (pts[:, 0] - g[0][:, 0])[ok]
+    true = disp[np.clip(np.round(pts[ok, 1]).astype(int), 0, 375), np.clip(np.round(pts[ok, 0]).astype(int), 0, 1240)]
+    assert ok.mean() > 0.9 and np.median(np.abs(d - true)) < 0.1          # sanity against the synthetic ground truth
+
+
+def test_temporal_tracking_bit_exact(ctx, po, kitti):
+    """TrackLastFrame (frontend.cpp:156-166): last left -> current left; here a shifted + noisy copy, with and
+    without initial guesses, other windows and iteration limits"""
+    L = kitti[0]
+    rng = np.random.default_rng(1)
+    cur = np.roll(np.roll(L, 2, axis=0), -6, axis=1)
+    cur = np.clip(cur.astype(np.int16) + rng.integers(-3, 4, cur.shape), 0, 255).astype(np.uint8)
+    pts = _points(po, L, 800)
+    guess = pts + np.array([-5.0, 1.5], np.float32)
+    for kw, init in ((dict(), guess), (dict(), None), (dict(winSize=7, maxLevel=2), guess), (dict(winSize=15, maxLevel=1, maxCount=5), None),
+                     (dict(maxLevel=0, epsilon=0.1), guess)):
+        g = lk.calcOpticalFlowPyrLK(ctx, L, cur, pts, init, **kw)
+        prm = po.lk_params(win=kw.get("winSize", 11), max_level=kw.get("maxLevel", 3), max_iters=kw.get("maxCount", 30),
+                           eps=kw.get("epsilon", 0.01), use_initial_flow=int(init is not None))
+        o = po.lk_track(L, cur, pts, init, prm=prm)
+        assert g[3] == o[3]
+        assert _same(g[1], o[1]) and _same(g[0], o[0]) and _same(g[2], o[2]), kw
+    g = lk.calcOpticalFlowPyrLK(ctx, L, cur, pts, guess)
+    ok = g[1] > 0
+    assert ok.mean() > 0.9 and np.abs(np.median((g[0] - pts)[ok], 0) - np.array([-6.0, 2.0])).max() < 0.05
+
+
+def test_edge_cases_bit_exact(ctx, po):
+    """points outside / at the border / on flat areas, a pyramid cut short, no points, bad arguments"""
+    L, R, _ = make_stereo_pair(seed=5, h=120, w=160, n_blobs=120)
+    pts = np.array([[-40.0, 30.0], [30.0, 400.0], [500.0, 30.0], [0.0, 0.0], [159.0, 119.0], [5.2, 3.7], [155.5, 60.0],
+                    [80.0, 60.0], [-5.5, -5.5], [164.9, 124.9]], np.float32)
+    for a, b in ((L, R), (L, L), (np.full_like(L, 90), np.full_like(L, 90))):
+        g = lk.calcOpticalFlowPyrLK(ctx, a, b, pts, pts)
+        o = po.lk_track(a, b, pts, pts)
+        assert g[3] == o[3] and _same(g[1], o[1]) and _same(g[0], o[0]) and _same(g[2], o[2])
+    tiny = make_stereo_pair(seed=6, h=40, w=60, n_blobs=30)[0]
+    g = lk.calcOpticalFlowPyrLK(ctx, tiny, tiny, np.array([[30.0, 20.0]], np.float32))
+    o = po.lk_track(tiny, tiny, np.array([[30.0, 20.0]], np.float32), prm=po.lk_params(use_initial_flow=0))
+    assert g[3] == o[3] == 1 and _same(g[0], o[0]) and _same(g[1], o[1])
+    g = lk.calcOpticalFlowPyrLK(ctx, L, R, np.zeros((0, 2), np.float32))
+    assert g[0].shape == (0, 2) and g[1].shape == (0,)
+    with pytest.raises(Exception):
+        lk.calcOpticalFlowPyrLK(ctx, L, R, pts, pts, winSize=10)          # even window
+    with pytest.raises(ValueError):
+        lk.calcOpticalFlowPyrLK(ctx, L, R[:50], pts)
