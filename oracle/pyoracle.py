@@ -414,3 +414,35 @@ def lk_track(prev, nxt, prev_pts, next_pts_init=None, prm=None):
     top = lib.orc_lk_track(_p(prev, u8_p), prev.strides[0], _p(nxt, u8_p), nxt.strides[0], prev.shape[0], prev.shape[1], n,
                            _p(pp, f32_p), _p(npts, f32_p), _p(status, u8_p), _p(err, f32_p), C.byref(prm))
     return npts, status, err, top
+
+
+# ---------------- pose-graph optimisation (N3) ----------------
+def se3_log(pose7):
+    out = np.zeros(6)
+    oracle_lib().orc_se3_log(_p(np.ascontiguousarray(pose7, dtype=np.float64), dbl_p), _p(out, dbl_p))
+    return out
+
+
+def pg_edge_eval(meas7, T0, T1):
+    e = np.zeros(6); Ji = np.zeros(36); Jj = np.zeros(36)
+    oracle_lib().orc_pg_edge_eval(_p(np.ascontiguousarray(meas7, dtype=np.float64), dbl_p), _p(np.ascontiguousarray(T0, dtype=np.float64), dbl_p),
+                                  _p(np.ascontiguousarray(T1, dtype=np.float64), dbl_p), _p(e, dbl_p), _p(Ji, dbl_p), _p(Jj, dbl_p))
+    return e, Ji.reshape(6, 6), Jj.reshape(6, 6)
+
+
+def pose_graph_opt(pr, which="oracle", iters=20):
+    """LoopClosing::PoseGraphOptimization on a flat problem; which = "oracle" (restatement) or "ref" (real g2o)."""
+    poses = np.ascontiguousarray(pr["poses"], dtype=np.float64).copy()
+    fixed = np.ascontiguousarray(pr["fixed"], dtype=np.uint8)
+    ei = np.ascontiguousarray(pr["ei"], dtype=np.int32); ej = np.ascontiguousarray(pr["ej"], dtype=np.int32)
+    meas = np.ascontiguousarray(pr["meas"], dtype=np.float64)
+    E = len(ei)
+    err = np.zeros((E, 6)); cap = iters + 2
+    n = C.c_int(0); chi = np.zeros(cap); lam = np.zeros(cap); tr = np.zeros(cap, np.int32)
+    lib = oracle_lib() if which == "oracle" else ref_lib()
+    fn = lib.orc_pose_graph_opt if which == "oracle" else lib.ref_pose_graph
+    fn.restype = C.c_int
+    done = fn(len(poses), _p(poses, dbl_p), _p(fixed, u8_p), E, _p(ei, i32_p), _p(ej, i32_p), _p(meas, dbl_p), iters,
+              _p(err, dbl_p), cap, C.byref(n), _p(chi, dbl_p), _p(lam, dbl_p), _p(tr, i32_p))
+    k = n.value
+    return dict(poses=poses, edge_err=err, n_iters=done, chi2=chi[:k].copy(), lambdas=lam[:k].copy(), trials=tr[:k].copy())

@@ -16,6 +16,8 @@
 //                     acceptance test of FrontEnd::BuidInitMap (src/ssvio/frontend.cpp:466).
 //   ref_se3_exp / ref_pose_oplus   Sophus::SE3d::exp, VertexPose::oplusImpl (g2otypes.hpp:36-41).
 //   ref_edge_eval     EdgeProjection error + g2o numeric Jacobian + Huber weights for ONE edge.
+//   ref_pose_graph    LoopClosing::PoseGraphOptimization (/root/reference/src/ssvio/loopclosing.cpp:458-539):
+//                     VertexPose + EdgePoseGraph, BlockSolver<6,6>, LinearSolverEigen, LM, optimize(20).
 //
 // backend.cpp / frontend.cpp themselves cannot be compiled here (they need OpenCV + Pangolin), so the
 // graph assembly is restated from the cited lines; all arithmetic is the reference's.
@@ -25,6 +27,7 @@
 
 #include "ssvio/algorithm.hpp"
 #include "ssvio/g2otypes.hpp"
+#include "g2o/solvers/eigen/linear_solver_eigen.h"
 
 namespace {
 
@@ -321,6 +324,85 @@ void ref_edge_eval(const double* pose7, const double* p3, const double* uv2, con
   g2o::Vector3 rho;
   rk->robustify(*chi2, rho);
   rho3[0] = rho[0]; rho3[1] = rho[1]; rho3[2] = rho[2];
+}
+
+
+// Pose-graph optimisation, loopclosing.cpp:458-539.  poses[P][7] in/out, fixed[P], edges: vertex 0 = ei, vertex 1 = ej,
+// measurement = relative pose (T_i * T_j^-1 at the time of creation), information = identity.
+// edge_err_out (optional, 6 per edge) = the edges' _error after the optimisation.
+int ref_pose_graph(int P, double* poses, const unsigned char* fixed, int E, const int* ei, const int* ej,
+                   const double* meas7, int iterations, double* edge_err_out, int stats_cap, int* stats_n,
+                   double* stats_chi2, double* stats_lambda, int* stats_trials)
+{
+  typedef g2o::BlockSolver<g2o::BlockSolverTraits<6, 6>> BlockSolverType;
+  typedef g2o::LinearSolverEigen<BlockSolverType::PoseMatrixType> LinearSolverType;
+  auto solver = new g2o::OptimizationAlgorithmLevenberg(
+      g2o::make_unique<BlockSolverType>(g2o::make_unique<LinearSolverType>()));
+  g2o::SparseOptimizer optimizer;
+  optimizer.setAlgorithm(solver);
+  std::vector<VertexPose*> vs(P);
+  for (int i = 0; i < P; ++i) {
+    VertexPose* v = new VertexPose();
+    v->setId(i);
+    v->setEstimate(pose_from(poses + 7 * i));
+    v->setMarginalized(false);
+    if (fixed[i]) v->setFixed(true);
+    optimizer.addVertex(v);
+    vs[i] = v;
+  }
+  std::vector<ssvio::EdgePoseGraph*> es(E);
+  for (int k = 0; k < E; ++k) {
+    ssvio::EdgePoseGraph* e = new ssvio::EdgePoseGraph();
+    e->setId(k);
+    e->setVertex(0, vs[ei[k]]);
+    e->setVertex(1, vs[ej[k]]);
+    e->setMeasurement(pose_from(meas7 + 7 * k));
+    e->setInformation(Eigen::Matrix<double, 6, 6>::Identity());
+    optimizer.addEdge(e);
+    es[k] = e;
+  }
+  IterRecorder rec;
+  rec.opt = &optimizer; rec.lm = solver;
+  optimizer.addPostIterationAction(&rec);
+  optimizer.initializeOptimization();
+  const int done = optimizer.optimize(iterations);
+  for (int i = 0; i < P; ++i) pose_to(vs[i]->estimate(), poses + 7 * i);
+  if (edge_err_out)
+    for (int k = 0; k < E; ++k)
+      for (int r = 0; r < 6; ++r) edge_err_out[6 * k + r] = es[k]->error()[r];
+  int n = 0;
+  for (size_t k = 0; k < rec.chi2.size() && (int)k < stats_cap; ++k, ++n) {
+    if (stats_chi2) stats_chi2[k] = rec.chi2[k];
+    if (stats_lambda) stats_lambda[k] = rec.lambda[k];
+    if (stats_trials) stats_trials[k] = rec.trials[k];
+  }
+  if (stats_n) *stats_n = n;
+  optimizer.removePostIterationAction(&rec);
+  return done;
+}
+
+
+// One EdgePoseGraph: error (g2otypes.hpp:169-176) and g2o's numeric Jacobians (base_binary_edge.hpp:61-141).
+void ref_pg_edge_eval(const double* meas7, const double* T0, const double* T1, double* err6, double* Ji36, double* Jj36)
+{
+  VertexPose v0, v1;
+  v0.setId(0); v1.setId(1);
+  v0.setEstimate(pose_from(T0)); v1.setEstimate(pose_from(T1));
+  ssvio::EdgePoseGraph e;
+  e.setVertex(0, &v0); e.setVertex(1, &v1);
+  e.setMeasurement(pose_from(meas7));
+  e.setInformation(Eigen::Matrix<double, 6, 6>::Identity());
+  e.computeError();
+  for (int r = 0; r < 6; ++r) err6[r] = e.error()[r];
+  g2o::JacobianWorkspace ws;
+  ws.updateSize(&e);
+  ws.allocate();
+  e.linearizeOplus(ws);
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) {
+      if (Ji36) Ji36[r * 6 + c] = e.jacobianOplusXi()(r, c);
+      if (Jj36) Jj36[r * 6 + c] = e.jacobianOplusXj()(r, c);
+    }
 }
 
 }  // extern "C"

@@ -138,6 +138,15 @@ void orc_lk_scharr(const uint8_t* src, int sstride, int rows, int cols, int16_t*
 int orc_lk_track(const uint8_t* prev, int pstride, const uint8_t* next, int nstride, int rows, int cols, int n,
                  const float* prev_pts, float* next_pts, uint8_t* status, float* err, const orc_lk_params* prm);
 
+/* ---------------- Pose-graph optimisation (N3: loopclosing.cpp:458-539, g2otypes.hpp:164-199) -- PINNED ---------------- */
+void orc_se3_log(const double* pose7, double* tangent6);
+void orc_se3_inverse(const double* pose7, double* out7);
+void orc_pg_edge_eval(const double* meas7, const double* T0, const double* T1, double* err6, double* Ji36, double* Jj36);
+/* poses in/out; returns LM iterations executed (<0: nothing to optimise); stats like orc_ba_solve */
+int orc_pose_graph_opt(int P, double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
+                       const double* meas7, int iterations, double* edge_err_out, int stats_cap, int* stats_n,
+                       double* stats_chi2, double* stats_lambda, int* stats_trials);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,6 +155,63 @@ def make_pose_only_problem(M=200, seed=3, frac_gross=0.1, K=KITTI_K):
                 uv=np.ascontiguousarray(uv))
 
 
+def pose_mul(a, b):
+    """SE3 product of two (qx qy qz qw tx ty tz) poses."""
+    q = quat_mul(a[:4], b[:4])
+    return np.concatenate([q / np.linalg.norm(q), a[4:] + quat_rot(a[:4], b[4:])])
+
+
+def pose_inv(a):
+    qi = np.array([-a[0], -a[1], -a[2], a[3]])
+    return np.concatenate([qi, -quat_rot(qi, a[4:])])
+
+
+def make_pose_graph_problem(P=60, n_loops=2, seed=11, n_active=7, drift=0.02, meas_noise=0.002):
+    """Pose graph of LoopClosing::PoseGraphOptimization (loopclosing.cpp:458-539): P keyframes along a closed
+    circuit (T_cw poses), one temporal edge per keyframe (to its predecessor) + n_loops loop edges from the newest
+    keyframes to old ones; measurement = T_i * T_j^-1 with a little noise; the initial estimate accumulates drift.
+    Fixed as in the reference: keyframe 0, the last n_active ("active") keyframes and the loop keyframes."""
+    rng = np.random.default_rng(seed)
+    gt = []
+    for i in range(P):
+        ang = 2 * np.pi * i / P
+        # camera moving on a circle of radius 40 m, looking along the tangent: T_wc then inverted to T_cw
+        q_wc = small_rot_quat(np.array([0.0, ang, 0.0]))
+        t_wc = np.array([40 * np.sin(ang), 0.1 * np.sin(3 * ang), 40 * (1 - np.cos(ang))])
+        gt.append(pose_inv(np.concatenate([q_wc / np.linalg.norm(q_wc), t_wc])))
+    gt = np.array(gt)
+    ei, ej, meas = [], [], []
+
+    def add_edge(i, j):
+        m = pose_mul(gt[i], pose_inv(gt[j]))
+        n = np.concatenate([small_rot_quat(rng.normal(0, meas_noise, 3)), rng.normal(0, 5 * meas_noise, 3)])
+        n[:4] /= np.linalg.norm(n[:4])
+        ei.append(i); ej.append(j); meas.append(pose_mul(n, m))
+    for i in range(1, P):
+        add_edge(i, i - 1)
+    loops = []
+    for k in range(n_loops):
+        i, j = P - 1 - k, (k * 3) % max(P // 4, 1)
+        add_edge(i, j)
+        loops.append(j)
+    # initial estimate: integrate the measurements with drift (the loop does not close)
+    init = [gt[0].copy()]
+    for i in range(1, P):
+        d = np.concatenate([small_rot_quat(rng.normal(0, drift * 0.1, 3)), rng.normal(0, drift, 3)])
+        d[:4] /= np.linalg.norm(d[:4])
+        init.append(pose_mul(pose_mul(d, meas[i - 1]), init[i - 1]))
+    init = np.array(init)
+    fixed = np.zeros(P, np.uint8)
+    fixed[0] = 1
+    fixed[P - n_active:] = 1
+    for j in loops:
+        fixed[j] = 1
+    # the fixed keyframes sit at their true poses (the reference corrects the active window before this step)
+    init[fixed > 0] = gt[fixed > 0]
+    return dict(P=P, E=len(ei), poses=np.ascontiguousarray(init), fixed=fixed, ei=np.array(ei, np.int32),
+                ej=np.array(ej, np.int32), meas=np.ascontiguousarray(np.array(meas)), gt_poses=gt)
+
+
 # ----------------------------------------------------------------------------------------------
 # synthetic stereo images (SURVEY.md section 8-D): textured left image + piecewise-planar disparity
 # ----------------------------------------------------------------------------------------------

@@ -31,6 +31,44 @@ BA_CASES = {
 }
 
 
+PG_CASES = {
+    "pg60": dict(P=60, n_loops=2, seed=11, meas_noise=0.02, drift=0.05),
+    "pg200": dict(P=200, n_loops=3, seed=12, meas_noise=0.01, drift=0.03, n_active=7),
+    "pg12": dict(P=12, n_loops=1, seed=13, meas_noise=0.03, drift=0.05, n_active=2),
+}
+
+
+def make_pose_graph_golden():
+    """ref_pg.npz: LoopClosing::PoseGraphOptimization (loopclosing.cpp:458-539) run by the REAL reference classes
+    (VertexPose, EdgePoseGraph, BlockSolver<6,6>, LinearSolverEigen, LM) + single-edge error / numeric Jacobians."""
+    import ctypes as C
+    g = {}
+    for name, cfg in PG_CASES.items():
+        pr = synth.make_pose_graph_problem(**cfg)
+        r = po.pose_graph_opt(pr, "ref", iters=20)
+        g[f"{name}_cfg"] = np.array([cfg["P"], cfg["n_loops"], cfg["seed"]])
+        g[f"{name}_input_sum"] = np.array([pr["poses"].sum(), pr["meas"].sum(), float(pr["fixed"].sum())])
+        for k in ("poses", "chi2", "lambdas", "trials", "edge_err"):
+            g[f"{name}_{k}"] = r[k]
+        g[f"{name}_n_iters"] = np.array(r["n_iters"])
+    rng = np.random.default_rng(77)
+    dbl_p = C.POINTER(C.c_double)
+    ref = po.ref_lib()
+    M, T0, T1, E, JI, JJ = [], [], [], [], [], []
+    for _ in range(64):
+        def rp():
+            q = synth.small_rot_quat(rng.normal(0, 0.8, 3)); q /= np.linalg.norm(q)
+            return np.concatenate([q, rng.normal(0, 5, 3)])
+        m, a, b = rp(), rp(), rp()
+        e = np.zeros(6); ji = np.zeros(36); jj = np.zeros(36)
+        ref.ref_pg_edge_eval(m.ctypes.data_as(dbl_p), a.ctypes.data_as(dbl_p), b.ctypes.data_as(dbl_p), e.ctypes.data_as(dbl_p),
+                             ji.ctypes.data_as(dbl_p), jj.ctypes.data_as(dbl_p))
+        M.append(m); T0.append(a); T1.append(b); E.append(e); JI.append(ji.reshape(6, 6)); JJ.append(jj.reshape(6, 6))
+    g.update(edge_M=np.array(M), edge_T0=np.array(T0), edge_T1=np.array(T1), edge_err=np.array(E), edge_Ji=np.array(JI), edge_Jj=np.array(JJ))
+    np.savez_compressed(os.path.join(OUT, "ref_pg.npz"), **g)
+    print("ref_pg.npz:", os.path.getsize(os.path.join(OUT, "ref_pg.npz")), "bytes,", len(g), "arrays")
+
+
 def main():
     assert po.have_ref(), "needs /root/reference (or a prebuilt oracle/_ref/libssvio_ref.so)"
     rng = np.random.default_rng(1234)
@@ -103,6 +141,7 @@ def main():
         g[f"{name}_input_sum"] = np.array([pp["xyz"].sum(), pp["uv"].sum()])
     np.savez_compressed(os.path.join(OUT, "ref_golden.npz"), **g)
     print("ref_golden.npz:", os.path.getsize(os.path.join(OUT, "ref_golden.npz")), "bytes,", len(g), "arrays")
+    make_pose_graph_golden()
 
     # ---- self pins of the ORB restatement ----
     s = {}
