@@ -321,6 +321,38 @@ SSX_API ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level
 SSX_API ssx_status ssx_lk_stage_deriv(ssx_ctx* ctx, int32_t level, int16_t* out, int32_t out_cap, int32_t* rows,
                                       int32_t* cols);
 
+/* ------------------------------------------------------------------------------------------------
+ * N3: pose-graph optimisation.
+ * Replaces the optimisation of LoopClosing::PoseGraphOptimization
+ * (/root/reference/src/ssvio/loopclosing.cpp:458-539): one VertexPose per keyframe (pose_fixed = the initial, the
+ * active and the loop keyframes, :484-489), one EdgePoseGraph per temporal (:502-514) or loop (:515-528) constraint
+ * with error log(M^-1 T_i T_j^-1) (include/ssvio/g2otypes.hpp:164-176), identity information, no robust kernel,
+ * g2o numeric Jacobians, Levenberg-Marquardt, optimizer.optimize(iterations = 20).
+ * poses are T_cw as (qx qy qz qw tx ty tz), in/out (fixed keyframes are returned unchanged).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ssx_pose_graph_problem {
+  int32_t n_poses;
+  int32_t n_edges;
+  double* poses;                /* n_poses x 7, in/out */
+  const uint8_t* pose_fixed;    /* n_poses */
+  const int32_t* edge_i;        /* n_edges: vertex 0 of the edge (the keyframe itself) */
+  const int32_t* edge_j;        /* n_edges: vertex 1 (its predecessor / its loop keyframe) */
+  const double* edge_meas;      /* n_edges x 7: the measured relative pose T_i * T_j^-1 */
+  double* edge_err_out;         /* optional, n_edges x 6: the edges' errors of the last evaluation */
+  int32_t stats_cap;            /* optional per-iteration statistics (chi2 after the iteration, lambda, trials) */
+  double* stats_chi2;
+  double* stats_lambda;
+  int32_t* stats_trials;
+} ssx_pose_graph_problem;
+typedef struct ssx_pose_graph_result {
+  int32_t n_iters;              /* LM iterations executed (0: nothing to optimise) */
+  int32_t stats_n;
+  double chi2_initial;
+  double chi2_final;
+} ssx_pose_graph_result;
+SSX_API ssx_status ssx_pose_graph_opt(ssx_ctx* ctx, const ssx_pose_graph_problem* prob, int32_t iterations,
+                                      ssx_pose_graph_result* res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,3 +96,38 @@ def pose_only_opt(ctx: Context, pose, K, xyz, uv, rounds=4, iters=10, chi2_th=5.
                                         rounds, iters, C.c_double(chi2_th), C.c_double(huber_delta), ptr(inl, u8_p),
                                         C.byref(n)))
     return dict(pose=pose, inliers=inl, n_inliers=n.value)
+
+
+class PoseGraphProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_edges", C.c_int32), ("poses", C.POINTER(C.c_double)),
+                ("pose_fixed", C.POINTER(C.c_ubyte)), ("edge_i", C.POINTER(C.c_int32)), ("edge_j", C.POINTER(C.c_int32)),
+                ("edge_meas", C.POINTER(C.c_double)), ("edge_err_out", C.POINTER(C.c_double)), ("stats_cap", C.c_int32),
+                ("stats_chi2", C.POINTER(C.c_double)), ("stats_lambda", C.POINTER(C.c_double)),
+                ("stats_trials", C.POINTER(C.c_int32))]
+
+
+class PoseGraphResult(C.Structure):
+    _fields_ = [("n_iters", C.c_int32), ("stats_n", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double)]
+
+
+def pose_graph_opt(ctx, pr, iters=20):
+    """LoopClosing::PoseGraphOptimization (loopclosing.cpp:458-539) on a flat problem:
+    pr = dict(poses [P,7], fixed [P], ei [E], ej [E], meas [E,7])."""
+    poses = np.ascontiguousarray(pr["poses"], dtype=np.float64).copy()
+    fixed = np.ascontiguousarray(pr["fixed"], dtype=np.uint8)
+    ei = np.ascontiguousarray(pr["ei"], dtype=np.int32); ej = np.ascontiguousarray(pr["ej"], dtype=np.int32)
+    meas = np.ascontiguousarray(pr["meas"], dtype=np.float64)
+    E = len(ei)
+    err = np.zeros((max(E, 1), 6)); cap = iters + 2
+    chi = np.zeros(cap); lam = np.zeros(cap); tr = np.zeros(cap, np.int32)
+    dp = C.POINTER(C.c_double)
+    prob = PoseGraphProblem(len(poses), E, poses.ctypes.data_as(dp), fixed.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                            ei.ctypes.data_as(C.POINTER(C.c_int32)), ej.ctypes.data_as(C.POINTER(C.c_int32)),
+                            meas.ctypes.data_as(dp), err.ctypes.data_as(dp), cap, chi.ctypes.data_as(dp),
+                            lam.ctypes.data_as(dp), tr.ctypes.data_as(C.POINTER(C.c_int32)))
+    res = PoseGraphResult()
+    ctx.lib.ssx_pose_graph_opt.restype = C.c_int
+    ctx.check(ctx.lib.ssx_pose_graph_opt(ctx.handle, C.byref(prob), int(iters), C.byref(res)))
+    k = res.stats_n
+    return dict(poses=poses, edge_err=err[:E], n_iters=res.n_iters, chi2=chi[:k].copy(), lambdas=lam[:k].copy(),
+                trials=tr[:k].copy(), chi2_initial=res.chi2_initial, chi2_final=res.chi2_final)

@@ -1230,6 +1230,91 @@ ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, const BigDev& bd, cons
   return SSX_OK;
 }
 
+// Large systems: which 64x64 tiles of the Cholesky factor can be non-zero (shared by the large-window BA and the
+// pose-graph optimisation).  blk_pa / blk_pb = the non-zero 6x6 blocks (free pose indices) of this rank's share of
+// the system matrix.
+ssx_status build_tile_lists(ssx_ctx* ctx, BaWorkspace* ws, const std::vector<int>& blk_pa, const std::vector<int>& blk_pb,
+                            const Comm& cm, BigDev& bd, std::vector<int>& tl_row_cnt, std::vector<int>& tl_pair_cnt)
+{
+  ssx_status st = SSX_OK;
+  {
+  // large windows: which 64x64 tiles of the factor can be non-zero.  The local co-visibility gives the tiles of this
+  // rank's share of S; the union over the ranks (one small all-reduce of the T x T indicator) is the pattern of
+  // the reduced system, and a symbolic elimination at tile level adds the fill.  A sliding window / odometry chain
+  // gives a block-banded S: the panels then touch a handful of tiles instead of (T-k)^2 / 2.
+    const int T = bd.T;
+    SSX_HIP_TRY(ctx, ws->tiles_h.reserve(sizeof(double) * (size_t)T * T + 64));
+    double* hp = ws->tiles_h.as<double>();
+    std::fill(hp, hp + (size_t)T * T, 0.0);
+    for (size_t q = 0; q < blk_pa.size(); ++q) {
+      const int pa = blk_pa[q], pb = blk_pb[q];
+      for (int ta = (6 * pa) / NB; ta <= (6 * pa + 5) / NB; ++ta)
+        for (int tb = (6 * pb) / NB; tb <= (6 * pb + 5) / NB; ++tb)
+          hp[(size_t)std::max(ta, tb) * T + std::min(ta, tb)] = 1.0;
+    }
+    if (cm.fn) {
+      SSX_HIP_TRY(ctx, ws->tiles.reserve(sizeof(double) * (size_t)T * T + 64));
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->tiles.p, hp, sizeof(double) * (size_t)T * T, hipMemcpyHostToDevice, ctx->stream));
+      st = allreduce(ctx, cm, ws->tiles.as<double>(), (size_t)T * T);
+      if (st != SSX_OK) return st;
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(hp, ws->tiles.p, sizeof(double) * (size_t)T * T, hipMemcpyDeviceToHost, ctx->stream));
+      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<uint8_t> pat((size_t)T * T, 0);
+    for (size_t i = 0; i < (size_t)T * T; ++i) pat[i] = hp[i] != 0.0;
+    std::vector<int> init_bi, init_bj;
+    for (int i = 0; i < T; ++i)
+      for (int j = 0; j <= i; ++j)
+        if (pat[(size_t)i * T + j] || i == j) { init_bi.push_back(i); init_bj.push_back(j); }
+    std::vector<int> row_ptr(T + 1, 0), rows, pair_ptr(T + 1, 0), pair_bi, pair_bj, col_ptr(T + 1, 0), cols;
+    std::vector<int> R;
+    for (int k = 0; k < T; ++k) {
+      R.clear();
+      for (int i = k + 1; i < T; ++i) if (pat[(size_t)i * T + k]) R.push_back(i);
+      for (size_t a = 0; a < R.size(); ++a)
+        for (size_t c = 0; c <= a; ++c) pat[(size_t)R[a] * T + R[c]] = 1;       // fill
+      R.push_back(T);                                                             // the rhs row tile
+      for (int i : R) rows.push_back(i);
+      row_ptr[k + 1] = (int)rows.size();
+      for (size_t a = 0; a < R.size(); ++a)
+        for (size_t c = 0; c <= a; ++c)
+          if (R[c] != T) { pair_bi.push_back(R[a]); pair_bj.push_back(R[c]); }
+      pair_ptr[k + 1] = (int)pair_bi.size();
+    }
+    for (int k = 0; k < T; ++k) {
+      for (int j = 0; j < k; ++j) if (pat[(size_t)k * T + j]) cols.push_back(j);
+      col_ptr[k + 1] = (int)cols.size();
+    }
+    tl_row_cnt.resize(T); tl_pair_cnt.resize(T);
+    for (int k = 0; k < T; ++k) { tl_row_cnt[k] = row_ptr[k + 1] - row_ptr[k]; tl_pair_cnt[k] = pair_ptr[k + 1] - pair_ptr[k]; }
+    Layout tl;
+    const size_t o_rp = tl.take(sizeof(int) * (T + 1)), o_r = tl.take(sizeof(int) * (rows.size() + 1));
+    const size_t o_pp = tl.take(sizeof(int) * (T + 1)), o_pbi = tl.take(sizeof(int) * (pair_bi.size() + 1));
+    const size_t o_pbj = tl.take(sizeof(int) * (pair_bj.size() + 1));
+    const size_t o_cp = tl.take(sizeof(int) * (T + 1)), o_c = tl.take(sizeof(int) * (cols.size() + 1));
+    const size_t o_ibi = tl.take(sizeof(int) * (init_bi.size() + 1)), o_ibj = tl.take(sizeof(int) * (init_bj.size() + 1));
+    const size_t tl_lists = tl.off;
+    const size_t o_spack = tl.take(cm.fn ? sizeof(double) * (init_bi.size() * (size_t)NB_TILE + bd.n_pad + 8) : 256);
+    SSX_HIP_TRY(ctx, ws->tiles_h.reserve(tl_lists));
+    SSX_HIP_TRY(ctx, ws->tiles.reserve(tl.off));
+    char* th = ws->tiles_h.as<char>();
+    memcpy(th + o_rp, row_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_r, rows.data(), sizeof(int) * rows.size());
+    memcpy(th + o_pp, pair_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_pbi, pair_bi.data(), sizeof(int) * pair_bi.size());
+    memcpy(th + o_pbj, pair_bj.data(), sizeof(int) * pair_bj.size());
+    memcpy(th + o_cp, col_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_c, cols.data(), sizeof(int) * cols.size());
+    memcpy(th + o_ibi, init_bi.data(), sizeof(int) * init_bi.size()); memcpy(th + o_ibj, init_bj.data(), sizeof(int) * init_bj.size());
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->tiles.p, th, tl_lists, hipMemcpyHostToDevice, ctx->stream));
+    char* tb = ws->tiles.as<char>();
+    bd.n_init = (int)init_bi.size();
+    bd.tl_init_bi = (const int*)(tb + o_ibi); bd.tl_init_bj = (const int*)(tb + o_ibj);
+    bd.Spack = (double*)(tb + o_spack);
+    bd.tl_row_ptr = (const int*)(tb + o_rp); bd.tl_rows = (const int*)(tb + o_r);
+    bd.tl_pair_ptr = (const int*)(tb + o_pp); bd.tl_pair_bi = (const int*)(tb + o_pbi); bd.tl_pair_bj = (const int*)(tb + o_pbj);
+    bd.tl_col_ptr = (const int*)(tb + o_cp); bd.tl_cols = (const int*)(tb + o_c);
+  }
+  return SSX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1343,81 +1428,10 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
     attr_set = true;
   }
-  // large windows: which 64x64 tiles of the factor can be non-zero.  The local co-visibility gives the tiles of this
-  // rank's share of S; the union over the ranks (one small all-reduce of the T x T indicator) is the pattern of
-  // the reduced system, and a symbolic elimination at tile level adds the fill.  A sliding window / odometry chain
-  // gives a block-banded S: the panels then touch a handful of tiles instead of (T-k)^2 / 2.
   std::vector<int> tl_row_cnt, tl_pair_cnt;
   if (d.big) {
-    const int T = bd.T;
-    SSX_HIP_TRY(ctx, ws->tiles_h.reserve(sizeof(double) * (size_t)T * T + 64));
-    double* hp = ws->tiles_h.as<double>();
-    std::fill(hp, hp + (size_t)T * T, 0.0);
-    for (size_t q = 0; q < h.sblk_pa.size(); ++q) {
-      const int pa = h.sblk_pa[q], pb = h.sblk_pb[q];
-      for (int ta = (6 * pa) / NB; ta <= (6 * pa + 5) / NB; ++ta)
-        for (int tb = (6 * pb) / NB; tb <= (6 * pb + 5) / NB; ++tb)
-          hp[(size_t)std::max(ta, tb) * T + std::min(ta, tb)] = 1.0;
-    }
-    if (cm.fn) {
-      SSX_HIP_TRY(ctx, ws->tiles.reserve(sizeof(double) * (size_t)T * T + 64));
-      SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->tiles.p, hp, sizeof(double) * (size_t)T * T, hipMemcpyHostToDevice, ctx->stream));
-      st = allreduce(ctx, cm, ws->tiles.as<double>(), (size_t)T * T);
-      if (st != SSX_OK) return st;
-      SSX_HIP_TRY(ctx, hipMemcpyAsync(hp, ws->tiles.p, sizeof(double) * (size_t)T * T, hipMemcpyDeviceToHost, ctx->stream));
-      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    std::vector<uint8_t> pat((size_t)T * T, 0);
-    for (size_t i = 0; i < (size_t)T * T; ++i) pat[i] = hp[i] != 0.0;
-    std::vector<int> init_bi, init_bj;
-    for (int i = 0; i < T; ++i)
-      for (int j = 0; j <= i; ++j)
-        if (pat[(size_t)i * T + j] || i == j) { init_bi.push_back(i); init_bj.push_back(j); }
-    std::vector<int> row_ptr(T + 1, 0), rows, pair_ptr(T + 1, 0), pair_bi, pair_bj, col_ptr(T + 1, 0), cols;
-    std::vector<int> R;
-    for (int k = 0; k < T; ++k) {
-      R.clear();
-      for (int i = k + 1; i < T; ++i) if (pat[(size_t)i * T + k]) R.push_back(i);
-      for (size_t a = 0; a < R.size(); ++a)
-        for (size_t c = 0; c <= a; ++c) pat[(size_t)R[a] * T + R[c]] = 1;       // fill
-      R.push_back(T);                                                             // the rhs row tile
-      for (int i : R) rows.push_back(i);
-      row_ptr[k + 1] = (int)rows.size();
-      for (size_t a = 0; a < R.size(); ++a)
-        for (size_t c = 0; c <= a; ++c)
-          if (R[c] != T) { pair_bi.push_back(R[a]); pair_bj.push_back(R[c]); }
-      pair_ptr[k + 1] = (int)pair_bi.size();
-    }
-    for (int k = 0; k < T; ++k) {
-      for (int j = 0; j < k; ++j) if (pat[(size_t)k * T + j]) cols.push_back(j);
-      col_ptr[k + 1] = (int)cols.size();
-    }
-    tl_row_cnt.resize(T); tl_pair_cnt.resize(T);
-    for (int k = 0; k < T; ++k) { tl_row_cnt[k] = row_ptr[k + 1] - row_ptr[k]; tl_pair_cnt[k] = pair_ptr[k + 1] - pair_ptr[k]; }
-    Layout tl;
-    const size_t o_rp = tl.take(sizeof(int) * (T + 1)), o_r = tl.take(sizeof(int) * (rows.size() + 1));
-    const size_t o_pp = tl.take(sizeof(int) * (T + 1)), o_pbi = tl.take(sizeof(int) * (pair_bi.size() + 1));
-    const size_t o_pbj = tl.take(sizeof(int) * (pair_bj.size() + 1));
-    const size_t o_cp = tl.take(sizeof(int) * (T + 1)), o_c = tl.take(sizeof(int) * (cols.size() + 1));
-    const size_t o_ibi = tl.take(sizeof(int) * (init_bi.size() + 1)), o_ibj = tl.take(sizeof(int) * (init_bj.size() + 1));
-    const size_t tl_lists = tl.off;
-    const size_t o_spack = tl.take(cm.fn ? sizeof(double) * (init_bi.size() * (size_t)NB_TILE + bd.n_pad + 8) : 256);
-    SSX_HIP_TRY(ctx, ws->tiles_h.reserve(tl_lists));
-    SSX_HIP_TRY(ctx, ws->tiles.reserve(tl.off));
-    char* th = ws->tiles_h.as<char>();
-    memcpy(th + o_rp, row_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_r, rows.data(), sizeof(int) * rows.size());
-    memcpy(th + o_pp, pair_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_pbi, pair_bi.data(), sizeof(int) * pair_bi.size());
-    memcpy(th + o_pbj, pair_bj.data(), sizeof(int) * pair_bj.size());
-    memcpy(th + o_cp, col_ptr.data(), sizeof(int) * (T + 1)); memcpy(th + o_c, cols.data(), sizeof(int) * cols.size());
-    memcpy(th + o_ibi, init_bi.data(), sizeof(int) * init_bi.size()); memcpy(th + o_ibj, init_bj.data(), sizeof(int) * init_bj.size());
-    SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->tiles.p, th, tl_lists, hipMemcpyHostToDevice, ctx->stream));
-    char* tb = ws->tiles.as<char>();
-    bd.n_init = (int)init_bi.size();
-    bd.tl_init_bi = (const int*)(tb + o_ibi); bd.tl_init_bj = (const int*)(tb + o_ibj);
-    bd.Spack = (double*)(tb + o_spack);
-    bd.tl_row_ptr = (const int*)(tb + o_rp); bd.tl_rows = (const int*)(tb + o_r);
-    bd.tl_pair_ptr = (const int*)(tb + o_pp); bd.tl_pair_bi = (const int*)(tb + o_pbi); bd.tl_pair_bj = (const int*)(tb + o_pbj);
-    bd.tl_col_ptr = (const int*)(tb + o_cp); bd.tl_cols = (const int*)(tb + o_c);
+    st = build_tile_lists(ctx, ws, h.sblk_pa, h.sblk_pb, cm, bd, tl_row_cnt, tl_pair_cnt);
+    if (st != SSX_OK) return st;
   }
   // large windows: Schur blocks -> dense S (+ rhs row) -> all-reduce -> blocked Cholesky (MFMA) -> back-substitution
   auto big_trial = [&](double lambda, int dev_lambda, int cur_) -> ssx_status {
@@ -1583,3 +1597,5 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
 }
 
 }  // extern "C"
+
+#include "pg.inc"

@@ -111,6 +111,79 @@ SSX_HD void pose_oplus(const double* T, const double* d, double* out)
   se3_mul(ex, T, out);
 }
 
+// Sophus SE3::inverse (se3.hpp:208-211): the SO3 constructor re-normalises the conjugate quaternion
+SSX_HD void se3_inverse(const double* T, double* out)
+{
+  double q[4] = {-T[0], -T[1], -T[2], T[3]};
+  const double len = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] /= len; q[1] /= len; q[2] /= len; q[3] /= len;
+  const double nt[3] = {T[4] * -1.0, T[5] * -1.0, T[6] * -1.0};
+  double r[3];
+  quat_rotate(q, nt, r);
+  out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
+  out[4] = r[0]; out[5] = r[1]; out[6] = r[2];
+}
+
+// Sophus SE3::log (se3.hpp:223-256) with SO3::logAndTheta (so3.hpp:245-286); tangent = (upsilon, omega)
+SSX_HD void se3_log(const double* T, double* out)
+{
+  const double eps = 1e-10;
+  const double squared_n = T[0] * T[0] + T[1] * T[1] + T[2] * T[2];
+  const double w = T[3];
+  double k, theta;                       // k = 2 atan(n / w) / n
+  if (squared_n < eps * eps) {
+    k = 2.0 / w - (2.0 / 3.0) * (squared_n) / (w * (w * w));
+    theta = 2.0 * squared_n / w;
+  } else {
+    const double n = sqrt(squared_n);
+    if (fabs(w) < eps) k = (w > 0.0 ? 3.14159265358979323846 : -3.14159265358979323846) / n;
+    else k = 2.0 * atan(n / w) / n;
+    theta = k * n;
+  }
+  const double ox = k * T[0], oy = k * T[1], oz = k * T[2];
+  double c;
+  if (fabs(theta) < eps) c = 1. / 12.;
+  else {
+    const double half_theta = 0.5 * theta;
+    c = (1.0 - theta * cos(half_theta) / (2.0 * sin(half_theta))) / (theta * theta);
+  }
+  // V^-1 = I - 0.5 Omega + c Omega^2,  Omega^2 = omega omega^T - |omega|^2 I
+  const double o2 = ox * ox + oy * oy + oz * oz;
+  const double t0 = T[4], t1 = T[5], t2 = T[6];
+  const double od = ox * t0 + oy * t1 + oz * t2;
+  out[0] = t0 - 0.5 * (oy * t2 - oz * t1) + c * (ox * od - o2 * t0);
+  out[1] = t1 - 0.5 * (oz * t0 - ox * t2) + c * (oy * od - o2 * t1);
+  out[2] = t2 - 0.5 * (ox * t1 - oy * t0) + c * (oz * od - o2 * t2);
+  out[3] = ox; out[4] = oy; out[5] = oz;
+}
+
+// EdgePoseGraph::computeError (g2otypes.hpp:169-176): e = log(M^-1 * T0 * T1^-1)
+SSX_HD void pg_error(const double* M, const double* T0, const double* T1, double* e)
+{
+  double Mi[7], T1i[7], A[7], B[7];
+  se3_inverse(M, Mi);
+  se3_inverse(T1, T1i);
+  se3_mul(Mi, T0, A);
+  se3_mul(A, T1i, B);
+  se3_log(B, e);
+}
+
+// g2o's central differences on the oplus of vertex `which` (base_binary_edge.hpp:61-141), delta = 1e-9; J 6x6 row-major
+SSX_HD void pg_jac_numeric(const double* M, const double* T0, const double* T1, int which, double* J)
+{
+  const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+  for (int d = 0; d < 6; ++d) {
+    double add[6] = {0, 0, 0, 0, 0, 0}, Tp[7], Tm[7], ep[6], em[6];
+    add[d] = delta;
+    pose_oplus(which == 0 ? T0 : T1, add, Tp);
+    add[d] = -delta;
+    pose_oplus(which == 0 ? T0 : T1, add, Tm);
+    if (which == 0) { pg_error(M, Tp, T1, ep); pg_error(M, Tm, T1, em); }
+    else { pg_error(M, T0, Tp, ep); pg_error(M, T0, Tm, em); }
+    for (int r = 0; r < 6; ++r) J[r * 6 + d] = scalar * (ep[r] - em[r]);
+  }
+}
+
 // e = uv - hnorm(K * (ext * (T * p)));   p1 = T*p and pc = ext*p1 are returned for the Jacobians
 SSX_HD void edge_error(const double* T, const double* p, const double* ext, const Cam& K,
                        double u, double v, double* e, double* p1, double* pc)

@@ -52,6 +52,9 @@ def test_struct_layout_matches_ctypes():
             names[extra] = cls
     from ssvio_amd import lk
     names["ssx_lk_params"] = lk.LkParams
+    from ssvio_amd import ba as _ba
+    names["ssx_pose_graph_problem"] = _ba.PoseGraphProblem
+    names["ssx_pose_graph_result"] = _ba.PoseGraphResult
     prog = '#include <stdio.h>\n#include "ssx.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
