@@ -52,3 +52,29 @@ def make_allreduce_hook(device, group=None):
             return 1
 
     return hook
+
+
+def make_allreduce_hook_host_staged(device, group=None):
+    """Same contract as make_allreduce_hook for process groups WITHOUT device collectives (gloo): the buffer is
+    staged through host memory.  Slow by construction; it exists so that the multi-rank control flow of
+    ssx_ba_solve (identical LM decisions on every rank, tile-pattern exchange, packed tile all-reduce) can be tested
+    with several processes on ONE GPU."""
+    import torch
+    import torch.distributed as dist
+
+    class _Dev:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+    def hook(user, buf, count, stream):
+        try:
+            t = torch.as_tensor(_Dev(buf, count), device=device)
+            h = t.cpu()                                   # ordered on the current stream (= the ctx stream), then waits
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+            return 0
+        except Exception as e:
+            print("ssvio_amd.dist_ba: host-staged all_reduce failed:", e, flush=True)
+            return 1
+
+    return hook

@@ -1,0 +1,64 @@
+"""Two ranks on ONE GPU (gloo process group, host-staged all-reduce hook): the multi-rank control flow of
+ssx_ba_solve -- landmark shards, all-reduced pose blocks / reduced system / trial scalars, identical LM decisions on
+both ranks, and for large windows the tile-pattern exchange + packed non-zero-tile all-reduce -- must reproduce the
+single-rank solve up to the summation order of the two partial sums (1e-9 relative)."""
+import os
+import pickle
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "small": dict(cfg=dict(P=10, L=900, seed=4), kw=dict()),
+    "large": dict(cfg=dict(P=40, L=1500, obs_per_lm=5, seed=9, loop=False, fix_first_pose=True), kw=dict(outer_rounds=1, iters=6)),
+}
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    import ssvio_amd
+    from ssvio_amd import ba, dist_ba
+    from ssvio_amd.synth import make_ba_problem
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    res = {}
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        ctx = ssvio_amd.Context(0, stream=s.cuda_stream)
+        hook = dist_ba.make_allreduce_hook_host_staged(dev)
+        for name, c in CASES.items():
+            pr = make_ba_problem(**c["cfg"])
+            loc = dist_ba.shard_problem(pr, rank, world)
+            r = ba.ba_solve(ctx, loc, allreduce=hook, rank=rank, world_size=world, **c["kw"])
+            res[name] = dict(poses=r["poses"], points=r["points"], chi2=r["chi2"], trials=r["trials"], lm_global=loc["lm_global"])
+        ctx.close()
+    pickle.dump(res, open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_single_rank_solve(ctx):
+    import torch.multiprocessing as mp
+    from ssvio_amd import ba
+    from ssvio_amd.synth import make_ba_problem
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, 29751, d), nprocs=2, join=True)
+        r0 = pickle.load(open(os.path.join(d, "rank0.pkl"), "rb")); r1 = pickle.load(open(os.path.join(d, "rank1.pkl"), "rb"))
+    for name, c in CASES.items():
+        pr = make_ba_problem(**c["cfg"])
+        one = ba.ba_solve(ctx, pr, **c["kw"])
+        a, b = r0[name], r1[name]
+        # both ranks took the same decisions and hold the same (replicated) poses
+        assert np.array_equal(a["trials"], b["trials"]) and np.array_equal(a["chi2"], b["chi2"]) and np.array_equal(a["poses"], b["poses"])
+        assert np.array_equal(a["trials"], one["trials"]), name
+        np.testing.assert_allclose(a["chi2"], one["chi2"], rtol=1e-9)
+        np.testing.assert_allclose(a["poses"], one["poses"], rtol=0, atol=1e-9)
+        pts = np.zeros_like(one["points"])
+        pts[a["lm_global"]] = a["points"]; pts[b["lm_global"]] = b["points"]
+        np.testing.assert_allclose(pts, one["points"], rtol=0, atol=1e-8)
