@@ -152,7 +152,7 @@ constexpr int SLOTS = 4;     // window pixels per lane (win <= 15 -> 225 <= 256)
 
 __global__ __launch_bounds__(256) void k_lk_track(LkDev d)
 {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int i = blockIdx.x * 4 + wave;
   if (i >= d.n) return;
   const int win = d.win, nwin = win * win, pad = d.pad;

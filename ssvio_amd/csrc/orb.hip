@@ -193,7 +193,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int p, int t)
 __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, int cell_end)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int cell = cell_begin + blockIdx.x * (blockDim.x >> 6) + wave, img = blockIdx.y;   // 1..4 cells per workgroup
   if (cell >= cell_end) return;
   const Cell c = o.cells[cell];
@@ -492,19 +492,27 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 // Stage ROWS patch rows as NDW ALIGNED dwords each (level pitches and offsets are multiples of 128 bytes), starting
 // at the dword that holds column x0 of row y0; returns x0 & 3, the byte offset of x0 inside each staged row.
-// (MUL, SH): i / NDW == (i * MUL) >> SH over the index range used.
+// (MUL, SH): i / NDW == (i * MUL) >> SH for i < 64 (the first round; later rounds advance row / dword / byte offset
+// incrementally: 64 = (64 / NDW) rows + (64 % NDW) dwords).
 template <int ROWS, int NDW, int MUL, int SH>
 __device__ __forceinline__ int stage_patch(uint32_t* sp, const uint8_t* src, int pitch, int x0, int y0, int lane)
 {
   const int ax = x0 & ~3;
   const uint8_t* base = src + (size_t)y0 * pitch + ax;
+  int d = 0;
+  {
+    const int r = (lane * MUL) >> SH;
+    d = lane - r * NDW;
+    base += r * pitch + 4 * d;
+  }
+  const int step = (64 / NDW) * pitch + 4 * (64 % NDW), wrap = pitch - 4 * NDW;
 #pragma unroll
   for (int i0 = 0; i0 < ROWS * NDW; i0 += 64) {
     const int i = i0 + lane;
-    if (i < ROWS * NDW) {
-      const int r = (i * MUL) >> SH, d = i - r * NDW;
-      sp[i] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * d);
-    }
+    if (i < ROWS * NDW) sp[i] = *reinterpret_cast<const uint32_t*>(base);
+    d += 64 % NDW;
+    base += step;
+    if (d >= NDW) { d -= NDW; base += wrap; }
   }
   return x0 - ax;
 }
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(OrbDev o)
 {
   __shared__ uint32_t sPatch[4][PATCH_LDS_DW];
   const int img = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int slot = blockIdx.x * 4 + wave;
   int level = 0, base = 0, n = o.sel_count[img * o.nlevels];
   while (level + 1 < o.nlevels && slot >= base + n) { base += n; ++level; n = o.sel_count[img * o.nlevels + level]; }
@@ -654,7 +662,7 @@ struct DescribeAt {
 __global__ __launch_bounds__(256) void k_describe_at(OrbDev o, DescribeAt a)
 {
   __shared__ uint32_t sPatch[4][PATCH_LDS_DW];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int k = blockIdx.x * 4 + wave;
   bool active = k < a.n_in;
   ssx_keypoint kp{};

@@ -95,7 +95,7 @@ __device__ __forceinline__ int hamming256(const uint8_t* a, const uint8_t* b)
 __global__ __launch_bounds__(256) void k_match(MatchDev m)
 {
   const int pair = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int i = blockIdx.x * 4 + wave;
   const int nL = min(m.n[2 * pair], m.out_cap), nR = min(m.n[2 * pair + 1], m.out_cap);
   if (i >= nL) return;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_match(MatchDev m)
 // generic brute force: query block x all train descriptors (host-array entry point ssx_bf_match)
 __global__ __launch_bounds__(256) void k_bf_match(const uint8_t* dq, int nq, const uint8_t* dt, int nt, int* idx, int* dist)
 {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int i = blockIdx.x * 4 + wave;
   if (i >= nq) return;
   unsigned best = (257u << 16) | 0xFFFFu;
