@@ -522,23 +522,47 @@ constexpr int BP = 37, BR = 18;      // blurred patch side / radius: |rotated pa
 constexpr int BP_NDW = 10;           // 37 bytes + <= 3 bytes of alignment
 constexpr int PATCH_LDS_DW = 31 * OP_NDW + BP * BP_NDW;   // both patches of one keypoint
 
-// IC_Angle (orbextractor.cpp:25-44): integer moments of the circular patch; two lanes per row (u < 0 | u >= 0)
-__device__ __forceinline__ float ic_angle(const uint8_t* sp, int off, int lane)
+// IC_Angle (orbextractor.cpp:25-44): integer moments of the circular patch.  Two lanes per patch row (bytes 0..15 |
+// 16..31 of the row); a lane's 16 pixels are four dwords cut from the staged row with v_alignbyte, and
+//   sum u * I = sum (u + 15) * I - 15 * sum I
+// is two v_dot4_u32_u8 per dword against the tabulated byte weights (u + 15, and 1) of the row's circular mask.
+struct IcTables { uint2 w[16][8]; };   // [|v|][dword of the 32-byte row]: x = weights u+15, y = mask, zero outside |u| <= umax(|v|)
+
+__device__ __forceinline__ void ic_tables_init(IcTables& tb)
+{
+  const int t = threadIdx.x;
+  if (t < 128) {
+    const int av = t >> 3, k = t & 7, dmax = c_umax[av];
+    uint32_t w1 = 0, w0 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = 4 * k + j - 15;
+      if (u >= -dmax && u <= dmax) { w1 |= (uint32_t)(u + 15) << (8 * j); w0 |= 1u << (8 * j); }
+    }
+    tb.w[av][k] = make_uint2(w1, w0);
+  }
+}
+
+__device__ __forceinline__ float ic_angle(const uint32_t* sp, int off, int lane, const IcTables& tb)
 {
   int m10 = 0, m01 = 0;
   if (lane < 62) {
     const int row = lane >> 1, half = lane & 1;
-    const int v = row - 15;
-    const int dmax = c_umax[v < 0 ? -v : v];
-    const uint8_t* rp = sp + row * (4 * OP_NDW) + off + 15;
-    const int u0 = half ? 0 : -dmax, u1 = half ? dmax : -1;
-    int sum = 0;
-    for (int u = u0; u <= u1; ++u) {
-      const int val = rp[u];
-      m10 += u * val;
-      sum += val;
+    const int v = row - 15, av = v < 0 ? -v : v;
+    const uint32_t* rp = sp + row * OP_NDW + 4 * half;
+    uint32_t d[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[k] = rp[k];
+    uint32_t s1 = 0, s0 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t px = __builtin_amdgcn_alignbyte(d[k + 1], d[k], off);
+      const uint2 w = tb.w[av][4 * half + k];
+      s1 = __builtin_amdgcn_udot4(px, w.x, s1, false);
+      s0 = __builtin_amdgcn_udot4(px, w.y, s0, false);
     }
-    m01 = v * sum;
+    m10 = (int)s1 - 15 * (int)s0;
+    m01 = v * (int)s0;
   }
 #pragma unroll
   for (int o2 = 32; o2 > 0; o2 >>= 1) { m10 += __shfl_xor(m10, o2); m01 += __shfl_xor(m01, o2); }
@@ -606,6 +630,9 @@ __device__ __forceinline__ void brief_words(const uint8_t* sp, int off, float an
 __global__ __launch_bounds__(256) void k_orient_brief(OrbDev o)
 {
   __shared__ uint32_t sPatch[4][PATCH_LDS_DW];
+  __shared__ IcTables sIc;
+  ic_tables_init(sIc);
+  __syncthreads();                                      // the only workgroup barrier; waves leave only after it
   const int img = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int slot = blockIdx.x * 4 + wave;
@@ -625,7 +652,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(OrbDev o)
   const int off_b = stage_patch<BP, BP_NDW, 205, 11>(sp + 31 * OP_NDW, o.blur + lvl, pitch, cx - BR, cy - BR, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const float angle = ic_angle(reinterpret_cast<const uint8_t*>(sp), off_o, lane);
+  const float angle = ic_angle(sp, off_o, lane, sIc);
   unsigned long long words[4];
   brief_words(reinterpret_cast<const uint8_t*>(sp + 31 * OP_NDW), off_b, angle, lane, words);
   if (lane < 4) {
@@ -662,6 +689,8 @@ struct DescribeAt {
 __global__ __launch_bounds__(256) void k_describe_at(OrbDev o, DescribeAt a)
 {
   __shared__ uint32_t sPatch[4][PATCH_LDS_DW];
+  __shared__ IcTables sIc;
+  ic_tables_init(sIc);                                  // published by the __syncthreads() after the patch staging
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int k = blockIdx.x * 4 + wave;
   bool active = k < a.n_in;
@@ -690,7 +719,7 @@ __global__ __launch_bounds__(256) void k_describe_at(OrbDev o, DescribeAt a)
   if (active) off_o = stage_patch<31, OP_NDW, 57, 9>(sp, lvl, pitch, cx - 15, cy - 15, lane);
   __syncthreads();
   float angle = 0.f;
-  if (active) angle = ic_angle(reinterpret_cast<const uint8_t*>(sp), off_o, lane);
+  if (active) angle = ic_angle(sp, off_o, lane, sIc);
   // CalcDescriptors: pt (already multiplied back by scale) is divided by scale AGAIN before describing
   float ox = kp.x * sc, oy = kp.y * sc;                        // kps.pt *= scale  (the output coordinates)
   const float dx = ox / sc, dy = oy / sc;
