@@ -1472,9 +1472,16 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   while (round < opt.outer_rounds) {
     // ---- one g2o optimize(iters): OptimizationAlgorithmLevenberg::solve per iteration ----
     double lambda = -1.0, ni = 2.0;
+    // An accepted trial is the rule, so the NEXT iteration's linearisation (at the trial state) is enqueued before
+    // the host waits for the trial's scalars: the GPU works through the ~25 us of the host round trip instead of
+    // idling.  A rejected trial pays one extra linearisation at the kept state (identical values: deterministic).
+    bool spec_done = false;
     for (int it = 0; it < opt.iters && active; ++it) {
-      st = launch_linearize(ctx, d, bd, cm, opt.jac_mode, cur, it == 0);
-      if (st != SSX_OK) return st;
+      if (!spec_done) {
+        st = launch_linearize(ctx, d, bd, cm, opt.jac_mode, cur, it == 0);
+        if (st != SSX_OK) return st;
+      }
+      spec_done = false;
       double currentChi = 0.0, rho = 0.0, tempChi = 0.0;
       int qmax = 0;
       bool lambda_bad = false;
@@ -1502,7 +1509,15 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
         }
         SSX_HIP_TRY(ctx, hipGetLastError());
         SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 12, hipMemcpyDeviceToHost, ctx->stream));
-        SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the one host round trip of an LM trial
+        const bool spec_pending = it + 1 < opt.iters;
+        if (spec_pending) {
+          SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_spec, ctx->stream));      // the scalars are complete here
+          st = launch_linearize(ctx, d, bd, cm, opt.jac_mode, cur ^ 1, 0);
+          if (st != SSX_OK) return st;
+          SSX_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_spec));              // the one host round trip of an LM trial
+        } else {
+          SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
         have_trial_err = true;
         if (qmax == 0) {
           currentChi = hscal[SC_CHI2_CUR];
@@ -1524,10 +1539,16 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
           ni = 2;
           currentChi = tempChi;
           cur ^= 1;   // accept: the trial buffers become the state
+          spec_done = spec_pending;
         } else {
           lambda *= ni;
           ni *= 2;
           if (!std::isfinite(lambda)) { lambda_bad = true; break; }
+          if (spec_pending && rho < 0 && qmax + 1 < 10) {
+            // rejected and another trial follows: bring the linearisation of the kept state back
+            st = launch_linearize(ctx, d, bd, cm, opt.jac_mode, cur, 0);
+            if (st != SSX_OK) return st;
+          }
         }
         qmax++;
       } while (rho < 0 && qmax < 10);

@@ -46,6 +46,7 @@ ssx_status ssx_ctx_create(const ssx_config* cfg, ssx_ctx** out)
       (void)hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
     }
   }
+  (void)hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming);
@@ -67,6 +68,7 @@ void ssx_ctx_destroy(ssx_ctx* ctx)
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+  if (ctx->ev_spec) (void)hipEventDestroy(ctx->ev_spec);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_pyr) (void)hipEventDestroy(ctx->ev_pyr);

@@ -128,7 +128,7 @@ struct ssx_ctx {
   void (*orb_free)(OrbWorkspace*) = nullptr;
   void* lk = nullptr;                        // lk.hip workspace
   void (*lk_free)(void*) = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_spec = nullptr;
   hipStream_t aux = nullptr;                 // second stream: independent stages overlap (blur || detect)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pyr = nullptr, ev_fast0 = nullptr;
   SsxProf prof;
