@@ -60,19 +60,34 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # SSX_BENCH_SINGLE_GPU_GLOO=1 is a TEST MODE for boxes with one GPU: all ranks share cuda:0, the process group is
+    # gloo and the BA all-reduce hook is staged through host memory; it exercises every multi-rank code path of this
+    # script (its numbers mean nothing).  The real thing is one rank per GPU over RCCL.
+    test_mode = world > 1 and os.environ.get("SSX_BENCH_SINGLE_GPU_GLOO") == "1"
+    dev_index = 0 if test_mode else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if test_mode:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{dev_index}"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if test_mode else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     import ssvio_amd
     from ssvio_amd import _lib, ba, orb
     from ssvio_amd.synth import KITTI_H, KITTI_W, make_ba_problem, make_stereo_pair
 
     stream = torch.cuda.Stream(device=dev)
-    ctx = ssvio_amd.Context(local_rank, stream=stream.cuda_stream)
+    ctx = ssvio_amd.Context(dev_index, stream=stream.cuda_stream)
 
     def barrier():
         ctx.synchronize()
@@ -94,10 +109,7 @@ def main():
         orb.stereo_batch_enqueue(ctx)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
     frames = world * B * args.steps
     value = frames / elapsed
 
@@ -161,7 +173,8 @@ def main():
     if world > 1:
         from ssvio_amd import dist_ba
         pr_local = dist_ba.shard_problem(pr, rank, world)
-        ba_kwargs = dict(allreduce=dist_ba.make_allreduce_hook(dev), rank=rank, world_size=world)
+        hook = dist_ba.make_allreduce_hook_host_staged(dev) if test_mode else dist_ba.make_allreduce_hook(dev)
+        ba_kwargs = dict(allreduce=hook, rank=rank, world_size=world)
     else:
         pr_local = pr
     with torch.cuda.stream(stream):
@@ -176,10 +189,7 @@ def main():
             n_it += r["n_iters"]
         barrier()
         ba_elapsed = time.perf_counter() - tb
-    if world > 1:
-        t = torch.tensor([ba_elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ba_elapsed = float(t.item())
+    ba_elapsed = max_over_ranks(ba_elapsed)
     ba_iters_s = n_it / ba_elapsed
     ba_solve_ms = ba_elapsed / BA_REP * 1e3
 
@@ -201,10 +211,7 @@ def main():
             n_it4 += r4["n_iters"]
         barrier()
         c4_elapsed = time.perf_counter() - tb
-    if world > 1:
-        t = torch.tensor([c4_elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        c4_elapsed = float(t.item())
+    c4_elapsed = max_over_ranks(c4_elapsed)
     c4 = {"workload": f"C4 shape: 500 KF on a loop x {C4_LM_PER_GPU * world} landmarks x {int(pr4['E'])} edges "
                       f"({C4_LM_PER_GPU} landmarks per GPU, weak scaling), analytic Jacobians, f64",
           "iters_per_s": round(n_it4 / c4_elapsed, 2),
