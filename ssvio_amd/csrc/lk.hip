@@ -55,8 +55,9 @@ struct LkWorkspace {
   bool planned = false;
 };
 
-void lk_ws_free(LkWorkspace* w)
+void lk_ws_free(void* p)
 {
+  LkWorkspace* w = static_cast<LkWorkspace*>(p);
   if (!w) return;
   w->arena.release(); w->io.release(); w->stage.release();
   delete w;
@@ -64,7 +65,7 @@ void lk_ws_free(LkWorkspace* w)
 
 LkWorkspace* lk_ws(ssx_ctx* ctx)
 {
-  if (!ctx->lk) { ctx->lk = new LkWorkspace(); ctx->lk_free = reinterpret_cast<void (*)(void*)>(lk_ws_free); }
+  if (!ctx->lk) { ctx->lk = new LkWorkspace(); ctx->lk_free = lk_ws_free; }
   return static_cast<LkWorkspace*>(ctx->lk);
 }
 
