@@ -264,3 +264,29 @@ def make_stereo_pair(seed=0, h=KITTI_H, w=KITTI_W, n_blobs=4000, bf=KITTI_BF):
     right += rng.normal(0, 2.0, right.shape).astype(np.float32)
     right = np.clip(np.rint(right), 0, 255).astype(np.uint8)
     return left, right, disp
+
+
+def make_lateral_sequence(n_frames=12, step=0.12, seed=0, h=KITTI_H, w=KITTI_W, n_blobs=4000, bf=KITTI_BF, baseline=KITTI_BASELINE):
+    """A stereo SEQUENCE of the make_stereo_pair scene seen from a rig that moves sideways (along +x, the direction of
+    the right camera) by `step` baselines per frame: a camera at lateral offset a * baseline sees the texture shifted
+    by a * disparity, so frame k is left = base(u + a_k d), right = base(u + (a_k + 1) d).  Returns
+    (frames [(left, right)], T_cw [n,7] ground-truth poses with world = camera 0, disp)."""
+    base, _, disp = make_stereo_pair(seed=seed, h=h, w=w, n_blobs=n_blobs, bf=bf)
+    rng = np.random.default_rng(5000 + seed)
+    lf = base.astype(np.float32)
+    rows = np.arange(h)[:, None]
+
+    def render(alpha):
+        xs = np.arange(w, dtype=np.float32)[None, :] + np.float32(alpha) * disp
+        x0 = np.clip(np.floor(xs).astype(np.int32), 0, w - 1)
+        x1 = np.clip(x0 + 1, 0, w - 1)
+        fx = np.clip(xs - np.floor(xs), 0, 1)
+        img = lf[rows, x0] * (1 - fx) + lf[rows, x1] * fx
+        img += rng.normal(0, 1.5, img.shape).astype(np.float32)
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    frames, poses = [], []
+    for k in range(n_frames):
+        a = step * k
+        frames.append((render(a), render(a + 1.0)))
+        poses.append(np.array([0, 0, 0, 1, -a * baseline, 0, 0], dtype=np.float64))       # T_cw: camera centre at (+a b, 0, 0)
+    return frames, np.array(poses), disp
