@@ -21,7 +21,7 @@
 //     oracle);
 //   * phase 2 orders the expandable nodes by (size, creation index) descending by counting ranks, and cuts the
 //     list at the first prefix that reaches N nodes;
-//   * the winner of every final node is one LDS atomicMax on (response << 14 | 16383 - candidate index).
+//   * the winner of every final node is one LDS atomicMax on (response << 16 | 65535 - candidate index).
 // Tie-break of equal sizes in phase 2: creation order (the reference compares heap pointers,
 // orbextractor.cpp:486, which is not reproducible); identical to the oracle.
 //
@@ -39,10 +39,7 @@ namespace {
 typedef unsigned long long u64;
 constexpr int T = OCT_THREADS;
 constexpr int NW = T / 64;
-constexpr int KPT = CAND_CAP / T;          // candidates per thread (registers)
 constexpr unsigned NONE = 0xFFFFu;
-static_assert(KPT * 2 <= 32, "quadrants of a thread's keys are packed 2 bits each in one 32-bit register");
-
 struct Box { int16_t ulx, uly, brx, bry; };   // node corners (UL, BR), relative to the level's border
 
 // node-level arrays, LN entries each (OCT_NODE_BYTES per entry): LDS, or global scratch for very large budgets
@@ -118,8 +115,10 @@ __device__ __forceinline__ uint32_t pk_r(uint32_t p) { return p >> 24; }
 __device__ __forceinline__ int nonzero4(u64 c) { return (f16(c, 0) > 0) + (f16(c, 1) > 0) + (f16(c, 2) > 0) + (f16(c, 3) > 0); }
 __device__ __forceinline__ int above1_4(u64 c) { return (f16(c, 0) > 1) + (f16(c, 1) > 1) + (f16(c, 2) > 1) + (f16(c, 3) > 1); }
 
-// GLOBAL_TAB = false: node tables in dynamic LDS (OCT_NODE_BYTES * LN bytes); true: in the global scratch block
-template <bool GLOBAL_TAB>
+// GLOBAL_TAB = false: node tables in dynamic LDS (OCT_NODE_BYTES * LN bytes); true: in the global scratch block.
+// GLOBAL_KEYS = false: per-key state (6 bytes per candidate, <= 16384 candidates per level) in LDS; true: in the
+// global scratch block (images above ~0.6 Mpx: up to 65536 candidates per level, 64 keys per thread).
+template <bool GLOBAL_TAB, bool GLOBAL_KEYS>
 __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -133,16 +132,25 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
   const int LN = d.oct_ln;
   Tab tb;
   uint32_t* s_cellpos;                                                 // [cells of the level + 1], dynamic LDS
+  const int CAP = d.oct_cand_cap;
+  uint8_t* scratch = d.oct + (size_t)il * d.oct_stride;                // [keys (GLOBAL_KEYS) | node tables (GLOBAL_TAB)]
   if constexpr (GLOBAL_TAB) {
-    tb = carve(d.oct + (size_t)il * d.oct_stride, LN);
+    tb = carve(scratch + (GLOBAL_KEYS ? 6 * (size_t)CAP : 0), LN);
     s_cellpos = reinterpret_cast<uint32_t*>(smem);
   } else {
     tb = carve(smem, LN);
     s_cellpos = reinterpret_cast<uint32_t*>(smem + (((size_t)OCT_NODE_BYTES * LN + 15) & ~size_t(15)));
   }
-  // per-key state, slot k of thread t at [k * T + t]
-  uint32_t* s_kpk = s_cellpos + ((d.oct_max_cells + 1 + 3) & ~3);       // [CAND_CAP] x | y << 12 | score << 24
-  uint16_t* s_kn = reinterpret_cast<uint16_t*>(s_kpk + CAND_CAP);        // [CAND_CAP] node of the key
+  // per-key state, slot k of thread t at [k * T + t]: packed candidate, and node id | quadrant << 14
+  uint32_t* s_kpk;                                                     // [CAP] x | y << 12 | score << 24
+  uint16_t* s_kn;                                                      // [CAP]
+  if constexpr (GLOBAL_KEYS) {
+    s_kpk = reinterpret_cast<uint32_t*>(scratch);
+    s_kn = reinterpret_cast<uint16_t*>(s_kpk + CAP);
+  } else {
+    s_kpk = s_cellpos + ((d.oct_max_cells + 1 + 3) & ~3);
+    s_kn = reinterpret_cast<uint16_t*>(s_kpk + CAP);
+  }
   const int N = d.feat[level];
   const int cell0 = d.lvl_cell0[level], cell1 = d.lvl_cell0[level + 1];
   const int ncell = cell1 - cell0;
@@ -165,9 +173,9 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
     if (t == 0) {
       s_cellpos[ncell] = (uint32_t)total;
       d.lvl_ncand[il] = (int)total;
-      if (total > (u64)CAND_CAP) atomicOr(&d.status[img], 1);
+      if (total > (u64)CAP) atomicOr(&d.status[img], 1);
     }
-    M = (int)min(total, (u64)CAND_CAP);
+    M = (int)min(total, (u64)CAP);
     if (t < 64) s_root[t] = 0;
   }
   __syncthreads();
@@ -280,16 +288,15 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
     }
     __syncthreads();
     // ---------------- key pass 1: quadrant counts of the divided nodes ----------------
-    uint32_t kq = 0;
     {
       unsigned run_pi = NONE;
       u64 run_c = 0;
       for (int k = 0; k < nk; ++k) {
-        const int j = s_kn[k * T + t];
+        const int j = s_kn[k * T + t] & 0x3FFF;
         const uint32_t v = s_kpk[k * T + t];
         const unsigned pi = tb.pidx[j];
         const int q = quadrant(pk_x(v), pk_y(v), bx[j]);
-        kq |= (uint32_t)q << (2 * k);
+        s_kn[k * T + t] = (uint16_t)(j | (q << 14));                     // the quadrant rides in the top two bits
         if (pi != run_pi) {
           if (run_pi != NONE) atomicAdd(&tb.c4[run_pi], run_c);
           run_pi = pi; run_c = 0;
@@ -380,9 +387,9 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
     __syncthreads();
     // ---------------- key pass 2: rename every key's node ----------------
     for (int k = 0; k < nk; ++k) {
-      const int j = s_kn[k * T + t];
+      const int kn = s_kn[k * T + t];
+      const int j = kn & 0x3FFF, q = kn >> 14;
       const unsigned pi = tb.pidx[j];
-      const int q = (int)((kq >> (2 * k)) & 3);
       s_kn[k * T + t] = (pi != NONE) ? (uint16_t)f16(tb.kid4[pi], q) : tb.newpos[j];
     }
     __syncthreads();
@@ -404,8 +411,8 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
       int run_j = -1;
       uint32_t run_best = 0;
       for (int k = 0; k < nk; ++k) {
-        const int j = s_kn[k * T + t];
-        const uint32_t v = (pk_r(s_kpk[k * T + t]) << 14) | (uint32_t)(0x3FFF - (p0 + k));
+        const int j = s_kn[k * T + t] & 0x3FFF;          // (quadrant bits may be left over when the loop ended on a capacity break)
+        const uint32_t v = (pk_r(s_kpk[k * T + t]) << 16) | (uint32_t)(0xFFFF - (p0 + k));
         if (j != run_j) {
           if (run_j >= 0) atomicMax(&best[run_j], run_best);
           run_j = j; run_best = 0;
@@ -417,9 +424,9 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(OrbDev d)
     __syncthreads();
     const int nOut = min(nNodes, SEL_CAP);
     for (int k = 0; k < nk; ++k) {
-      const int j = s_kn[k * T + t];
+      const int j = s_kn[k * T + t] & 0x3FFF;
       const uint32_t c = s_kpk[k * T + t];
-      if (j < nOut && best[j] == ((pk_r(c) << 14) | (uint32_t)(0x3FFF - (p0 + k)))) sel[j] = c;
+      if (j < nOut && best[j] == ((pk_r(c) << 16) | (uint32_t)(0xFFFF - (p0 + k)))) sel[j] = c;
     }
     if (t == 0) {
       *sel_count = nOut;
@@ -437,8 +444,9 @@ void launch_octree(const OrbDev& o, hipStream_t s)
   // all level-0 workgroups first and spreads them over the whole chip.
   const dim3 grid(o.I, o.detect_only ? 1 : o.nlevels);
   const size_t tab = o.oct_global_tab ? 0 : (((size_t)OCT_NODE_BYTES * o.oct_ln + 15) & ~size_t(15));
-  const size_t lds = tab + 4 * (size_t)((o.oct_max_cells + 1 + 3) & ~3) + 6 * (size_t)CAND_CAP;
-  auto kern = o.oct_global_tab ? k_octree<true> : k_octree<false>;
+  const size_t lds = tab + 4 * (size_t)((o.oct_max_cells + 1 + 3) & ~3) + (o.oct_global_keys ? 0 : 6 * (size_t)o.oct_cand_cap);
+  void (*kern)(OrbDev) = o.oct_global_tab ? (o.oct_global_keys ? k_octree<true, true> : k_octree<true, false>)
+                                          : (o.oct_global_keys ? k_octree<false, true> : k_octree<false, false>);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, grid, dim3(OCT_THREADS), lds, s, o);

@@ -894,12 +894,17 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
     d.oct_ln = (maxN + 8 + 7) & ~7;
     d.oct_max_cells = 1;
     for (int l = 0; l < nlevels; ++l) d.oct_max_cells = std::max(d.oct_max_cells, d.lvl_cell0[l + 1] - d.lvl_cell0[l]);
-    if (4 * (size_t)(d.oct_max_cells + 8) + 6 * (size_t)CAND_CAP > (size_t)OCT_LDS_BUDGET) {
+    // per-key state: in LDS for images up to ~0.6 Mpx (16384 candidates per level), else in global scratch
+    d.oct_global_keys = (size_t)d.lvl_rows[0] * d.lvl_cols[0] > 600000;
+    d.oct_cand_cap = d.oct_global_keys ? CAND_CAP_BIG : CAND_CAP;
+    const size_t key_lds = d.oct_global_keys ? 0 : 6 * (size_t)CAND_CAP;
+    if (4 * (size_t)(d.oct_max_cells + 8) + key_lds > (size_t)OCT_LDS_BUDGET) {
       ctx->set_error("ssx_orb: %d grid cells on one level exceed the octree workgroup's LDS", d.oct_max_cells);
       return SSX_ERR_UNSUPPORTED;
     }
-    d.oct_global_tab = (size_t)OCT_NODE_BYTES * d.oct_ln + 4 * (size_t)(d.oct_max_cells + 8) + 6 * (size_t)CAND_CAP > (size_t)OCT_LDS_BUDGET;
-    d.oct_stride = d.oct_global_tab ? (((size_t)OCT_NODE_BYTES * d.oct_ln + 255) & ~size_t(255)) : 0;
+    d.oct_global_tab = (size_t)OCT_NODE_BYTES * d.oct_ln + 4 * (size_t)(d.oct_max_cells + 8) + key_lds > (size_t)OCT_LDS_BUDGET;
+    d.oct_stride = ((d.oct_global_keys ? 6 * (size_t)CAND_CAP_BIG : 0) + (d.oct_global_tab ? (size_t)OCT_NODE_BYTES * d.oct_ln : 0) + 255) & ~size_t(255);
+    if (!d.oct_global_keys && !d.oct_global_tab) d.oct_stride = 0;
   }
   {
     int tile = 16, npx = 1, t0 = 0;

@@ -11,7 +11,8 @@ namespace ssxorb {
 
 constexpr int MAX_LEVELS = 8;
 constexpr int CELL_CAP = 256;      // candidates kept per grid cell (31x32 interior: NMS leaves < 250)
-constexpr int CAND_CAP = 16384;    // candidates per (image, level) fed to the octree
+constexpr int CAND_CAP = 16384;    // candidates per (image, level) the octree keeps in LDS (16 per thread)
+constexpr int CAND_CAP_BIG = 65536;  // ... and in global scratch for larger images (64 per thread)
 constexpr int SEL_CAP = 4096;      // selected keypoints per (image, level)
 constexpr int EDGE_THRESHOLD = 19; // orbextractor.cpp:13
 constexpr int OCT_THREADS = 1024;
@@ -62,6 +63,8 @@ struct OrbDev {
   uint8_t* oct;                  // [I][nlevels][oct_stride] (only with oct_global_tab)
   size_t oct_stride;
   int oct_max_cells;             // most grid cells on one level (cell-prefix array in LDS)
+  int oct_cand_cap;              // candidates per (image, level): CAND_CAP (keys in LDS) or CAND_CAP_BIG (keys in global scratch)
+  int oct_global_keys;
   int oct_ln;                    // node-table capacity: max(N, 256) + 8 over the levels (N = per-level budget)
   int oct_global_tab;            // node tables in global scratch (budgets too large for LDS)
   int* lvl_ncand;                // [I][nlevels]

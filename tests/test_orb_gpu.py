@@ -246,15 +246,14 @@ def test_matcher_and_triangulation_edge_cases(ctx, po, pair_small):
     np.testing.assert_allclose(xyz[m], o["xyz"][m], rtol=1e-9, atol=1e-9)
 
 
-def test_other_image_sizes_and_loud_capacity_limit(ctx, po):
-    """641x479 and 1280x720 are bit-exact; a densely textured 1920x1080 frame has more than 16384 FAST candidates on
-    level 0 (the octree's per-level capacity, 16 keys per thread x 1024 threads) and must FAIL LOUDLY, never truncate"""
-    from ssvio_amd._lib import SsxError
-    for h, w, nb in ((479, 641, 1500), (720, 1280, 6000)):
+def test_other_image_sizes(ctx, po):
+    """641x479 (octree keys in LDS, <= 16384 candidates per level) and 1280x720 / 1920x1080 (keys in the global scratch
+    block, <= 65536 candidates per level) are all bit-exact"""
+    for h, w, nb in ((479, 641, 1500), (720, 1280, 6000), (1080, 1920, 12000)):
         L = make_stereo_pair(seed=2, h=h, w=w, n_blobs=nb)[0]
         gk, gd = sorb.ORBextractor(ctx, nfeatures=2000).DetectAndCompute(L)
         ok, od = po.orb_extract(L, prm=po.orb_params(nfeatures=2000))
         assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
-    big = make_stereo_pair(seed=2, h=1080, w=1920, n_blobs=12000)[0]
-    with pytest.raises(SsxError, match="capacity"):
-        sorb.ORBextractor(ctx, nfeatures=2000).DetectAndCompute(big)
+        gdet = sorb.ORBextractor(ctx, nfeatures=300).Detect(L)
+        odet = po.orb_detect(L, prm=po.orb_params(nfeatures=300))
+        assert gdet.tobytes() == odet.tobytes()
