@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU (batch per launch)")
-    ap.add_argument("--cpu-sample", type=int, default=12, help="stereo pairs timed on the CPU baseline")
+    ap.add_argument("--cpu-sample", type=int, default=40, help="stereo pairs timed on the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
