@@ -150,11 +150,17 @@ __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_eleme
 __device__ __forceinline__ int fast_score(const uint8_t* c, int p, int t)
 {
   const short v = (short)c[0];
+  // seven row bases (one add each), the column offsets 0..6 ride in the load instructions' immediate field
+  constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+  const uint8_t* rowp[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) rowp[j] = c - 3 + (j - 3) * p;
   s16x2 D[12];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const short r0 = (short)c[c_ring_dx[k] + c_ring_dy[k] * p];
-    const short r1 = (short)c[c_ring_dx[k + 8] + c_ring_dy[k + 8] * p];
+    const short r0 = (short)rowp[RDY[k] + 3][RDX[k] + 3];
+    const short r1 = (short)rowp[RDY[k + 8] + 3][RDX[k + 8] + 3];
     D[k] = s16x2{v, v} - s16x2{r0, r1};
   }
   // index j >= 8 of any packed array is the half swap of index j - 8
@@ -207,10 +213,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
   uint8_t* sImg = smem + (size_t)wave * o.fast_lds_per_wave;
   uint8_t* sScore = sImg + o.fast_tile_bytes;
   uint16_t* sList = reinterpret_cast<uint16_t*>(sScore + o.fast_tile_bytes);   // compacted pixel indices
-  const float inv_ndw = 1.0f / (float)ndw;
-  for (int i = lane; i < h * ndw; i += 64) {
-    const int y = (int)(((float)i + 0.5f) * inv_ndw), xd = i - y * ndw;   // exact: i < 1368, ndw <= 19
-    reinterpret_cast<uint32_t*>(sImg)[i] = *reinterpret_cast<const uint32_t*>(lvl + (size_t)(c.y0 + y) * pitch + tx0 + 4 * xd);
+  {
+    // lane -> (row, dword) once; every further round advances by 64 dwords = q64 rows + r64 dwords (wave-uniform)
+    const float inv_ndw = 1.0f / (float)ndw;
+    const int y0l = (int)(((float)lane + 0.5f) * inv_ndw);           // exact: lane < 64, ndw <= 19
+    int xd = lane - y0l * ndw;
+    const int q64 = 64 / ndw, r64 = 64 - q64 * ndw;
+    const uint8_t* src = lvl + (size_t)(c.y0 + y0l) * pitch + tx0 + 4 * xd;
+    const int step = q64 * pitch + 4 * r64, wrap = pitch - 4 * ndw;
+    for (int i = lane; i < h * ndw; i += 64) {
+      reinterpret_cast<uint32_t*>(sImg)[i] = *reinterpret_cast<const uint32_t*>(src);
+      xd += r64;
+      src += step;
+      if (xd >= ndw) { xd -= ndw; src += wrap; }
+    }
   }
   const int iw = w - 6, ih = h - 6;                // cv::FAST ignores a 3-px border of the ROI
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
