@@ -46,8 +46,8 @@ __constant__ int c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 
 // so plan() tabulates them once per level on the host with the exact float sequence of cv::resize.  One thread =
 // 4 destination pixels of one row = one QUAD row of the column table (ResizeQuad): the 8 source bytes starting at
 // s0 (ONE unaligned 8-byte load per source row) hold every left/right neighbour of the quad, two v_perm_b32 with
-// the tabulated selectors gather them, then the integer blend and one aligned dword store.  A 64x4 block covers
-// 256 columns x 4 rows.  WIDE8 = false (a level whose quads span more than 8 source bytes, scale factor > 2)
+// the tabulated selectors gather them, then the integer blend and one aligned dword store; a thread does this
+// for RS_ROWS consecutive rows with all row loads in flight together.  A 64x4 block covers 256 columns x 16 rows.  WIDE8 = false (a level whose quads span more than 8 source bytes, scale factor > 2)
 // falls back to byte loads.
 struct ResizeQuad {          // 32 bytes
   uint32_t s0;               // first source column of the quad
@@ -56,48 +56,61 @@ struct ResizeQuad {          // 32 bytes
   uint32_t w[4];             // a0 | a1 << 16 per destination column (0 for columns past dcols)
 };
 
+constexpr int RS_ROWS = 4;   // destination rows per thread: their 8 source-row loads are issued together
 template <bool WIDE8>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base,
                                                 size_t img_stride_bytes, int spitch, int drows, int dcols, int dpitch,
                                                 const ResizeQuad* __restrict__ xtab, const uint2* __restrict__ ytab)
 {
   const int q = blockIdx.x * 64 + threadIdx.x;      // quad of destination columns
-  const int dy = blockIdx.y * 4 + threadIdx.y;
-  if (dy >= drows || 4 * q >= dcols) return;
+  // a wave = RS_ROWS consecutive destination rows of one quad column range: row tables and bases are scalar
+  const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_ROWS;
+  if (dy0 >= drows || 4 * q >= dcols) return;
   const uint8_t* src = src_base + (size_t)blockIdx.z * img_stride_bytes;
   uint8_t* dst = dst_base + (size_t)blockIdx.z * img_stride_bytes;
-  const uint2 yt = ytab[dy];
   const uint4 ta = reinterpret_cast<const uint4*>(xtab)[2 * q], tw = reinterpret_cast<const uint4*>(xtab)[2 * q + 1];
-  const uint8_t* r0 = src + (size_t)(yt.x & 0xFFFFu) * spitch + ta.x;
-  const uint8_t* r1 = src + (size_t)(yt.x >> 16) * spitch + ta.x;
-  const int b0 = (int)(yt.y & 0xFFFFu), b1 = (int)(yt.y >> 16);
-  uint32_t p00, p01, p10, p11;       // row 0 left / right neighbours, row 1 left / right (4 bytes each)
-  if (WIDE8) {
-    uint2 w0, w1;
-    __builtin_memcpy(&w0, r0, 8);
-    __builtin_memcpy(&w1, r1, 8);
-    p00 = __builtin_amdgcn_perm(w0.y, w0.x, ta.y); p01 = __builtin_amdgcn_perm(w0.y, w0.x, ta.z);
-    p10 = __builtin_amdgcn_perm(w1.y, w1.x, ta.y); p11 = __builtin_amdgcn_perm(w1.y, w1.x, ta.z);
-  } else {
-    p00 = p01 = p10 = p11 = 0;
+  // the kernel is bound by dependent memory round trips (table -> source rows), not by bandwidth or VALU: issue
+  // all source-row loads of the RS_ROWS rows before the first use
+  uint32_t p00[RS_ROWS], p01[RS_ROWS], p10[RS_ROWS], p11[RS_ROWS];
+  int b0[RS_ROWS], b1[RS_ROWS];
+  uint2 w0[RS_ROWS], w1[RS_ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int o0 = (ta.y >> (8 * k)) & 0xFF, o1 = (ta.z >> (8 * k)) & 0xFF;
-      p00 |= (uint32_t)r0[o0] << (8 * k); p01 |= (uint32_t)r0[o1] << (8 * k);
-      p10 |= (uint32_t)r1[o0] << (8 * k); p11 |= (uint32_t)r1[o1] << (8 * k);
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const uint2 yt = ytab[min(dy0 + r, drows - 1)];
+    b0[r] = (int)(yt.y & 0xFFFFu); b1[r] = (int)(yt.y >> 16);
+    const uint8_t* r0 = src + (size_t)(yt.x & 0xFFFFu) * spitch + ta.x;
+    const uint8_t* r1 = src + (size_t)(yt.x >> 16) * spitch + ta.x;
+    if (WIDE8) {
+      __builtin_memcpy(&w0[r], r0, 8);
+      __builtin_memcpy(&w1[r], r1, 8);
+    } else {
+      p00[r] = p01[r] = p10[r] = p11[r] = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int o0 = (ta.y >> (8 * k)) & 0xFF, o1 = (ta.z >> (8 * k)) & 0xFF;
+        p00[r] |= (uint32_t)r0[o0] << (8 * k); p01[r] |= (uint32_t)r0[o1] << (8 * k);
+        p10[r] |= (uint32_t)r1[o0] << (8 * k); p11[r] |= (uint32_t)r1[o1] << (8 * k);
+      }
     }
   }
   const uint32_t wa[4] = {tw.x, tw.y, tw.z, tw.w};
-  uint32_t out = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int a0 = (int)(wa[k] & 0xFFFFu), a1 = (int)(wa[k] >> 16);
-    const int S0 = (int)((p00 >> (8 * k)) & 0xFF) * a0 + (int)((p01 >> (8 * k)) & 0xFF) * a1;
-    const int S1 = (int)((p10 >> (8 * k)) & 0xFF) * a0 + (int)((p11 >> (8 * k)) & 0xFF) * a1;
-    const uint32_t v = (uint32_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
-    out |= (v & 0xFFu) << (8 * k);
+  for (int r = 0; r < RS_ROWS; ++r) {
+    if (WIDE8) {
+      p00[r] = __builtin_amdgcn_perm(w0[r].y, w0[r].x, ta.y); p01[r] = __builtin_amdgcn_perm(w0[r].y, w0[r].x, ta.z);
+      p10[r] = __builtin_amdgcn_perm(w1[r].y, w1[r].x, ta.y); p11[r] = __builtin_amdgcn_perm(w1[r].y, w1[r].x, ta.z);
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int a0 = (int)(wa[k] & 0xFFFFu), a1 = (int)(wa[k] >> 16);
+      const int S0 = (int)((p00[r] >> (8 * k)) & 0xFF) * a0 + (int)((p01[r] >> (8 * k)) & 0xFF) * a1;
+      const int S1 = (int)((p10[r] >> (8 * k)) & 0xFF) * a0 + (int)((p11[r] >> (8 * k)) & 0xFF) * a1;
+      const uint32_t v = (uint32_t)((((b0[r] * (S0 >> 4)) >> 16) + ((b1[r] * (S1 >> 4)) >> 16) + 2) >> 2);
+      out |= (v & 0xFFu) << (8 * k);
+    }
+    if (dy0 + r < drows) *reinterpret_cast<uint32_t*>(dst + (size_t)(dy0 + r) * dpitch + 4 * q) = out;
   }
-  *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + 4 * q) = out;
 }
 
 // copy a pitched host-layout image into level 0 of the pyramid (pitch change): 8 destination bytes per thread
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
                                                      uint8_t* __restrict__ dst_base, size_t img_stride_bytes,
                                                      int rows, int cols, int dpitch)
 {
-  const int x = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
   if (x >= cols || y >= rows) return;
   const uint8_t* srow = in + (size_t)blockIdx.z * in_img_bytes + (size_t)y * in_stride;
   uint32_t w[2] = {0u, 0u};
@@ -1042,7 +1055,7 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
 static void launch_pyramid(ssx_ctx* ctx, const OrbDev& d, hipStream_t s, int images)
 {
   for (int l = 1; l < d.nlevels; ++l) {
-    const dim3 grid((d.lvl_cols[l] + 255) / 256, (d.lvl_rows[l] + 3) / 4, images);
+    const dim3 grid((d.lvl_cols[l] + 255) / 256, (d.lvl_rows[l] + 4 * RS_ROWS - 1) / (4 * RS_ROWS), images);
     auto kern = d.rs_wide8[l] ? k_resize<true> : k_resize<false>;
     for (int m = 0; m < (d.has_mask ? 2 : 1); ++m) {
       uint8_t* pyr = m ? d.maskpyr : d.pyr;
