@@ -665,8 +665,20 @@ __global__ __launch_bounds__(256) void k_orient_brief(OrbDev o)
   const int img = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   const int slot = blockIdx.x * 4 + wave;
-  int level = 0, base = 0, n = o.sel_count[img * o.nlevels];
-  while (level + 1 < o.nlevels && slot >= base + n) { base += n; ++level; n = o.sel_count[img * o.nlevels + level]; }
+  // level of this output slot: all per-level counts are fetched at once (independent scalar loads) -- a search loop
+  // that loads one count per iteration costs one dependent memory round trip per level, and this kernel is bound
+  // by exactly such round trips
+  int cnt[MAX_LEVELS];
+#pragma unroll
+  for (int l = 0; l < MAX_LEVELS; ++l) cnt[l] = l < o.nlevels ? o.sel_count[img * o.nlevels + l] : 0;
+  int level = 0, base = 0, n = cnt[0];
+#pragma unroll
+  for (int l = 1; l < MAX_LEVELS; ++l) {
+    const bool next = l < o.nlevels && level == l - 1 && slot >= base + n;
+    base = next ? base + n : base;
+    level = next ? l : level;
+    n = next ? cnt[l] : n;
+  }
   const int k = slot - base;
   if (k >= n) return;                                   // past the last level's keypoints (wave-uniform)
   if (slot >= o.out_cap) { if (lane == 0) atomicOr(&o.status[img], 4); return; }
