@@ -257,3 +257,13 @@ def test_other_image_sizes(ctx, po):
         gdet = sorb.ORBextractor(ctx, nfeatures=300).Detect(L)
         odet = po.orb_detect(L, prm=po.orb_params(nfeatures=300))
         assert gdet.tobytes() == odet.tobytes()
+
+
+def test_degenerate_small_images(ctx, po):
+    """pyramid levels that shrink below the border (no cells), images barely larger than the border: same (possibly
+    empty) result as the oracle, no error"""
+    for h, w, nl, nf in ((100, 130, 8, 500), (60, 90, 8, 200), (41, 41, 8, 50), (45, 300, 6, 300), (300, 45, 6, 300)):
+        L = make_stereo_pair(seed=3, h=h, w=w, n_blobs=max(h * w // 120, 10))[0]
+        gk, gd = sorb.ORBextractor(ctx, nfeatures=nf, nlevels=nl).DetectAndCompute(L)
+        ok, od = po.orb_extract(L, prm=po.orb_params(nfeatures=nf, nlevels=nl))
+        assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
