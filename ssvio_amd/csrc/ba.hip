@@ -1227,7 +1227,8 @@ ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, const BigDev& bd, cons
 // pose-graph optimisation).  blk_pa / blk_pb = the non-zero 6x6 blocks (free pose indices) of this rank's share of
 // the system matrix.
 ssx_status build_tile_lists(ssx_ctx* ctx, BaWorkspace* ws, const std::vector<int>& blk_pa, const std::vector<int>& blk_pb,
-                            const Comm& cm, BigDev& bd, std::vector<int>& tl_row_cnt, std::vector<int>& tl_pair_cnt)
+                            const Comm& cm, BigDev& bd, std::vector<int>& tl_row_cnt, std::vector<int>& tl_pair_cnt,
+                            std::vector<uint8_t>& tl_next_diag)
 {
   ssx_status st = SSX_OK;
   {
@@ -1278,8 +1279,13 @@ ssx_status build_tile_lists(ssx_ctx* ctx, BaWorkspace* ws, const std::vector<int
       for (int j = 0; j < k; ++j) if (pat[(size_t)k * T + j]) cols.push_back(j);
       col_ptr[k + 1] = (int)cols.size();
     }
-    tl_row_cnt.resize(T); tl_pair_cnt.resize(T);
-    for (int k = 0; k < T; ++k) { tl_row_cnt[k] = row_ptr[k + 1] - row_ptr[k]; tl_pair_cnt[k] = pair_ptr[k + 1] - pair_ptr[k]; }
+    tl_row_cnt.resize(T); tl_pair_cnt.resize(T); tl_next_diag.assign(T, 0);
+    for (int k = 0; k < T; ++k) {
+      tl_row_cnt[k] = row_ptr[k + 1] - row_ptr[k]; tl_pair_cnt[k] = pair_ptr[k + 1] - pair_ptr[k];
+      // panel k's pair list holds (k+1, k+1) iff tile (k+1, k) is non-zero: k_syrk64 then also factors panel k+1's diagonal tile
+      for (int q = pair_ptr[k]; q < pair_ptr[k + 1]; ++q)
+        if (pair_bi[q] == k + 1 && pair_bj[q] == k + 1) tl_next_diag[k] = 1;
+    }
     Layout tl;
     const size_t o_rp = tl.take(sizeof(int) * (T + 1)), o_r = tl.take(sizeof(int) * (rows.size() + 1));
     const size_t o_pp = tl.take(sizeof(int) * (T + 1)), o_pbi = tl.take(sizeof(int) * (pair_bi.size() + 1));
@@ -1422,8 +1428,9 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     attr_set = true;
   }
   std::vector<int> tl_row_cnt, tl_pair_cnt;
+  std::vector<uint8_t> tl_next_diag;
   if (d.big) {
-    st = build_tile_lists(ctx, ws, h.sblk_pa, h.sblk_pb, cm, bd, tl_row_cnt, tl_pair_cnt);
+    st = build_tile_lists(ctx, ws, h.sblk_pa, h.sblk_pb, cm, bd, tl_row_cnt, tl_pair_cnt, tl_next_diag);
     if (st != SSX_OK) return st;
   }
   // large windows: Schur blocks -> dense S (+ rhs row) -> all-reduce -> blocked Cholesky (MFMA) -> back-substitution
@@ -1442,10 +1449,11 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     }
     SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_add_lambda, dim3((bd.n + 255) / 256), dim3(256), 0, s, d, bd, lambda, dev_lambda));
     for (int kb = 0; kb < bd.T; ++kb) {
-      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(CH), 0, s, d, bd, kb));
+      if (kb == 0 || !tl_next_diag[kb - 1])   // else the previous panel's k_syrk64 has factored this diagonal tile
+        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(CH), 0, s, d, bd, kb));
       // the structurally non-zero row tiles below the panel (always the rhs row tile), then their pairs
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_trsm64, dim3(tl_row_cnt[kb]), dim3(CH), 0, s, bd, kb));
-      if (tl_pair_cnt[kb] > 0) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_syrk64, dim3(tl_pair_cnt[kb]), dim3(CH), 0, s, bd, kb));
+      if (tl_pair_cnt[kb] > 0) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_syrk64, dim3(tl_pair_cnt[kb]), dim3(CH), 0, s, d, bd, kb));
     }
     SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_backsolve, dim3(1), dim3(1024), 0, s, bd));
     const int nparts = std::min(32, (d.P + CH - 1) / CH);
