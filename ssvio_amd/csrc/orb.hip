@@ -261,20 +261,25 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
     {
       const int xs = xoff + 3, xe = xs + iw;            // interior columns of the tile
       const int qx0 = xs & ~3;
-      const int nq = (iw > 0 && ih > 0) ? ((xe - qx0 + 3) >> 2) : 0;   // quads per interior row
-      const int nitems = nq * max(ih, 0);
+      const int nq = (iw > 0 && ih > 0) ? ((xe - qx0 + 3) >> 2) : 0;   // quads per interior row (<= 18)
+      // lane -> (row inside a round, quad) ONCE: a round covers R = 64 / nq whole rows, so the quad column, its
+      // border mask and the dword index are loop invariants and a round only adds R rows
+      const int R = nq > 0 ? 64 / nq : 0;
       const float inv_nq = nq > 0 ? 1.0f / (float)nq : 0.f;
+      const int rl = (int)(((float)lane + 0.5f) * inv_nq), ql = lane - rl * nq;
+      const bool lane_on = nq > 0 && rl < R;
+      const int x4 = qx0 + 4 * (lane_on ? ql : 0);
+      bool vk[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) vk[k] = lane_on && (x4 + k >= xs) && (x4 + k < xe);
       const uint32_t t2 = (uint32_t)th | ((uint32_t)th << 16);
       const uint32_t* dw = reinterpret_cast<const uint32_t*>(sImg);
-      for (int base = 0; base < nitems; base += 64) {
-        const int item = base + lane;
-        const bool in = item < nitems;
-        const int it = in ? item : 0;
-        const int yy = (int)(((float)it + 0.5f) * inv_nq);
-        const int x4 = qx0 + 4 * (it - yy * nq);
-        const int y = 3 + yy;
-        const int ci = y * ndw + (x4 >> 2);
-        const uint32_t C0 = dw[ci - 1], C1 = dw[ci], C2 = dw[ci + 1], Tp = dw[ci - 3 * ndw], Bt = dw[ci + 3 * ndw];
+      int ci = (3 + (lane_on ? rl : 0)) * ndw + (x4 >> 2);
+      int off0 = (3 + (lane_on ? rl : 0)) * tw + x4;
+      for (int row0 = 0; row0 < ih; row0 += R, ci += R * ndw, off0 += R * tw) {
+        const bool in = lane_on && (row0 + rl < ih);
+        const int cj = in ? ci : 3 * ndw + 1;                          // a harmless address for idle lanes
+        const uint32_t C0 = dw[cj - 1], C1 = dw[cj], C2 = dw[cj + 1], Tp = dw[cj - 3 * ndw], Bt = dw[cj + 3 * ndw];
         const uint32_t Lf = __builtin_amdgcn_alignbyte(C1, C0, 1);     // pixels x-3 of the quad
         const uint32_t Rt = __builtin_amdgcn_alignbyte(C2, C1, 3);     // pixels x+3
         uint32_t flag[2];
@@ -299,12 +304,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
         unsigned long long bal[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          fk[k] = fk[k] && in && (x4 + k >= xs) && (x4 + k < xe);
+          fk[k] = fk[k] && in && vk[k];
           bal[k] = __ballot(fk[k]);
           before += __popcll(bal[k] & lt_mask);
           total += __popcll(bal[k]);
         }
-        const int off0 = y * tw + x4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (fk[k]) sList[before + mine] = (uint16_t)(off0 + k);
