@@ -314,6 +314,14 @@ SSX_API ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_
                                 int32_t next_stride, int32_t rows, int32_t cols, int32_t n, const float* prev_pts,
                                 float* next_pts, uint8_t* status, float* err, const ssx_lk_params* prm,
                                 int32_t* top_level);
+/* Frame-to-frame chaining (FrontEnd::TrackLastFrame calls LK on (last, current) every frame, frontend.cpp:156-166):
+ * the previous image is the `next` image of the last ssx_lk_track / ssx_lk_track_next call on this context, whose
+ * pyramid is still on the device -- only the new image is uploaded and reduced. Same results as ssx_lk_track on the
+ * two images; SSX_ERR_INVALID_ARG when there is no such call or the size / window / max_level changed. A context
+ * holds one chain: keep the left-right stereo LK calls of a keyframe on a second context. */
+SSX_API ssx_status ssx_lk_track_next(ssx_ctx* ctx, const uint8_t* next, int32_t next_stride, int32_t rows,
+                                     int32_t cols, int32_t n, const float* prev_pts, float* next_pts,
+                                     uint8_t* status, float* err, const ssx_lk_params* prm, int32_t* top_level);
 /* Test access to the pyramids (which = 0 previous, 1 next) and the Scharr images (int16 dx, dy interleaved) of
  * the last ssx_lk_track call. */
 SSX_API ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level, uint8_t* out, int32_t out_cap,

@@ -196,4 +196,21 @@ inline void calcOpticalFlowPyrLK(Context& ctx, const uint8_t* prevImg, int prevS
                          status.data(), err.data(), &p, nullptr));
 }
 
+// The same call for consecutive frames (TrackLastFrame): prevImg is the nextImg of the last call on ctx and is not
+// passed again -- its pyramid is still on the device (ssx_lk_track_next).
+inline void calcOpticalFlowPyrLKNext(Context& ctx, const uint8_t* nextImg, int nextStep, int rows, int cols,
+                                     const std::vector<float>& prevPts, std::vector<float>& nextPts,
+                                     std::vector<uint8_t>& status, std::vector<float>& err, int win = 11, int maxLevel = 3,
+                                     int maxCount = 30, double epsilon = 0.01, bool useInitialFlow = true)
+{
+  if (prevPts.size() != nextPts.size() || (prevPts.size() & 1)) throw std::invalid_argument("calcOpticalFlowPyrLK: point vectors");
+  const int n = (int)(prevPts.size() / 2);
+  status.assign(n, 0); err.assign(n, 0.f);
+  ssx_lk_params p;
+  ssx_lk_default_params(&p);
+  p.win = win; p.max_level = maxLevel; p.max_iters = maxCount; p.eps = epsilon; p.use_initial_flow = useInitialFlow ? 1 : 0;
+  ctx.check(ssx_lk_track_next(ctx.get(), nextImg, nextStep, rows, cols, n, prevPts.data(), nextPts.data(), status.data(),
+                              err.data(), &p, nullptr));
+}
+
 }  // namespace ssx

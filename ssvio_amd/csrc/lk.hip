@@ -53,6 +53,7 @@ struct LkWorkspace {
   LkDev dev{};
   int rows = 0, cols = 0, win = 0, max_level = -1;
   bool planned = false;
+  bool have_next = false;                // pyr[1] holds the pyramid of the last call's next image
 };
 
 void lk_ws_free(void* p)
@@ -312,37 +313,38 @@ ssx_status lk_plan(ssx_ctx* ctx, int rows, int cols, const ssx_lk_params& prm)
   ws->dev = d;
   ws->rows = rows; ws->cols = cols; ws->win = prm.win; ws->max_level = prm.max_level;
   ws->planned = true;
+  ws->have_next = false;
   return SSX_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-void ssx_lk_default_params(ssx_lk_params* p)
+// One tracking call. prev == nullptr: the previous image is the next image of the last call, whose pyramid is still
+// in pyr[1] -- the two pyramid slots swap roles and only the new image is uploaded and reduced.
+ssx_status lk_run(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const uint8_t* next, int32_t next_stride,
+                  int32_t rows, int32_t cols, int32_t n, const float* prev_pts, float* next_pts, uint8_t* status,
+                  float* err, const ssx_lk_params* prm_in, int32_t* top_level)
 {
-  if (!p) return;
-  memset(p, 0, sizeof(*p));
-  p->win = 11; p->max_level = 3; p->max_iters = 30; p->eps = 0.01; p->min_eig_threshold = 1e-4f; p->use_initial_flow = 1;
-}
-
-ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const uint8_t* next, int32_t next_stride,
-                        int32_t rows, int32_t cols, int32_t n, const float* prev_pts, float* next_pts, uint8_t* status,
-                        float* err, const ssx_lk_params* prm_in, int32_t* top_level)
-{
-  if (!ctx || !prev || !next || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return SSX_ERR_INVALID_ARG;
   ssx_lk_params prm;
   if (prm_in) prm = *prm_in; else ssx_lk_default_params(&prm);
-  if (prev_stride < cols || next_stride < cols) { ctx->set_error("ssx_lk: stride smaller than the image width"); return SSX_ERR_INVALID_ARG; }
+  if ((prev && prev_stride < cols) || next_stride < cols) { ctx->set_error("ssx_lk: stride smaller than the image width"); return SSX_ERR_INVALID_ARG; }
+  const bool reuse = prev == nullptr;
+  if (reuse) {
+    LkWorkspace* w = lk_ws(ctx);
+    if (!w->planned || !w->have_next || w->rows != rows || w->cols != cols || w->win != prm.win || w->max_level != prm.max_level) {
+      ctx->set_error("ssx_lk_track_next: no previous ssx_lk_track call with the same image size, window and max_level on this context");
+      return SSX_ERR_INVALID_ARG;
+    }
+  }
   ssx_status st = lk_plan(ctx, rows, cols, prm);
   if (st != SSX_OK) return st;
   LkWorkspace* ws = lk_ws(ctx);
+  if (reuse) std::swap(ws->dev.pyr[0], ws->dev.pyr[1]);
+  ws->have_next = false;
   LkDev d = ws->dev;
   hipStream_t s = ctx->stream;
-  // inputs: two images + points through pinned staging
+  // inputs: the image(s) + points through pinned staging
   const size_t img_bytes = (size_t)rows * cols;
   Layout io;
-  const size_t o_i0 = io.take(img_bytes), o_i1 = io.take(img_bytes);
+  const size_t o_i1 = io.take(img_bytes), o_i0 = reuse ? 0 : io.take(img_bytes);
   const size_t o_pp = io.take(sizeof(float) * 2 * (size_t)std::max(n, 1));
   const size_t o_np = io.take(sizeof(float) * 2 * (size_t)std::max(n, 1));
   const size_t in_bytes = io.off;
@@ -352,13 +354,13 @@ ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, 
   SSX_HIP_TRY(ctx, ws->stage.reserve(io.off));
   char* hs = ws->stage.as<char>();
   for (int y = 0; y < rows; ++y) {
-    memcpy(hs + o_i0 + (size_t)y * cols, prev + (size_t)y * prev_stride, cols);
+    if (!reuse) memcpy(hs + o_i0 + (size_t)y * cols, prev + (size_t)y * prev_stride, cols);
     memcpy(hs + o_i1 + (size_t)y * cols, next + (size_t)y * next_stride, cols);
   }
   if (n > 0) { memcpy(hs + o_pp, prev_pts, sizeof(float) * 2 * n); memcpy(hs + o_np, next_pts, sizeof(float) * 2 * n); }
   char* db = ws->io.as<char>();
   SSX_HIP_TRY(ctx, hipMemcpyAsync(db, hs, in_bytes, hipMemcpyHostToDevice, s));
-  for (int which = 0; which < 2; ++which) {
+  for (int which = reuse ? 1 : 0; which < 2; ++which) {
     const dim3 g0((d.cols[0] + 2 * d.pad + 255) / 256, d.rows[0] + 2 * d.pad);
     hipLaunchKernelGGL(k_lk_pad_level0, g0, dim3(256), 0, s, (const uint8_t*)(db + (which ? o_i1 : o_i0)), cols, d, which);
     for (int l = 1; l < d.levels; ++l) {
@@ -384,6 +386,7 @@ ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, 
     SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_np, db + o_np, io.off - o_np, hipMemcpyDeviceToHost, s));
   }
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  ws->have_next = true;
   if (n > 0) {
     memcpy(next_pts, hs + o_np, sizeof(float) * 2 * n);
     memcpy(status, hs + o_st, (size_t)n);
@@ -391,6 +394,33 @@ ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, 
   }
   if (top_level) *top_level = d.levels - 1;
   return SSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ssx_lk_default_params(ssx_lk_params* p)
+{
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->win = 11; p->max_level = 3; p->max_iters = 30; p->eps = 0.01; p->min_eig_threshold = 1e-4f; p->use_initial_flow = 1;
+}
+
+ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const uint8_t* next, int32_t next_stride,
+                        int32_t rows, int32_t cols, int32_t n, const float* prev_pts, float* next_pts, uint8_t* status,
+                        float* err, const ssx_lk_params* prm_in, int32_t* top_level)
+{
+  if (!ctx || !prev || !next || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return SSX_ERR_INVALID_ARG;
+  return lk_run(ctx, prev, prev_stride, next, next_stride, rows, cols, n, prev_pts, next_pts, status, err, prm_in, top_level);
+}
+
+ssx_status ssx_lk_track_next(ssx_ctx* ctx, const uint8_t* next, int32_t next_stride, int32_t rows, int32_t cols, int32_t n,
+                             const float* prev_pts, float* next_pts, uint8_t* status, float* err,
+                             const ssx_lk_params* prm_in, int32_t* top_level)
+{
+  if (!ctx || !next || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return SSX_ERR_INVALID_ARG;
+  return lk_run(ctx, nullptr, 0, next, next_stride, rows, cols, n, prev_pts, next_pts, status, err, prm_in, top_level);
 }
 
 // test / debug access to the pyramid and derivative images of the last ssx_lk_track call

@@ -28,10 +28,15 @@ def calcOpticalFlowPyrLK(ctx: Context, prev, nxt, prev_pts, next_pts=None, winSi
                          epsilon=0.01, minEigThreshold=1e-4):
     """cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(win, win), maxLevel,
     TermCriteria(COUNT+EPS, maxCount, epsilon), next_pts is None ? 0 : OPTFLOW_USE_INITIAL_FLOW, minEigThreshold).
-    Returns (next_pts [n,2] f32, status [n] u8, err [n] f32, top_level)."""
-    prev = _img(prev); nxt = _img(nxt)
-    if prev.shape != nxt.shape:
-        raise ValueError("calcOpticalFlowPyrLK: the two images must have the same size")
+    Returns (next_pts [n,2] f32, status [n] u8, err [n] f32, top_level).
+    prev=None chains frames (ssx_lk_track_next): the previous image is the `nxt` image of the last call on ctx,
+    whose pyramid is still on the device."""
+    nxt = _img(nxt)
+    chain = prev is None
+    if not chain:
+        prev = _img(prev)
+        if prev.shape != nxt.shape:
+            raise ValueError("calcOpticalFlowPyrLK: the two images must have the same size")
     pp = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
     use_init = next_pts is not None
     npts = np.ascontiguousarray(next_pts, dtype=np.float32).reshape(-1, 2).copy() if use_init else pp.copy()
@@ -43,6 +48,12 @@ def calcOpticalFlowPyrLK(ctx: Context, prev, nxt, prev_pts, next_pts=None, winSi
     top = C.c_int32(0)
     lib = ctx.lib
     lib.ssx_lk_track.restype = C.c_int
+    lib.ssx_lk_track_next.restype = C.c_int
+    if chain:
+        ctx.check(lib.ssx_lk_track_next(ctx.handle, nxt.ctypes.data_as(u8_p), nxt.strides[0], nxt.shape[0], nxt.shape[1], n,
+                                        pp.ctypes.data_as(f32_p), npts.ctypes.data_as(f32_p), status.ctypes.data_as(u8_p),
+                                        err.ctypes.data_as(f32_p), C.byref(prm), C.byref(top)))
+        return npts, status, err, top.value
     ctx.check(lib.ssx_lk_track(ctx.handle, prev.ctypes.data_as(u8_p), prev.strides[0], nxt.ctypes.data_as(u8_p), nxt.strides[0],
                                prev.shape[0], prev.shape[1], n, pp.ctypes.data_as(f32_p), npts.ctypes.data_as(f32_p),
                                status.ctypes.data_as(u8_p), err.ctypes.data_as(f32_p), C.byref(prm), C.byref(top)))

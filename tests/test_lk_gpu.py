@@ -93,3 +93,32 @@ def test_edge_cases_bit_exact(ctx, po):
         lk.calcOpticalFlowPyrLK(ctx, L, R, pts, pts, winSize=10)          # even window
     with pytest.raises(ValueError):
         lk.calcOpticalFlowPyrLK(ctx, L, R[:50], pts)
+
+
+def test_chained_tracking_reuses_the_previous_pyramid(ctx, po):
+    """ssx_lk_track_next: frame t -> t+1 with the pyramid of frame t kept from the previous call; same bits as the
+    two-image call and as the oracle, over a 4-frame sequence; refused without a matching previous call"""
+    from ssvio_amd import Context
+    from ssvio_amd._lib import SsxError
+    from ssvio_amd.synth import make_lateral_sequence
+    frames = [f[0] for f in make_lateral_sequence(n_frames=4, seed=2)[0]]
+    pts = _points(po, frames[0], 600)
+    fresh = Context(0)
+    with pytest.raises(SsxError):
+        lk.calcOpticalFlowPyrLK(fresh, None, frames[1], pts)              # nothing to chain to
+    g = lk.calcOpticalFlowPyrLK(fresh, frames[0], frames[1], pts)
+    o = po.lk_track(frames[0], frames[1], pts, prm=po.lk_params(use_initial_flow=0))
+    assert _same(g[0], o[0]) and _same(g[1], o[1])
+    for t in (1, 2):
+        keep = g[1] > 0
+        pts = g[0][keep]
+        g = lk.calcOpticalFlowPyrLK(fresh, None, frames[t + 1], pts)
+        o = po.lk_track(frames[t], frames[t + 1], pts, prm=po.lk_params(use_initial_flow=0))
+        assert _same(g[0], o[0]) and _same(g[1], o[1]) and _same(g[2], o[2]), t
+        assert np.array_equal(lk.stage_level(fresh, 0, 2), po.lk_pyr_down(po.lk_pyr_down(frames[t])))
+        assert (g[1] > 0).mean() > 0.8
+    with pytest.raises(SsxError):
+        lk.calcOpticalFlowPyrLK(fresh, None, frames[3], pts, winSize=7)   # other window: the kept pyramid does not fit
+    with pytest.raises(SsxError):
+        lk.calcOpticalFlowPyrLK(fresh, None, frames[3][:100], pts)        # other size
+    fresh.close()

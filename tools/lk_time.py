@@ -14,3 +14,7 @@ t = time.perf_counter(); N = 20
 for _ in range(N): r = lk.calcOpticalFlowPyrLK(ctx, L, R, pts, pts)
 dt = (time.perf_counter() - t) / N
 print(f"points {len(pts)} tracked {int(r[1].sum())} ms/call {dt*1e3:.3f} (host images in, results out)")
+t = time.perf_counter()
+for i in range(N): r2 = lk.calcOpticalFlowPyrLK(ctx, None, L if i & 1 else R, pts, pts)
+dt2 = (time.perf_counter() - t) / N
+print(f"chained (ssx_lk_track_next, previous pyramid kept): ms/call {dt2*1e3:.3f}")
