@@ -78,5 +78,39 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# ---- host layer (ssvio_amd/host): plain C++17 over the C ABI, built with g++ -------------------------------------
+HOST = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HOST, "libssx_host.so")
+HOST_EXE = os.path.join(HOST, "ssx_run_kitti")
+HOST_LIB_SRCS = ["dataset.cpp", "map.cpp", "frontend.cpp", "backend.cpp", "system.cpp", "ssx_compute.cpp"]
+HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+
+
+def build_host(force: bool = False):
+    """libssx_host.so (data model, map, front-end / backend state machines, KITTI + PNG input, Compute on libssx.so)
+    and the ssx_run_kitti executable.  Returns (library, executable)."""
+    lib = build(force=False)
+    deps = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".hpp"))]
+    deps += [os.path.join(CSRC, "se3.hpp"), os.path.join(HERE, "..", "include", "ssx.h"), os.path.join(HERE, "..", "include", "ssx_shim.hpp"),
+             os.path.abspath(__file__), lib]
+    newest = max(os.path.getmtime(d) for d in deps)
+    if not force and all(os.path.exists(f) and os.path.getmtime(f) >= newest for f in (HOST_LIB, HOST_EXE)):
+        return HOST_LIB, HOST_EXE
+    cxx = shutil.which("g++")
+    if not cxx:
+        raise RuntimeError("g++ not found: the host layer cannot be built")
+    rpath = ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [cxx, *HOST_FLAGS, "-shared", *[os.path.join(HOST, f) for f in HOST_LIB_SRCS], lib, "-lz", *rpath, "-o", HOST_LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on the host library:\n{r.stderr[-6000:]}")
+    cmd = [cxx, *HOST_FLAGS, os.path.join(HOST, "run_kitti.cpp"), HOST_LIB, lib, "-lz", *rpath, "-o", HOST_EXE]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on ssx_run_kitti:\n{r.stderr[-6000:]}")
+    return HOST_LIB, HOST_EXE
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(*build_host(force="--force" in sys.argv))

@@ -1,0 +1,94 @@
+// ssvio_amd/host/run_kitti.cpp -- headless equivalent of the reference's test_system
+// (/root/reference/test/test_system.cpp:18-53): load a KITTI-layout stereo sequence, feed every pair to System::RunStep,
+// save the keyframe trajectory in TUM format.  Same two flags (gflags spelling), plus a frame limit and an output path.
+//
+//   ssx_run_kitti --config_yaml_path=cfg.yaml --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=out.txt] [--device=0]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "system.hpp"
+
+namespace {
+
+bool flag(const char* arg, const char* name, std::string& out)
+{
+  std::string a(arg);
+  while (!a.empty() && a[0] == '-') a.erase(0, 1);
+  const size_t n = std::strlen(name);
+  if (a.compare(0, n, name) != 0 || a.size() <= n || a[n] != '=') return false;
+  out = a.substr(n + 1);
+  return true;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+  std::string config, dataset, max_frames_s, trajectory, device_s;
+  for (int i = 1; i < argc; ++i) {
+    if (flag(argv[i], "config_yaml_path", config) || flag(argv[i], "kitti_dataset_path", dataset) || flag(argv[i], "max_frames", max_frames_s) ||
+        flag(argv[i], "trajectory", trajectory) || flag(argv[i], "device", device_s))
+      continue;
+    std::fprintf(stderr, "unknown argument %s\n", argv[i]);
+    return 2;
+  }
+  if (config.empty() || dataset.empty()) {
+    std::fprintf(stderr, "usage: %s --config_yaml_path=<yaml> --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=<tum file>] [--device=0]\n",
+                 argv[0]);
+    return 2;
+  }
+  using namespace ssx::host;
+  using clk = std::chrono::steady_clock;
+  try {
+    std::vector<std::string> left_paths, right_paths;
+    std::vector<double> timestamps;
+    LoadKittiImagesTimestamps(dataset, left_paths, right_paths, timestamps);
+    size_t num_images = left_paths.size();
+    if (!max_frames_s.empty()) num_images = std::min(num_images, (size_t)std::atol(max_frames_s.c_str()));
+    std::printf("Num Images: %zu\n", num_images);
+
+    System system(config, nullptr, device_s.empty() ? 0 : std::atoi(device_s.c_str()));
+    double t_io = 0, t_step = 0;
+    for (size_t ni = 0; ni < num_images; ++ni) {
+      const auto t0 = clk::now();
+      ImagePtr left = imread_gray(left_paths[ni]), right = imread_gray(right_paths[ni]);
+      if (left->empty() || right->empty()) {
+        std::fprintf(stderr, "Failed to load image at: %s\n", (left->empty() ? left_paths[ni] : right_paths[ni]).c_str());
+        return 1;
+      }
+      const auto t1 = clk::now();
+      system.RunStep(left, right, timestamps[ni]);
+      const auto t2 = clk::now();
+      t_io += std::chrono::duration<double>(t1 - t0).count();
+      t_step += std::chrono::duration<double>(t2 - t1).count();
+      if (ni % 100 == 99) std::printf("Has processed %zu frames.\n", ni + 1);
+    }
+    system.SaveTrajectoryTUM(trajectory);
+
+    const StageTimes& st = system.frontend().times();
+    const Backend::Stats& bs = system.backend().stats();
+    const char* status[] = {"INITING", "TRACKING_GOOD", "TRACKING_BAD", "LOST"};
+    std::printf("frames %zu  keyframes %zu  map points %zu  final status %s\n", num_images, system.map().GetAllKeyFrames().size(),
+                system.map().GetAllMapPoints().size(), status[(int)system.frontend().status()]);
+    std::printf("RunStep %.3f ms/frame (%.1f frames/s); image decode %.3f ms/frame\n", 1e3 * t_step / std::max<size_t>(num_images, 1),
+                num_images / std::max(t_step, 1e-9), 1e3 * t_io / std::max<size_t>(num_images, 1));
+    auto line = [](const char* name, double s, long n) {
+      if (n) std::printf("  %-24s %6ld calls  %8.3f ms/call\n", name, n, 1e3 * s / n);
+    };
+    line("Detect", st.detect, st.n_detect);
+    line("LK last -> current", st.lk_temporal, st.n_lk_temporal);
+    line("LK left -> right", st.lk_stereo, st.n_lk_stereo);
+    line("pose-only LM", st.pose_only, st.n_pose_only);
+    line("triangulation", st.triangulate, st.n_triangulate);
+    line("keyframe insert + BA", st.bundle_adjust, st.n_bundle_adjust);
+    std::printf("  local BA: %ld windows, %ld LM iterations, %ld edges, %ld outlier edges\n", bs.windows, bs.lm_iterations, bs.edges, bs.outlier_edges);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "fatal: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

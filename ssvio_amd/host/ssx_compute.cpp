@@ -1,0 +1,76 @@
+// ssvio_amd/host/ssx_compute.cpp -- Compute on libssx.so (see compute.hpp)
+#include <stdexcept>
+#include <string>
+
+#include "../../include/ssx_shim.hpp"
+#include "compute.hpp"
+
+namespace ssx::host {
+namespace {
+
+class SsxCompute final : public Compute {
+ public:
+  explicit SsxCompute(int device) : frame_(device), chain_(device), backend_(device) {}
+
+  void Detect(const Image& img, const uint8_t* mask, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
+  {
+    kps.assign((size_t)prm.nfeatures + 4 * (size_t)prm.nlevels + 64, ssx_keypoint{});
+    int32_t n = 0;
+    frame_.check(ssx_orb_detect(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, mask, img.cols, &prm, (int32_t)kps.size(),
+                                kps.data(), &n));
+    kps.resize(n);
+  }
+
+  void TrackLK(const Image& prev, const Image& next, const std::vector<float>& prev_pts, std::vector<float>& next_pts,
+               std::vector<uint8_t>& status, bool temporal) override
+  {
+    const int n = (int)(prev_pts.size() / 2);
+    status.assign(n, 0);
+    ssx_lk_params p;
+    ssx_lk_default_params(&p);
+    p.win = 11; p.max_level = 3; p.max_iters = 30; p.eps = 0.01; p.use_initial_flow = 1;
+    if (!temporal) {
+      frame_.check(ssx_lk_track(frame_.get(), prev.ptr(), prev.cols, next.ptr(), next.cols, prev.rows, prev.cols, n, prev_pts.data(),
+                                next_pts.data(), status.data(), nullptr, &p, nullptr));
+      return;
+    }
+    // consecutive frames: the pyramid of `prev` is still on the device when it was the `next` image of the last call
+    if (prev.id != 0 && prev.id == chain_next_id_ && prev.rows == chain_rows_ && prev.cols == chain_cols_) {
+      chain_.check(ssx_lk_track_next(chain_.get(), next.ptr(), next.cols, next.rows, next.cols, n, prev_pts.data(), next_pts.data(),
+                                     status.data(), nullptr, &p, nullptr));
+    } else {
+      chain_.check(ssx_lk_track(chain_.get(), prev.ptr(), prev.cols, next.ptr(), next.cols, prev.rows, prev.cols, n, prev_pts.data(),
+                                next_pts.data(), status.data(), nullptr, &p, nullptr));
+    }
+    chain_next_id_ = next.id; chain_rows_ = next.rows; chain_cols_ = next.cols;
+  }
+
+  int PoseOnly(double* pose_io, const double* K4, int M, const double* xyz, const double* uv, uint8_t* inlier) override
+  {
+    int32_t n_in = 0;
+    frame_.check(ssx_pose_only_opt(frame_.get(), pose_io, K4, M, xyz, uv, 4, 10, 5.991, 1.0, inlier, &n_in));
+    return n_in;
+  }
+
+  void Triangulate(int n, const double* uvL, const double* uvR, const ssx_stereo_rig& rig, const double* T_wc, double* xyz,
+                   uint8_t* ok) override
+  {
+    frame_.check(ssx_triangulate(frame_.get(), n, uvL, uvR, &rig, T_wc, xyz, ok));
+  }
+
+  void BundleAdjust(const ssx_ba_problem& prob, const ssx_ba_options& opt, ssx_ba_result& res) override
+  {
+    backend_.check(ssx_ba_solve(backend_.get(), &prob, &opt, &res));
+  }
+
+ private:
+  ssx::Context frame_, chain_, backend_;
+  uint64_t chain_next_id_ = 0;
+  int chain_rows_ = 0, chain_cols_ = 0;
+};
+
+}  // namespace
+
+std::unique_ptr<Compute> MakeSsxCompute(int device) { return std::make_unique<SsxCompute>(device); }
+
+}  // namespace ssx::host

@@ -1,0 +1,36 @@
+// tests/host/oracle_runner.cpp -- TEST INFRASTRUCTURE: ssx_run_kitti's loop on the CPU oracle.
+//   oracle_runner <config yaml> <sequence dir> <trajectory out> [max frames]
+// Prints one line per frame: "frame <id> status <s> features <n> keyframes <k> points <p>".
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+
+#include "../../ssvio_amd/host/system.hpp"
+#include "oracle_compute.hpp"
+
+int main(int argc, char** argv)
+{
+  using namespace ssx::host;
+  if (argc < 4) return 2;
+  try {
+    std::vector<std::string> left, right;
+    std::vector<double> ts;
+    LoadKittiImagesTimestamps(argv[2], left, right, ts);
+    size_t n = left.size();
+    if (argc > 4) n = std::min(n, (size_t)std::atol(argv[4]));
+    std::unique_ptr<Compute> compute;
+    if (!std::getenv("SSX_HOST_TEST_GPU")) compute = std::make_unique<OracleCompute>();   // unset: the oracle; set: libssx.so
+    System system(argv[1], std::move(compute));
+    for (size_t i = 0; i < n; ++i) {
+      system.RunStep(imread_gray(left[i]), imread_gray(right[i]), ts[i]);
+      std::printf("frame %zu status %d features %zu keyframes %zu points %zu active_kfs %zu active_points %zu\n", i, (int)system.frontend().status(),
+                  system.frontend().current_frame()->features_left.size(), system.map().GetAllKeyFrames().size(),
+                  system.map().GetAllMapPoints().size(), system.map().GetActiveKeyFrames().size(), system.map().GetActiveMapPoints().size());
+    }
+    system.SaveTrajectoryTUM(argv[3]);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "fatal: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,184 @@
+// tests/host/test_units.cpp -- unit checks of the host layer that need neither a GPU nor the oracle:
+// Setting (cv::FileStorage subset), the KITTI listing, the PNG reader (against raw pixels written by the Python test),
+// MapPoint / Map bookkeeping and the active window, the TUM quaternion.
+//   test_units <work dir>      work dir holds cfg.yaml, seq/, png/<name>.png + png/<name>.raw
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+#include <string>
+
+#include "../../ssvio_amd/host/map.hpp"
+#include "../../ssvio_amd/host/setting.hpp"
+
+using namespace ssx::host;
+
+static int g_failed = 0;
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "%s:%d: CHECK(%s) failed\n", __FILE__, __LINE__, #c); ++g_failed; } } while (0)
+
+static std::vector<uint8_t> slurp(const std::string& p)
+{
+  std::ifstream f(p, std::ios::binary);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static void test_setting(const std::string& dir)
+{
+  Setting s(dir + "/cfg.yaml");
+  CHECK(s.Get<int>("Map.ActiveMap.Size") == 3);
+  CHECK(s.Get<float>("Camera1.fx") == 718.856f);
+  CHECK(s.Get<double>("Camera.Base.Line") == 386.1448);
+  CHECK(s.Get<int>("ORBextractor.nLevels") == 8);
+  CHECK(s.Get<float>("ORBextractor.scaleFactor") == 1.2f);
+  CHECK(s.Get<std::string>("Trajectory.Save.Path") == dir + "/traj #1.txt");   // quoted: the '#' is not a comment
+  CHECK(s.Get<int>("Viewer.ViewpointY") == 1000);                              // trailing comment stripped
+  CHECK(s.Get<int>("No.Such.Key") == 0 && s.Get<std::string>("No.Such.Key").empty() && !s.Has("No.Such.Key"));
+  Setting t;
+  t.ParseLine("Half.Even: 2.5");
+  t.ParseLine("Half.Even3: 3.5");
+  CHECK(t.Get<int>("Half.Even") == 2 && t.Get<int>("Half.Even3") == 4);      // cvRound
+  bool threw = false;
+  try { Setting bad(dir + "/missing.yaml"); } catch (const std::exception&) { threw = true; }
+  CHECK(threw);
+}
+
+static void test_kitti_listing(const std::string& dir)
+{
+  std::vector<std::string> l, r;
+  std::vector<double> t;
+  LoadKittiImagesTimestamps(dir + "/seq", l, r, t);
+  CHECK(t.size() == 3 && l.size() == 3 && r.size() == 3);
+  CHECK(t[0] == 0.0 && std::fabs(t[1] - 0.1037) < 1e-12 && std::fabs(t[2] - 0.2075) < 1e-12);
+  CHECK(l[2] == dir + "/seq/image_0/000002.png" && r[0] == dir + "/seq/image_1/000000.png");
+  bool threw = false;
+  try { LoadKittiImagesTimestamps(dir + "/nowhere", l, r, t); } catch (const std::exception&) { threw = true; }
+  CHECK(threw);
+}
+
+static void test_png(const std::string& dir)
+{
+  std::ifstream list(dir + "/png/list.txt");
+  std::string name;
+  int rows, cols, n = 0;
+  while (list >> name >> rows >> cols) {
+    ImagePtr img = imread_gray(dir + "/png/" + name + ".png");
+    const std::vector<uint8_t> raw = slurp(dir + "/png/" + name + ".raw");
+    CHECK(img->rows == rows && img->cols == cols);
+    CHECK(img->data == raw);
+    CHECK(img->id != 0);
+    ++n;
+  }
+  CHECK(n >= 6);
+  CHECK(imread_gray(dir + "/png/does_not_exist.png")->empty());               // cv::imread: empty Mat
+  for (const char* bad : {"rgb.png", "palette.png", "interlaced.png", "truncated.png", "corrupt.png"}) {
+    bool threw = false;
+    try { imread_gray(dir + "/png/" + bad); } catch (const std::exception& e) { threw = true; }
+    CHECK(threw);
+  }
+}
+
+static FeaturePtr feature(float x, float y) { auto f = std::make_shared<Feature>(); f->x = x; f->y = y; return f; }
+
+static KeyFramePtr keyframe_at(Map& map, double tx, const std::vector<MapPointPtr>& seen)
+{
+  FramePtr fr = map.NewFrame(nullptr, nullptr, 0.1 * tx);
+  for (auto& mp : seen) { auto f = feature(10, 10); f->map_point = (long)mp->id; fr->features_left.push_back(f); }
+  fr->features_left.push_back(feature(20, 20));                               // a feature without a map point
+  KeyFramePtr kf = map.CreateKF(fr);
+  kf->pose = SE3::translation(-tx, 0, 0);
+  return kf;
+}
+
+static void test_map()
+{
+  Map map(3);
+  const double p[3] = {1, 2, 3};
+  std::vector<MapPointPtr> pts;
+  for (int i = 0; i < 4; ++i) { pts.push_back(map.NewMapPoint(p)); map.InsertMapPoint(pts.back()); }
+  CHECK(pts[3]->id == 3 && map.GetAllMapPoints().size() == 4);
+  bool threw = false;
+  try { map.InsertMapPoint(pts[0]); } catch (const std::logic_error&) { threw = true; }
+  CHECK(threw);
+
+  // keyframes 0..2 fill the window; observations and active observations follow CreateKF / InsertKeyFrame
+  KeyFramePtr k0 = keyframe_at(map, 0.0, {pts[0], pts[1]});
+  CHECK(k0->key_frame_id == 0 && k0->features_left[0]->keyframe == 0 && pts[0]->observed_times == 1 && pts[0]->active_observed_times == 0);
+  map.InsertKeyFrame(k0);
+  CHECK(pts[0]->active_observed_times == 1 && map.GetActiveMapPoints().size() == 2);
+  KeyFramePtr k1 = keyframe_at(map, 1.0, {pts[1], pts[2]});
+  map.InsertKeyFrame(k1);
+  KeyFramePtr k2 = keyframe_at(map, 2.0, {pts[2]});
+  map.InsertKeyFrame(k2);
+  CHECK(map.GetActiveKeyFrames().size() == 3 && map.GetAllKeyFrames().size() == 3 && map.GetActiveMapPoints().size() == 3);
+  CHECK(pts[1]->observed_times == 2 && pts[1]->active_observed_times == 2);
+
+  // a 4th keyframe 1 m further: nothing is closer than 0.2, so the farthest one (keyframe 0) leaves the window,
+  // its active observations go, and point 0 (seen only there) leaves the active map but stays in the map
+  KeyFramePtr k3 = keyframe_at(map, 3.0, {pts[2], pts[3]});
+  map.InsertKeyFrame(k3);
+  CHECK(map.GetActiveKeyFrames().size() == 3 && !map.GetActiveKeyFrames().count(0) && map.GetAllKeyFrames().size() == 4);
+  CHECK(pts[0]->active_observed_times == 0 && pts[0]->observed_times == 1 && pts[1]->active_observed_times == 1);
+  CHECK(!map.GetActiveMapPoints().count(0) && map.GetAllMapPoints().count(0) && map.GetActiveMapPoints().size() == 3);
+
+  // a 5th keyframe 0.03 m from keyframe 2: now the nearest one is dropped, not the farthest.  (The reference only
+  // updates its running minimum in the `else` of the maximum test, so which keyframe counts as "nearest" can depend on
+  // the container's iteration order; keyframe 2 is the middle one in either direction, where the answer is the same.)
+  KeyFramePtr k4 = keyframe_at(map, 2.03, {pts[3]});
+  map.InsertKeyFrame(k4);
+  CHECK(map.GetActiveKeyFrames().size() == 3 && !map.GetActiveKeyFrames().count(2) && map.GetActiveKeyFrames().count(1) &&
+        map.GetActiveKeyFrames().count(3));
+
+  // outlier list, removal = the "expired" weak pointer of the reference
+  FeaturePtr f = k4->features_left[0];
+  CHECK(map.Lock(f) == pts[3]);
+  map.AddOutlierMapPoint(pts[3]->id);
+  map.RemoveAllOutlierMapPoints();
+  CHECK(map.Lock(f) == nullptr && !map.GetAllMapPoints().count(3) && !map.GetActiveMapPoints().count(3));
+  CHECK(map.Lock(k4->features_left[1]) == nullptr);                            // never had one
+
+  // RemoveObservation clears the feature's link, RemoveActiveObservation only the count
+  FeaturePtr g = k1->features_left[0];                                        // observes point 1
+  pts[1]->RemoveActiveObservation(g);
+  CHECK(pts[1]->active_observed_times == 0 && g->map_point == 1);
+  pts[1]->RemoveObservation(g);
+  CHECK(pts[1]->observed_times == 1 && g->map_point == kNoMapPoint);
+  map.RemoveOldActiveMapPoints();
+  CHECK(!map.GetActiveMapPoints().count(1));
+  map.RemoveMapPoint(pts[2]);
+  CHECK(!map.GetAllMapPoints().count(2) && !map.GetActiveMapPoints().count(2));
+}
+
+static void test_se3()
+{
+  // rotation of 2 rad about (1,2,2)/3: trace < 0 branch of the matrix -> quaternion conversion
+  const double s = std::sin(1.0), c = std::cos(1.0);
+  const double q[7] = {s / 3, 2 * s / 3, 2 * s / 3, c, 0.5, -1, 2};
+  SE3 T(q);
+  double out[4];
+  T.rotation_quaternion(out);
+  for (int i = 0; i < 4; ++i) CHECK(std::fabs(out[i] - q[i]) < 1e-14);
+  const double q2[7] = {std::sin(1.5), 0, 0, std::cos(1.5), 0, 0, 0};        // 3 rad about x
+  SE3(q2).rotation_quaternion(out);
+  CHECK(std::fabs(out[0] - q2[0]) < 1e-14 && std::fabs(out[3] - q2[3]) < 1e-14);
+  SE3 I = T * T.inverse();
+  CHECK(I.log_norm() < 1e-14);
+  CHECK(std::fabs(SE3::translation(0.3, 0, 0.4).log_norm() - 0.5) < 1e-15);
+  double p[3] = {1, 0, 0}, r[3];
+  SE3::translation(1, 2, 3).act(p, r);
+  CHECK(r[0] == 2 && r[1] == 2 && r[2] == 3);
+}
+
+int main(int argc, char** argv)
+{
+  if (argc < 2) return 2;
+  const std::string dir = argv[1];
+  test_setting(dir);
+  test_kitti_listing(dir);
+  test_png(dir);
+  test_map();
+  test_se3();
+  if (g_failed) { std::fprintf(stderr, "%d check(s) failed\n", g_failed); return 1; }
+  std::printf("host unit checks ok\n");
+  return 0;
+}

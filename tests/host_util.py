@@ -1,0 +1,84 @@
+"""Helpers of the host-layer tests: build the test binaries (C++ unit checks, the oracle-backed runner), write a
+settings file with the reference's keys, write a synthetic stereo sequence in KITTI layout."""
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "host", "build")
+
+# the keys System / FrontEnd / Backend read (values of the reference's KITTI settings)
+DEFAULT_CONFIG = {
+    "Camera1.fx": 718.856, "Camera1.fy": 718.856, "Camera1.cx": 607.1928, "Camera1.cy": 185.2157,
+    "Camera2.fx": 718.856, "Camera2.fy": 718.856, "Camera2.cx": 607.1928, "Camera2.cy": 185.2157,
+    "Camera.width": 1241, "Camera.height": 376, "Camera.Base.Line": 386.1448, "Camera.NeedUndistortion": 0, "Camera.fps": 10,
+    "Map.ActiveMap.Size": 12,
+    "numFeatures.initGood": 100, "numFeatures.trackingGood": 50, "numFeatures.trackingBad": 10,
+    "ORBextractor.nInitFeatures": 300, "ORBextractor.nNewFeatures": 100, "ORBextractor.scaleFactor": 1.2, "ORBextractor.nLevels": 8,
+    "ORBextractor.iniThFAST": 20, "ORBextractor.minThFAST": 7,
+    "Min.Init.Landmark.Num": 200,
+    "Viewer.ViewpointY": "1000 # a trailing comment",
+    "Backend.Open": 1,
+    "Trajectory.Save.Path": '"trajectory.txt"',
+}
+
+
+def write_config(path, overrides):
+    cfg = dict(DEFAULT_CONFIG); cfg.update(overrides)
+    with open(path, "w") as f:
+        f.write("%YAML:1.0\n# settings of the headless runner\n")
+        for k, v in cfg.items():
+            f.write(f"{k}: {v}\n")
+    return path
+
+
+def write_sequence(root, n_frames=12, step=0.12, seed=0, dt=0.1):
+    """make_lateral_sequence as <root>/seq/{times.txt,image_0,image_1}.  Returns dir, dt, camera centres [n,3]."""
+    from PIL import Image
+
+    from ssvio_amd.synth import KITTI_BASELINE, make_lateral_sequence
+    frames, gt, _ = make_lateral_sequence(n_frames=n_frames, step=step, seed=seed)
+    d = os.path.join(root, "seq")
+    for sub in ("image_0", "image_1"):
+        os.makedirs(os.path.join(d, sub), exist_ok=True)
+    with open(os.path.join(d, "times.txt"), "w") as f:
+        for i, (L, R) in enumerate(frames):
+            f.write(f"{i * dt:e}\n")
+            Image.fromarray(L).save(os.path.join(d, "image_0", f"{i:06d}.png"))
+            Image.fromarray(R).save(os.path.join(d, "image_1", f"{i:06d}.png"))
+    centres = np.stack([-gt[:, 4], -gt[:, 5], -gt[:, 6]], 1)          # identity rotations: centre = -t
+    return dict(dir=d, dt=dt, centres=centres, step_m=step * KITTI_BASELINE, frames=frames)
+
+
+def parse_runner_log(text):
+    out = []
+    for line in text.splitlines():
+        w = line.split()
+        if len(w) >= 14 and w[0] == "frame":
+            out.append(dict(frame=int(w[1]), status=int(w[3]), features=int(w[5]), keyframes=int(w[7]), points=int(w[9]),
+                            active_kfs=int(w[11]), active_points=int(w[13])))
+    return out
+
+
+def build_test_binaries():
+    """tests/host/build/{test_units, oracle_runner}; the product pieces come from ssvio_amd.build.build_host()"""
+    from oracle import pyoracle
+    from ssvio_amd import build as b
+    host_lib, host_exe = b.build_host()
+    pyoracle.build()
+    oracle_lib = os.path.join(ROOT, "oracle", "liboracle.so")
+    os.makedirs(OUT, exist_ok=True)
+    flags = [*b.HOST_FLAGS, "-I", ROOT]
+    rpath = ["-Wl,-rpath," + os.path.dirname(host_lib), "-Wl,-rpath," + os.path.dirname(b.LIB), "-Wl,-rpath," + os.path.dirname(oracle_lib),
+             "-Wl,-rpath,/opt/rocm/lib"]
+    units = os.path.join(OUT, "test_units")
+    runner = os.path.join(OUT, "oracle_runner")
+    src = os.path.join(ROOT, "tests", "host")
+    newest = max(os.path.getmtime(p) for p in (host_lib, oracle_lib, os.path.join(src, "test_units.cpp"), os.path.join(src, "oracle_runner.cpp"),
+                                               os.path.join(src, "oracle_compute.hpp")))
+    if not (os.path.exists(units) and os.path.getmtime(units) >= newest):
+        subprocess.check_call(["g++", *flags, os.path.join(src, "test_units.cpp"), host_lib, b.LIB, *rpath, "-o", units])
+    if not (os.path.exists(runner) and os.path.getmtime(runner) >= newest):
+        subprocess.check_call(["g++", *flags, os.path.join(src, "oracle_runner.cpp"), host_lib, b.LIB, oracle_lib, *rpath, "-o", runner])
+    return dict(units=units, oracle_runner=runner, run_kitti=host_exe, host_lib=host_lib)

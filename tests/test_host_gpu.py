@@ -1,0 +1,60 @@
+"""System-level parity of the host layer on the GPU: the headless runner ssx_run_kitti and the
+same host code on the CPU oracle process one synthetic KITTI-layout sequence; every per-frame decision (status,
+feature / keyframe / map-point counts, window contents) must be identical and the TUM trajectories must agree to the
+file's precision.  Detection and LK are bit-exact between the two, so the first difference can only come from the
+pose-only / BA solvers (tolerance-level, far below any decision threshold here)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import host_util as hu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def built():
+    return hu.build_test_binaries()
+
+
+@pytest.mark.parametrize("overrides", [{"Map.ActiveMap.Size": 3, "numFeatures.trackingGood": 100000},
+                                       {"numFeatures.trackingGood": 280},
+                                       {"Map.ActiveMap.Size": 4, "numFeatures.trackingGood": 100000, "Backend.Jacobian.Numeric": 1}])
+def test_runner_matches_the_oracle(built, tmp_path, overrides):
+    seq = hu.write_sequence(str(tmp_path), n_frames=12, step=0.6)
+    cfg = os.path.join(str(tmp_path), "cfg.yaml")
+    t_gpu, t_cpu, t_exe = (os.path.join(str(tmp_path), n) for n in ("gpu.txt", "cpu.txt", "exe.txt"))
+    hu.write_config(cfg, dict(overrides, **{"Trajectory.Save.Path": f'"{t_exe}"'}))
+    cpu = subprocess.run([built["oracle_runner"], cfg, seq["dir"], t_cpu], capture_output=True, text=True, timeout=600)
+    gpu = subprocess.run([built["oracle_runner"], cfg, seq["dir"], t_gpu], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SSX_HOST_TEST_GPU="1"))
+    assert cpu.returncode == 0 and gpu.returncode == 0, cpu.stderr + gpu.stderr
+    assert hu.parse_runner_log(gpu.stdout) == hu.parse_runner_log(cpu.stdout)
+    a, b = np.loadtxt(t_gpu, ndmin=2), np.loadtxt(t_cpu, ndmin=2)
+    # g2o's numeric Jacobians (delta 1e-9) amplify rounding differences by ~1e7: the gauge-free window drifts apart
+    # by tens of micrometres there; with analytic Jacobians the files agree to their last printed digit or two
+    tol = 2e-4 if overrides.get("Backend.Jacobian.Numeric") else 2e-5
+    assert a.shape == b.shape and np.abs(a - b).max() <= tol, np.abs(a - b).max()
+    # the product executable: same trajectory file as the instrumented run, gflags-style arguments, summary on stdout
+    exe = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}"], capture_output=True, text=True,
+                         timeout=600)
+    assert exe.returncode == 0, exe.stdout + exe.stderr
+    assert open(t_exe).read() == open(t_gpu).read()
+    assert "Num Images: 12" in exe.stdout and "frames/s" in exe.stdout and "local BA:" in exe.stdout
+    err = np.abs((a[:, 1:4] - a[0, 1:4]) - seq["centres"][np.rint(a[:, 0] / seq["dt"]).astype(int)])
+    assert err.max() < 0.03
+
+
+def test_runner_arguments(built, tmp_path):
+    r = subprocess.run([built["run_kitti"]], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {})
+    r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={tmp_path}/nope"], capture_output=True, text=True)
+    assert r.returncode == 1 and "times.txt" in r.stderr
+    seq = hu.write_sequence(str(tmp_path), n_frames=3)
+    out = os.path.join(str(tmp_path), "t.txt")
+    r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", "--max_frames=2", f"--trajectory={out}"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Num Images: 2" in r.stdout and len(open(out).read().splitlines()) == 1
