@@ -6,11 +6,15 @@
 // 4 rounds x optimize(10) with chi2 > 5.991 => outlier (level 1) after every round and the kernels removed before
 // the last round (frontend.cpp:236-269).
 //
-// The problem is tiny (50-300 edges, 6 unknowns) and strictly sequential across LM trials, so the WHOLE procedure --
+// The problem is tiny (50-400 edges, 6 unknowns) and strictly sequential across LM trials, so the WHOLE procedure --
 // all rounds, iterations and LM trials -- runs inside ONE launch of ONE 256-thread workgroup: no host round trip,
-// no second kernel.  Edges are strided over the threads; the 6x6 normal equations (21 + 6 + chi2 values) are reduced
-// with one fixed-shape LDS tree per linearisation (deterministic); thread 0 runs the 6x6 Cholesky and the LM
-// bookkeeping of OptimizationAlgorithmLevenberg::solve (thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:58-175).
+// no second kernel.  k_pose_only<EPT> (M <= 256 * EPT) keeps every edge (map point, pixel, last error, level) in the
+// registers of its thread for the whole launch; the 6x6 normal equations (21 + 6 values) and every chi2 are summed by
+// a wave butterfly + one LDS exchange between the 4 waves (ONE barrier per sum, double-buffered), and every thread
+// then runs the 6x6 Cholesky, the pose update and the LM bookkeeping of OptimizationAlgorithmLevenberg::solve
+// (thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:58-175) redundantly on identical values -- no
+// broadcast, no second barrier.  k_pose_only_generic (any M) is the same procedure with the edges in global memory
+// and an LDS tree reduction.
 #include <cmath>
 
 #include "ctx.hpp"
@@ -30,7 +34,8 @@ struct PoDev {
   double* err;         // M x 2 (last computed error of each edge, like g2o's _error)
   uint8_t* level;      // M: 1 = outlier level (not optimised)
   uint8_t* outlier;    // M: features[i]->is_outlier_
-  double* pose;        // 7 in/out
+  double* pose;        // 7 in (the generic kernel also writes its result here)
+  double* pose_out;    // 7 out
   int* n_inliers;
 };
 
@@ -56,7 +61,7 @@ __device__ __forceinline__ void tree_reduce(double (*sRed)[PT], int n)
   }
 }
 
-__global__ __launch_bounds__(PT) void k_pose_only(PoDev d)
+__global__ __launch_bounds__(PT) void k_pose_only_generic(PoDev d)
 {
   __shared__ double sRed[NRED][PT];
   __shared__ double sT[7], sTbak[7], sX[6];
@@ -248,7 +253,270 @@ __global__ __launch_bounds__(PT) void k_pose_only(PoDev d)
       __syncthreads();
     }
   }
-  if (t < 7) d.pose[t] = sT[t];
+  if (t < 7) d.pose_out[t] = sT[t];
+  if (t == 0) *d.n_inliers = d.M - cnt_outliers;
+}
+
+// ---- register-resident variant ------------------------------------------------------------------------------------
+constexpr int NW = PT / 64;
+
+// lane exchange inside a row of 16 lanes on the VALU (DPP) -- a shuffle through the LDS crossbar costs ~100 cycles of
+// latency per step, and the 27-value reduction below is on the critical path of every LM iteration
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane_f64(double v, int lane)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// sum over the 64 lanes, the same value in every lane
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+  v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_f64<0x141>(v);    // row_half_mirror: the other quad of the 8-lane half
+  v += dpp_f64<0x140>(v);    // row_mirror: the other half of the 16-lane row
+  return (read_lane_f64(v, 0) + read_lane_f64(v, 16)) + (read_lane_f64(v, 32) + read_lane_f64(v, 48));
+}
+
+// sum of N values per thread over the workgroup, returned to every thread.  buf alternates between calls, so a single
+// barrier per call is enough: a thread can only reach the next call on the same buffer after every thread has passed
+// the barrier of the call in between, i.e. has finished reading.
+template <int N>
+__device__ __forceinline__ void block_sum(double* v, double (*sPart)[NRED][NW], int& buf)
+{
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_sum_f64(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) sPart[buf][k][wave] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double s = sPart[buf][k][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += sPart[buf][k][w];
+    v[k] = s;
+  }
+  buf ^= 1;
+}
+
+// (H + lambda I) x = b for the upper-triangular H[21] by Cholesky, fully unrolled; false when a pivot is not positive
+// (LinearSolverDense: Eigen's LDLT reports failure the same way)
+__device__ __forceinline__ bool solve6(const double* Hb, double lambda, double* x)
+{
+  double A[6][6];
+  int q = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+#pragma unroll
+    for (int c = a; c < 6; ++c) { A[c][a] = Hb[q]; ++q; }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) A[a][a] += lambda;
+  bool ok = true;
+  double rd[6];                                              // 1 / L[j][j]
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double dj = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) dj -= A[j][k] * A[j][k];
+    if (!(dj > 0.0) || !isfinite(dj)) { ok = false; dj = 1.0; }
+    const double inv = 1.0 / sqrt(dj);
+    rd[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double sum = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) sum -= A[i][k] * A[j][k];
+      A[i][j] = sum * inv;
+    }
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double sum = Hb[21 + i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) sum -= A[i][k] * y[k];
+    y[i] = sum * rd[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double sum = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) sum -= A[k][i] * x[k];
+    x[i] = sum * rd[i];
+  }
+  if (!ok) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+  }
+  return ok;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(PT) void k_pose_only(PoDev d)
+{
+  __shared__ double sPart[2][NRED][NW];
+  const int t = threadIdx.x;
+  int buf = 0;
+  // this thread's edges: i = t + k * PT
+  double X[EPT][3], z[EPT][2], e[EPT][2];
+  bool valid[EPT], level[EPT], outl[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int i = t + k * PT;
+    valid[k] = i < d.M;
+    level[k] = false; outl[k] = false;
+    e[k][0] = 0.0; e[k][1] = 0.0;
+    const int ii = valid[k] ? i : 0;
+    X[k][0] = d.xyz[3 * ii]; X[k][1] = d.xyz[3 * ii + 1]; X[k][2] = d.xyz[3 * ii + 2];
+    z[k][0] = d.uv[2 * ii]; z[k][1] = d.uv[2 * ii + 1];
+  }
+  double T[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) T[k] = d.pose[k];
+  bool use_kernel = true;
+  const ssx::Cam K = d.K;
+  const double delta = d.huber_delta;
+
+  // errors of the active (level 0) edges at pose T + their robust chi2, summed over the workgroup
+  auto errors_and_chi2 = [&]() {
+    double chi = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      double pc[3];
+      ssx::se3_act(T, X[k], pc);
+      const double hx = K.fx * pc[0] + K.cx * pc[2], hy = K.fy * pc[1] + K.cy * pc[2];
+      const double e0 = z[k][0] - hx / pc[2], e1 = z[k][1] - hy / pc[2];
+      const bool act = valid[k] && !level[k];
+      e[k][0] = act ? e0 : e[k][0];
+      e[k][1] = act ? e1 : e[k][1];
+      const double c2 = e0 * e0 + e1 * e1;
+      double r0 = c2, w = 1.0;
+      if (use_kernel) ssx::huber(c2, delta, r0, w);
+      chi += act ? r0 : 0.0;
+    }
+    block_sum<1>(&chi, sPart, buf);
+    return chi;
+  };
+
+  int cnt_outliers = 0;
+  for (int round = 0; round < d.rounds; ++round) {
+    double na = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) na += (valid[k] && !level[k]) ? 1.0 : 0.0;
+    block_sum<1>(&na, sPart, buf);
+    const bool any_active = na > 0.0;                       // initializeOptimization(0): only level-0 edges are active
+    double lambda = 0.0, ni = 2.0, current_chi = 0.0;
+    for (int it = 0; it < d.iters && any_active; ++it) {
+      // solve() starts with computeActiveErrors() + activeRobustChi2(); after an accepted trial (the only way to get
+      // here with it > 0) the errors and the chi2 of that trial ARE those values -- no second pass over the edges
+      if (it == 0) current_chi = errors_and_chi2();
+      // ---- linearise: H (upper 21) and b (6) ----
+      double Hb[27];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) Hb[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        double pc[3];
+        ssx::se3_act(T, X[k], pc);
+        const double Xc = pc[0], Yc = pc[1], Zc = pc[2];
+        const double Zinv = 1.0 / (Zc + 1e-18), Zinv2 = Zinv * Zinv;
+        // EdgeProjectionPoseOnly::linearizeOplus, g2otypes.hpp:86-101
+        const double J[12] = {-K.fx * Zinv, 0, K.fx * Xc * Zinv2, K.fx * Xc * Yc * Zinv2, -K.fx - K.fx * Xc * Xc * Zinv2, K.fx * Yc * Zinv,
+                              0, -K.fy * Zinv, K.fy * Yc * Zinv2, K.fy + K.fy * Yc * Yc * Zinv2, -K.fy * Xc * Yc * Zinv2, -K.fy * Xc * Zinv};
+        const double e0 = e[k][0], e1 = e[k][1];
+        double r0, w = 1.0;
+        if (use_kernel) ssx::huber(e0 * e0 + e1 * e1, delta, r0, w);
+        w = (valid[k] && !level[k]) ? w : 0.0;
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c = a; c < 6; ++c) { Hb[q] += J[a] * w * J[c] + J[6 + a] * w * J[6 + c]; ++q; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Hb[21 + a] -= w * (J[a] * e0 + J[6 + a] * e1);
+      }
+      block_sum<27>(Hb, sPart, buf);
+      if (it == 0) {
+        // computeLambdaInit: 1e-5 * max |diag(H)|; diagonal entries of the upper layout: 0,6,11,15,18,20
+        const double m = fmax(fmax(fmax(fabs(Hb[0]), fabs(Hb[6])), fmax(fabs(Hb[11]), fabs(Hb[15]))), fmax(fabs(Hb[18]), fabs(Hb[20])));
+        lambda = 1e-5 * m; ni = 2.0;
+      }
+      // ---- LM trials ----
+      int qmax = 0;
+      bool stop = false;
+      while (true) {
+        double Tbak[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) Tbak[k] = T[k];
+        double x[6];
+        const bool ok = solve6(Hb, lambda, x);
+        double Tn[7];
+        ssx::pose_oplus(T, x, Tn);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) T[k] = Tn[k];
+        double temp_chi = errors_and_chi2();
+        if (!ok) temp_chi = 1.7976931348623157e308;
+        double scale = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) scale += x[j] * (lambda * x[j] + Hb[21 + j]);
+        scale += 1e-3;
+        const double rho = (current_chi - temp_chi) / scale;
+        bool lambda_bad = false;
+        if (rho > 0 && isfinite(temp_chi)) {
+          const double c = 2 * rho - 1;
+          double alpha = 1. - c * c * c;
+          alpha = fmin(alpha, 2. / 3.);
+          lambda *= fmax(1. / 3., alpha);
+          ni = 2.0;
+          current_chi = temp_chi;
+        } else {
+          lambda *= ni;
+          ni *= 2.0;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) T[k] = Tbak[k];          // pop(): vertices only, errors stay at the trial state
+          if (!isfinite(lambda)) lambda_bad = true;
+        }
+        qmax += lambda_bad ? 0 : 1;
+        // do { } while (rho < 0 && qmax < 10);  then Terminate if qmax == 10 || rho == 0 || lambda non-finite
+        stop = (qmax == 10 || rho == 0 || lambda_bad);
+        if (!(!lambda_bad && rho < 0 && qmax < 10)) break;
+      }
+      if (stop) break;                                         // Terminate: optimize() stops iterating
+    }
+    // frontend.cpp:243-268: recompute the error only for features flagged outlier, classify, set levels
+    double co = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (outl[k]) {
+        double pc[3];
+        ssx::se3_act(T, X[k], pc);
+        const double hx = K.fx * pc[0] + K.cx * pc[2], hy = K.fy * pc[1] + K.cy * pc[2];
+        e[k][0] = z[k][0] - hx / pc[2]; e[k][1] = z[k][1] - hy / pc[2];
+      }
+      const double c2 = e[k][0] * e[k][0] + e[k][1] * e[k][1];
+      const bool out = valid[k] && c2 > d.chi2_th;
+      outl[k] = out; level[k] = out;
+      co += out ? 1.0 : 0.0;
+    }
+    block_sum<1>(&co, sPart, buf);
+    cnt_outliers = (int)co;
+    if (round == d.rounds - 2) use_kernel = false;             // e->setRobustKernel(nullptr)
+  }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k)
+    if (valid[k]) d.outlier[t + k * PT] = outl[k] ? 1 : 0;
+  if (t < 7) d.pose_out[t] = T[t];
   if (t == 0) *d.n_inliers = d.M - cnt_outliers;
 }
 
@@ -275,8 +543,9 @@ extern "C" ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const dou
   const size_t in_bytes = lay.off;
   const size_t o_err = lay.take(sizeof(double) * 2 * (size_t)M);
   const size_t o_level = lay.take((size_t)M);
-  const size_t o_out = lay.take((size_t)M);
-  const size_t o_n = lay.take(sizeof(int) * 2);
+  // results, contiguous so that one copy brings them back: pose | inlier count | outlier flags
+  const size_t o_res = lay.take(sizeof(double) * 8 + sizeof(int) * 2 + (size_t)M);
+  const size_t o_pose_out = o_res, o_n = o_res + sizeof(double) * 8, o_out = o_n + sizeof(int) * 2;
   SSX_HIP_TRY(ctx, arena.reserve(lay.off));
   SSX_HIP_TRY(ctx, stage.reserve(lay.off));
   char* hs = stage.as<char>();
@@ -290,14 +559,18 @@ extern "C" ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const dou
   d.K = ssx::Cam{K4[0], K4[1], K4[2], K4[3]};
   d.xyz = (const double*)(base + o_xyz); d.uv = (const double*)(base + o_uv);
   d.err = (double*)(base + o_err); d.level = (uint8_t*)(base + o_level); d.outlier = (uint8_t*)(base + o_out);
-  d.pose = (double*)(base + o_pose); d.n_inliers = (int*)(base + o_n);
-  SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(PT), 0, ctx->stream, d));
+  d.pose = (double*)(base + o_pose); d.pose_out = (double*)(base + o_pose_out); d.n_inliers = (int*)(base + o_n);
+  if (M <= PT * 2) {
+    SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only<2>, dim3(1), dim3(PT), 0, ctx->stream, d));
+  } else if (M <= PT * 6) {
+    SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only<6>, dim3(1), dim3(PT), 0, ctx->stream, d));
+  } else {
+    SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only_generic, dim3(1), dim3(PT), 0, ctx->stream, d));
+  }
   SSX_HIP_TRY(ctx, hipGetLastError());
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_pose, base + o_pose, sizeof(double) * 7, hipMemcpyDeviceToHost, ctx->stream));
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_out, base + o_out, M, hipMemcpyDeviceToHost, ctx->stream));
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_n, base + o_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_res, base + o_res, sizeof(double) * 8 + sizeof(int) * 2 + (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(pose_io, hs + o_pose, sizeof(double) * 7);
+  memcpy(pose_io, hs + o_pose_out, sizeof(double) * 7);
   if (inlier_out) for (int i = 0; i < M; ++i) inlier_out[i] = !reinterpret_cast<uint8_t*>(hs + o_out)[i];
   if (n_inliers) *n_inliers = *reinterpret_cast<int*>(hs + o_n);
   return SSX_OK;

@@ -180,6 +180,12 @@ def test_pose_only_edge_cases(ctx, po):
     assert g["n_inliers"] == o["n_inliers"] and np.array_equal(g["inliers"], o["inliers"])
     np.testing.assert_allclose(g["pose"], o["pose"], rtol=0, atol=2e-9)
     assert np.abs(g["pose"] - pp["gt_pose"]).max() < 5e-3                 # recovers the true pose despite 30 % outliers
+    for M in (1, 7, 256, 257, 512, 513, 1536, 1537, 2500):                # both register-resident variants and the generic kernel
+        pp2 = make_pose_only_problem(M=M, seed=100 + M, frac_gross=0.1)
+        g2 = ba.pose_only_opt(ctx, pp2["pose"], pp2["K"], pp2["xyz"], pp2["uv"])
+        o2 = po.pose_only(pp2)
+        assert g2["n_inliers"] == o2["n_inliers"] and np.array_equal(g2["inliers"], o2["inliers"]), M
+        np.testing.assert_allclose(g2["pose"], o2["pose"], rtol=0, atol=1e-8 if M < 8 else 2e-9, err_msg=str(M))
     e = ba.pose_only_opt(ctx, pp["pose"], pp["K"], pp["xyz"][:0], pp["uv"][:0])
     assert e["n_inliers"] == 0 and np.array_equal(e["pose"], pp["pose"])
     z = ba.pose_only_opt(ctx, pp["pose"], pp["K"], pp["xyz"], pp["uv"], rounds=0)
