@@ -100,11 +100,11 @@ def build_host(force: bool = False):
     if not cxx:
         raise RuntimeError("g++ not found: the host layer cannot be built")
     rpath = ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
-    cmd = [cxx, *HOST_FLAGS, "-shared", *[os.path.join(HOST, f) for f in HOST_LIB_SRCS], lib, "-lz", *rpath, "-o", HOST_LIB]
+    cmd = [cxx, *HOST_FLAGS, "-shared", *[os.path.join(HOST, f) for f in HOST_LIB_SRCS], lib, "-lz", "-lpthread", *rpath, "-o", HOST_LIB]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"g++ failed on the host library:\n{r.stderr[-6000:]}")
-    cmd = [cxx, *HOST_FLAGS, os.path.join(HOST, "run_kitti.cpp"), HOST_LIB, lib, "-lz", *rpath, "-o", HOST_EXE]
+    cmd = [cxx, *HOST_FLAGS, os.path.join(HOST, "run_kitti.cpp"), HOST_LIB, lib, "-lz", "-lpthread", *rpath, "-o", HOST_EXE]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"g++ failed on ssx_run_kitti:\n{r.stderr[-6000:]}")

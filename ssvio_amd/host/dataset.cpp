@@ -3,6 +3,7 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -125,6 +126,68 @@ ImagePtr imread_gray(const std::string& path)
   if (!f.is_open()) return std::make_shared<Image>();
   std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   return decode_png_gray(bytes.data(), bytes.size());
+}
+
+StereoPrefetcher::StereoPrefetcher(std::vector<std::string> left_paths, std::vector<std::string> right_paths, size_t count, int threads,
+                                   size_t depth)
+    : left_(std::move(left_paths)), right_(std::move(right_paths)), count_(std::min(count, left_.size())), depth_(std::max<size_t>(depth, 1)),
+      slots_(depth_)
+{
+  for (int i = 0; i < std::max(threads, 1); ++i) workers_.emplace_back([this] { Work(); });
+}
+
+StereoPrefetcher::~StereoPrefetcher()
+{
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    stop_ = true;
+  }
+  cv_work_.notify_all();
+  for (auto& w : workers_) w.join();
+}
+
+void StereoPrefetcher::Work()
+{
+  for (;;) {
+    size_t i;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      // claim the next frame once its ring slot has been handed out
+      cv_work_.wait(lk, [this] { return stop_ || (next_claim_ < count_ && next_claim_ < next_out_ + depth_); });
+      if (stop_) return;
+      i = next_claim_++;
+    }
+    Pair pair;
+    std::exception_ptr error;
+    try {
+      pair.left = imread_gray(left_[i]);
+      pair.right = imread_gray(right_[i]);
+    } catch (...) {
+      error = std::current_exception();
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      Slot& s = slots_[i % depth_];
+      s.pair = std::move(pair); s.error = error; s.ready = true;
+    }
+    cv_ready_.notify_all();
+  }
+}
+
+StereoPrefetcher::Pair StereoPrefetcher::Next()
+{
+  std::unique_lock<std::mutex> lk(m_);
+  if (next_out_ >= count_) throw std::out_of_range("StereoPrefetcher: past the end of the sequence");
+  Slot& s = slots_[next_out_ % depth_];
+  cv_ready_.wait(lk, [&s] { return s.ready; });
+  Pair out = std::move(s.pair);
+  std::exception_ptr error = s.error;
+  s = Slot();
+  ++next_out_;
+  lk.unlock();
+  cv_work_.notify_all();
+  if (error) std::rethrow_exception(error);
+  return out;
 }
 
 }  // namespace ssx::host

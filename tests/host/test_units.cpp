@@ -78,6 +78,41 @@ static void test_png(const std::string& dir)
   }
 }
 
+static void test_prefetcher(const std::string& dir)
+{
+  // the PNG set of test_png as a "sequence": in-order delivery from several threads through a ring smaller than the
+  // sequence, the same pixels as the synchronous reader, errors surfacing on the frame they belong to
+  std::ifstream list(dir + "/png/list.txt");
+  std::vector<std::string> paths;
+  std::string name;
+  int rows, cols;
+  while (list >> name >> rows >> cols) paths.push_back(dir + "/png/" + name + ".png");
+  std::vector<std::string> left, right;
+  for (int rep = 0; rep < 3; ++rep)
+    for (size_t i = 0; i < paths.size(); ++i) { left.push_back(paths[i]); right.push_back(paths[(i + 1) % paths.size()]); }
+  {
+    StereoPrefetcher pf(left, right, left.size(), 3, 4);
+    for (size_t i = 0; i < left.size(); ++i) {
+      StereoPrefetcher::Pair p = pf.Next();
+      CHECK(p.left->data == imread_gray(left[i])->data && p.right->data == imread_gray(right[i])->data);
+    }
+    bool threw = false;
+    try { pf.Next(); } catch (const std::out_of_range&) { threw = true; }
+    CHECK(threw);
+  }
+  {
+    std::vector<std::string> l2 = {paths[0], dir + "/png/rgb.png", paths[1], dir + "/png/missing.png"}, r2 = {paths[1], paths[0], paths[2], paths[0]};
+    StereoPrefetcher pf(l2, r2, 4, 2, 2);
+    CHECK(!pf.Next().left->empty());
+    bool threw = false;
+    try { pf.Next(); } catch (const std::runtime_error&) { threw = true; }     // colour PNG: refused
+    CHECK(threw);
+    CHECK(!pf.Next().left->empty());                                            // the stream goes on after an error
+    CHECK(pf.Next().left->empty());                                             // unreadable file: empty image, like cv::imread
+  }
+  { StereoPrefetcher unused(left, right, left.size(), 4, 8); }                  // destruction with work outstanding
+}
+
 static FeaturePtr feature(float x, float y) { auto f = std::make_shared<Feature>(); f->x = x; f->y = y; return f; }
 
 static KeyFramePtr keyframe_at(Map& map, double tx, const std::vector<MapPointPtr>& seen)
@@ -176,6 +211,7 @@ int main(int argc, char** argv)
   test_setting(dir);
   test_kitti_listing(dir);
   test_png(dir);
+  test_prefetcher(dir);
   test_map();
   test_se3();
   if (g_failed) { std::fprintf(stderr, "%d check(s) failed\n", g_failed); return 1; }

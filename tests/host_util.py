@@ -78,7 +78,7 @@ def build_test_binaries():
     newest = max(os.path.getmtime(p) for p in (host_lib, oracle_lib, os.path.join(src, "test_units.cpp"), os.path.join(src, "oracle_runner.cpp"),
                                                os.path.join(src, "oracle_compute.hpp")))
     if not (os.path.exists(units) and os.path.getmtime(units) >= newest):
-        subprocess.check_call(["g++", *flags, os.path.join(src, "test_units.cpp"), host_lib, b.LIB, *rpath, "-o", units])
+        subprocess.check_call(["g++", *flags, os.path.join(src, "test_units.cpp"), host_lib, b.LIB, "-lpthread", *rpath, "-o", units])
     if not (os.path.exists(runner) and os.path.getmtime(runner) >= newest):
-        subprocess.check_call(["g++", *flags, os.path.join(src, "oracle_runner.cpp"), host_lib, b.LIB, oracle_lib, *rpath, "-o", runner])
+        subprocess.check_call(["g++", *flags, os.path.join(src, "oracle_runner.cpp"), host_lib, b.LIB, oracle_lib, "-lpthread", *rpath, "-o", runner])
     return dict(units=units, oracle_runner=runner, run_kitti=host_exe, host_lib=host_lib)
