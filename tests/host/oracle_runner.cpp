@@ -1,6 +1,7 @@
 // tests/host/oracle_runner.cpp -- TEST INFRASTRUCTURE: ssx_run_kitti's loop on the CPU oracle.
 //   oracle_runner <config yaml> <sequence dir> <trajectory out> [max frames]
 // Prints one line per frame: "frame <id> status <s> features <n> keyframes <k> points <p>".
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -21,12 +22,18 @@ int main(int argc, char** argv)
     std::unique_ptr<Compute> compute;
     if (!std::getenv("SSX_HOST_TEST_GPU")) compute = std::make_unique<OracleCompute>();   // unset: the oracle; set: libssx.so
     System system(argv[1], std::move(compute));
+    double t_steps = 0, t_first = 0;
     for (size_t i = 0; i < n; ++i) {
-      system.RunStep(imread_gray(left[i]), imread_gray(right[i]), ts[i]);
+      ImagePtr l = imread_gray(left[i]), r = imread_gray(right[i]);
+      const auto t0 = std::chrono::steady_clock::now();
+      system.RunStep(l, r, ts[i]);
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      (i == 0 ? t_first : t_steps) += dt;
       std::printf("frame %zu status %d features %zu keyframes %zu points %zu active_kfs %zu active_points %zu\n", i, (int)system.frontend().status(),
                   system.frontend().current_frame()->features_left.size(), system.map().GetAllKeyFrames().size(),
                   system.map().GetAllMapPoints().size(), system.map().GetActiveKeyFrames().size(), system.map().GetActiveMapPoints().size());
     }
+    std::printf("runstep_seconds first %.6f rest %.6f\n", t_first, t_steps);
     system.SaveTrajectoryTUM(argv[3]);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "fatal: %s\n", e.what());
