@@ -308,6 +308,50 @@ __device__ __forceinline__ void block_sum(double* v, double (*sPart)[NRED][NW], 
   buf ^= 1;
 }
 
+// The 27 sums of a linearisation (upper H + b).  A butterfly over all lanes costs ~30 instructions per value on the
+// critical path; here every thread drops its 27 values into LDS ([value][thread], conflict-free), thread (value k,
+// part p) of the first 216 adds 32 of them (reads rotated by the lane so a wave touches every bank pair at most
+// twice), 3 DPP steps fold the 8 parts, and every thread reads the 27 totals back: ~130 instructions, two barriers.
+// sT is private to this function (the alternating buffers of block_sum are not touched).
+__device__ __forceinline__ void block_sum27(double* v, double (*sT)[PT], double* sTot)
+{
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) sT[k][t] = v[k];
+  __syncthreads();
+  if (t < 27 * 8) {
+    const int k = t >> 3, part = t & 7;
+    const double* row = &sT[k][part * 32];
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) {
+      s0 += row[(j + t) & 31];
+      s1 += row[(j + 1 + t) & 31];
+    }
+    double s = s0 + s1;
+    s += dpp_f64<0xB1>(s);
+    s += dpp_f64<0x4E>(s);
+    s += dpp_f64<0x141>(s);
+    if (part == 0) sTot[k] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 27; ++k) v[k] = sTot[k];
+}
+
+// 1 / sqrt(d): v_rsq_f64 + two Newton steps instead of an IEEE sqrt followed by an IEEE divide (~45 dependent
+// instructions -> 9) on the serial pivot chain
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+  double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = fma(-(d * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
 // (H + lambda I) x = b for the upper-triangular H[21] by Cholesky, fully unrolled; false when a pivot is not positive
 // (LinearSolverDense: Eigen's LDLT reports failure the same way)
 __device__ __forceinline__ bool solve6(const double* Hb, double lambda, double* x)
@@ -329,7 +373,7 @@ __device__ __forceinline__ bool solve6(const double* Hb, double lambda, double* 
 #pragma unroll
     for (int k = 0; k < j; ++k) dj -= A[j][k] * A[j][k];
     if (!(dj > 0.0) || !isfinite(dj)) { ok = false; dj = 1.0; }
-    const double inv = 1.0 / sqrt(dj);
+    const double inv = rsqrt_nr(dj);
     rd[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
@@ -365,6 +409,8 @@ template <int EPT>
 __global__ __launch_bounds__(PT) void k_pose_only(PoDev d)
 {
   __shared__ double sPart[2][NRED][NW];
+  __shared__ double sT[27][PT];
+  __shared__ double sTot[27];
   const int t = threadIdx.x;
   int buf = 0;
   // this thread's edges: i = t + k * PT
@@ -446,7 +492,7 @@ __global__ __launch_bounds__(PT) void k_pose_only(PoDev d)
 #pragma unroll
         for (int a = 0; a < 6; ++a) Hb[21 + a] -= w * (J[a] * e0 + J[6 + a] * e1);
       }
-      block_sum<27>(Hb, sPart, buf);
+      block_sum27(Hb, sT, sTot);
       if (it == 0) {
         // computeLambdaInit: 1e-5 * max |diag(H)|; diagonal entries of the upper layout: 0,6,11,15,18,20
         const double m = fmax(fmax(fmax(fabs(Hb[0]), fabs(Hb[6])), fmax(fabs(Hb[11]), fabs(Hb[15]))), fmax(fabs(Hb[18]), fabs(Hb[20])));
