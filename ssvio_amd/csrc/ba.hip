@@ -106,11 +106,18 @@ struct BaDev {
   double* trial_slab;       // nCh x 3
   double* scal_comm;        // [tempChi, scale_l, nout]  all-reduced per trial
   double* scal;             // SC_N scalars
+  double* lm_stat;          // device-driven LM: [3][SSX_BA_MAX_STATS] chi2 | lambda | trials per iteration
 };
 
 // scal[] slots
 enum { SC_CHI2_CUR = 0, SC_MAXDIAG = 1, SC_SOLVE_OK = 2, SC_SCALE_P = 3, SC_TEMP_CHI = 4, SC_SCALE_L = 5,
-       SC_NOUT = 6, SC_LAMBDA = 7, SC_N = 16 };
+       SC_NOUT = 6, SC_LAMBDA = 7,
+       // control block of the device-driven LM loop (small windows): the LM bookkeeping of
+       // OptimizationAlgorithmLevenberg::solve runs on the device after every trial, so a whole optimize(iters) is
+       // enqueued without a host round trip.  Kernels launched with cur < 0 take the state buffer from SC_CUR and
+       // return at once when SC_STOP is set.
+       SC_NI = 8, SC_CUR = 9, SC_IT = 10, SC_QMAX = 11, SC_STOP = 12, SC_NEEDLIN = 13, SC_ITERS = 14, SC_NSTAT = 15,
+       SC_CURCHI = 16, SC_TRIALS_RUN = 17, SC_N = 32 };
 
 __device__ __forceinline__ double block_sum_256(double v, double* s)
 {
@@ -159,6 +166,10 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   __shared__ uint16_t sPptr[SSX_BA_SMALL_P + 1];
 
   const int c = blockIdx.x, t = threadIdx.x;
+  if (cur < 0) {                                   // device-driven LM: skip when stopped or when the linearisation at the
+    if (d.scal[SC_STOP] != 0.0 || d.scal[SC_NEEDLIN] == 0.0) return;   // kept state is still valid (rejected trial)
+    cur = (int)d.scal[SC_CUR];
+  }
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
   const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
   const int ne = e1 - e0, nl = lm1 - lm0;
@@ -305,16 +316,79 @@ __global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d)
 // after the (optional) all-reduce of iter_comm: chi2, max diagonal, and lambda_0 = 1e-5 * max on iteration 0
 __global__ void k_lambda_init(BaDev d, int first_iteration)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (blockIdx.x != 0) return;
+  const int t = threadIdx.x;                       // one wave
   const double* tail = d.iter_comm + d.nP * 27;
-  double m = 0.0;
-  for (int r = 0; r < d.world; ++r) m = fmax(m, tail[1 + r]);
   const int diag[6] = {0, 6, 11, 15, 18, 20};
-  for (int p = 0; p < d.nP; ++p)
-    for (int k = 0; k < 6; ++k) m = fmax(m, fabs(d.iter_comm[p * UPPER6 + diag[k]]));
+  double m = 0.0;
+  for (int r = t; r < d.world; r += 64) m = fmax(m, tail[1 + r]);
+  for (int i = t; i < d.nP * 6; i += 64) m = fmax(m, fabs(d.iter_comm[(i / 6) * UPPER6 + diag[i % 6]]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if (t != 0) return;
   d.scal[SC_CHI2_CUR] = tail[0];
   d.scal[SC_MAXDIAG] = m;
   if (first_iteration) d.scal[SC_LAMBDA] = 1e-5 * m;
+}
+
+// Device-driven LM: start of one optimize(iters) at state buffer `cur` (stop = 1: nothing to optimise on any rank)
+__global__ void k_lm_begin(BaDev d, int cur, int iters, int nstat, int stop)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  d.scal[SC_NI] = 2.0; d.scal[SC_CUR] = (double)cur; d.scal[SC_IT] = 0.0; d.scal[SC_QMAX] = 0.0;
+  d.scal[SC_STOP] = (stop || iters <= 0) ? 1.0 : 0.0; d.scal[SC_NEEDLIN] = 1.0; d.scal[SC_ITERS] = (double)iters;
+  d.scal[SC_NSTAT] = (double)nstat; d.scal[SC_CURCHI] = 0.0; d.scal[SC_TRIALS_RUN] = 0.0;
+}
+
+// The bookkeeping of one LM trial (OptimizationAlgorithmLevenberg::solve, optimization_algorithm_levenberg.cpp:99-140)
+// on the trial's scalars; one thread, called by the kernel that completes them.
+__device__ void lm_step(const BaDev& d)
+{
+  double* sc = d.scal;
+  if (sc[SC_STOP] != 0.0) return;
+  double lambda = sc[SC_LAMBDA], ni = sc[SC_NI];
+  int it = (int)sc[SC_IT], q = (int)sc[SC_QMAX], cur = (int)sc[SC_CUR];
+  double current_chi = sc[SC_CURCHI];
+  if (q == 0) {
+    current_chi = sc[SC_CHI2_CUR];
+    if (it == 0) ni = 2.0;
+  }
+  const bool ok = sc[SC_SOLVE_OK] != 0.0;
+  const double temp_chi = ok ? sc[SC_TEMP_CHI] : 1.7976931348623157e308;
+  double rho = current_chi - temp_chi;
+  rho /= sc[SC_SCALE_P] + sc[SC_SCALE_L] + 1e-3;
+  bool lambda_bad = false, accepted = false;
+  if (rho > 0 && isfinite(temp_chi)) {
+    double alpha = 1. - pow((2 * rho - 1), 3.0);
+    alpha = fmin(alpha, 2. / 3.);
+    lambda *= fmax(1. / 3., alpha);
+    ni = 2.0;
+    current_chi = temp_chi;
+    cur ^= 1;                                      // accept: the trial buffers become the state
+    accepted = true;
+  } else {
+    lambda *= ni;
+    ni *= 2.0;
+    if (!isfinite(lambda)) lambda_bad = true;
+  }
+  if (!lambda_bad) ++q;
+  sc[SC_LAMBDA] = lambda; sc[SC_NI] = ni; sc[SC_CUR] = (double)cur; sc[SC_CURCHI] = current_chi;
+  sc[SC_TRIALS_RUN] += 1.0;
+  if (!lambda_bad && rho < 0 && q < 10) {          // another trial of the same iteration, same linearisation
+    sc[SC_QMAX] = (double)q; sc[SC_NEEDLIN] = 0.0;
+    return;
+  }
+  const int ns = (int)sc[SC_NSTAT];
+  if (ns < SSX_BA_MAX_STATS) {
+    d.lm_stat[ns] = temp_chi;
+    d.lm_stat[SSX_BA_MAX_STATS + ns] = lambda;
+    d.lm_stat[2 * SSX_BA_MAX_STATS + ns] = (double)q;
+  }
+  sc[SC_NSTAT] = (double)(ns + 1);
+  ++it;
+  sc[SC_IT] = (double)it; sc[SC_QMAX] = 0.0; sc[SC_NEEDLIN] = 1.0;
+  (void)accepted;
+  if (q == 10 || rho == 0 || lambda_bad || it >= (int)sc[SC_ITERS]) sc[SC_STOP] = 1.0;
 }
 
 __global__ void k_set_lambda(BaDev d, double lambda)
@@ -346,6 +420,7 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int us
   uint8_t* sPb = sPa + MAX_PAIRS;                                    // [MAX_PAIRS]
 
   const int c = blockIdx.x, t = threadIdx.x;
+  if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
   const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
@@ -496,6 +571,10 @@ __global__ __launch_bounds__(256) void k_solve(BaDev d, int cur, double lambda_a
   __shared__ double sX[NMAX + 8];
   const int n = 6 * d.nP;
   const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+  if (cur < 0) {
+    if (d.scal[SC_STOP] != 0.0) return;
+    cur = (int)d.scal[SC_CUR];
+  }
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const double* S = d.trial_comm;
   const double* bs = d.trial_comm + (size_t)n * n;
@@ -685,6 +764,10 @@ __global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, doubl
   __shared__ double sPt[3][CH];
   __shared__ double sRed[CH];
   const int c = blockIdx.x, t = threadIdx.x;
+  if (cur < 0) {
+    if (d.scal[SC_STOP] != 0.0) return;
+    cur = (int)d.scal[SC_CUR];
+  }
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
   const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
@@ -754,7 +837,7 @@ __global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, doubl
   }
 }
 
-__global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d)
+__global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d, int lm)
 {
   __shared__ double sRed[CH];
   double chi = 0.0, sl = 0.0, no = 0.0;
@@ -774,16 +857,18 @@ __global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d)
     d.scal[SC_TEMP_CHI] = chi;
     d.scal[SC_SCALE_L] = sl;
     d.scal[SC_NOUT] = no;
+    if (lm) lm_step(d);                            // device-driven LM on one GPU: the trial is complete here
   }
 }
 
 // copy the (all-reduced) trial scalars next to the others so that ONE 64-byte download returns everything
-__global__ void k_publish_trial(BaDev d)
+__global__ void k_publish_trial(BaDev d, int lm)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     d.scal[SC_TEMP_CHI] = d.scal_comm[0];
     d.scal[SC_SCALE_L] = d.scal_comm[1];
     d.scal[SC_NOUT] = d.scal_comm[2];
+    if (lm) lm_step(d);                            // every rank takes the same decision from the all-reduced scalars
   }
 }
 
@@ -1082,11 +1167,12 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_trial = all.take(sizeof(double) * 3 * (nCh + 1));
   const size_t o_scal_comm = all.take(sizeof(double) * 4);
   const size_t o_scal = all.take(sizeof(double) * SC_N);
+  const size_t o_lmstat = all.take(sizeof(double) * 3 * SSX_BA_MAX_STATS);
 
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
   SSX_HIP_TRY(ctx, ws->arena.reserve(all.off));
   SSX_HIP_TRY(ctx, ws->stage.reserve(std::max(in_bytes, sizeof(double) * (7 * (size_t)P + 3 * (size_t)L + 2 * (size_t)E))));
-  SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * SC_N));
+  SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * (SC_N + 3 * SSX_BA_MAX_STATS)));
   char* hs = ws->stage.as<char>();
   memcpy(hs + o_pose_free, h.pose_free.data(), sizeof(int) * P);
   if (nLm) {
@@ -1168,6 +1254,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.trial_slab = (double*)(base + o_trial);
   d.scal_comm = (double*)(base + o_scal_comm);
   d.scal = (double*)(base + o_scal);
+  d.lm_stat = (double*)(base + o_lmstat);
   bd = BigDev{};
   if (big) {
     bd.n = n; bd.n_pad = n_pad; bd.ld = n_pad; bd.T = n_pad / NB; bd.nBlkS = (int)nBlkS;
@@ -1477,6 +1564,65 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     // the host waits for the trial's scalars: the GPU works through the ~25 us of the host round trip instead of
     // idling.  A rejected trial pays one extra linearisation at the kept state (identical values: deterministic).
     bool spec_done = false;
+    if (!d.big) {
+      // ---- small windows: the whole optimize(iters) is enqueued; lm_step() on the device decides after every trial ----
+      // One slot = (re)linearise if needed + one trial.  A rejected trial consumes a slot without finishing its
+      // iteration, so after the first `iters` slots the host looks at the control block once and tops up.
+      hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(1), 0, ctx->stream, d, cur, opt.iters, res->n_iters, active ? 0 : 1);
+      int slots_total = 0;
+      bool first_slot = true;
+      while (active && opt.iters > 0) {
+        int slots = slots_total == 0 ? opt.iters : std::max(1, opt.iters - (int)hscal[SC_IT]);
+        for (int sidx = 0; sidx < slots; ++sidx) {
+          if (nCh > 0) {
+            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1));
+            else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1));
+          }
+          SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 15) / 16)), dim3(CH), 0, ctx->stream, d));
+          st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
+          if (st != SSX_OK) return st;
+          if (first_slot || cm.fn) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_slot ? 1 : 0));
+          first_slot = false;
+          if (n > 0) {
+            if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, 0.0, 2));
+            SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
+            st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
+            if (st != SSX_OK) return st;
+          }
+          if (n <= NB) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
+          else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, ctx->stream, d, -1, 0.0, 1));
+          if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
+          SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, cm.fn ? 0 : 1));
+          if (cm.fn) {
+            st = allreduce(ctx, cm, d.scal_comm, 3);
+            if (st != SSX_OK) return st;
+            SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_publish_trial, dim3(1), dim3(1), 0, ctx->stream, d, 1));
+          }
+        }
+        slots_total += slots;
+        SSX_HIP_TRY(ctx, hipGetLastError());
+        SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, ctx->stream));
+        SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the one host round trip of an optimize(iters)
+        if (hscal[SC_STOP] != 0.0) break;
+      }
+      if (active && opt.iters > 0) {
+        cur = (int)hscal[SC_CUR];
+        n_out_total = hscal[SC_NOUT];
+        if (hscal[SC_TRIALS_RUN] > 0.0) have_trial_err = true;
+        const int n_done = (int)hscal[SC_NSTAT];
+        if (n_done > res->n_iters) {
+          double* hstat = hscal + SC_N;                                // pinned, behind the scalar block
+          SSX_HIP_TRY(ctx, hipMemcpyAsync(hstat, d.lm_stat, sizeof(double) * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, ctx->stream));
+          SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+          for (int k = res->n_iters; k < n_done && k < SSX_BA_MAX_STATS; ++k) {
+            res->iter_chi2[k] = hstat[k];
+            res->iter_lambda[k] = hstat[SSX_BA_MAX_STATS + k];
+            res->iter_trials[k] = (int)hstat[2 * SSX_BA_MAX_STATS + k];
+          }
+          res->n_iters = n_done;
+        }
+      }
+    } else
     for (int it = 0; it < opt.iters && active; ++it) {
       if (!spec_done) {
         st = launch_linearize(ctx, d, bd, cm, opt.jac_mode, cur, it == 0);
@@ -1503,11 +1649,11 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
         else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, ctx->stream, d, cur, lambda, dev_lambda));
         }
         if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
-        SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d));
+        SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, 0));
         if (cm.fn) {
           st = allreduce(ctx, cm, d.scal_comm, 3);
           if (st != SSX_OK) return st;
-          SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_publish_trial, dim3(1), dim3(1), 0, ctx->stream, d));
+          SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_publish_trial, dim3(1), dim3(1), 0, ctx->stream, d, 0));
         }
         SSX_HIP_TRY(ctx, hipGetLastError());
         SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
