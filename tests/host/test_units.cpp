@@ -207,6 +207,15 @@ static void test_se3()
 int main(int argc, char** argv)
 {
   if (argc < 2) return 2;
+  if (std::string(argv[1]) == "--dump-setting" && argc >= 3) {    // test_units --dump-setting <yaml> key...
+    Setting cfg(argv[2]);
+    for (int i = 3; i < argc; ++i) {
+      int vi = 0; double vd = 0; bool numeric = true;
+      try { vi = cfg.Get<int>(argv[i]); vd = cfg.Get<double>(argv[i]); } catch (const std::runtime_error&) { numeric = false; }   // a string value
+      std::printf("%s=%s|%d|%.12g|%d\n", argv[i], cfg.Get<std::string>(argv[i]).c_str(), vi, vd, numeric ? 1 : 0);
+    }
+    return 0;
+  }
   const std::string dir = argv[1];
   test_setting(dir);
   test_kitti_listing(dir);

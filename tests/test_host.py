@@ -91,6 +91,31 @@ def test_host_units(built, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+REF_YAML = "/root/reference/config/kitti_00.yaml"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="the reference tree is only present in the build container")
+def test_reads_the_reference_settings_file(built):
+    """the runner takes ssvio's own config/kitti_00.yaml: every key System / FrontEnd / Map read parses to the value
+    cv::FileStorage would return"""
+    want = {"Camera1.fx": 718.856, "Camera1.cy": 185.2157, "Camera2.cx": 607.1928, "Camera.Base.Line": 386.1448,
+            "Camera.NeedUndistortion": 0, "Map.ActiveMap.Size": 12, "numFeatures.initGood": 100, "numFeatures.trackingGood": 50,
+            "numFeatures.trackingBad": 10, "ORBextractor.nInitFeatures": 300, "ORBextractor.nNewFeatures": 100,
+            "ORBextractor.scaleFactor": 1.2, "ORBextractor.nLevels": 8, "ORBextractor.iniThFAST": 20, "ORBextractor.minThFAST": 7,
+            "Min.Init.Landmark.Num": 200, "Backend.Open": 1, "Viewer.ViewpointY": 1000}
+    r = subprocess.run([built["units"], "--dump-setting", REF_YAML, *want, "Trajectory.Save.Path", "Backend.Jacobian.Numeric"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = dict(line.split("=", 1) for line in r.stdout.splitlines())
+    for k, v in want.items():
+        text, as_int, as_double, numeric = got[k].split("|")
+        assert numeric == "1", k
+        assert float(as_double) == pytest.approx(v, abs=0, rel=1e-12), k
+        assert int(as_int) == int(round(v)), k
+    assert got["Trajectory.Save.Path"].split("|")[0].endswith(".txt") and got["Trajectory.Save.Path"].split("|")[3] == "0"   # a quoted string
+    assert got["Backend.Jacobian.Numeric"].split("|")[:2] == ["", "0"]          # our extra key: absent -> 0 (analytic)
+
+
 def _run(built, tmp_path, overrides, n_frames=12, step=0.6):
     seq = hu.write_sequence(str(tmp_path), n_frames=n_frames, step=step)
     cfg = os.path.join(str(tmp_path), "cfg.yaml")
