@@ -290,3 +290,74 @@ def make_lateral_sequence(n_frames=12, step=0.12, seed=0, h=KITTI_H, w=KITTI_W, 
         frames.append((render(a), render(a + 1.0)))
         poses.append(np.array([0, 0, 0, 1, -a * baseline, 0, 0], dtype=np.float64))       # T_cw: camera centre at (+a b, 0, 0)
     return frames, np.array(poses), disp
+
+
+def _cell_hash(a, b, salt):
+    """deterministic pseudo-random value in [0, 1) per integer cell (a, b)"""
+    a = a.astype(np.int64) + 100003; b = b.astype(np.int64) + 100019          # keep the cell indices positive
+    h = (a * 73856093) ^ (b * 19349663) ^ (np.asarray(salt, dtype=np.int64) * 83492791)
+    h = (h ^ (h >> 13)) * 1274126177
+    h = h ^ (h >> 16)
+    return (h & 0xFFFF).astype(np.float32) / 65536.0
+
+
+def _block_texture(a, b, salt):
+    """piecewise-constant random blocks at three scales (0.2 m, 0.8 m, 3.2 m): block junctions are FAST corners at any
+    viewing distance between a few and a few tens of metres"""
+    t = np.zeros(a.shape, np.float32)
+    for k, (size, wgt) in enumerate(((0.2, 0.45), (0.8, 0.35), (3.2, 0.2))):
+        t += wgt * _cell_hash(np.floor(a / size), np.floor(b / size), salt * 7 + k)
+    return t
+
+
+def make_corridor_sequence(n_frames=40, step=0.8, seed=0, h=KITTI_H, w=KITTI_W, K=KITTI_K, baseline=KITTI_BASELINE, lateral_amp=0.3,
+                           half_width=6.0, cam_height=1.65, wall_height=6.0, backdrop=120.0, supersample=2):
+    """A KITTI-00-shaped stereo sequence: the rig drives FORWARD (+z) by `step` metres per frame (0.8 m ~ KITTI at 10 Hz)
+    with a slow lateral sway, through a textured corridor (ground plane, two walls, a far backdrop), rendered by ray
+    casting each pixel against the planes -- exact perspective, exact stereo geometry, ground-truth poses.  Rotations
+    are identity.  The backdrop is a world plane `backdrop` metres beyond the end of the drive.
+    Returns (frames [(left, right)], T_cw [n,7], centres [n,3])."""
+    rng = np.random.default_rng(9000 + seed)
+    fx, fy, cx, cy = K
+    ss = supersample
+    us = (np.arange(w * ss, dtype=np.float32) + 0.5) / ss - 0.5
+    vs = (np.arange(h * ss, dtype=np.float32) + 0.5) / ss - 0.5
+    dx = ((us - cx) / fx)[None, :].repeat(h * ss, 0)                   # ray direction (dx, dy, 1)
+    dy = ((vs - cy) / fy)[:, None].repeat(w * ss, 1)
+
+    z_end = step * n_frames + backdrop
+
+    def render(c):
+        big = np.float32(1e9)
+        # positive ray parameters of the four surfaces (inf where the ray does not hit the half-space in front)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t_ground = np.where(dy > 1e-6, (cam_height - c[1]) / dy, big)
+            t_left = np.where(dx < -1e-6, (-half_width - c[0]) / dx, big)
+            t_right = np.where(dx > 1e-6, (half_width - c[0]) / dx, big)
+        t_back = np.full_like(dx, np.float32(z_end - c[2]))
+        t = np.minimum(np.minimum(t_ground, t_back), np.minimum(t_left, t_right)).astype(np.float32)
+        X = c[0] + t * dx; Y = c[1] + t * dy; Z = c[2] + t
+        which = np.select([t == t_ground, t == t_left, t == t_right], [0, 1, 2], 3)
+        # walls end at wall_height above the ground: above that, the backdrop
+        above = ((which == 1) | (which == 2)) & (Y < cam_height - wall_height)
+        t2 = np.where(above, t_back, t)
+        X = np.where(above, c[0] + t2 * dx, X); Y = np.where(above, c[1] + t2 * dy, Y); Z = np.where(above, c[2] + t2, Z)
+        which = np.where(above, 3, which)
+        # texture coordinates of the surface hit: ground (X, Z), walls (Y, Z), far plane (X, Y) / 10 (2 m ... 32 m blocks)
+        ta = np.select([which == 0, which == 3], [X, X * 0.1], Y)
+        tb = np.where(which == 3, Y * 0.1, Z)
+        tex = _block_texture(ta, tb, seed * 4 + which)
+        img = 30.0 + 200.0 * tex
+        img = img.reshape(h, ss, w, ss).mean(axis=(1, 3))
+        img += rng.normal(0, 1.0, img.shape)
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+    frames, poses, centres = [], [], []
+    for k in range(n_frames):
+        c = np.array([lateral_amp * np.sin(0.15 * k), 0.0, step * k], dtype=np.float32)
+        left = render(c)
+        right = render(c + np.array([baseline, 0, 0], dtype=np.float32))
+        frames.append((left, right))
+        centres.append(c.astype(np.float64))
+        poses.append(np.array([0, 0, 0, 1, -c[0], -c[1], -c[2]], dtype=np.float64))   # T_cw, identity rotation
+    return frames, np.array(poses), np.array(centres)

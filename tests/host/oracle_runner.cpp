@@ -29,9 +29,13 @@ int main(int argc, char** argv)
       system.RunStep(l, r, ts[i]);
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       (i == 0 ? t_first : t_steps) += dt;
-      std::printf("frame %zu status %d features %zu keyframes %zu points %zu active_kfs %zu active_points %zu\n", i, (int)system.frontend().status(),
-                  system.frontend().current_frame()->features_left.size(), system.map().GetAllKeyFrames().size(),
-                  system.map().GetAllMapPoints().size(), system.map().GetActiveKeyFrames().size(), system.map().GetActiveMapPoints().size());
+      // camera centre of the frame: T_cw = relative pose to the reference keyframe * that keyframe's pose
+      SE3 T_wc;
+      if (system.frontend().reference_kf()) T_wc = (system.frontend().current_frame()->relative_pose_to_kf * system.frontend().reference_kf()->pose).inverse();
+      std::printf("frame %zu status %d features %zu keyframes %zu points %zu active_kfs %zu active_points %zu centre %.6f %.6f %.6f\n", i,
+                  (int)system.frontend().status(), system.frontend().current_frame()->features_left.size(), system.map().GetAllKeyFrames().size(),
+                  system.map().GetAllMapPoints().size(), system.map().GetActiveKeyFrames().size(), system.map().GetActiveMapPoints().size(),
+                  T_wc.d[4], T_wc.d[5], T_wc.d[6]);
     }
     std::printf("runstep_seconds first %.6f rest %.6f\n", t_first, t_steps);
     system.SaveTrajectoryTUM(argv[3]);

@@ -51,13 +51,30 @@ def write_sequence(root, n_frames=12, step=0.12, seed=0, dt=0.1):
     return dict(dir=d, dt=dt, centres=centres, step_m=step * KITTI_BASELINE, frames=frames)
 
 
+def write_corridor_sequence(root, n_frames=30, step=0.8, seed=0, dt=0.1):
+    """make_corridor_sequence (forward drive, KITTI-00-shaped) as <root>/seq/..."""
+    from PIL import Image
+
+    from ssvio_amd.synth import make_corridor_sequence
+    frames, gt, centres = make_corridor_sequence(n_frames=n_frames, step=step, seed=seed)
+    d = os.path.join(root, "seq")
+    for sub in ("image_0", "image_1"):
+        os.makedirs(os.path.join(d, sub), exist_ok=True)
+    with open(os.path.join(d, "times.txt"), "w") as f:
+        for i, (L, R) in enumerate(frames):
+            f.write(f"{i * dt:e}\n")
+            Image.fromarray(L).save(os.path.join(d, "image_0", f"{i:06d}.png"))
+            Image.fromarray(R).save(os.path.join(d, "image_1", f"{i:06d}.png"))
+    return dict(dir=d, dt=dt, centres=centres, frames=frames)
+
+
 def parse_runner_log(text):
     out = []
     for line in text.splitlines():
         w = line.split()
         if len(w) >= 14 and w[0] == "frame":
             out.append(dict(frame=int(w[1]), status=int(w[3]), features=int(w[5]), keyframes=int(w[7]), points=int(w[9]),
-                            active_kfs=int(w[11]), active_points=int(w[13])))
+                            active_kfs=int(w[11]), active_points=int(w[13]), centre=tuple(float(x) for x in w[15:18])))
     return out
 
 

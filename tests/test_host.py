@@ -166,6 +166,27 @@ def test_tracking_between_keyframes_on_the_oracle(built, tmp_path):
     assert err.max() < 0.03, err.max()
 
 
+def test_forward_drive_with_the_reference_thresholds(built, tmp_path):
+    """BASELINE configs[0] shape: the rig drives forward 0.8 m per frame through a rendered corridor, settings exactly
+    as config/kitti_00.yaml (300 / 100 features, keyframe when <= 50 inliers remain).  Frame-to-frame tracking against
+    the initial stereo map stays within 0.5 % of the ground truth; a keyframe is inserted when the features run out."""
+    seq = hu.write_corridor_sequence(str(tmp_path), n_frames=22)
+    cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {})
+    traj = os.path.join(str(tmp_path), "traj.txt")
+    r = subprocess.run([built["oracle_runner"], cfg, seq["dir"], traj], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    log = hu.parse_runner_log(r.stdout)
+    assert len(log) == 22 and all(f["status"] in (1, 2) for f in log)
+    first_new_kf = next(i for i in range(1, 22) if log[i]["keyframes"] > 1)
+    assert 10 <= first_new_kf <= 21 and log[first_new_kf]["status"] == 2
+    feats = [f["features"] for f in log[:first_new_kf]]
+    assert feats[0] >= 290 and all(b <= a for a, b in zip(feats, feats[1:])) and feats[-1] <= 60     # features leave the view
+    for i in range(1, first_new_kf):                                             # pose-only tracking against the stereo map
+        err = np.abs(np.array(log[i]["centre"]) - seq["centres"][i]).max()
+        assert err < 0.005 * seq["centres"][i][2] + 0.01, (i, err)
+    assert log[first_new_kf]["features"] > feats[-1] + 50                        # ~100 new features at the keyframe
+
+
 def test_runner_reports_bad_input(built, tmp_path):
     cfg = os.path.join(str(tmp_path), "cfg.yaml")
     hu.write_config(cfg, {})
