@@ -187,7 +187,11 @@ typedef struct {          /* ORBextractor ctor arguments (orbextractor.hpp:44-45
 
 SSX_API void ssx_orb_default_params(ssx_orb_params* p); /* 2000, 1.2, 8, 20, 7 (config/kitti_00.yaml:41-49) */
 
-/* ORBextractor::Detect: single-level grid FAST + octree.  mask may be NULL (all 255).  Empty image:
+/* Output capacity `cap` of the two calls below: a pyramid level returns at most max(N_level + 3, 4 * nIni) keypoints
+ * (the quadtree stops within 3 nodes of its budget, but its first subdivision already makes up to 4 * nIni <= 256
+ * nodes however small the budget is); nfeatures + 260 * nlevels is always enough.  SSX_ERR_CAPACITY otherwise.
+ *
+ * ORBextractor::Detect: single-level grid FAST + octree.  mask may be NULL (all 255).  Empty image:
  * returns SSX_OK with *n = 0 (the reference silently returns, orbextractor.cpp:758-759).
  * Output: keypoints {pt, size 7, angle -1, response = FAST score, octave 0, class_id -1}. */
 SSX_API ssx_status ssx_orb_detect(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,

@@ -85,7 +85,8 @@ class ORBextractor {
   const ssx_orb_params& params() const { return prm_; }
 
  private:
-  size_t capacity() const { return (size_t)prm_.nfeatures + 4 * (size_t)prm_.nlevels + 64; }
+  // a level can return up to max(budget + 3, 4 * nIni <= 256) keypoints (the first quadtree subdivision)
+  size_t capacity() const { return (size_t)prm_.nfeatures + 260 * (size_t)prm_.nlevels + 64; }
   Context& ctx_;
   ssx_orb_params prm_;
 };

@@ -920,7 +920,14 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
     off += (size_t)d.lvl_pitch[l] * d.lvl_rows[l];
     d.lvl_cell0[l] = (int)cells.size();
     make_cells(d.lvl_rows[l], d.lvl_cols[l], l, cells);
-    out_cap += d.feat[l] + 4;
+    // a level yields at most max(N + 3, 4 * nIni) keypoints: the quadtree stops within 3 nodes of its budget N, but
+    // its very first subdivision already makes up to 4 * nIni nodes (nIni = aspect ratio of the level) however
+    // small N is (DistributeOctTree, orbextractor.cpp:347-349, 394-470)
+    {
+      const int bw = d.lvl_cols[l] - 2 * (EDGE_THRESHOLD - 3), bh = d.lvl_rows[l] - 2 * (EDGE_THRESHOLD - 3);
+      const int n_ini = bh > 0 ? (int)std::lround((double)bw / (double)bh) : 0;
+      out_cap += std::max(d.feat[l] + 4, 4 * std::max(n_ini, 0) + 4);
+    }
     if (d.feat[l] + 8 > SEL_CAP) {
       ctx->set_error("ssx_orb: %d features on level %d exceed the octree node capacity", d.feat[l], l);
       return SSX_ERR_UNSUPPORTED;

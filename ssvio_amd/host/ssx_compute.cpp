@@ -14,7 +14,7 @@ class SsxCompute final : public Compute {
 
   void Detect(const Image& img, const uint8_t* mask, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
   {
-    kps.assign((size_t)prm.nfeatures + 4 * (size_t)prm.nlevels + 64, ssx_keypoint{});
+    kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});      // Detect is single-level: <= max(N + 3, 4 * nIni <= 256)
     int32_t n = 0;
     frame_.check(ssx_orb_detect(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, mask, img.cols, &prm, (int32_t)kps.size(),
                                 kps.data(), &n));

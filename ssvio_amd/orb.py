@@ -30,7 +30,8 @@ class ORBextractor:
         self.prm = OrbParams(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST))
 
     def _cap(self):
-        return self.prm.nfeatures + 4 * self.prm.nlevels + 64
+        # a level can return up to max(budget + 3, 4 * nIni) keypoints (first quadtree subdivision), see plan() in orb.hip
+        return self.prm.nfeatures + 260 * self.prm.nlevels + 64
 
     def Detect(self, image, mask=None):
         """ORBextractor::Detect (orbextractor.cpp:755-842): returns keypoints; empty image -> empty result."""

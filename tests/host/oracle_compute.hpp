@@ -17,7 +17,7 @@ class OracleCompute final : public Compute {
   {
     static_assert(sizeof(orc_keypoint) == sizeof(ssx_keypoint), "keypoint layouts");
     orc_orb_params p{prm.nfeatures, prm.scale_factor, prm.nlevels, prm.ini_th_fast, prm.min_th_fast};
-    kps.assign((size_t)prm.nfeatures + 4 * (size_t)prm.nlevels + 64, ssx_keypoint{});
+    kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});
     const int n = orc_orb_detect(img.ptr(), img.cols, img.rows, img.cols, mask, img.cols, &p, (int)kps.size(),
                                  reinterpret_cast<orc_keypoint*>(kps.data()));
     if (n < 0) throw std::runtime_error("orc_orb_detect failed");

@@ -206,6 +206,22 @@ def test_extract_other_pyramids_bit_exact(ctx, po, pair_small, pair_kitti, scale
         assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
 
 
+def test_tiny_budgets_return_more_than_the_budget(ctx, po):
+    """a wide image with a handful of features per level: the first quadtree subdivision already makes up to
+    4 * nIni nodes, so a level returns more keypoints than its budget + 3 (found by tools/fuzz_parity.py: the output
+    arrays used to be sized for budget + 4 per level)"""
+    from ssvio_amd.synth import make_stereo_pair
+    L = make_stereo_pair(seed=1008, h=368, w=1341, n_blobs=4100)[0]
+    for nfeat, nlev, sf in ((50, 8, 1.1), (8, 8, 1.2), (20, 3, 1.5)):
+        ex = sorb.ORBextractor(ctx, nfeatures=nfeat, scaleFactor=sf, nlevels=nlev, iniThFAST=35, minThFAST=3)
+        gk, gd = ex.DetectAndCompute(L)
+        ok, od = po.orb_extract(L, prm=po.orb_params(nfeatures=nfeat, scale_factor=sf, nlevels=nlev, ini_th=35, min_th=3))
+        assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+        assert len(gk) > nfeat + 3 * nlev
+        dk = ex.Detect(L); do = po.orb_detect(L, prm=po.orb_params(nfeatures=nfeat, scale_factor=sf, nlevels=nlev, ini_th=35, min_th=3))
+        assert dk.tobytes() == do.tobytes()
+
+
 def test_low_contrast_cells_fall_back_to_min_threshold(ctx, po, pair_small):
     """cells without a corner at iniThFAST are re-run at minThFAST (orbextractor.cpp:598-606): a low-contrast
     image makes most cells take the second pass, a high iniThFAST all of them"""
