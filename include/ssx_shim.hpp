@@ -158,7 +158,7 @@ class StereoFrontEnd {
 
   Result Process(const uint8_t* imgL, const uint8_t* imgR, int stride, int rows, int cols, const double* T_wc = nullptr)
   {
-    const size_t cap = (size_t)orb_.nfeatures + 4 * (size_t)orb_.nlevels + 64;
+    const size_t cap = (size_t)orb_.nfeatures + 260 * (size_t)orb_.nlevels + 64;   // see ORBextractor::capacity()
     Result r;
     r.kpsL.resize(cap); r.kpsR.resize(cap); r.descL.resize(cap * 32); r.descR.resize(cap * 32);
     r.match_idx.resize(cap); r.match_dist.resize(cap); r.xyz.resize(cap * 3); r.ok.resize(cap);

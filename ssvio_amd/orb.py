@@ -164,7 +164,7 @@ def stereo_frame(ctx: Context, imgL, imgR, orb: OrbParams | None = None, mp=None
     orb = orb or OrbParams(2000, 1.2, 8, 20, 7)
     mp = mp or match_params(scale_factor=orb.scale_factor)
     rig = rig or stereo_rig()
-    fb = _FrameBuffers(orb.nfeatures + 4 * orb.nlevels + 64)
+    fb = _FrameBuffers(orb.nfeatures + 260 * orb.nlevels + 64)
     T = None if T_wc is None else np.ascontiguousarray(T_wc, dtype=np.float64)
     ctx.check(ctx.lib.ssx_stereo_frame(ctx.handle, ptr(imgL, u8_p), ptr(imgR, u8_p), imgL.strides[0], imgL.shape[0],
                                        imgL.shape[1], C.byref(orb), C.byref(mp), C.byref(rig), ptr(T, dbl_p), C.byref(fb.out)))
