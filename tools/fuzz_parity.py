@@ -32,6 +32,8 @@ def check(name, cond, info):
 for r in range(rounds):
     t0 = time.time()
     h = int(rng.integers(60, 900)); w = int(rng.integers(80, 1500))
+    if rng.random() < 0.15: h, w = int(rng.integers(700, 1200)), int(rng.integers(1300, 2100))     # > 0.6 Mpx: the global-key octree path
+    if rng.random() < 0.1: h, w = int(rng.integers(40, 70)), int(rng.integers(40, 90))            # barely larger than the borders
     nblobs = int(h * w / 120)
     L, R, _ = make_stereo_pair(seed=1000 * seed + r, h=h, w=w, n_blobs=nblobs)
     if rng.random() < 0.25:
