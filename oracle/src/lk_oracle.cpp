@@ -155,7 +155,9 @@ int orc_lk_track(const uint8_t* prev, int pstride, const uint8_t* next, int nstr
       next_pts[2 * i] = nx; next_pts[2 * i + 1] = ny;
       px -= half; py -= half;
       const int ipx = cv_floor(px), ipy = cv_floor(py);
-      if (ipx < -win || ipx >= I.cols || ipy < -win || ipy >= I.rows) {
+      // a non-finite position is outside every image (OpenCV leaves this case to the float -> int conversion,
+      // which is undefined for NaN / inf; the kernel and this restatement agree on "outside")
+      if (!(std::isfinite(px) && std::isfinite(py)) || ipx < -win || ipx >= I.cols || ipy < -win || ipy >= I.rows) {
         if (level == 0) { status[i] = 0; if (err) err[i] = 0.f; }
         continue;
       }
@@ -184,7 +186,7 @@ int orc_lk_track(const uint8_t* prev, int pstride, const uint8_t* next, int nstr
       float pdx = 0.f, pdy = 0.f;
       for (int j = 0; j < max_count; ++j) {
         const int inx = cv_floor(nx), iny = cv_floor(ny);
-        if (inx < -win || inx >= J.cols || iny < -win || iny >= J.rows) {
+        if (!(std::isfinite(nx) && std::isfinite(ny)) || inx < -win || inx >= J.cols || iny < -win || iny >= J.rows) {
           if (level == 0) status[i] = 0;
           break;
         }
@@ -212,7 +214,7 @@ int orc_lk_track(const uint8_t* prev, int pstride, const uint8_t* next, int nstr
       if (status[i] && err && level == 0) {
         const float ex = next_pts[2 * i] - half, ey = next_pts[2 * i + 1] - half;
         const int inx = cv_floor(ex), iny = cv_floor(ey);
-        if (inx < -win || inx >= J.cols || iny < -win || iny >= J.rows) { status[i] = 0; continue; }
+        if (!(std::isfinite(ex) && std::isfinite(ey)) || inx < -win || inx >= J.cols || iny < -win || iny >= J.rows) { status[i] = 0; continue; }
         const float aa = ex - inx, bb = ey - iny;
         iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS)); iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
         iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS)); iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;

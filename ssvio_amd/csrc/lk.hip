@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void k_lk_track(LkDev d)
     outx = nx; outy = ny;
     px -= half; py -= half;
     const int ipx = cv_floor(px), ipy = cv_floor(py);
-    if (ipx < -win || ipx >= cols || ipy < -win || ipy >= rows) {
+    // a non-finite position is outside every image (float -> int conversion of NaN / inf differs between CPU and GPU)
+    if (!(isfinite(px) && isfinite(py)) || ipx < -win || ipx >= cols || ipy < -win || ipy >= rows) {
       if (level == 0) { status = 0; errv = 0.f; }
       continue;
     }
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void k_lk_track(LkDev d)
     float pdx = 0.f, pdy = 0.f;
     for (int j = 0; j < d.max_iters; ++j) {
       const int inx = cv_floor(nx), iny = cv_floor(ny);
-      if (inx < -win || inx >= cols || iny < -win || iny >= rows) {
+      if (!(isfinite(nx) && isfinite(ny)) || inx < -win || inx >= cols || iny < -win || iny >= rows) {
         if (level == 0) status = 0;
         break;
       }
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void k_lk_track(LkDev d)
     if (status && level == 0) {
       const float ex = outx - half, ey = outy - half;
       const int inx = cv_floor(ex), iny = cv_floor(ey);
-      if (inx < -win || inx >= cols || iny < -win || iny >= rows) { status = 0; continue; }
+      if (!(isfinite(ex) && isfinite(ey)) || inx < -win || inx >= cols || iny < -win || iny >= rows) { status = 0; continue; }
       w = bilinear(ex - (float)inx, ey - (float)iny);
       long long e = 0;
 #pragma unroll

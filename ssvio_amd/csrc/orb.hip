@@ -1232,6 +1232,10 @@ ssx_status ssx_orb_detect(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int3
   if (!ctx || !prm || !n) return SSX_ERR_INVALID_ARG;
   *n = 0;
   if (!img || rows <= 0 || cols <= 0) return SSX_OK;   // `if (_image.empty()) return;` orbextractor.cpp:758
+  if (stride < cols || (mask && mask_stride < cols) || cap < 0 || (cap > 0 && !kps_out)) {
+    ctx->set_error("ssx_orb_detect: stride smaller than the image width, negative capacity or no output array");
+    return SSX_ERR_INVALID_ARG;
+  }
   ssx_status st = run_host_image(ctx, img, stride, rows, cols, mask, mask_stride, *prm, true);
   if (st != SSX_OK) return st;
   return fetch_image_result(ctx, 0, cap, kps_out, nullptr, n);
@@ -1244,6 +1248,10 @@ ssx_status ssx_orb_extract(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int
   if (!ctx || !prm || !n) return SSX_ERR_INVALID_ARG;
   *n = 0;
   if (!img || rows <= 0 || cols <= 0) return SSX_OK;   // orbextractor.cpp:691
+  if (stride < cols || (mask && mask_stride < cols) || cap < 0 || (cap > 0 && (!kps_out || !desc_out))) {
+    ctx->set_error("ssx_orb_extract: stride smaller than the image width, negative capacity or no output arrays");
+    return SSX_ERR_INVALID_ARG;
+  }
   ssx_status st = run_host_image(ctx, img, stride, rows, cols, mask, mask_stride, *prm, false);
   if (st != SSX_OK) return st;
   return fetch_image_result(ctx, 0, cap, kps_out, desc_out, n);
@@ -1256,6 +1264,10 @@ ssx_status ssx_orb_describe_at(ssx_ctx* ctx, const uint8_t* img, int32_t stride,
   if (!ctx || !prm || !n) return SSX_ERR_INVALID_ARG;
   *n = 0;
   if (!img || rows <= 0 || cols <= 0 || n_in <= 0 || !kps_in) return SSX_OK;   // LOG(ERROR) + return in the reference
+  if (stride < cols || !kps_out || !desc_out) {
+    ctx->set_error("ssx_orb_describe_at: stride smaller than the image width or no output arrays");
+    return SSX_ERR_INVALID_ARG;
+  }
   ssx_status st = plan(ctx, rows, cols, 1, *prm, false, false);
   if (st != SSX_OK) return st;
   OrbWorkspace* ws = get_ws(ctx);

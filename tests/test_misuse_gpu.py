@@ -1,0 +1,139 @@
+"""The C ABI under misuse: null pointers, negative / zero / inconsistent sizes, out-of-range indices, NaN inputs.
+Every call must come back with an error status (or a documented empty result) -- never crash, never hang, and the
+context must stay usable afterwards (the reference signals such conditions by assert / LOG(FATAL); ssx.h promises
+status codes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ssvio_amd import _lib, ba, lk, orb
+from ssvio_amd._lib import SsxError
+from ssvio_amd.synth import make_ba_problem, make_pose_graph_problem, make_pose_only_problem, make_stereo_pair
+
+pytestmark = pytest.mark.gpu
+
+NULL = None
+
+
+def _usable(ctx, po):
+    L = make_stereo_pair(seed=3, h=120, w=200, n_blobs=200)[0]
+    k, d = orb.ORBextractor(ctx, 100, 1.2, 3).DetectAndCompute(L)
+    ko, do = po.orb_extract(L, prm=po.orb_params(nfeatures=100, nlevels=3))
+    assert k.tobytes() == ko.tobytes() and np.array_equal(d, do)
+
+
+def test_orb_entry_points_reject_bad_arguments(ctx, po):
+    lib, h = ctx.lib, ctx.handle
+    img = make_stereo_pair(seed=1, h=100, w=160, n_blobs=150)[0]
+    prm = orb.OrbParams(100, 1.2, 3, 20, 7)
+    kps = np.zeros(600, dtype=orb.KP_DTYPE); desc = np.zeros((600, 32), np.uint8); n = C.c_int32(0)
+    p_img, p_k, p_d = img.ctypes.data_as(_lib.u8_p), kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(_lib.u8_p)
+    bad = [
+        lib.ssx_orb_extract(NULL, p_img, 160, 100, 160, NULL, 0, C.byref(prm), 600, p_k, p_d, C.byref(n)),          # no context
+        lib.ssx_orb_extract(h, p_img, 100, 100, 160, NULL, 0, C.byref(prm), 600, p_k, p_d, C.byref(n)),             # stride < cols
+        lib.ssx_orb_extract(h, p_img, 160, 100, 160, NULL, 0, NULL, 600, p_k, p_d, C.byref(n)),                     # no parameters
+        lib.ssx_orb_extract(h, p_img, 160, 100, 160, NULL, 0, C.byref(prm), 600, p_k, p_d, NULL),                   # no count
+        lib.ssx_orb_extract(h, p_img, 160, 100, 160, NULL, 0, C.byref(prm), 3, p_k, p_d, C.byref(n)),               # capacity too small
+        lib.ssx_orb_extract(h, p_img, 160, 100, 160, NULL, 0, C.byref(orb.OrbParams(100, 1.2, 0, 20, 7)), 600, p_k, p_d, C.byref(n)),   # 0 levels
+        lib.ssx_orb_extract(h, p_img, 160, 100, 160, NULL, 0, C.byref(orb.OrbParams(100, 0.9, 3, 20, 7)), 600, p_k, p_d, C.byref(n)),   # scale < 1
+        lib.ssx_orb_extract(h, p_img, 160, 100, 160, NULL, 0, C.byref(orb.OrbParams(-5, 1.2, 3, 20, 7)), 600, p_k, p_d, C.byref(n)),    # negative budget
+        lib.ssx_orb_extract(h, p_img, 160, 100, 160, NULL, 0, C.byref(orb.OrbParams(100, 1.2, 40, 20, 7)), 600, p_k, p_d, C.byref(n)),  # too many levels
+        lib.ssx_orb_detect(h, p_img, 160, 100000, 160, NULL, 0, C.byref(prm), 600, p_k, C.byref(n)),                # absurd height
+    ]
+    assert all(st != _lib.SSX_OK for st in bad), [int(x) for x in bad]
+    assert len(ctx.lib.ssx_last_error(h)) > 0
+    # empty image (no rows or no data): OK with n = 0, like the reference's silent return on image.empty()
+    assert lib.ssx_orb_detect(h, p_img, 160, 0, 0, NULL, 0, C.byref(prm), 600, p_k, C.byref(n)) == _lib.SSX_OK and n.value == 0
+    assert lib.ssx_orb_extract(h, NULL, 160, 100, 160, NULL, 0, C.byref(prm), 600, p_k, p_d, C.byref(n)) == _lib.SSX_OK and n.value == 0
+    _usable(ctx, po)
+
+
+def test_matching_and_triangulation_reject_bad_arguments(ctx, po):
+    lib, h = ctx.lib, ctx.handle
+    k = np.zeros(8, dtype=orb.KP_DTYPE); d = np.zeros((8, 32), np.uint8); idx = np.zeros(8, np.int32); dist = np.zeros(8, np.int32)
+    mp = orb.match_params(); rig = orb.stereo_rig()
+    pk, pd = k.ctypes.data_as(C.c_void_p), d.ctypes.data_as(_lib.u8_p)
+    pi, pdist = idx.ctypes.data_as(_lib.i32_p), dist.ctypes.data_as(_lib.i32_p)
+    assert lib.ssx_stereo_match(h, NULL, pd, 8, pk, pd, 8, C.byref(mp), pi, pdist) != _lib.SSX_OK
+    assert lib.ssx_stereo_match(h, pk, pd, -1, pk, pd, 8, C.byref(mp), pi, pdist) != _lib.SSX_OK
+    assert lib.ssx_stereo_match(h, pk, pd, 8, pk, pd, 8, NULL, pi, pdist) != _lib.SSX_OK
+    assert lib.ssx_bf_match(h, NULL, 8, pd, 8, pi, pdist) != _lib.SSX_OK
+    assert lib.ssx_bf_match(h, pd, 8, pd, -3, pi, pdist) != _lib.SSX_OK
+    uv = np.zeros((4, 2)); xyz = np.zeros((4, 3)); ok = np.zeros(4, np.uint8)
+    pu, px, po_ = uv.ctypes.data_as(_lib.dbl_p), xyz.ctypes.data_as(_lib.dbl_p), ok.ctypes.data_as(_lib.u8_p)
+    assert lib.ssx_triangulate(h, 4, NULL, pu, C.byref(rig), NULL, px, po_) != _lib.SSX_OK
+    assert lib.ssx_triangulate(h, -4, pu, pu, C.byref(rig), NULL, px, po_) != _lib.SSX_OK
+    assert lib.ssx_triangulate(h, 4, pu, pu, NULL, NULL, px, po_) != _lib.SSX_OK
+    # NaN / inf pixels must not be reported as valid points
+    uvn = np.array([[np.nan, 10.0], [np.inf, 5.0], [100.0, 50.0], [200.0, np.nan]]); uvr = np.array([[1.0, 10.0], [2.0, 5.0], [np.nan, 50.0], [190.0, 60.0]])
+    xyz2, ok2 = orb.triangulate(ctx, uvn, uvr)
+    assert not np.asarray(ok2).any()
+    _usable(ctx, po)
+
+
+def test_lk_rejects_bad_arguments(ctx, po):
+    lib, h = ctx.lib, ctx.handle
+    img = make_stereo_pair(seed=2, h=100, w=160, n_blobs=150)[0]
+    p_img = img.ctypes.data_as(_lib.u8_p)
+    pts = np.array([[50.0, 40.0], [np.nan, 10.0], [1e9, -1e9], [np.inf, 20.0]], np.float32); out = pts.copy()
+    st = np.zeros(4, np.uint8)
+    pp, pn, ps = pts.ctypes.data_as(_lib.f32_p), out.ctypes.data_as(_lib.f32_p), st.ctypes.data_as(_lib.u8_p)
+    lib.ssx_lk_track.restype = C.c_int
+    assert lib.ssx_lk_track(h, NULL, 160, p_img, 160, 100, 160, 4, pp, pn, ps, NULL, NULL, NULL) != _lib.SSX_OK
+    assert lib.ssx_lk_track(h, p_img, 160, p_img, 160, 100, 160, -1, pp, pn, ps, NULL, NULL, NULL) != _lib.SSX_OK
+    assert lib.ssx_lk_track(h, p_img, 100, p_img, 160, 100, 160, 4, pp, pn, ps, NULL, NULL, NULL) != _lib.SSX_OK      # stride < cols
+    assert lib.ssx_lk_track(h, p_img, 160, p_img, 160, 1, 160, 4, pp, pn, ps, NULL, NULL, NULL) != _lib.SSX_OK        # 1-row image
+    assert lib.ssx_lk_track(h, p_img, 160, p_img, 160, 100, 160, 4, pp, NULL, ps, NULL, NULL, NULL) != _lib.SSX_OK
+    # non-finite / absurd points: status 0, no crash, finite points still tracked as the oracle tracks them
+    g = lk.calcOpticalFlowPyrLK(ctx, img, img, pts, pts)
+    o = po.lk_track(img, img, pts, pts)
+    assert np.array_equal(g[1], o[1]) and g[1][0] == 1 and not g[1][1:].any()
+    _usable(ctx, po)
+
+
+def test_ba_and_pose_graph_reject_bad_problems(ctx, po):
+    pr = make_ba_problem(P=4, L=60, obs_per_lm=3, seed=1)
+    keep = []
+    for field, value in (("P", 0), ("P", -3), ("L", -1), ("E", -5)):           # the counts of the raw C struct
+        s = ba._problem_struct(pr, keep); setattr(s, field, value)
+        res = _lib.BaResult()
+        assert ctx.lib.ssx_ba_solve(ctx.handle, C.byref(s), None, C.byref(res)) != _lib.SSX_OK, (field, value)
+    s = ba._problem_struct(pr, keep); s.poses = None
+    assert ctx.lib.ssx_ba_solve(ctx.handle, C.byref(s), None, C.byref(_lib.BaResult())) != _lib.SSX_OK
+    assert ctx.lib.ssx_ba_solve(ctx.handle, None, None, C.byref(_lib.BaResult())) != _lib.SSX_OK
+    assert ctx.lib.ssx_ba_solve(ctx.handle, C.byref(ba._problem_struct(pr, keep)), None, None) != _lib.SSX_OK
+    q = dict(pr); q["edge_pose"] = pr["edge_pose"].copy(); q["edge_pose"][7] = 99            # pose index out of range
+    with pytest.raises(SsxError):
+        ba.ba_solve(ctx, q)
+    q = dict(pr); q["edge_point"] = pr["edge_point"].copy(); q["edge_point"][3] = -1         # negative landmark index
+    with pytest.raises(SsxError):
+        ba.ba_solve(ctx, q)
+    # NaN measurements / poses: no crash, no hang, the call returns (the LM rejects every trial or reports failure)
+    q = dict(pr); q["edge_uv"] = pr["edge_uv"].copy(); q["edge_uv"][5] = np.nan
+    try:
+        r = ba.ba_solve(ctx, q)
+        assert r["n_iters"] <= 50
+    except SsxError:
+        pass
+    q = dict(pr); q["poses"] = pr["poses"].copy(); q["poses"][1, 5] = np.inf
+    try:
+        ba.ba_solve(ctx, q)
+    except SsxError:
+        pass
+    # a healthy solve still matches the oracle afterwards
+    g = ba.ba_solve(ctx, pr); o = po.ba_solve(pr, "oracle", jac_mode=0)
+    assert np.array_equal(g["trials"], o["trials"]) and np.abs(np.sqrt(g["edge_chi2"]) - np.sqrt(o["edge_chi2"])).max() < 1e-4
+    pp = make_pose_only_problem(M=50, seed=2)
+    bad_uv = pp["uv"].copy(); bad_uv[3] = np.nan
+    try:
+        ba.pose_only_opt(ctx, pp["pose"], pp["K"], pp["xyz"], bad_uv)
+    except SsxError:
+        pass
+    pg = make_pose_graph_problem(P=12, n_loops=1, seed=3, n_active=3)
+    q = dict(pg); q["ei"] = np.asarray(pg["ei"]).copy(); q["ei"][0] = 500
+    with pytest.raises(Exception):
+        ba.pose_graph_opt(ctx, q)
+    g = ba.pose_graph_opt(ctx, pg, iters=5); o = po.pose_graph_opt(pg, iters=5)
+    assert np.abs(g["poses"] - o["poses"]).max() < 2e-4
+    _usable(ctx, po)
