@@ -55,6 +55,7 @@ FrontEnd::FrontEnd(const Setting& cfg, Compute& compute, std::shared_ptr<Map> ma
 // frontend.cpp:34-80
 bool FrontEnd::GrabSteroImage(ImagePtr left, ImagePtr right, double timestamp)
 {
+  std::lock_guard<std::mutex> map_lock(map_->update_mutex);           // frontend.cpp:49: the whole frame is tracked under the map mutex
   current_frame_ = map_->NewFrame(std::move(left), std::move(right), timestamp);
   switch (track_status_) {
     case FrontendStatus::INITING: SteroInit(); break;

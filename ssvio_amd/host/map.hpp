@@ -12,6 +12,7 @@
 #pragma once
 #include <list>
 #include <memory>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -89,6 +90,11 @@ class Map {
   void RemoveMapPoint(const MapPointPtr& mp);
   void AddOutlierMapPoint(unsigned long id) { outlier_map_points_.push_back(id); }
   void RemoveAllOutlierMapPoints();
+
+  // Map::mmutex_map_update_ of the reference (map.hpp:66): the front-end holds it while it tracks a frame, the
+  // backend while it inserts a keyframe, reads the active window and writes an optimisation back.  Only contended
+  // when the backend runs on its own thread (Backend.Async).
+  std::mutex update_mutex;
 
   const MapPointsType& GetAllMapPoints() const { return all_map_points_; }
   const KeyFramesType& GetAllKeyFrames() const { return all_key_frames_; }

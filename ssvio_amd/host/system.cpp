@@ -38,6 +38,8 @@ bool System::RunStep(ImagePtr left, ImagePtr right, double timestamp)
 
 void System::SaveTrajectoryTUM(const std::string& path_in) const
 {
+  backend_->WaitIdle();                                               // asynchronous backend: let the last windows finish
+  std::lock_guard<std::mutex> map_lock(map_->update_mutex);
   const std::string path = path_in.empty() ? setting_.Get<std::string>("Trajectory.Save.Path") : path_in;
   std::ofstream out(path, std::ios_base::out | std::ios_base::trunc);
   if (!out.is_open()) throw std::runtime_error("SaveTrajectoryTUM: cannot write " + path);

@@ -29,6 +29,7 @@ int main(int argc, char** argv)
       system.RunStep(l, r, ts[i]);
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       (i == 0 ? t_first : t_steps) += dt;
+      std::lock_guard<std::mutex> map_lock(system.map().update_mutex);     // the backend may run on its own thread (Backend.Async)
       // camera centre of the frame: T_cw = relative pose to the reference keyframe * that keyframe's pose
       SE3 T_wc;
       if (system.frontend().reference_kf()) T_wc = (system.frontend().current_frame()->relative_pose_to_kf * system.frontend().reference_kf()->pose).inverse();

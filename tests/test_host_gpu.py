@@ -68,6 +68,21 @@ def test_forward_drive_matches_the_oracle(built, tmp_path):
     assert a.shape == b.shape and np.abs(a - b).max() <= 1e-3, np.abs(a - b).max()
 
 
+def test_asynchronous_backend(built, tmp_path):
+    """Backend.Async: 1 on the GPU library: the worker thread optimises windows on its own context while the front-end
+    tracks; timing-dependent, so: all keyframes present, never lost, trajectory on the ground truth (three runs)"""
+    seq = hu.write_sequence(str(tmp_path), n_frames=12, step=0.6)
+    cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {"Map.ActiveMap.Size": 3, "numFeatures.trackingGood": 100000, "Backend.Async": 1})
+    for rep in range(3):
+        out = os.path.join(str(tmp_path), f"t{rep}.txt")
+        r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", f"--trajectory={out}"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "keyframes 12" in r.stdout and "LOST" not in r.stdout, r.stdout + r.stderr
+        tum = np.loadtxt(out, ndmin=2)
+        assert tum.shape == (12, 8)
+        assert np.abs((tum[:, 1:4] - tum[0, 1:4]) - seq["centres"]).max() < 0.05
+
+
 def test_runner_arguments(built, tmp_path):
     r = subprocess.run([built["run_kitti"]], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr

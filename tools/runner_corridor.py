@@ -28,6 +28,12 @@ with tempfile.TemporaryDirectory() as d:
               f"max |centre - truth| {err:.3f} m over {seq['centres'][-1][2]:.1f} m")
     same = [{k: v for k, v in f.items() if k != "centre"} for f in res["gpu"][1]] == [{k: v for k, v in f.items() if k != "centre"} for f in res["oracle"][1]]
     print(f"  same decisions on every frame: {same}; ratio oracle / gpu: {res['oracle'][0] / res['gpu'][0]:.1f}x")
-    r = subprocess.run([b["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", f"--trajectory={d}/t.txt", "--decode_threads=16"],
-                       capture_output=True, text=True)
-    print(r.stdout)
+    for async_ in (0, 1):
+        cfg2 = hu.write_config(os.path.join(d, f"cfg{async_}.yaml"), {"Backend.Async": async_})
+        r = subprocess.run([b["run_kitti"], f"--config_yaml_path={cfg2}", f"--kitti_dataset_path={seq['dir']}", f"--trajectory={d}/t{async_}.txt", "--decode_threads=16"],
+                           capture_output=True, text=True)
+        tum = np.loadtxt(f"{d}/t{async_}.txt", ndmin=2)
+        fk = np.rint(tum[:, 0] / seq["dt"]).astype(int)
+        err = np.abs(tum[:, 1:4] - seq["centres"][fk]).max()
+        print(f"--- ssx_run_kitti, Backend.Async = {async_}: keyframes at {fk.tolist()}, max |keyframe centre - truth| {err:.3f} m")
+        print(r.stdout, r.stderr[-400:])
