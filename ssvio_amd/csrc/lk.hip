@@ -130,11 +130,30 @@ __global__ __launch_bounds__(256) void k_lk_scharr(LkDev d, int level)
   d.deriv[d.doff[level] + (size_t)y * d.pitch[level] + x] = out;
 }
 
+// exact 64-bit sum over the wave, the same value in every lane.  Lane exchanges inside a row of 16 run on the VALU (DPP:
+// ~10 cycles a step instead of a ~100-cycle trip through the LDS crossbar per __shfl), the four row totals are read with
+// v_readlane; integer addition is associative, so the order does not matter.
+template <int CTRL>
+__device__ __forceinline__ long long dpp_i64(long long v)
+{
+  int lo = (int)(unsigned)(unsigned long long)v, hi = (int)(unsigned)((unsigned long long)v >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long long read_lane_i64(long long v, int lane)
+{
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), lane);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ long long wave_sum(long long v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_i64<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_i64<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_i64<0x141>(v);     // row_half_mirror
+  v += dpp_i64<0x140>(v);     // row_mirror
+  return (read_lane_i64(v, 0) + read_lane_i64(v, 16)) + (read_lane_i64(v, 32) + read_lane_i64(v, 48));
 }
 __device__ __forceinline__ int cv_floor(float v) { int i = (int)v; return i - (i > v); }
 __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
