@@ -170,12 +170,44 @@ __device__ __forceinline__ Weights bilinear(float a, float b)
 }
 
 constexpr int SLOTS = 4;     // window pixels per lane (win <= 15 -> 225 <= 256)
+constexpr int RG = 32;       // side of the per-wave LDS copy of the search neighbourhood in the next image
+
+// The iterations of one level read a (win+1)^2 window of J whose position moves by a fraction of a pixel per step:
+// a 32x32 byte neighbourhood around the starting position is copied to LDS once (16 loads per lane, all in flight
+// together) and every iteration reads from there (LDS latency instead of an L2 round trip on the critical path of
+// each of up to 30 dependent iterations); the copy is redone only when the window leaves it.  Pixels outside the
+// padded image are never part of a valid window and are written as 0.
+struct Region { int ox, oy; };
+__device__ __forceinline__ Region stage_region(uint8_t* sR, const uint8_t* J, int pitch, int rows, int cols, int pad, int win, int inx, int iny, int lane)
+{
+  const int margin = (RG - (win + 1)) >> 1;
+  Region r{inx - margin, iny - margin};
+  __builtin_amdgcn_wave_barrier();                 // earlier reads of the old copy are done
+  uint8_t v[RG * RG / 64];
+#pragma unroll
+  for (int k = 0; k < RG * RG / 64; ++k) {
+    const int idx = lane + 64 * k, y = r.oy + (idx >> 5), x = r.ox + (idx & (RG - 1));
+    const bool in = x >= -pad && x < cols + pad && y >= -pad && y < rows + pad;
+    v[k] = in ? J[(size_t)(y + pad) * pitch + (x + pad)] : (uint8_t)0;
+  }
+#pragma unroll
+  for (int k = 0; k < RG * RG / 64; ++k) sR[lane + 64 * k] = v[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  return r;
+}
+__device__ __forceinline__ bool region_holds(const Region& r, int win, int inx, int iny)
+{
+  return inx >= r.ox && iny >= r.oy && inx + win + 1 <= r.ox + RG && iny + win + 1 <= r.oy + RG;
+}
 
 __global__ __launch_bounds__(256) void k_lk_track(LkDev d)
 {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
+  __shared__ uint8_t sRegion[4][RG * RG];
   const int i = blockIdx.x * 4 + wave;
   if (i >= d.n) return;
+  uint8_t* sR = sRegion[wave];
   const int win = d.win, nwin = win * win, pad = d.pad;
   const float half = (float)(win - 1) * 0.5f;
   int wy[SLOTS], wx[SLOTS];
@@ -242,19 +274,26 @@ __global__ __launch_bounds__(256) void k_lk_track(LkDev d)
     D = 1.f / D;
     nx -= half; ny -= half;
     float pdx = 0.f, pdy = 0.f;
+    Region reg{0, 0};
+    bool have_region = false;
     for (int j = 0; j < d.max_iters; ++j) {
       const int inx = cv_floor(nx), iny = cv_floor(ny);
       if (!(isfinite(nx) && isfinite(ny)) || inx < -win || inx >= cols || iny < -win || iny >= rows) {
         if (level == 0) status = 0;
         break;
       }
+      if (!have_region || !region_holds(reg, win, inx, iny)) {          // wave-uniform: nx, ny are the same in every lane
+        reg = stage_region(sR, J, pitch, rows, cols, pad, win, inx, iny, lane);
+        have_region = true;
+      }
       w = bilinear(nx - (float)inx, ny - (float)iny);
       long long sb1 = 0, sb2 = 0;
+      const int rbase = (iny - reg.oy) * RG + (inx - reg.ox);
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s)
         if (on[s]) {
-          const uint8_t* p = J + (size_t)(wy[s] + iny + pad) * pitch + (wx[s] + inx + pad);
-          const int diff = descale(p[0] * w.w00 + p[1] * w.w01 + p[pitch] * w.w10 + p[pitch + 1] * w.w11, 14 - 5) - Iw[s];
+          const uint8_t* p = sR + rbase + wy[s] * RG + wx[s];
+          const int diff = descale(p[0] * w.w00 + p[1] * w.w01 + p[RG] * w.w10 + p[RG + 1] * w.w11, 14 - 5) - Iw[s];
           sb1 += (long long)diff * Ix[s]; sb2 += (long long)diff * Iy[s];
         }
       sb1 = wave_sum(sb1); sb2 = wave_sum(sb2);
@@ -273,13 +312,15 @@ __global__ __launch_bounds__(256) void k_lk_track(LkDev d)
       const float ex = outx - half, ey = outy - half;
       const int inx = cv_floor(ex), iny = cv_floor(ey);
       if (!(isfinite(ex) && isfinite(ey)) || inx < -win || inx >= cols || iny < -win || iny >= rows) { status = 0; continue; }
+      if (!have_region || !region_holds(reg, win, inx, iny)) reg = stage_region(sR, J, pitch, rows, cols, pad, win, inx, iny, lane);
       w = bilinear(ex - (float)inx, ey - (float)iny);
       long long e = 0;
+      const int rbase = (iny - reg.oy) * RG + (inx - reg.ox);
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s)
         if (on[s]) {
-          const uint8_t* p = J + (size_t)(wy[s] + iny + pad) * pitch + (wx[s] + inx + pad);
-          const int diff = descale(p[0] * w.w00 + p[1] * w.w01 + p[pitch] * w.w10 + p[pitch + 1] * w.w11, 14 - 5) - Iw[s];
+          const uint8_t* p = sR + rbase + wy[s] * RG + wx[s];
+          const int diff = descale(p[0] * w.w00 + p[1] * w.w01 + p[RG] * w.w10 + p[RG + 1] * w.w11, 14 - 5) - Iw[s];
           e += diff < 0 ? -diff : diff;
         }
       e = wave_sum(e);
