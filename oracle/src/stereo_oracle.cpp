@@ -109,7 +109,11 @@ void orc_triangulate(int n, const double* uvL, const double* uvR, double fx, dou
     const double w = V[3 * 4 + 3];
     double p[3] = {V[0 * 4 + 3] / w, V[1 * 4 + 3] / w, V[2 * 4 + 3] / w};
     const double ratio = sv[3] / sv[2];
-    const bool ok = (ratio < 1e-2) && (p[2] > 0);
+    // no positive disparity = a point at or behind infinity: w (and the sign of z) is rounding noise when uL == uR, so
+    // the callers' z > 0 test is decided on the disparity and the point is zeroed (same rule in the kernel)
+    const bool positive_disparity = uvL[2 * i] - uvR[2 * i] > 0.0;
+    const bool ok = (ratio < 1e-2) && (p[2] > 0) && positive_disparity;
+    if (!positive_disparity) { p[0] = 0.0; p[1] = 0.0; p[2] = 0.0; }
     if (T_wc7) {  // new map points: world = T_wc * p_cam1 (frontend.cpp:503,531)
       double r[3];
       quat_rotate(T_wc7, p, r);

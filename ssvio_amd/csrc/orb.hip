@@ -1078,6 +1078,7 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
 static void launch_pyramid(ssx_ctx* ctx, const OrbDev& d, hipStream_t s, int images)
 {
   for (int l = 1; l < d.nlevels; ++l) {
+    if (d.lvl_cols[l] <= 0 || d.lvl_rows[l] <= 0) break;     // a tiny image runs out of pixels before it runs out of levels: nothing there
     const dim3 grid((d.lvl_cols[l] + 255) / 256, (d.lvl_rows[l] + 4 * RS_ROWS - 1) / (4 * RS_ROWS), images);
     auto kern = d.rs_wide8[l] ? k_resize<true> : k_resize<false>;
     for (int m = 0; m < (d.has_mask ? 2 : 1); ++m) {

@@ -264,8 +264,12 @@ __device__ __forceinline__ void triangulate_one(double uL, double vL, double uR,
   }
   const double iw = 1.0 / vw;
   double p[3] = {vx * iw, vy * iw, vz * iw};
-  // sigma3 / sigma2 < 1e-2 on the squared values (algorithm.hpp:38)
-  *ok = ((smin < 1e-4 * s2) && (p[2] > 0)) ? 1 : 0;
+  // sigma3 / sigma2 < 1e-2 on the squared values (algorithm.hpp:38).  A pair without positive disparity is a point at
+  // or behind infinity: with uL == uR the homogeneous w is rounding noise and the sign of z with it, so the z > 0 test
+  // of the callers (frontend.cpp:466,528) is taken on the disparity there -- deterministic, and the point is zeroed.
+  const bool positive_disparity = uL - uR > 0.0;
+  *ok = ((smin < 1e-4 * s2) && (p[2] > 0) && positive_disparity) ? 1 : 0;
+  if (!positive_disparity) { p[0] = 0.0; p[1] = 0.0; p[2] = 0.0; }
   if (T_wc) {
     const double qx = T_wc[0], qy = T_wc[1], qz = T_wc[2], qw = T_wc[3];
     double ux = qy * p[2] - qz * p[1], uy = qz * p[0] - qx * p[2], uz = qx * p[1] - qy * p[0];

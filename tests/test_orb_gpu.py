@@ -222,6 +222,34 @@ def test_tiny_budgets_return_more_than_the_budget(ctx, po):
         assert dk.tobytes() == do.tobytes()
 
 
+def test_triangulation_without_positive_disparity(ctx, po):
+    """uL == uR is a point at infinity: the homogeneous w is rounding noise, so z > 0 is decided on the disparity --
+    flag 0 and a zeroed point, the same in the kernel and in the oracle (found by tools/fuzz_parity2.py); with T_wc the
+    zeroed camera point maps to the camera centre"""
+    uvL = np.array([[100.0, 50.0], [640.25, 180.5], [300.0, 200.0], [900.0, 100.0], [20.0, 300.0]])
+    uvR = uvL - np.array([[0.0, 0.0], [0.0, 0.3], [-3.0, 0.0], [1e-9, 0.0], [25.0, 0.1]])
+    for T in (None, np.array([0, 0, np.sin(0.1), np.cos(0.1), 1.0, -2.0, 0.5])):
+        xyz, ok = sorb.triangulate(ctx, uvL, uvR, T_wc=T)
+        t = po.triangulate(uvL, uvR, KITTI_K, KITTI_BASELINE, T_wc=T)
+        assert np.array_equal(np.asarray(ok).astype(bool), t["ok"].astype(bool))
+        assert np.asarray(ok).tolist() == [0, 0, 0, 1, 1]
+        z = np.zeros(3) if T is None else T[4:]
+        assert np.array_equal(np.asarray(xyz)[:3], np.tile(z, (3, 1))) and np.array_equal(t["xyz"][:3], np.tile(z, (3, 1)))
+        assert np.abs(np.asarray(xyz)[4] - t["xyz"][4]).max() < 1e-9 * np.abs(t["xyz"][4]).max()
+
+
+def test_more_levels_than_the_image_has_pixels_for(ctx, po):
+    """48x79 at scale 2.0 has no pixels left from level 6 on (OpenCV's resize would throw in the reference): the empty
+    levels contribute nothing, the others are as always (found by tools/fuzz_parity.py)"""
+    from ssvio_amd.synth import make_stereo_pair
+    for (h, w, nfeat, nlev, sf) in ((48, 79, 300, 8, 2.0), (63, 69, 2000, 8, 2.0), (40, 40, 100, 8, 1.5)):
+        L = make_stereo_pair(seed=h + w, h=h, w=w, n_blobs=max(h * w // 100, 8))[0]
+        ex = sorb.ORBextractor(ctx, nfeatures=nfeat, scaleFactor=sf, nlevels=nlev, iniThFAST=10, minThFAST=3)
+        gk, gd = ex.DetectAndCompute(L)
+        ok, od = po.orb_extract(L, prm=po.orb_params(nfeatures=nfeat, scale_factor=sf, nlevels=nlev, ini_th=10, min_th=3))
+        assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+
+
 def test_low_contrast_cells_fall_back_to_min_threshold(ctx, po, pair_small):
     """cells without a corner at iniThFAST are re-run at minThFAST (orbextractor.cpp:598-606): a low-contrast
     image makes most cells take the second pass, a high iniThFAST all of them"""
