@@ -253,6 +253,8 @@ typedef struct {           /* the rig System::GenerateSteroCamera builds (src/ss
 
 /* ssvio::triangulation (include/ssvio/algorithm.hpp:23-45) for left = [I|0], right = [I|(-baseline,0,0)] with
  * Camera::pixel2camera (src/ssvio/camera.cpp:25-30); ok = sigma3/sigma2 < 1e-2 && z > 0 (frontend.cpp:466,528).
+ * A pair without positive disparity (uL <= uR: a point at or behind infinity, where the sign of z is rounding noise)
+ * is reported ok = 0 with a zeroed camera-frame point.
  * T_wc (nullable, 7 doubles) maps the camera-frame point to the world (frontend.cpp:503,531). */
 SSX_API ssx_status ssx_triangulate(ssx_ctx* ctx, int32_t n, const double* uvL, const double* uvR,
                                    const ssx_stereo_rig* rig, const double* T_wc, double* xyz_out,
