@@ -216,6 +216,19 @@ int main(int argc, char** argv)
     }
     return 0;
   }
+  if (std::string(argv[1]) == "--decode") {                       // test_units --decode <file>...: never crashes, one line per file
+    for (int i = 2; i < argc; ++i) {
+      try {
+        ImagePtr im = imread_gray(argv[i]);
+        unsigned long sum = 0;
+        for (uint8_t v : im->data) sum += v;
+        std::printf("%s ok %d %d %lu\n", argv[i], im->rows, im->cols, sum);
+      } catch (const std::exception& e) {
+        std::printf("%s error %s\n", argv[i], e.what());
+      }
+    }
+    return 0;
+  }
   const std::string dir = argv[1];
   test_setting(dir);
   test_kitti_listing(dir);

@@ -50,6 +50,52 @@ def _filtered(rows, bpp, ft):
     return out
 
 
+def test_png_reader_survives_malformed_files(built, tmp_path):
+    """300 structurally valid-looking PNG files (correct signature and CRCs, so the reader gets past the chunk layer)
+    with random headers, filter bytes, truncated / oversized / garbage pixel streams: every file is either decoded to
+    the right size or refused with a message -- the process never crashes; well-formed ones match PIL"""
+    rng = np.random.default_rng(7)
+    from PIL import Image
+    files, expect = [], {}
+    for i in range(300):
+        w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+        depth = int(rng.choice([8, 16, 1, 2, 4, 3])); ctype = int(rng.choice([0, 4, 2, 3, 6, 1])); interlace = int(rng.random() < 0.1)
+        if rng.random() < 0.35: depth, ctype, interlace = 8, 0, 0                      # a good share of plain grey files
+        bpp = max(1, depth // 8) * {0: 1, 4: 2, 2: 3, 3: 1, 6: 4}.get(ctype, 1)
+        rows = [bytes(rng.integers(0, 256, w * bpp, dtype=np.uint8)) for _ in range(h)]
+        filters = rng.integers(0, 5 if rng.random() < 0.8 else 8, h).tolist()
+        raw = b"".join(bytes([f]) + r for f, r in zip(filters, rows))
+        mode = 0 if rng.random() < 0.4 else int(rng.integers(1, 6))
+        if mode == 1: raw = raw[:int(rng.integers(0, len(raw)))]                       # too few pixels
+        if mode == 2: raw = raw + bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))   # too many
+        z = zlib.compress(raw)
+        if mode == 3: z = z[:int(rng.integers(0, len(z)))]                             # truncated deflate stream
+        if mode == 4: z = bytes(rng.integers(0, 256, len(z), dtype=np.uint8))          # garbage instead of deflate
+        chunks = [_chunk(b"IHDR", struct.pack(">IIBBBBB", w if mode != 5 else 0, h, depth, ctype, 0, 0, interlace))]
+        if rng.random() < 0.3: chunks.append(_chunk(b"tEXt", b"Comment\0fuzz"))
+        cut = int(rng.integers(0, len(z) + 1))
+        chunks += [_chunk(b"IDAT", z[:cut]), _chunk(b"IDAT", z[cut:])]
+        if rng.random() < 0.9: chunks.append(_chunk(b"IEND", b""))
+        path = os.path.join(str(tmp_path), f"f{i:04d}.png")
+        open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + b"".join(chunks))
+        files.append(path)
+        if mode == 0 and interlace == 0 and depth == 8 and ctype == 0 and max(filters) <= 4:
+            expect[path] = np.asarray(Image.open(path))                               # PIL agrees it is well-formed
+    r = subprocess.run([built["units"], "--decode", *files], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == len(files)
+    n_ok = 0
+    for path, line in zip(files, lines):
+        w_ = line.split()
+        assert w_[0] == path and w_[1] in ("ok", "error"), line
+        if path in expect:
+            e = expect[path]
+            assert w_[1] == "ok" and (int(w_[2]), int(w_[3]), int(w_[4])) == (e.shape[0], e.shape[1], int(e.sum())), line
+            n_ok += 1
+    assert n_ok >= 5
+
+
 def test_host_units(built, tmp_path):
     d = str(tmp_path)
     hu.write_config(os.path.join(d, "cfg.yaml"), {"Map.ActiveMap.Size": 3, "Trajectory.Save.Path": '"%s/traj #1.txt"' % d})
