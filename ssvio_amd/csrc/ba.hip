@@ -480,29 +480,53 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int us
   }
   __syncthreads();
 
-  // owned entries of the reduced system: each walks the (edge a, edge b) pairs of ITS block, landmark order
+  // The reduced system's blocks: FOUR threads per block, each owning a 3x3 quarter of the 6x6 -- it walks the (edge a,
+  // edge b) pairs of the block in landmark order with 9 independent accumulators: 18 LDS doubles per pair feed 27
+  // fused multiply-adds (the former one-thread-per-entry loop read 6 doubles for 3 and ran as one dependent chain).
   double* slab = d.schur_slab + (size_t)c * (d.nBlk * 36 + nP * 6);
   const int nS = d.nBlk * 36;
-  for (int idx = t; idx < nS; idx += CH) {
-    const int blk = idx / 36, rc = idx - blk * 36;
-    const int r = rc / 6, cc = rc - r * 6;
+  for (int item = t; item < 4 * d.nBlk; item += CH) {
+    const int blk = item >> 2, qr = (item >> 1) & 1, qc = item & 1;      // rows 3 qr .. 3 qr + 2, columns 3 qc .. 3 qc + 2
     const int q0 = sBptr[blk], q1 = sBptr[blk + 1];
-    double acc = 0.0;
+    double acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = 0.0;
+    const double* bdp = sBD + (qr * 9) * PW;                             // component (row r, m) of W Dinv = r * 3 + m
+    const double* wp = sW + (qc * 9) * PW;
     for (int q = q0; q < q1; ++q) {
       const int ea = sPa[q], eb = sPb[q];
-      acc += sBD[(r * 3) * PW + ea] * sW[(cc * 3) * PW + eb] + sBD[(r * 3 + 1) * PW + ea] * sW[(cc * 3 + 1) * PW + eb] +
-             sBD[(r * 3 + 2) * PW + ea] * sW[(cc * 3 + 2) * PW + eb];
+      double bd[3][3], w[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { bd[i][m] = bdp[(i * 3 + m) * PW + ea]; w[i][m] = wp[(i * 3 + m) * PW + eb]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] += bd[i][0] * w[j][0] + bd[i][1] * w[j][1] + bd[i][2] * w[j][2];
     }
-    slab[idx] = acc;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j] = acc[i][j];
   }
-  for (int idx = t; idx < nP * 6; idx += CH) {
+  // c: four threads per entry share the pose's edge list, partial sums folded inside the quad
+  for (int base = 0; base < nP * 6 * 4; base += CH) {
+    const int item = base + t;
+    const bool on = item < nP * 6 * 4;
+    const int idx = on ? item >> 2 : 0, part = item & 3;
     const int p = idx / 6, a = idx - p * 6;
     double acc = 0.0;
-    for (int s = sPptr[p]; s < sPptr[p + 1]; ++s) {
-      const int j = sOrd[s];
-      if (sLeader[j]) acc += sC[a * PW + j];
-    }
-    slab[nS + idx] = acc;
+    if (on)
+      for (int s = sPptr[p] + part; s < sPptr[p + 1]; s += 4) {
+        const int j = sOrd[s];
+        if (sLeader[j]) acc += sC[a * PW + j];
+      }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (on && part == 0) slab[nS + idx] = acc;
   }
 }
 
