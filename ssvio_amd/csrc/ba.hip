@@ -1448,7 +1448,10 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
                             double* chi2)
 {
   if (!ctx || !prob) return SSX_ERR_INVALID_ARG;
-  HostPrep h;
+  // the index lists are rebuilt per call (the window changes with every keyframe) but their storage is kept per thread:
+  // ~20 vectors of up to E entries are not re-allocated and re-faulted every solve
+  static thread_local HostPrep h_tls;
+  HostPrep& h = h_tls;
   ssx_status st = prepare(ctx, prob, h);
   if (st != SSX_OK) return st;
   BaDev d;
@@ -1510,7 +1513,10 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   if (!ctx || !prob || !res) return SSX_ERR_INVALID_ARG;
   ssx_ba_options opt;
   if (opt_in) opt = *opt_in; else ssx_ba_default_options(&opt);
-  HostPrep h;
+  // the index lists are rebuilt per call (the window changes with every keyframe) but their storage is kept per thread:
+  // ~20 vectors of up to E entries are not re-allocated and re-faulted every solve
+  static thread_local HostPrep h_tls;
+  HostPrep& h = h_tls;
   ssx_status st = prepare(ctx, prob, h);
   if (st != SSX_OK) return st;
   Comm cm;
