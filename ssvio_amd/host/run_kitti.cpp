@@ -3,15 +3,19 @@
 // save the keyframe trajectory in TUM format.  Same two flags (gflags spelling), plus a frame limit and an output path.
 //
 //   ssx_run_kitti --config_yaml_path=cfg.yaml --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=out.txt]
-//                 [--device=0] [--decode_threads=8]
+//                 [--device=0] [--decode_threads=8] [--streams=1]
 // The PNG pairs are decoded ahead of the tracker on worker threads (StereoPrefetcher); everything else is the
-// reference's single loop.
+// reference's single loop.  --streams=K runs K independent copies of the loop in K threads of this process (each with
+// its own System, GPU contexts and prefetcher) on the same sequence: a single stream is latency-bound, several fill the
+// GPU (BASELINE configs[4] runs one stream per GPU; this is the one-GPU version of it).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "system.hpp"
 
@@ -31,16 +35,16 @@ bool flag(const char* arg, const char* name, std::string& out)
 
 int main(int argc, char** argv)
 {
-  std::string config, dataset, max_frames_s, trajectory, device_s, threads_s;
+  std::string config, dataset, max_frames_s, trajectory, device_s, threads_s, streams_s;
   for (int i = 1; i < argc; ++i) {
     if (flag(argv[i], "config_yaml_path", config) || flag(argv[i], "kitti_dataset_path", dataset) || flag(argv[i], "max_frames", max_frames_s) ||
-        flag(argv[i], "trajectory", trajectory) || flag(argv[i], "device", device_s) || flag(argv[i], "decode_threads", threads_s))
+        flag(argv[i], "trajectory", trajectory) || flag(argv[i], "device", device_s) || flag(argv[i], "decode_threads", threads_s) || flag(argv[i], "streams", streams_s))
       continue;
     std::fprintf(stderr, "unknown argument %s\n", argv[i]);
     return 2;
   }
   if (config.empty() || dataset.empty()) {
-    std::fprintf(stderr, "usage: %s --config_yaml_path=<yaml> --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=<tum file>] [--device=0] [--decode_threads=8]\n",
+    std::fprintf(stderr, "usage: %s --config_yaml_path=<yaml> --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=<tum file>] [--device=0] [--decode_threads=8] [--streams=1]\n",
                  argv[0]);
     return 2;
   }
@@ -54,6 +58,45 @@ int main(int argc, char** argv)
     if (!max_frames_s.empty()) num_images = std::min(num_images, (size_t)std::atol(max_frames_s.c_str()));
     std::printf("Num Images: %zu\n", num_images);
 
+    const int streams = streams_s.empty() ? 1 : std::max(1, std::atoi(streams_s.c_str()));
+    if (streams > 1) {
+      const int device = device_s.empty() ? 0 : std::atoi(device_s.c_str());
+      const int dthreads = threads_s.empty() ? 8 : std::atoi(threads_s.c_str());
+      std::vector<double> seconds(streams, 0.0);
+      std::vector<size_t> keyframes(streams, 0);
+      std::vector<std::string> errors(streams);
+      std::vector<std::thread> workers;
+      const auto t_all0 = clk::now();
+      for (int k = 0; k < streams; ++k)
+        workers.emplace_back([&, k] {
+          try {
+            System sys(config, nullptr, device);
+            StereoPrefetcher pf(left_paths, right_paths, num_images, dthreads);
+            const auto t0 = clk::now();
+            for (size_t ni = 0; ni < num_images; ++ni) {
+              StereoPrefetcher::Pair pair = pf.Next();
+              if (pair.left->empty() || pair.right->empty()) throw std::runtime_error("Failed to load image " + left_paths[ni]);
+              sys.RunStep(pair.left, pair.right, timestamps[ni]);
+            }
+            sys.backend().WaitIdle();
+            seconds[k] = std::chrono::duration<double>(clk::now() - t0).count();
+            keyframes[k] = sys.map().GetAllKeyFrames().size();
+            if (!trajectory.empty()) sys.SaveTrajectoryTUM(trajectory + "." + std::to_string(k));
+          } catch (const std::exception& e) {
+            errors[k] = e.what();
+          }
+        });
+      for (auto& w : workers) w.join();
+      const double wall = std::chrono::duration<double>(clk::now() - t_all0).count();
+      double sum = 0;
+      for (int k = 0; k < streams; ++k) {
+        if (!errors[k].empty()) { std::fprintf(stderr, "fatal (stream %d): %s\n", k, errors[k].c_str()); return 1; }
+        sum += num_images / std::max(seconds[k], 1e-9);
+        std::printf("stream %d: %.1f frames/s, %zu keyframes\n", k, num_images / std::max(seconds[k], 1e-9), keyframes[k]);
+      }
+      std::printf("%d streams: aggregate %.1f frames/s (sum of the streams' loops incl. decoding), wall %.2f s incl. context creation\n", streams, sum, wall);
+      return 0;
+    }
     System system(config, nullptr, device_s.empty() ? 0 : std::atoi(device_s.c_str()));
     double t_io = 0, t_step = 0;
     StereoPrefetcher prefetch(left_paths, right_paths, num_images, threads_s.empty() ? 8 : std::atoi(threads_s.c_str()));

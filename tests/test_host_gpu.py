@@ -83,6 +83,22 @@ def test_asynchronous_backend(built, tmp_path):
         assert np.abs((tum[:, 1:4] - tum[0, 1:4]) - seq["centres"]).max() < 0.05
 
 
+def test_several_streams_in_one_process(built, tmp_path):
+    """--streams=3: three independent copies of the loop in threads of one process, each with its own contexts; every
+    stream must produce the trajectory of the single-stream run (synchronous backend: deterministic)"""
+    seq = hu.write_sequence(str(tmp_path), n_frames=10, step=0.6)
+    cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {"Map.ActiveMap.Size": 3, "numFeatures.trackingGood": 100000})
+    one, many = os.path.join(str(tmp_path), "one.txt"), os.path.join(str(tmp_path), "many.txt")
+    base = [built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}"]
+    r1 = subprocess.run(base + [f"--trajectory={one}"], capture_output=True, text=True, timeout=300)
+    r3 = subprocess.run(base + [f"--trajectory={many}", "--streams=3", "--decode_threads=2"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and r3.returncode == 0, r1.stderr + r3.stderr
+    assert "3 streams: aggregate" in r3.stdout and r3.stdout.count("keyframes") == 3
+    ref = open(one).read()
+    for k in range(3):
+        assert open(f"{many}.{k}").read() == ref
+
+
 def test_runner_arguments(built, tmp_path):
     r = subprocess.run([built["run_kitti"]], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
