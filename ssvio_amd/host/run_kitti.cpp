@@ -3,7 +3,7 @@
 // save the keyframe trajectory in TUM format.  Same two flags (gflags spelling), plus a frame limit and an output path.
 //
 //   ssx_run_kitti --config_yaml_path=cfg.yaml --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=out.txt]
-//                 [--device=0] [--decode_threads=8] [--streams=1]
+//                 [--device=0] [--decode_threads=8] [--streams=1] [--preload=0]
 // The PNG pairs are decoded ahead of the tracker on worker threads (StereoPrefetcher); everything else is the
 // reference's single loop.  --streams=K runs K independent copies of the loop in K threads of this process (each with
 // its own System, GPU contexts and prefetcher) on the same sequence: a single stream is latency-bound, several fill the
@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -35,16 +36,16 @@ bool flag(const char* arg, const char* name, std::string& out)
 
 int main(int argc, char** argv)
 {
-  std::string config, dataset, max_frames_s, trajectory, device_s, threads_s, streams_s;
+  std::string config, dataset, max_frames_s, trajectory, device_s, threads_s, streams_s, preload_s;
   for (int i = 1; i < argc; ++i) {
     if (flag(argv[i], "config_yaml_path", config) || flag(argv[i], "kitti_dataset_path", dataset) || flag(argv[i], "max_frames", max_frames_s) ||
-        flag(argv[i], "trajectory", trajectory) || flag(argv[i], "device", device_s) || flag(argv[i], "decode_threads", threads_s) || flag(argv[i], "streams", streams_s))
+        flag(argv[i], "trajectory", trajectory) || flag(argv[i], "device", device_s) || flag(argv[i], "decode_threads", threads_s) || flag(argv[i], "streams", streams_s) || flag(argv[i], "preload", preload_s))
       continue;
     std::fprintf(stderr, "unknown argument %s\n", argv[i]);
     return 2;
   }
   if (config.empty() || dataset.empty()) {
-    std::fprintf(stderr, "usage: %s --config_yaml_path=<yaml> --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=<tum file>] [--device=0] [--decode_threads=8] [--streams=1]\n",
+    std::fprintf(stderr, "usage: %s --config_yaml_path=<yaml> --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=<tum file>] [--device=0] [--decode_threads=8] [--streams=1] [--preload=0]\n",
                  argv[0]);
     return 2;
   }
@@ -65,16 +66,23 @@ int main(int argc, char** argv)
       std::vector<double> seconds(streams, 0.0);
       std::vector<size_t> keyframes(streams, 0);
       std::vector<std::string> errors(streams);
+      // --preload=1: decode the whole sequence once, before the clock starts (isolates tracking from PNG decoding)
+      std::vector<StereoPrefetcher::Pair> preloaded;
+      if (!preload_s.empty() && std::atoi(preload_s.c_str()) != 0) {
+        StereoPrefetcher pf(left_paths, right_paths, num_images, 32);
+        for (size_t ni = 0; ni < num_images; ++ni) preloaded.push_back(pf.Next());
+      }
       std::vector<std::thread> workers;
       const auto t_all0 = clk::now();
       for (int k = 0; k < streams; ++k)
         workers.emplace_back([&, k] {
           try {
             System sys(config, nullptr, device);
-            StereoPrefetcher pf(left_paths, right_paths, num_images, dthreads);
+            std::unique_ptr<StereoPrefetcher> pf;
+            if (preloaded.empty()) pf = std::make_unique<StereoPrefetcher>(left_paths, right_paths, num_images, dthreads);
             const auto t0 = clk::now();
             for (size_t ni = 0; ni < num_images; ++ni) {
-              StereoPrefetcher::Pair pair = pf.Next();
+              StereoPrefetcher::Pair pair = pf ? pf->Next() : preloaded[ni];
               if (pair.left->empty() || pair.right->empty()) throw std::runtime_error("Failed to load image " + left_paths[ni]);
               sys.RunStep(pair.left, pair.right, timestamps[ni]);
             }
