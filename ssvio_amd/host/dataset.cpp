@@ -88,24 +88,30 @@ ImagePtr decode_png_gray(const uint8_t* b, size_t size)
   uLongf out_len = (uLongf)raw.size();
   const int zr = uncompress(raw.data(), &out_len, z.data(), (uLong)z.size());
   if (zr != Z_OK || out_len != raw.size()) throw std::runtime_error("png: inflate failed or wrong image size");
-  // undo the scanline filters in place
+  // undo the scanline filters in place, one specialised loop per filter type (the per-byte dispatch of a generic loop
+  // costs more than the inflate)
   std::vector<uint8_t> zero(row, 0);
+  const size_t B = (size_t)bpp;
   for (uint32_t y = 0; y < h; ++y) {
     uint8_t* cur = raw.data() + (size_t)y * (row + 1) + 1;
     const uint8_t* up = y ? cur - (row + 1) : zero.data();
-    const int ft = cur[-1];
-    for (size_t i = 0; i < row; ++i) {
-      const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, bb = up[i], c = i >= (size_t)bpp ? up[i - bpp] : 0;
-      int v = cur[i];
-      switch (ft) {
-        case 0: break;
-        case 1: v += a; break;
-        case 2: v += bb; break;
-        case 3: v += (a + bb) >> 1; break;
-        case 4: v += paeth(a, bb, c); break;
-        default: throw std::runtime_error("png: unknown filter type");
-      }
-      cur[i] = (uint8_t)v;
+    switch (cur[-1]) {
+      case 0: break;
+      case 1:
+        for (size_t i = B; i < row; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - B]);
+        break;
+      case 2:
+        for (size_t i = 0; i < row; ++i) cur[i] = (uint8_t)(cur[i] + up[i]);
+        break;
+      case 3:
+        for (size_t i = 0; i < B && i < row; ++i) cur[i] = (uint8_t)(cur[i] + (up[i] >> 1));
+        for (size_t i = B; i < row; ++i) cur[i] = (uint8_t)(cur[i] + ((cur[i - B] + up[i]) >> 1));
+        break;
+      case 4:
+        for (size_t i = 0; i < B && i < row; ++i) cur[i] = (uint8_t)(cur[i] + up[i]);               // paeth(0, b, 0) = b
+        for (size_t i = B; i < row; ++i) cur[i] = (uint8_t)(cur[i] + paeth(cur[i - B], up[i], up[i - B]));
+        break;
+      default: throw std::runtime_error("png: unknown filter type");
     }
   }
   auto img = std::make_shared<Image>();
