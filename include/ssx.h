@@ -367,6 +367,39 @@ typedef struct ssx_pose_graph_result {
 SSX_API ssx_status ssx_pose_graph_opt(ssx_ctx* ctx, const ssx_pose_graph_problem* prob, int32_t iterations,
                                       ssx_pose_graph_result* res);
 
+/* ------------------------------------------------------------------------------------------------
+ * Bag of words for loop detection -- replaces ORBVocabulary::transform / ::score, i.e.
+ * DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ssvio/orbvocabulary.hpp:10) as LoopClosing uses it:
+ *   dbow2_vocabulary_->transform(desc, keyframe->bow2_vec_)      src/ssvio/loopclosing.cpp:633
+ *   dbow2_vocabulary_->score(current->bow2_vec_, db->bow2_vec_)  src/ssvio/loopclosing.cpp:84
+ * The vocabulary is a k-ary tree of 32-byte descriptors kept in HBM; a descriptor descends to the child with the
+ * smallest Hamming distance (the first one on ties) until it reaches a leaf = its word
+ * (thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1260).  L1_NORM scoring only (what ORBvoc.txt declares).
+ * A vocabulary belongs to the context it was created on and must be destroyed before it.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ssx_vocabulary ssx_vocabulary;
+/* Flat tree: node 0 = root; node i >= 1: parent[i] (< i), is_leaf[i], desc[32 i .. 32 i + 31], weight[i]; entry 0 of
+ * each array is ignored.  Word ids number the leaves in node order.  weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY
+ * (DBoW2::WeightingType); scoring must be 0 (L1_NORM). */
+SSX_API ssx_status ssx_voc_create(ssx_ctx* ctx, int32_t k, int32_t L, int32_t scoring, int32_t weighting, int32_t n_nodes,
+                                  const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc,
+                                  const double* weight, ssx_vocabulary** out);
+/* TemplatedVocabulary::loadFromTextFile (TemplatedVocabulary.h:1337-1420): the ORBvoc.txt format */
+SSX_API ssx_status ssx_voc_load_text(ssx_ctx* ctx, const char* path, ssx_vocabulary** out);
+SSX_API void ssx_voc_destroy(ssx_vocabulary* voc);
+SSX_API ssx_status ssx_voc_info(const ssx_vocabulary* voc, int32_t* k, int32_t* L, int32_t* n_nodes, int32_t* n_words,
+                                int32_t* weighting);
+/* transform(): desc = n x 32 bytes.  words_out / weights_out (n each, nullable): word id and node weight of every
+ * feature (-1 / 0 when the vocabulary is empty).  ids_out / vals_out (capacity cap): the BowVector -- word ids in
+ * ascending order with their L1-normalised values; *n_entries = its size (SSX_ERR_CAPACITY when cap is too small,
+ * except cap == 0 with ids_out == NULL: only the size and the per-feature outputs are wanted). */
+SSX_API ssx_status ssx_voc_transform(ssx_vocabulary* voc, const uint8_t* desc, int32_t n, int32_t* words_out,
+                                     double* weights_out, int32_t cap, int32_t* ids_out, double* vals_out,
+                                     int32_t* n_entries);
+/* L1Scoring::score (thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68) of two BowVectors; host arithmetic, in [0, 1] */
+SSX_API double ssx_bow_score_l1(int32_t n1, const int32_t* id1, const double* v1, int32_t n2, const int32_t* id2,
+                                const double* v2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@
 //   ssx::StereoFrontEnd          DetectFeatures + FindFeaturesInRight + triangulation in one device-resident call
 //   ssx::calcOpticalFlowPyrLK    cv::calcOpticalFlowPyrLK as frontend.cpp:156-166 / :374-384 call it
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -213,5 +214,47 @@ inline void calcOpticalFlowPyrLKNext(Context& ctx, const uint8_t* nextImg, int n
   ctx.check(ssx_lk_track_next(ctx.get(), nextImg, nextStep, rows, cols, n, prevPts.data(), nextPts.data(), status.data(),
                               err.data(), &p, nullptr));
 }
+
+// ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, include/ssvio/orbvocabulary.hpp:10) as LoopClosing
+// uses it: loadFromTextFile, transform(descriptors, BowVector), score(BowVector, BowVector).  A BowVector here is the
+// sorted (word id, value) pairs of DBoW2::BowVector (a std::map<WordId, WordValue>).
+struct BowVector {
+  std::vector<int32_t> ids;
+  std::vector<double> values;
+  bool empty() const { return ids.empty(); }
+};
+
+class ORBVocabulary {
+ public:
+  explicit ORBVocabulary(Context& ctx) : ctx_(ctx) {}
+  ~ORBVocabulary() { ssx_voc_destroy(voc_); }
+  ORBVocabulary(const ORBVocabulary&) = delete;
+  ORBVocabulary& operator=(const ORBVocabulary&) = delete;
+
+  bool loadFromTextFile(const std::string& filename)                 // loopclosing.cpp:33-41
+  {
+    ssx_voc_destroy(voc_);
+    voc_ = nullptr;
+    return ssx_voc_load_text(ctx_.get(), filename.c_str(), &voc_) == SSX_OK;
+  }
+  // descriptors: n x 32 bytes (the rows of the CV_8U n x 32 descriptor matrix)
+  void transform(const uint8_t* descriptors, int n, BowVector& v) const
+  {
+    v.ids.assign((size_t)std::max(n, 1), 0);
+    v.values.assign((size_t)std::max(n, 1), 0.0);
+    int32_t m = 0;
+    if (voc_) ctx_.check(ssx_voc_transform(voc_, descriptors, n, nullptr, nullptr, (int32_t)v.ids.size(), v.ids.data(), v.values.data(), &m));
+    v.ids.resize(m);
+    v.values.resize(m);
+  }
+  double score(const BowVector& a, const BowVector& b) const
+  {
+    return ssx_bow_score_l1((int32_t)a.ids.size(), a.ids.data(), a.values.data(), (int32_t)b.ids.size(), b.ids.data(), b.values.data());
+  }
+
+ private:
+  Context& ctx_;
+  ssx_vocabulary* voc_ = nullptr;
+};
 
 }  // namespace ssx

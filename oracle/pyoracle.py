@@ -446,3 +446,36 @@ def pose_graph_opt(pr, which="oracle", iters=20):
               _p(err, dbl_p), cap, C.byref(n), _p(chi, dbl_p), _p(lam, dbl_p), _p(tr, i32_p))
     k = n.value
     return dict(poses=poses, edge_err=err, n_iters=done, chi2=chi[:k].copy(), lambdas=lam[:k].copy(), trials=tr[:k].copy())
+
+
+# ---------------- bag of words (N2) ----------------
+def voc_transform_features(voc, feat):
+    """per-descriptor (word id, weight) by the restated tree descent of TemplatedVocabulary::transform"""
+    parent = np.ascontiguousarray(voc["parent"], dtype=np.int32); leaf = np.ascontiguousarray(voc["is_leaf"], dtype=np.uint8)
+    desc = np.ascontiguousarray(voc["desc"], dtype=np.uint8); weight = np.ascontiguousarray(voc["weight"], dtype=np.float64)
+    feat = np.ascontiguousarray(feat, dtype=np.uint8).reshape(-1, 32)
+    word = np.zeros(len(feat), np.int32); w = np.zeros(len(feat), np.float64)
+    oracle_lib().orc_voc_transform_features(len(parent), _p(parent, i32_p), _p(leaf, u8_p), _p(desc, u8_p), _p(weight, dbl_p), _p(feat, u8_p),
+                                            len(feat), _p(word, i32_p), _p(w, dbl_p))
+    return word, w
+
+
+def bow_vector(word, weight, weighting=0):
+    word = np.ascontiguousarray(word, dtype=np.int32); weight = np.ascontiguousarray(weight, dtype=np.float64)
+    cap = max(len(word), 1)
+    ids = np.zeros(cap, np.int32); vals = np.zeros(cap, np.float64)
+    m = oracle_lib().orc_bow_vector(len(word), _p(word, i32_p), _p(weight, dbl_p), int(weighting), cap, _p(ids, i32_p), _p(vals, dbl_p))
+    return ids[:m].copy(), vals[:m].copy()
+
+
+def voc_transform(voc, feat, weighting=0):
+    word, w = voc_transform_features(voc, feat)
+    return bow_vector(word, w, weighting)
+
+
+def bow_score_l1(a, b):
+    fn = oracle_lib().orc_bow_score_l1
+    fn.restype = C.c_double
+    ia, va = np.ascontiguousarray(a[0], dtype=np.int32), np.ascontiguousarray(a[1], dtype=np.float64)
+    ib, vb = np.ascontiguousarray(b[0], dtype=np.int32), np.ascontiguousarray(b[1], dtype=np.float64)
+    return float(fn(len(ia), _p(ia, i32_p), _p(va, dbl_p), len(ib), _p(ib, i32_p), _p(vb, dbl_p)))

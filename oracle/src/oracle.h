@@ -147,6 +147,13 @@ int orc_pose_graph_opt(int P, double* poses, const uint8_t* fixed, int E, const 
                        const double* meas7, int iterations, double* edge_err_out, int stats_cap, int* stats_n,
                        double* stats_chi2, double* stats_lambda, int* stats_trials);
 
+/* ---------------- bag of words (N2: DBoW2 transform / score, loopclosing.cpp:84,633) ---------------- */
+int orc_voc_words(int n_nodes, const int32_t* parent, const uint8_t* is_leaf, int32_t* word_of);
+void orc_voc_transform_features(int n_nodes, const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc, const double* weight,
+                                const uint8_t* feat, int n, int32_t* word_out, double* weight_out);
+int orc_bow_vector(int n, const int32_t* word, const double* weight, int weighting, int cap, int32_t* ids_out, double* vals_out);
+double orc_bow_score_l1(int n1, const int32_t* id1, const double* v1, int n2, const int32_t* id2, const double* v2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -361,3 +361,36 @@ def make_corridor_sequence(n_frames=40, step=0.8, seed=0, h=KITTI_H, w=KITTI_W, 
         centres.append(c.astype(np.float64))
         poses.append(np.array([0, 0, 0, 1, -c[0], -c[1], -c[2]], dtype=np.float64))   # T_cw, identity rotation
     return frames, np.array(poses), np.array(centres)
+
+
+def make_vocabulary(k=10, L=3, seed=0, stop_fraction=0.02):
+    """A synthetic DBoW2-style vocabulary: a full k-ary tree of depth L with random 256-bit node descriptors (children
+    are noisy copies of their parent, so descents are meaningful), idf-like leaf weights, a few stopped words (weight 0).
+    Nodes in breadth-first order like DBoW2 writes them.  Returns dict(k, L, parent, is_leaf, desc [n,32], weight)."""
+    rng = np.random.default_rng(4000 + seed)
+    parent, is_leaf, desc, weight = [-1], [0], [np.zeros(32, np.uint8)], [0.0]
+    level = [0]
+    root_desc = rng.integers(0, 256, 32, dtype=np.uint8)
+    node_desc = {0: root_desc}
+    for depth in range(1, L + 1):
+        nxt = []
+        for p in level:
+            for _ in range(k):
+                flips = rng.random(256) < (0.25 if depth == 1 else 0.12)
+                d = np.unpackbits(node_desc[p]) ^ flips.astype(np.uint8)
+                d = np.packbits(d)
+                nid = len(parent)
+                parent.append(p); is_leaf.append(1 if depth == L else 0); desc.append(d); node_desc[nid] = d
+                weight.append(0.0 if (depth == L and rng.random() < stop_fraction) else (float(rng.uniform(0.5, 9.0)) if depth == L else 0.0))
+                nxt.append(nid)
+        level = nxt
+    return dict(k=k, L=L, parent=np.array(parent, np.int32), is_leaf=np.array(is_leaf, np.uint8), desc=np.stack(desc).astype(np.uint8),
+                weight=np.array(weight, np.float64))
+
+
+def write_vocabulary_text(path, voc, scoring=0, weighting=0):
+    """TemplatedVocabulary::saveToTextFile layout (the ORBvoc.txt format): 'k L scoring weighting', one node per line"""
+    with open(path, "w") as f:
+        f.write(f"{voc['k']} {voc['L']} {scoring} {weighting}\n")
+        for i in range(1, len(voc["parent"])):
+            f.write(f"{voc['parent'][i]} {int(voc['is_leaf'][i])} " + " ".join(str(int(b)) for b in voc["desc"][i]) + f" {float(voc['weight'][i])!r}\n")
