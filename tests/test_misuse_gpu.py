@@ -137,3 +137,39 @@ def test_ba_and_pose_graph_reject_bad_problems(ctx, po):
     g = ba.pose_graph_opt(ctx, pg, iters=5); o = po.pose_graph_opt(pg, iters=5)
     assert np.abs(g["poses"] - o["poses"]).max() < 2e-4
     _usable(ctx, po)
+
+
+def test_vocabulary_entry_points_reject_bad_arguments(ctx, po):
+    from ssvio_amd import voc as svoc
+    from ssvio_amd.synth import make_vocabulary
+    lib, h = ctx.lib, ctx.handle
+    vv = make_vocabulary(k=4, L=2, seed=1)
+    out = C.c_void_p()
+    par, leaf = vv["parent"], vv["is_leaf"]
+    pp, pl, pd, pw = par.ctypes.data_as(_lib.i32_p), leaf.ctypes.data_as(_lib.u8_p), vv["desc"].ctypes.data_as(_lib.u8_p), vv["weight"].ctypes.data_as(_lib.dbl_p)
+    n = len(par)
+    assert lib.ssx_voc_create(None, 4, 2, 0, 0, n, pp, pl, pd, pw, C.byref(out)) != _lib.SSX_OK
+    assert lib.ssx_voc_create(h, 4, 2, 0, 0, n, None, pl, pd, pw, C.byref(out)) != _lib.SSX_OK
+    assert lib.ssx_voc_create(h, 4, 2, 0, 0, 0, pp, pl, pd, pw, C.byref(out)) != _lib.SSX_OK
+    assert lib.ssx_voc_create(h, 4, 2, 0, 7, n, pp, pl, pd, pw, C.byref(out)) != _lib.SSX_OK            # unknown weighting
+    assert lib.ssx_voc_create(h, 4, 2, 0, 0, n, pp, pl, pd, pw, None) != _lib.SSX_OK
+    wrong_leaf = leaf.copy(); wrong_leaf[1] = 1                                                            # an inner node flagged as a leaf
+    assert lib.ssx_voc_create(h, 4, 2, 0, 0, n, pp, wrong_leaf.ctypes.data_as(_lib.u8_p), pd, pw, C.byref(out)) != _lib.SSX_OK
+    assert lib.ssx_voc_load_text(h, None, C.byref(out)) != _lib.SSX_OK
+    V = svoc.Vocabulary.from_arrays(ctx, 4, 2, par, leaf, vv["desc"], vv["weight"])
+    d = np.zeros((5, 32), np.uint8); ids = np.zeros(5, np.int32); vals = np.zeros(5); m = C.c_int32(0)
+    pdd, pi, pv = d.ctypes.data_as(_lib.u8_p), ids.ctypes.data_as(_lib.i32_p), vals.ctypes.data_as(_lib.dbl_p)
+    assert lib.ssx_voc_transform(None, pdd, 5, None, None, 5, pi, pv, C.byref(m)) != _lib.SSX_OK
+    assert lib.ssx_voc_transform(V.handle, None, 5, None, None, 5, pi, pv, C.byref(m)) != _lib.SSX_OK
+    assert lib.ssx_voc_transform(V.handle, pdd, -2, None, None, 5, pi, pv, C.byref(m)) != _lib.SSX_OK
+    assert lib.ssx_voc_transform(V.handle, pdd, 5, None, None, 5, None, pv, C.byref(m)) != _lib.SSX_OK
+    feats = np.random.default_rng(0).integers(0, 256, (400, 32), dtype=np.uint8)
+    assert lib.ssx_voc_transform(V.handle, feats.ctypes.data_as(_lib.u8_p), 400, None, None, 1, pi, pv, C.byref(m)) == _lib.SSX_ERR_CAPACITY and m.value > 1
+    assert lib.ssx_voc_transform(V.handle, feats.ctypes.data_as(_lib.u8_p), 400, None, None, 0, None, None, C.byref(m)) == _lib.SSX_OK and m.value > 1   # size query
+    lib.ssx_bow_score_l1.restype = C.c_double
+    assert lib.ssx_bow_score_l1(-1, None, None, 3, pi, pv) == 0.0 and lib.ssx_bow_score_l1(3, None, None, 3, pi, pv) == 0.0
+    lib.ssx_voc_destroy(None)                                                                              # no-op
+    gi, gv = V.transform(feats); oi, ov = po.voc_transform(vv, feats)
+    assert np.array_equal(gi, oi) and gv.tobytes() == ov.tobytes()
+    V.close()
+    _usable(ctx, po)

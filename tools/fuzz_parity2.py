@@ -91,6 +91,18 @@ for r in range(rounds):
             o2 = po.lk_track(frames[1], frames[2], o1[0], prm=po.lk_params(use_initial_flow=0))
             check("lk_chain", same(g1[0], o1[0]) and same(g2[0], o2[0]) and same(g2[1], o2[1]), dict(round=r, h=h, w=w))
             c2.close()
+        # bag of words on a random vocabulary
+        from ssvio_amd import voc as svoc
+        from ssvio_amd.synth import make_vocabulary
+        vk = int(rng.integers(2, 21)); vL = int(rng.integers(1, 5 if vk > 8 else 7)); wt = int(rng.integers(0, 4))
+        vv = make_vocabulary(k=vk, L=vL, seed=int(rng.integers(1000)), stop_fraction=float(rng.choice([0.0, 0.05, 0.5])))
+        V = svoc.Vocabulary.from_arrays(ctx, vk, vL, vv["parent"], vv["is_leaf"], vv["desc"], vv["weight"], weighting=wt)
+        fd = dL if len(dL) and rng.random() < 0.5 else rng.integers(0, 256, (int(rng.integers(0, 3000)), 32), dtype=np.uint8)
+        gi, gv, gw, gwt = V.transform(fd, with_features=True)
+        ow, owt = po.voc_transform_features(vv, fd); oi, ov = po.bow_vector(ow, owt, weighting=wt)
+        check("voc", np.array_equal(gw, ow) and gwt.tobytes() == owt.tobytes() and np.array_equal(gi, oi) and gv.tobytes() == ov.tobytes(),
+              dict(round=r, k=vk, L=vL, weighting=wt, n=len(fd)))
+        V.close()
         # BA variants
         P = int(rng.choice([2, 5, 9, 16, 17, 24, 40])); Lm = int(rng.integers(100, 2500)); k = int(rng.integers(2, 7))
         pr = make_ba_problem(P=P, L=Lm, obs_per_lm=min(k, P), seed=int(rng.integers(1 << 30)), fix_first_pose=bool(P > 16 or rng.random() < 0.5),
