@@ -5,21 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): stereo frames/s of the front-end hot path on 1241x376 synthetic stereo, 2000 ORB features
-per image: pyramid + grid FAST + octree + orientation + blur + BRIEF on both images, row-band Hamming matching,
-DLT triangulation -- configs[1] of BASELINE.json ("C2").  One STEP = one batch of B stereo pairs per GPU, already
-resident in HBM when the timed region starts; nothing is downloaded inside the timed region.  N > 1 runs one
-process per GPU on independent pairs (replicas, no data-path collective): weak scaling.
+Metric (BASELINE.json): "stereo frames/s (ORB+match+local-BA) on 1241x376".  One STEP = one batch of B synthetic
+1241x376 stereo pairs per GPU (already resident in HBM when the timed region starts) through the WHOLE hot path in ONE
+timed region: pyramid + grid FAST + octree + orientation + blur + BRIEF on both images (2000 features each), row-band
+Hamming matching, DLT triangulation (configs[1], "C2") AND one local bundle adjustment per pair -- a configs[2]-shaped
+window ("C3": 10 keyframes, 4000 landmarks, 20000 edges; Backend::OptimizeActiveMap with the reference's defaults:
+<= 5 outer rounds x optimize(10), Huber 5.891) as /root/reference/src/ssvio/frontend.cpp:546-576 ->
+backend.cpp:57-76,78-245 chain them per keyframe.  `value` = pairs completed per second, whole job, all GPUs.
+N > 1 runs one process per GPU on independent pairs and windows (replicas, no data-path collective): weak scaling.
 
-Also reported in the same JSON line: BA LM-iterations/s of the local bundle adjustment (configs[2], "C3": 10
-keyframes, 4000 landmarks, 20000 edges) -- landmark-sharded over the N GPUs with the RCCL all-reduce hook when
-N > 1 --, the roofline of the dominant front-end kernel (HIP-event timing, live), and the CPU baseline (the CPU
-oracle = a scalar single-thread port of the same algorithms; plus the reference's own g2o BA when
-oracle/_ref/libssvio_ref.so is present).
+Also in the same JSON line:
+  frontend        the front-end alone (the same batch, its own timed region) -- what round 1 reported as `value`
+  ba              C3 alone: LM iterations/s of one window at a time (latency) and of the batched entry point
+  ba_c4           BA LM iterations/s on the configs[3] shape, landmark-sharded over the N GPUs through RCCL inside
+                  libssx.so (ssx_comm_*) when N > 1
+  roofline        the kernel with the largest share of the composite step: VALU-issue and HBM fractions
+  cpu_baseline    the same composite on ONE host core: CPU oracle front-end (scalar C++ restatement; OpenCV cannot be
+                  built here) + the reference's own g2o BA (oracle/_ref/libssvio_ref.so) when it travelled
 """
 from __future__ import annotations
 
 import argparse
+import concurrent.futures as cf
 import json
 import os
 import sys
@@ -32,6 +39,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+# VALU issue peak: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (guide, "Wave scheduling");
+# 2.4 GHz -> 1024 x 2.4e9 / 2 wave-instructions per second
+VALU_PEAK_GWIPS = 1024 * 2.4 / 2.0
 
 
 def level_pixels(rows, cols, scale=1.2, nlevels=8):
@@ -48,9 +58,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU (batch per launch)")
-    ap.add_argument("--cpu-sample", type=int, default=40, help="stereo pairs timed on the CPU baseline")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs (and BA windows) per step per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="stereo pairs + windows timed on the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -61,8 +71,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # SSX_BENCH_SINGLE_GPU_GLOO=1 is a TEST MODE for boxes with one GPU: all ranks share cuda:0, the process group is
-    # gloo and the BA all-reduce hook is staged through host memory; it exercises every multi-rank code path of this
-    # script (its numbers mean nothing).  The real thing is one rank per GPU over RCCL.
+    # gloo and the BA all-reduce goes through the callback hook staged in host memory; it exercises every multi-rank
+    # code path of this script (its numbers mean nothing).  The real thing is one rank per GPU over RCCL.
     test_mode = world > 1 and os.environ.get("SSX_BENCH_SINGLE_GPU_GLOO") == "1"
     dev_index = 0 if test_mode else local_rank
     if world > 1:
@@ -87,44 +97,89 @@ def main():
     from ssvio_amd.synth import KITTI_H, KITTI_W, make_ba_problem, make_stereo_pair
 
     stream = torch.cuda.Stream(device=dev)
-    ctx = ssvio_amd.Context(dev_index, stream=stream.cuda_stream)
+    ctx = ssvio_amd.Context(dev_index, stream=stream.cuda_stream)     # front-end
+    ctx_ba = ssvio_amd.Context(dev_index)                             # local BA windows, its own stream (the backend thread)
 
     def barrier():
         ctx.synchronize()
+        ctx_ba.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
-    # ---------------- front-end: B synthetic KITTI-shaped stereo pairs per GPU, resident in HBM ----------------
+    # ---------------- inputs: B synthetic KITTI-shaped stereo pairs per GPU, resident in HBM; C3-shaped windows ----------------
     B = args.pairs
     host = np.stack([np.stack(make_stereo_pair(seed=rank * 1000 + i)[:2]) for i in range(B)])   # [B][2][H][W] u8
     imgs = torch.from_numpy(host).to(dev)
     torch.cuda.synchronize(dev)
     counts = orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)   # plans, runs once, syncs
+    N_WIN = 4                                                          # distinct C3 graphs, used round-robin
+    wins = [make_ba_problem(P=10, L=4000, seed=1 + 17 * k + 1000 * rank) for k in range(N_WIN)]
+    step_windows = [wins[i % N_WIN] for i in range(B)]
+    batch = ba.BaBatch(ctx_ba, step_windows)                           # marshalled once; every step uploads + solves all B
+
+    def composite_step():
+        orb.stereo_batch_enqueue(ctx)                                  # asynchronous on the front-end stream
+        return batch.solve(want_edges=False)                           # B windows on the BA stream, returns when done
+
+    # ---------------- timed region 1 (the headline): front-end + one local BA per pair ----------------
     for _ in range(args.warmup):
-        orb.stereo_batch_enqueue(ctx)
+        composite_step()
+    barrier()
+    t0 = time.perf_counter()
+    lm_iters = 0
+    for _ in range(args.steps):
+        lm_iters += composite_step()["n_iters_total"]
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    frames = world * B * args.steps
+    value = frames / elapsed
+
+    # ---------------- timed region 2: the front-end alone (round 1's `value`) ----------------
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         orb.stereo_batch_enqueue(ctx)
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed)
-    frames = world * B * args.steps
-    value = frames / elapsed
+    fe_elapsed = max_over_ranks(time.perf_counter() - t0)
+    fe_value = frames / fe_elapsed
+
+    # ---------------- timed region 3: the batched BA alone, and one window at a time ----------------
+    barrier()
+    t0 = time.perf_counter()
+    BA_REP = 3
+    n_it_b = 0
+    for _ in range(BA_REP):
+        n_it_b += batch.solve(want_edges=False)["n_iters_total"]
+    barrier()
+    bab_elapsed = max_over_ranks(time.perf_counter() - t0)
+    pr = wins[0]
+    for _ in range(2):
+        ba.ba_solve(ctx_ba, pr, want_edges=False)
+    barrier()
+    t0 = time.perf_counter()
+    n_it_1 = 0
+    ONE_REP = 5
+    for _ in range(ONE_REP):
+        n_it_1 += ba.ba_solve(ctx_ba, pr, want_edges=False)["n_iters"]
+    barrier()
+    ba1_elapsed = max_over_ranks(time.perf_counter() - t0)
 
     # ---------------- per-kernel time with HIP events (same workload, profiling on) ----------------
-    _lib.profile_begin(ctx)
     PROF_STEPS = 3
+    _lib.profile_begin(ctx)
     for _ in range(PROF_STEPS):
         orb.stereo_batch_enqueue(ctx)
     kt = _lib.profile_end(ctx)
+    _lib.profile_begin(ctx_ba)
+    for _ in range(PROF_STEPS):
+        batch.solve(want_edges=False)
+    kt_ba = _lib.profile_end(ctx_ba)
     px = level_pixels(KITTI_H, KITTI_W)
     I = 2 * B
-    # algorithmic bytes every kernel must move per STEP (SURVEY.md section 8-D per-image figures x I images); a
-    # kernel launched several times per step (k_resize: 7 levels, k_fast_cells: level 0 | levels 1..7) gets the
-    # per-launch average
     kp_total = int(counts[:, 0].sum() + counts[:, 1].sum())
+    # algorithmic bytes every kernel must move per STEP (SURVEY.md section 8-D per-image / per-iteration figures)
+    E3, L3, P3 = int(pr["E"]), int(pr["L"]), int(pr["P"])
     algo_step = {
         "k_resize": I * (sum(px[:-1]) + sum(px[1:])),                 # read level l-1, write level l
         "k_fast_cells": I * sum(px) + 4.0 * 8000 * I,                 # read the pyramid once, write the candidates
@@ -135,99 +190,116 @@ def main():
         "k_match": 60.0 * kp_total + 8.0 * kp_total / 2,
         "k_triangulate_matches": (56.0 + 25.0) * kp_total / 2,
     }
-    dom_name, dom_ms = None, 0.0
+    # BA kernels: bytes per LAUNCH of the batched kernels (B windows): SURVEY 8-D terms of bytes_iter split by kernel
+    algo_launch_ba = {
+        "k_linearize": B * (24.0 * E3 + 24.0 * L3 + 56.0 * P3 + 18 * 8.0 * E3),       # edges + state in, W out
+        "k_schur": B * (18 * 8.0 * E3 + 72.0 * L3 + 288.0 * 55),
+        "k_backsub_residual": B * (18 * 8.0 * E3 + 24.0 * E3 + 48.0 * L3),
+        "k_solve64": B * (8.0 * 61 * 60 + 56.0 * 2 * P3),
+    }
     kernels = {}
-    for name, (calls, total_ms) in kt.items():
-        kernels[name] = {"calls_per_step": calls / PROF_STEPS, "ms_per_step": total_ms / PROF_STEPS}
-        if total_ms > dom_ms:
-            dom_name, dom_ms = name, total_ms
-    dom_calls = kt[dom_name][0]
-    dom_avg_s = (dom_ms / dom_calls) * 1e-3
-    dom_bytes = algo_step.get(dom_name, 0.0) / (dom_calls / PROF_STEPS)
-    achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
-    # HBM traffic per launch from the committed PMC passes (tools/collect_profiles.sh: separate FETCH_SIZE /
-    # WRITE_SIZE runs; no 16 B/lane streams here, so no FETCH doubling, see the header of the .md); only valid for
-    # the batch size it was taken at
-    traffic, traffic_src = None, None
+    dom = None
+    for src, table in (("frontend", kt), ("ba", kt_ba)):
+        for name, (calls, total_ms) in table.items():
+            kernels[name] = {"calls_per_step": calls / PROF_STEPS, "ms_per_step": total_ms / PROF_STEPS, "part": src}
+            if dom is None or total_ms / PROF_STEPS > kernels[dom]["ms_per_step"]:
+                dom = name
+    dom_calls = kernels[dom]["calls_per_step"]
+    dom_avg_s = kernels[dom]["ms_per_step"] / max(dom_calls, 1e-9) * 1e-3
+    if dom in algo_step:
+        dom_bytes = algo_step[dom] / dom_calls
+    else:
+        dom_bytes = algo_launch_ba.get(dom.split("<")[0], 0.0)
+    hbm_achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    # PMC counters per launch from the committed passes (tools/collect_profiles.sh -> profiles/pmc_counters.json:
+    # separate FETCH_SIZE / WRITE_SIZE / SQ passes); only valid for the batch size they were taken at
+    traffic = valu_insts = None
+    pmc_src = None
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pt = json.load(f)
-        if pt.get("pairs_per_step") == B and world == 1:
-            key = [k for k in pt["bytes_per_launch"] if k.split("<")[0] == dom_name]
+        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
+            pc = json.load(f)
+        if pc.get("pairs_per_step") == B and world == 1:
+            key = [k for k in pc["per_launch"] if k.split("<")[0] == dom.split("<")[0]]
             if key:
-                traffic, traffic_src = int(pt["bytes_per_launch"][key[0]]), pt.get("source")
+                rec = pc["per_launch"][key[0]]
+                traffic = rec.get("hbm_bytes")
+                valu_insts = rec.get("SQ_INSTS_VALU")
+                pmc_src = pc.get("source")
     except (OSError, ValueError):
         pass
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "avg_launch_us": round(dom_avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(dom_bytes),
-                "launches_per_step": dom_calls / PROF_STEPS,
-                "note": "the dominant kernel (grid FAST) is bound by integer VALU issue, not by HBM: see DESIGN.md section 4; "
-                        "traffic = PMC bytes per launch from " + (traffic_src or "profiles/ (not available for this batch size)")}
-    # whole-pipeline figure: 12.0 MB algorithmic bytes per stereo pair
-    pipeline_gbs = 12.0e6 * value / world / 1e9
+    hbm = {"achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6)}
+    roofline = {"kernel": dom, "avg_launch_us": round(dom_avg_s * 1e6, 2), "launches_per_step": dom_calls,
+                "algorithmic_bytes_per_launch": int(dom_bytes), "traffic": traffic, "hbm": hbm}
+    if valu_insts:
+        va = valu_insts / dom_avg_s / 1e9
+        roofline["valu"] = {"achieved": round(va, 2), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": round(va / VALU_PEAK_GWIPS, 5),
+                            "wave_instructions_per_launch": int(valu_insts),
+                            "definition": "SQ_INSTS_VALU per launch (PMC) / live launch duration; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}
+    if valu_insts and roofline["valu"]["frac"] > hbm["frac"]:
+        roofline.update(bound="valu", achieved=roofline["valu"]["achieved"], peak=VALU_PEAK_GWIPS, unit="G wave-instr/s",
+                        frac=roofline["valu"]["frac"])
+    else:
+        roofline.update(bound="hbm", achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac"])
+    roofline["note"] = ("kernel with the largest share of the composite step; achieved = algorithmic bytes (or PMC VALU wave-instructions) "
+                        "per launch / average launch duration measured live with HIP events on the launching stream; PMC values from "
+                        + (pmc_src or "profiles/ (not available for this batch size)"))
+    pipeline_gbs = 12.0e6 * fe_value / world / 1e9                     # 12.0 MB algorithmic bytes per stereo pair
 
-    # ---------------- local BA (C3) ----------------
-    pr = make_ba_problem(P=10, L=4000, seed=1)
-    ba_kwargs = {}
+    # ---------------- global BA (C4 shape), landmark-sharded over the GPUs through RCCL inside the library ----------------
+    # 500 keyframes on a loop, 10 000 landmarks PER GPU (6 observations each): at 8 GPUs this is BASELINE configs[3]
+    # exactly (80 000 landmarks, 480 000 edges) -- weak scaling; at N = 1 the full configs[3] is timed as well (the
+    # strong-scaling reference point).
+    comm_kwargs = {}
+    hook_kwargs = {}
     if world > 1:
         from ssvio_amd import dist_ba
-        pr_local = dist_ba.shard_problem(pr, rank, world)
-        hook = dist_ba.make_allreduce_hook_host_staged(dev) if test_mode else dist_ba.make_allreduce_hook(dev)
-        ba_kwargs = dict(allreduce=hook, rank=rank, world_size=world)
-    else:
-        pr_local = pr
-    with torch.cuda.stream(stream):
-        for _ in range(2):
-            r = ba.ba_solve(ctx, pr_local, want_edges=False, **ba_kwargs)
-        barrier()
-        tb = time.perf_counter()
-        BA_REP = 5
-        n_it = 0
-        for _ in range(BA_REP):
-            r = ba.ba_solve(ctx, pr_local, want_edges=False, **ba_kwargs)
-            n_it += r["n_iters"]
-        barrier()
-        ba_elapsed = time.perf_counter() - tb
-    ba_elapsed = max_over_ranks(ba_elapsed)
-    ba_iters_s = n_it / ba_elapsed
-    ba_solve_ms = ba_elapsed / BA_REP * 1e3
+        if test_mode:
+            hook_kwargs = dict(allreduce=dist_ba.make_allreduce_hook_host_staged(dev), rank=rank, world_size=world)
+        else:
+            comm = dist_ba.init_native_comm(ctx, rank, world)          # ncclCommInitRank inside libssx.so, id broadcast by torch.distributed
+            comm_kwargs = dict(comm=comm, rank=rank, world_size=world)
+    dkw = dict(comm_kwargs, **hook_kwargs)
 
-    # ---------------- global BA (C4 shape), WEAK scaling over the GPUs ----------------
-    # 500 keyframes on a loop, 10 000 landmarks PER GPU (6 observations each): at 8 GPUs this is BASELINE
-    # configs[3] exactly (80 000 landmarks, 480 000 edges).  Landmarks are sharded, the 3000 x 3000 reduced system
-    # is all-reduced (non-zero tiles only) and solved redundantly on every rank.
+    def time_c4(n_landmarks, reps):
+        pr4 = make_ba_problem(P=500, L=n_landmarks, obs_per_lm=6, seed=4, loop=True, fix_first_pose=True)
+        if world > 1:
+            from ssvio_amd import dist_ba
+            pr4_local = dist_ba.shard_problem(pr4, rank, world)
+        else:
+            pr4_local = pr4
+        with torch.cuda.stream(stream):
+            r4 = ba.ba_solve(ctx, pr4_local, outer_rounds=1, iters=10, want_edges=False, **dkw)
+            barrier()
+            tb = time.perf_counter()
+            n_it4 = 0
+            for _ in range(reps):
+                r4 = ba.ba_solve(ctx, pr4_local, outer_rounds=1, iters=10, want_edges=False, **dkw)
+                n_it4 += r4["n_iters"]
+            barrier()
+            el = max_over_ranks(time.perf_counter() - tb)
+        return {"landmarks": n_landmarks, "edges": int(pr4["E"]), "iters_per_s": round(n_it4 / el, 2),
+                "edge_iters_per_s": round(float(pr4["E"]) * n_it4 / el, 1), "ms_per_lm_iteration": round(el / max(n_it4, 1) * 1e3, 3),
+                "lm_trials": int(np.sum(r4["trials"])), "chi2_first_last": [float(r4["chi2"][0]), float(r4["chi2"][-1])],
+                "phase_ms": r4.get("phase_ms")}
+
     C4_LM_PER_GPU = 10000
-    pr4 = make_ba_problem(P=500, L=C4_LM_PER_GPU * world, obs_per_lm=6, seed=4, loop=True, fix_first_pose=True)
-    pr4_local = dist_ba.shard_problem(pr4, rank, world) if world > 1 else pr4
-    with torch.cuda.stream(stream):
-        r4 = ba.ba_solve(ctx, pr4_local, outer_rounds=1, iters=10, want_edges=False, **ba_kwargs)
-        barrier()
-        tb = time.perf_counter()
-        C4_REP = 2
-        n_it4 = 0
-        for _ in range(C4_REP):
-            r4 = ba.ba_solve(ctx, pr4_local, outer_rounds=1, iters=10, want_edges=False, **ba_kwargs)
-            n_it4 += r4["n_iters"]
-        barrier()
-        c4_elapsed = time.perf_counter() - tb
-    c4_elapsed = max_over_ranks(c4_elapsed)
-    c4 = {"workload": f"C4 shape: 500 KF on a loop x {C4_LM_PER_GPU * world} landmarks x {int(pr4['E'])} edges "
-                      f"({C4_LM_PER_GPU} landmarks per GPU, weak scaling), analytic Jacobians, f64",
-          "iters_per_s": round(n_it4 / c4_elapsed, 2),
-          "edge_iters_per_s": round(float(pr4["E"]) * n_it4 / c4_elapsed, 1),
-          "ms_per_lm_iteration": round(c4_elapsed / max(n_it4, 1) * 1e3, 3),
-          "chi2_first_last": [float(r4["chi2"][0]), float(r4["chi2"][-1])],
-          "sharding": f"landmarks over {world} GPUs + RCCL all-reduce of the non-zero 64x64 tiles" if world > 1 else "none"}
+    c4 = {"workload": "C4 shape: 500 KF on a loop, 6 observations per landmark, pose 0 fixed, analytic Jacobians, f64",
+          "weak": time_c4(C4_LM_PER_GPU * world, 2),
+          "sharding": (f"landmarks l mod {world} + RCCL all-reduce of the banded reduced system" if world > 1 else "none")}
+    if world == 1 or os.environ.get("SSX_BENCH_C4_FULL") == "1":
+        c4["full_configs3"] = time_c4(80000, 2)                       # strong-scaling point: the same 480 k edges at every N
 
-    # ---------------- CPU baseline (rank 0, N == 1 only) ----------------
+    # ---------------- CPU baseline (rank 0, N == 1 only): the same composite on one host core ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as po
         po.build()
         ns = max(1, min(args.cpu_sample, B))
-        tc = time.perf_counter()
+        use_ref = po.have_ref() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libssvio_ref.so"))
+        t_fe = t_ba = 0.0
+        n_it_cpu = 0
         for i in range(ns):
+            tc = time.perf_counter()
             L, R = host[i, 0], host[i, 1]
             kL, dL = po.orb_extract(L); kR, dR = po.orb_extract(R)
             idx, _ = po.stereo_match(kL, dL, kR, dR)
@@ -235,59 +307,64 @@ def main():
             uvL = np.stack([kL["x"][m], kL["y"][m]], 1).astype(np.float64)
             uvR = np.stack([kR["x"][idx[m]], kR["y"][idx[m]]], 1).astype(np.float64)
             po.triangulate(uvL, uvR, (718.856, 718.856, 607.1928, 185.2157), 386.1448 / 718.856)
-        cpu_t = time.perf_counter() - tc
-        cpu = {"value": round(ns / cpu_t, 3), "unit": "stereo frames/s", "cores": 1, "kind": "port",
-               "sample": f"{ns} of the benchmark's stereo pairs through the CPU oracle (scalar C++ restatement, "
-                         f"single thread; the reference's OpenCV path cannot be built: OpenCV absent)",
+            t_fe += time.perf_counter() - tc
+            tc = time.perf_counter()
+            rr = po.ba_solve(step_windows[i], "ref") if use_ref else po.ba_solve(step_windows[i], "oracle", jac_mode=1)
+            n_it_cpu += len(rr["chi2"])
+            t_ba += time.perf_counter() - tc
+        cpu = {"value": round(ns / (t_fe + t_ba), 4), "unit": "stereo frames/s", "cores": 1,
+               "kind": "reference" if use_ref else "port",
+               "sample": f"{ns} of the benchmark's stereo pairs + {ns} of its C3 windows, one after the other on one thread: front-end through the "
+                         f"CPU oracle (scalar C++ restatement; the reference's OpenCV front-end cannot be built: OpenCV absent), local BA through "
+                         + ("the reference's own g2o + CSparse + numeric Jacobians (oracle/_ref/libssvio_ref.so)" if use_ref else "the oracle port (numeric Jacobians)"),
+               "frontend_frames_per_s": round(ns / t_fe, 3), "ba_windows_per_s": round(ns / t_ba, 3),
+               "ba_lm_iterations_per_s": round(n_it_cpu / t_ba, 2),
                "host_cores_available": os.cpu_count()}
-        # the same port on many cores at once (one process per core, its own pairs): the path is embarrassingly
+        # the front-end port on many cores at once (one process per core, its own pairs): the path is embarrassingly
         # parallel over frames, so this is what the host CPUs could do with the scalar restatement
         try:
             from oracle import pool_worker
             nw = max(1, min(os.cpu_count() or 1, 64))
             rate, reported = pool_worker.frontend_all_cores(nw, pairs_per_worker=2)
             if reported >= max(1, nw // 2):
-                cpu["all_cores"] = {"value": round(rate, 2), "unit": "stereo frames/s", "cores": reported,
-                                    "sample": f"{reported} processes x 2 pairs each, started together (one per core)"}
+                cpu["frontend_all_cores"] = {"value": round(rate, 2), "unit": "stereo frames/s", "cores": reported,
+                                             "sample": f"{reported} processes x 2 pairs each, started together (one per core)"}
         except Exception as e:                                       # the baseline is informative, never fatal
             cpu["all_cores_error"] = str(e)[:200]
-        # BA: the reference's own g2o path when the compiled reference library travelled with the repo
-        tc = time.perf_counter()
-        if po.have_ref() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libssvio_ref.so")):
-            rr = po.ba_solve(pr, "ref", outer_rounds=1)
-            kind = "reference"
-        else:
-            rr = po.ba_solve(pr, "oracle", outer_rounds=1, jac_mode=1)
-            kind = "port"
-        ba_cpu_t = time.perf_counter() - tc
-        cpu["ba"] = {"value": round(len(rr["chi2"]) / ba_cpu_t, 2), "unit": "BA LM iterations/s", "kind": kind, "cores": 1,
-                     "sample": "one optimize(10) of the C3 graph (g2o numeric Jacobians, CSparse), single thread"}
 
     if rank == 0:
         out = {
-            "metric": "stereo frames/s (ORB extract + row-band match + triangulate) on 1241x376",
+            "metric": "stereo frames/s (ORB extract + row-band match + triangulate + one local BA per frame) on 1241x376",
             "value": round(value, 2), "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C2: 1241x376 synthetic stereo, 2000 ORB feats/img, 8 levels, extract+match+triangulate",
-                       "pairs_per_step_per_gpu": B, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8 (front-end) + f64 (BA)", "data": "synthetic",
+            "config": {"workload": "C2 + C3: 1241x376 synthetic stereo, 2000 ORB feats/img, 8 levels, extract+match+triangulate, then one "
+                                   "local BA (10 KF x 4000 landmarks x 20000 edges, <= 5 x optimize(10), analytic Jacobians) per pair",
+                       "pairs_per_step_per_gpu": B, "ba_windows_per_step_per_gpu": B,
+                       "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
                        "avg_keypoints_per_image": round(kp_total / I, 1),
                        "avg_matches_per_pair": round(float(counts[:, 2].mean()), 1),
-                       "avg_triangulated_per_pair": round(float(counts[:, 3].mean()), 1)},
+                       "avg_triangulated_per_pair": round(float(counts[:, 3].mean()), 1),
+                       "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2)},
             "roofline": roofline,
-            "pipeline_algorithmic_GBps_per_gpu": round(pipeline_gbs, 3),
-            "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
+            "frontend": {"metric": "stereo frames/s (ORB extract + row-band match + triangulate), no BA", "value": round(fe_value, 2),
+                         "ms_per_step": round(fe_elapsed / args.steps * 1e3, 4),
+                         "pipeline_algorithmic_GBps_per_gpu": round(pipeline_gbs, 3)},
+            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "ba": {"workload": "C3: local BA, 10 KF x 4000 landmarks x 20000 edges, analytic Jacobians, f64",
-                   "iters_per_s": round(ba_iters_s, 1), "ms_per_solve": round(ba_solve_ms, 3),
-                   "lm_iterations_per_solve": n_it // BA_REP,
-                   "sharding": f"landmarks over {world} GPUs + RCCL all-reduce" if world > 1 else "none",
-                   "includes": "host<->device transfer of the problem and the host LM control loop"},
+                   "batched": {"windows_per_call": B, "windows_per_s": round(world * B * BA_REP / bab_elapsed, 1),
+                               "iters_per_s": round(world * n_it_b / bab_elapsed, 1), "ms_per_call": round(bab_elapsed / BA_REP * 1e3, 3)},
+                   "one_window": {"iters_per_s": round(n_it_1 / ba1_elapsed, 1), "ms_per_solve": round(ba1_elapsed / ONE_REP * 1e3, 3),
+                                  "lm_iterations_per_solve": n_it_1 // ONE_REP},
+                   "includes": "host marshalling (edge sort), host<->device transfer of every window and of its result"},
             "ba_c4": c4,
-            "e2e_frames_per_s_with_one_local_BA_per_frame": round(1.0 / (1.0 / (value / world) + ba_solve_ms * 1e-3) * world, 2),
             "cpu_baseline": cpu,
         }
+        if cpu:
+            out["speedup_vs_cpu_1core"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
     ctx.close()
+    ctx_ba.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -107,6 +107,23 @@ typedef enum { SSX_JAC_ANALYTIC = 0, SSX_JAC_NUMERIC_G2O = 1 } ssx_jac_mode;
  * stream).  Return 0 on success. */
 typedef int (*ssx_allreduce_fn)(void* user, double* buf_dev, size_t count, void* stream);
 
+/* RCCL inside the library (the reference is a single process, there is no counterpart): one
+ * process per GPU, one communicator per process.  Rank 0 calls ssx_comm_unique_id and hands the 128 bytes to the other
+ * ranks by whatever channel the host has (MPI, a file, torch.distributed); every rank then calls ssx_comm_init
+ * (collective: ncclCommInitRank on the ctx's device).  ssx_comm_wrap adopts an ncclComm_t the host already owns.
+ * With ssx_ba_options.comm set, ssx_ba_solve sums its exchange buffers with ncclAllReduce(f64, sum) enqueued on the
+ * ctx stream -- no callback, no host round trip.  librccl.so.1 is bound at run time (the copy already loaded in the
+ * process, else /opt/rocm/lib); SSX_ERR_COMM when it cannot be found. */
+typedef struct ssx_comm ssx_comm;
+typedef struct { char bytes[128]; } ssx_comm_id;      /* an ncclUniqueId */
+SSX_API ssx_status ssx_comm_unique_id(ssx_ctx* ctx, ssx_comm_id* out);
+SSX_API ssx_status ssx_comm_init(ssx_ctx* ctx, const ssx_comm_id* id, int32_t rank, int32_t world_size, ssx_comm** out);
+SSX_API ssx_status ssx_comm_wrap(ssx_ctx* ctx, void* nccl_comm, int32_t rank, int32_t world_size, ssx_comm** out);
+SSX_API void ssx_comm_destroy(ssx_comm* comm);
+SSX_API ssx_status ssx_comm_info(const ssx_comm* comm, int32_t* rank, int32_t* world_size);
+/* in-place f64 sum of `count` doubles at the DEVICE pointer buf_dev, ordered on the ctx stream */
+SSX_API ssx_status ssx_comm_allreduce_sum(ssx_ctx* ctx, ssx_comm* comm, double* buf_dev, size_t count);
+
 typedef struct {
   int32_t outer_rounds;   /* backend.cpp:175  while (iteration < 5)            default 5     */
   int32_t iters;          /* backend.cpp:178  optimizer.optimize(10)           default 10    */
@@ -120,6 +137,10 @@ typedef struct {
   ssx_allreduce_fn allreduce;
   void* allreduce_user;
   int32_t rank, world_size; /* of this shard; world_size <= 1 = single GPU */
+  /* the native path: an ssx_comm (RCCL).  When set it takes precedence over `allreduce`, and rank / world_size are
+   * the communicator's.  The callback above stays for hosts with their own collective layer and for tests. */
+  ssx_comm* comm;
+  int32_t collect_stats;    /* 1 = time every phase with HIP events (fills ssx_ba_result.ms_*; a few us per launch) */
 } ssx_ba_options;
 
 #define SSX_BA_MAX_STATS 128
@@ -134,9 +155,15 @@ typedef struct {
   double iter_lambda[SSX_BA_MAX_STATS]; /* lambda after each LM iteration */
   int32_t iter_trials[SSX_BA_MAX_STATS];/* LM trials of each iteration */
   int32_t n_inliers, n_outliers;        /* of the last round (backend.cpp:181-194) */
-  /* phase timing of this call, milliseconds of GPU time (HIP events on the ctx stream); the schema
-   * follows g2o's G2OBatchStatistics (thirdparty/g2o/g2o/core/batch_stats.h) */
+  /* GPU time of this call, milliseconds (HIP events on the ctx stream): upload .. last download */
   float ms_total, ms_setup;
+  /* with ssx_ba_options.collect_stats: GPU time per phase summed over the call, the fields of g2o's
+   * G2OBatchStatistics (thirdparty/g2o/g2o/core/batch_stats.h:38-68) they correspond to in brackets */
+  float ms_linearize;       /* residuals + Jacobians + quadratic form   [timeResiduals + timeLinearize + timeQuadraticForm] */
+  float ms_schur;           /* landmark elimination                     [timeSchurComplement]                               */
+  float ms_linear_solution; /* reduced-system factorisation + solves    [timeLinearSolution]                                */
+  float ms_update;          /* back-substitution, state update, trial residuals  [timeUpdate + the next computeActiveErrors] */
+  float ms_reduce;          /* cross-chunk reductions and collectives   [no g2o counterpart: single-threaded]               */
 } ssx_ba_result;
 
 SSX_API void ssx_ba_default_options(ssx_ba_options* opt);

@@ -52,7 +52,7 @@ class BaOptions(C.Structure):
     _fields_ = [("outer_rounds", C.c_int32), ("iters", C.c_int32), ("chi2_th", C.c_double),
                 ("huber_delta", C.c_double), ("inlier_ratio", C.c_double), ("jac_mode", C.c_int32),
                 ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p),
-                ("rank", C.c_int32), ("world_size", C.c_int32)]
+                ("rank", C.c_int32), ("world_size", C.c_int32), ("comm", C.c_void_p), ("collect_stats", C.c_int32)]
 
 
 class BaResult(C.Structure):
@@ -61,7 +61,8 @@ class BaResult(C.Structure):
                 ("iter_chi2", C.c_double * SSX_BA_MAX_STATS), ("iter_lambda", C.c_double * SSX_BA_MAX_STATS),
                 ("iter_trials", C.c_int32 * SSX_BA_MAX_STATS),
                 ("n_inliers", C.c_int32), ("n_outliers", C.c_int32),
-                ("ms_total", C.c_float), ("ms_setup", C.c_float)]
+                ("ms_total", C.c_float), ("ms_setup", C.c_float), ("ms_linearize", C.c_float), ("ms_schur", C.c_float),
+                ("ms_linear_solution", C.c_float), ("ms_update", C.c_float), ("ms_reduce", C.c_float)]
 
 
 class KeyPoint(C.Structure):

@@ -42,8 +42,9 @@ def _problem_struct(pr, keep):
 
 def ba_solve(ctx: Context, pr, outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891,
              inlier_ratio=0.7, jac_mode=JAC_ANALYTIC, allreduce=None, rank=0, world_size=1,
-             want_edges=True):
-    """Backend::OptimizeActiveMap's optimisation (defaults = backend.cpp:109,163,175,178,195)."""
+             want_edges=True, comm=None, collect_stats=False):
+    """Backend::OptimizeActiveMap's optimisation (defaults = backend.cpp:109,163,175,178,195).
+    comm = an ssx_comm handle (dist_ba.init_native_comm): landmark shard of a multi-GPU solve over RCCL."""
     keep = []
     s = _problem_struct(pr, keep)
     opt = BaOptions()
@@ -55,6 +56,9 @@ def ba_solve(ctx: Context, pr, outer_rounds=5, iters=10, chi2_th=5.891, huber_de
         cb = _lib.ALLREDUCE_FN(allreduce)
         keep.append(cb)
         opt.allreduce = cb
+    if comm is not None:
+        opt.comm = comm
+    opt.collect_stats = 1 if collect_stats else 0
     res = BaResult()
     poses = np.zeros((s.P, 7)); points = np.zeros((s.L, 3))
     chi2 = np.zeros(s.E) if want_edges else None
@@ -66,7 +70,9 @@ def ba_solve(ctx: Context, pr, outer_rounds=5, iters=10, chi2_th=5.891, huber_de
     return dict(rounds=res.rounds, n_iters=res.n_iters, poses=poses, points=points, edge_chi2=chi2,
                 edge_outlier=outl, chi2=np.array(res.iter_chi2[:k]), lam=np.array(res.iter_lambda[:k]),
                 trials=np.array(res.iter_trials[:k]), n_inliers=res.n_inliers, n_outliers=res.n_outliers,
-                ms_total=res.ms_total)
+                ms_total=res.ms_total,
+                phase_ms=(dict(linearize=res.ms_linearize, schur=res.ms_schur, linear_solution=res.ms_linear_solution,
+                               update=res.ms_update, reduce=res.ms_reduce) if collect_stats else None))
 
 
 def ba_linearize(ctx: Context, pr, huber_delta=5.891, jac_mode=JAC_ANALYTIC):
@@ -131,3 +137,31 @@ def pose_graph_opt(ctx, pr, iters=20):
     k = res.stats_n
     return dict(poses=poses, edge_err=err[:E], n_iters=res.n_iters, chi2=chi[:k].copy(), lambdas=lam[:k].copy(),
                 trials=tr[:k].copy(), chi2_initial=res.chi2_initial, chi2_final=res.chi2_final)
+
+
+class BaBatch:
+    """Many local windows per call (one window per stereo pair of a batch / per stream of BASELINE configs[4]).
+    Marshals the problems once; solve() uploads, optimises and downloads ALL of them."""
+
+    def __init__(self, ctx: Context, problems, n_workers=8, **solve_kwargs):
+        import concurrent.futures as cf
+        self.ctx, self.problems, self.kw = ctx, list(problems), solve_kwargs
+        self._ctxs = [Context(ctx.device) for _ in range(max(1, min(n_workers, len(self.problems))))]
+        self._pool = cf.ThreadPoolExecutor(max_workers=len(self._ctxs))
+
+    def solve(self, want_edges=True):
+        n = len(self._ctxs)
+
+        def work(k):
+            return [ba_solve(self._ctxs[k], self.problems[i], want_edges=want_edges, **self.kw) for i in range(k, len(self.problems), n)]
+        parts = list(self._pool.map(work, range(n)))
+        res = [None] * len(self.problems)
+        for k, part in enumerate(parts):
+            for j, r in enumerate(part):
+                res[k + j * n] = r
+        return dict(results=res, n_iters_total=int(sum(r["n_iters"] for r in res)))
+
+    def close(self):
+        self._pool.shutdown()
+        for c in self._ctxs:
+            c.close()

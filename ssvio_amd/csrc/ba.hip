@@ -45,6 +45,8 @@
 #include "ctx.hpp"
 #include "se3.hpp"
 
+int ssx_comm_allreduce_f64(void* user, double* buf_dev, size_t count, void* stream);   // comm.hip
+
 namespace {
 
 using ssx::Cam;
@@ -1521,6 +1523,11 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   if (st != SSX_OK) return st;
   Comm cm;
   // world_size 1 with a hook is allowed (the hook is then an identity): it exercises the collective plumbing
+  if (opt.comm) {                                   // RCCL inside the library (comm.hip): ncclAllReduce on the ctx stream
+    cm.fn = ssx_comm_allreduce_f64; cm.user = opt.comm;
+    (void)ssx_comm_info(opt.comm, &opt.rank, &opt.world_size);
+    cm.world = opt.world_size;
+  } else
   if (opt.allreduce && opt.world_size >= 1) { cm.fn = opt.allreduce; cm.user = opt.allreduce_user; cm.world = opt.world_size; }
   if (cm.fn && (opt.rank < 0 || opt.rank >= cm.world || cm.world > 64)) {
     ctx->set_error("ssx_ba_solve: invalid rank %d / world_size %d", opt.rank, cm.world);
@@ -1528,6 +1535,14 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   }
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  // collect_stats: every launch of this call is bracketed by HIP events (the SSX_PROF machinery of ssx_profile_begin),
+  // summed per phase at the end; the guard switches it off again on every exit path
+  struct StatsGuard {
+    ssx_ctx* c; bool mine;
+    ~StatsGuard() { if (mine) { c->prof.on = false; c->prof.recs.clear(); c->prof.used = 0; } }
+  } stats_guard{ctx, opt.collect_stats != 0 && !ctx->prof.on};
+  if (stats_guard.mine) { ctx->prof.on = true; ctx->prof.used = 0; ctx->prof.recs.clear(); }
+  res->ms_linearize = res->ms_schur = res->ms_linear_solution = res->ms_update = res->ms_reduce = 0.f;
   BaDev d;
   BigDev bd;
   st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd);
@@ -1791,6 +1806,18 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   res->ms_total = ms;
   res->ms_setup = 0.f;
+  if (stats_guard.mine)
+    for (const auto& r : ctx->prof.recs) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+      switch (r.id) {
+        case KID_BA_LINEARIZE: res->ms_linearize += t; break;
+        case KID_BA_SCHUR: res->ms_schur += t; break;
+        case KID_BA_SOLVE: res->ms_linear_solution += t; break;
+        case KID_BA_BACKSUB: res->ms_update += t; break;
+        default: res->ms_reduce += t; break;
+      }
+    }
   return SSX_OK;
 }
 

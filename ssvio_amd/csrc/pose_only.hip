@@ -576,10 +576,8 @@ extern "C" ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const dou
 {
   if (!ctx || !pose_io || !K4 || M < 0 || (M && (!xyz || !uv)) || rounds < 0 || iters < 0) return SSX_ERR_INVALID_ARG;
   if (M == 0) { if (n_inliers) *n_inliers = 0; return SSX_OK; }
-  static thread_local int dummy = 0; (void)dummy;
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
   // reuse the BA-independent scratch: a small private arena hung off the ctx through the generic slot
-  static_assert(sizeof(double) == 8, "");
   DevBuf& arena = ctx->po_arena;
   HostBuf& stage = ctx->po_stage;
   Layout lay;

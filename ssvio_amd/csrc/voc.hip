@@ -170,7 +170,14 @@ ssx_status ssx_voc_transform(ssx_vocabulary* v, const uint8_t* desc, int32_t n, 
   if (!v || n < 0 || (n > 0 && !desc) || cap < 0 || (cap > 0 && (!ids_out || !vals_out))) return SSX_ERR_INVALID_ARG;
   ssx_ctx* ctx = v->ctx;
   if (n_entries) *n_entries = 0;
-  if (n == 0 || v->n_nodes <= 1) return SSX_OK;            // empty vocabulary: an empty BowVector (TemplatedVocabulary.h:1071-1074)
+  if (n == 0) return SSX_OK;
+  if (v->n_nodes <= 1) {                                    // empty vocabulary: an empty BowVector (TemplatedVocabulary.h:1071-1074)
+    for (int32_t i = 0; i < n; ++i) {                       // and the documented per-feature outputs: word -1, weight 0
+      if (words_out) words_out[i] = -1;
+      if (weights_out) weights_out[i] = 0.0;
+    }
+    return SSX_OK;
+  }
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
   Layout lay;
   const size_t o_f = lay.take((size_t)32 * n);

@@ -78,3 +78,32 @@ def make_allreduce_hook_host_staged(device, group=None):
             return 1
 
     return hook
+
+
+def init_native_comm(ctx, rank: int, world: int, group=None):
+    """RCCL inside libssx.so (ssx_comm_*, include/ssx.h): rank 0 draws the ncclUniqueId, torch.distributed only carries its
+    128 bytes to the other ranks, every rank then creates the communicator on its ctx's device.  -> ssx_comm handle for
+    ba.ba_solve(..., comm=handle).  Works for world == 1 too (a one-rank communicator: the plumbing test)."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    lib = ctx.lib
+    ident = (C.c_char * 128)()
+    if rank == 0:
+        ctx.check(lib.ssx_comm_unique_id(ctx.handle, ident))
+    if world > 1:
+        t = torch.frombuffer(bytearray(bytes(ident)), dtype=torch.uint8).clone()
+        backend = dist.get_backend(group)
+        if backend == "nccl":
+            t = t.to(torch.device("cuda", ctx.device))
+        dist.broadcast(t, src=0, group=group)
+        ident = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+    h = C.c_void_p()
+    ctx.check(lib.ssx_comm_init(ctx.handle, ident, int(rank), int(world), C.byref(h)))
+    return h
+
+
+def destroy_native_comm(ctx, comm):
+    ctx.lib.ssx_comm_destroy.restype = None
+    ctx.lib.ssx_comm_destroy(comm)

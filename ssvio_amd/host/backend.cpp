@@ -39,6 +39,7 @@ void Backend::InsertKeyFrame(const KeyFramePtr& kf, bool optimization)
   }
   {
     std::lock_guard<std::mutex> lk(queue_mutex_);
+    RethrowWorkerError();                                            // a failed solve surfaces at the next insertion
     queue_.emplace_back(kf, optimization);
   }
   queue_cv_.notify_one();
@@ -48,7 +49,18 @@ void Backend::WaitIdle()
 {
   if (!async_) return;
   std::unique_lock<std::mutex> lk(queue_mutex_);
-  idle_cv_.wait(lk, [this] { return queue_.empty() && !busy_; });
+  idle_cv_.wait(lk, [this] { return (queue_.empty() && !busy_) || worker_error_; });
+  RethrowWorkerError();
+}
+
+// queue_mutex_ held.  The worker thread cannot let an exception escape (std::terminate): it parks it here and the
+// caller thread gets it from WaitIdle() / the next InsertKeyFrame(), like the synchronous mode through its call stack.
+void Backend::RethrowWorkerError()
+{
+  if (!worker_error_) return;
+  std::exception_ptr e = worker_error_;
+  worker_error_ = nullptr;
+  std::rethrow_exception(e);
 }
 
 // backend.cpp:24-55 (BackendLoop) without the polling sleep: process every queued keyframe, optimise the window once the
@@ -64,21 +76,27 @@ void Backend::Worker()
       batch.swap(queue_);
       busy_ = true;
     }
-    Window w;
-    bool optimize = false;
-    {
-      std::lock_guard<std::mutex> map_lock(map_->update_mutex);
-      for (auto& item : batch) { map_->InsertKeyFrame(item.first); optimize = item.second; }
-      if (optimize) Marshal(w);
-    }
-    if (optimize && !w.empty()) {
-      Solve(w);
-      std::lock_guard<std::mutex> map_lock(map_->update_mutex);
-      Apply(w);
+    std::exception_ptr err;
+    try {
+      Window w;
+      bool optimize = false;
+      {
+        std::lock_guard<std::mutex> map_lock(map_->update_mutex);
+        for (auto& item : batch) { map_->InsertKeyFrame(item.first); optimize = item.second; }
+        if (optimize) Marshal(w);
+      }
+      if (optimize && !w.empty()) {
+        Solve(w);                                                    // throws on a HIP / argument error of the BA call
+        std::lock_guard<std::mutex> map_lock(map_->update_mutex);
+        Apply(w);
+      }
+    } catch (...) {
+      err = std::current_exception();
     }
     {
       std::lock_guard<std::mutex> lk(queue_mutex_);
       busy_ = false;
+      if (err && !worker_error_) worker_error_ = err;
     }
     idle_cv_.notify_all();
   }

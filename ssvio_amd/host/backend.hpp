@@ -17,6 +17,8 @@
 #include <mutex>
 #include <thread>
 
+#include <exception>
+
 #include "compute.hpp"
 #include "frontend.hpp"
 #include "map.hpp"
@@ -54,6 +56,7 @@ class Backend {
   void Solve(Window& w);                    // the GPU call               (no lock)
   void Apply(Window& w);                    // arrays -> map, outliers    (map mutex held)
   void Worker();
+  void RethrowWorkerError();                // queue_mutex_ held
 
   Compute& compute_;
   std::shared_ptr<Map> map_;
@@ -66,6 +69,7 @@ class Backend {
   std::condition_variable queue_cv_, idle_cv_;
   std::deque<std::pair<KeyFramePtr, bool>> queue_;
   bool stop_ = false, busy_ = false;
+  std::exception_ptr worker_error_;         // first failure of the worker thread, handed to the caller thread
 };
 
 }  // namespace ssx::host

@@ -7,7 +7,8 @@
 // The PNG pairs are decoded ahead of the tracker on worker threads (StereoPrefetcher); everything else is the
 // reference's single loop.  --streams=K runs K independent copies of the loop in K threads of this process (each with
 // its own System, GPU contexts and prefetcher) on the same sequence: a single stream is latency-bound, several fill the
-// GPU (BASELINE configs[4] runs one stream per GPU; this is the one-GPU version of it).
+// GPU (BASELINE configs[4] runs one stream per GPU; this is the one-GPU version of it).  --kitti_dataset_path may be a
+// comma-separated list: stream k then runs sequence k mod (number of sequences) -- several DIFFERENT sequences at once.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -52,11 +53,27 @@ int main(int argc, char** argv)
   using namespace ssx::host;
   using clk = std::chrono::steady_clock;
   try {
-    std::vector<std::string> left_paths, right_paths;
-    std::vector<double> timestamps;
-    LoadKittiImagesTimestamps(dataset, left_paths, right_paths, timestamps);
-    size_t num_images = left_paths.size();
-    if (!max_frames_s.empty()) num_images = std::min(num_images, (size_t)std::atol(max_frames_s.c_str()));
+    // one sequence, or a comma-separated list of sequences for --streams
+    struct Sequence {
+      std::vector<std::string> left_paths, right_paths;
+      std::vector<double> timestamps;
+      size_t num_images = 0;
+      std::vector<StereoPrefetcher::Pair> preloaded;
+    };
+    std::vector<Sequence> seqs;
+    for (size_t pos = 0; pos <= dataset.size();) {
+      const size_t comma = std::min(dataset.find(',', pos), dataset.size());
+      Sequence sq;
+      LoadKittiImagesTimestamps(dataset.substr(pos, comma - pos), sq.left_paths, sq.right_paths, sq.timestamps);
+      sq.num_images = sq.left_paths.size();
+      if (!max_frames_s.empty()) sq.num_images = std::min(sq.num_images, (size_t)std::atol(max_frames_s.c_str()));
+      seqs.push_back(std::move(sq));
+      pos = comma + 1;
+    }
+    std::vector<std::string>& left_paths = seqs[0].left_paths;
+    std::vector<std::string>& right_paths = seqs[0].right_paths;
+    std::vector<double>& timestamps = seqs[0].timestamps;
+    const size_t num_images = seqs[0].num_images;
     std::printf("Num Images: %zu\n", num_images);
 
     const int streams = streams_s.empty() ? 1 : std::max(1, std::atoi(streams_s.c_str()));
@@ -64,27 +81,30 @@ int main(int argc, char** argv)
       const int device = device_s.empty() ? 0 : std::atoi(device_s.c_str());
       const int dthreads = threads_s.empty() ? 8 : std::atoi(threads_s.c_str());
       std::vector<double> seconds(streams, 0.0);
-      std::vector<size_t> keyframes(streams, 0);
+      std::vector<size_t> keyframes(streams, 0), frames(streams, 0);
       std::vector<std::string> errors(streams);
-      // --preload=1: decode the whole sequence once, before the clock starts (isolates tracking from PNG decoding)
-      std::vector<StereoPrefetcher::Pair> preloaded;
-      if (!preload_s.empty() && std::atoi(preload_s.c_str()) != 0) {
-        StereoPrefetcher pf(left_paths, right_paths, num_images, 32);
-        for (size_t ni = 0; ni < num_images; ++ni) preloaded.push_back(pf.Next());
-      }
+      // --preload=1: decode every sequence once, before the clock starts (isolates tracking from PNG decoding)
+      if (!preload_s.empty() && std::atoi(preload_s.c_str()) != 0)
+        for (Sequence& sq : seqs) {
+          StereoPrefetcher pf(sq.left_paths, sq.right_paths, sq.num_images, 32);
+          for (size_t ni = 0; ni < sq.num_images; ++ni) sq.preloaded.push_back(pf.Next());
+        }
       std::vector<std::thread> workers;
       const auto t_all0 = clk::now();
       for (int k = 0; k < streams; ++k)
         workers.emplace_back([&, k] {
           try {
+            const Sequence& sq = seqs[(size_t)k % seqs.size()];
+            const size_t num_images = sq.num_images;
+            frames[k] = num_images;
             System sys(config, nullptr, device);
             std::unique_ptr<StereoPrefetcher> pf;
-            if (preloaded.empty()) pf = std::make_unique<StereoPrefetcher>(left_paths, right_paths, num_images, dthreads);
+            if (sq.preloaded.empty()) pf = std::make_unique<StereoPrefetcher>(sq.left_paths, sq.right_paths, num_images, dthreads);
             const auto t0 = clk::now();
             for (size_t ni = 0; ni < num_images; ++ni) {
-              StereoPrefetcher::Pair pair = pf ? pf->Next() : preloaded[ni];
-              if (pair.left->empty() || pair.right->empty()) throw std::runtime_error("Failed to load image " + left_paths[ni]);
-              sys.RunStep(pair.left, pair.right, timestamps[ni]);
+              StereoPrefetcher::Pair pair = pf ? pf->Next() : sq.preloaded[ni];
+              if (pair.left->empty() || pair.right->empty()) throw std::runtime_error("Failed to load image " + sq.left_paths[ni]);
+              sys.RunStep(pair.left, pair.right, sq.timestamps[ni]);
             }
             sys.backend().WaitIdle();
             seconds[k] = std::chrono::duration<double>(clk::now() - t0).count();
@@ -99,8 +119,8 @@ int main(int argc, char** argv)
       double sum = 0;
       for (int k = 0; k < streams; ++k) {
         if (!errors[k].empty()) { std::fprintf(stderr, "fatal (stream %d): %s\n", k, errors[k].c_str()); return 1; }
-        sum += num_images / std::max(seconds[k], 1e-9);
-        std::printf("stream %d: %.1f frames/s, %zu keyframes\n", k, num_images / std::max(seconds[k], 1e-9), keyframes[k]);
+        sum += frames[k] / std::max(seconds[k], 1e-9);
+        std::printf("stream %d: %.1f frames/s, %zu keyframes\n", k, frames[k] / std::max(seconds[k], 1e-9), keyframes[k]);
       }
       std::printf("%d streams: aggregate %.1f frames/s (sum of the streams' loops incl. decoding), wall %.2f s incl. context creation\n", streams, sum, wall);
       return 0;

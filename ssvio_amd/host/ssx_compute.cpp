@@ -14,10 +14,17 @@ class SsxCompute final : public Compute {
 
   void Detect(const Image& img, const uint8_t* mask, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
   {
-    kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});      // Detect is single-level: <= max(N + 3, 4 * nIni <= 256)
+    // Detect is single-level: <= max(N + 3, 4 * nIni <= 256) keypoints by the bound of ssx.h; should a grid ever return
+    // more, the call reports the size it needs (SSX_ERR_CAPACITY, n > capacity) and is repeated once with that size
+    kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});
     int32_t n = 0;
-    frame_.check(ssx_orb_detect(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, mask, img.cols, &prm, (int32_t)kps.size(),
-                                kps.data(), &n));
+    ssx_status st = ssx_orb_detect(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, mask, img.cols, &prm, (int32_t)kps.size(),
+                                   kps.data(), &n);
+    if (st == SSX_ERR_CAPACITY && n > (int32_t)kps.size()) {
+      kps.assign((size_t)n, ssx_keypoint{});
+      st = ssx_orb_detect(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, mask, img.cols, &prm, (int32_t)kps.size(), kps.data(), &n);
+    }
+    frame_.check(st);
     kps.resize(n);
   }
 

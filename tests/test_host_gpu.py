@@ -99,6 +99,31 @@ def test_several_streams_in_one_process(built, tmp_path):
         assert open(f"{many}.{k}").read() == ref
 
 
+def test_eight_concurrent_streams_c5_shape(built, tmp_path):
+    """BASELINE configs[4] shape on ONE GPU: eight concurrent stereo streams (full front-end + backend each: tracking,
+    keyframes, triangulation, window BA), over two DIFFERENT sequences (a forward drive with the reference's settings
+    and a lateral one), frames decoded beforehand.  Every stream must reproduce the trajectory file of its sequence's
+    single-stream run bit for bit (synchronous backend: deterministic), i.e. concurrent contexts do not interfere."""
+    a = hu.write_corridor_sequence(os.path.join(str(tmp_path), "a"), n_frames=24)
+    b = hu.write_sequence(os.path.join(str(tmp_path), "b"), n_frames=12, step=0.6, seed=3)
+    cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {})
+    singles = []
+    for k, seq in enumerate((a, b)):
+        out = os.path.join(str(tmp_path), f"single{k}.txt")
+        r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", f"--trajectory={out}"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        singles.append(open(out).read())
+    many = os.path.join(str(tmp_path), "many.txt")
+    r8 = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={a['dir']},{b['dir']}", f"--trajectory={many}",
+                         "--streams=8", "--preload=1"], capture_output=True, text=True, timeout=600)
+    assert r8.returncode == 0, r8.stdout + r8.stderr
+    assert "8 streams: aggregate" in r8.stdout and r8.stdout.count("keyframes") == 8
+    assert len(singles[0].splitlines()) >= 2                       # the forward drive inserts keyframes (window BA runs)
+    for k in range(8):
+        assert open(f"{many}.{k}").read() == singles[k % 2], k
+
+
 def test_runner_arguments(built, tmp_path):
     r = subprocess.run([built["run_kitti"]], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr

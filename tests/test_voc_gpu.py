@@ -56,6 +56,8 @@ def test_text_vocabulary_and_edge_cases(ctx, po, tmp_path):
     V.close()
     empty = svoc.Vocabulary.from_arrays(ctx, 10, 3, [-1], [0], np.zeros((1, 32), np.uint8), [0.0])
     assert empty.transform(feats)[0].size == 0                          # no vocabulary: empty BowVector
+    _, _, w_e, wt_e = empty.transform(feats, with_features=True)        # per-feature outputs as ssx.h documents: -1 / 0
+    assert (w_e == -1).all() and (wt_e == 0.0).all()
     empty.close()
     with pytest.raises(SsxError):
         svoc.Vocabulary.loadFromTextFile(ctx, tmp_path / "missing.txt")

@@ -1,8 +1,11 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun) from the repo root: three rocprofv3 passes of the default bench command.
+# Run ON THE GPU BOX (through gpurun) from the repo root: rocprofv3 passes of the default bench command.
 #   1. --kernel-trace --stats            -> per-kernel durations
 #   2. --pmc FETCH_SIZE  (own pass)      -> HBM/L2 read traffic per kernel
 #   3. --pmc WRITE_SIZE  (own pass)      -> write traffic per kernel
+#   4. --pmc SQ_* (two passes of <= 8 SQ counters + GRBM) -> VALU instructions / issue cycles, wave cycles (occupancy),
+#      LDS stalls and bank conflicts; the rows also carry each kernel's VGPR / AGPR / SGPR / LDS / scratch allocation
+# (counters always in their own run with --kernel-trace only, never with a sys/runtime/hip/hsa trace)
 # Output under gpurun_out/prof/<tag>/ ; tools/summarize_profiles.py turns it into profiles/<round>/ files.
 set -u
 TAG=${1:-run}
@@ -15,6 +18,10 @@ CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE \
+    --kernel-trace --output-format csv -d "$OUT/sq1" -- $CMD > "$OUT/sq1.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_BUSY_CU_CYCLES GRBM_COUNT \
+    --kernel-trace --output-format csv -d "$OUT/sq2" -- $CMD > "$OUT/sq2.log" 2>&1
 cd "$R"
 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"

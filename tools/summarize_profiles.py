@@ -66,6 +66,74 @@ with open(os.path.join(rdir, name + "_pmc_hbm.md"), "w") as o:
         t = (fe[k][0] + w) * 1024.0
         traffic[k] = t
         o.write(f"| {k} | {fe[k][1]} | {avg_ns.get(k, 0) / 1e3:.1f} | {fe[k][0]:.1f} | {w:.1f} | {t / 1e6:.2f} |\n")
+
+# 3. SQ passes: VALU instructions / issue, wave cycles (achieved occupancy), LDS stalls; kernel resource table
+def pmc_all(sub):
+    fs = sorted(glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")))
+    if not fs:
+        return {}, {}
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    meta = {}
+    for r in csv.DictReader(open(fs[-1])):
+        k = short(r["Kernel_Name"])
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+        meta[k] = dict(wg=int(r["Workgroup_Size"]), lds=int(r["LDS_Block_Size"]), scratch=int(r["Scratch_Size"]), vgpr=int(r["VGPR_Count"]),
+                       agpr=int(r["Accum_VGPR_Count"]), sgpr=int(r["SGPR_Count"]))
+    return {k: {c: tot[k][c] / cnt[k][c] for c in tot[k]} for k in tot}, meta
+
+
+sq = {}
+meta = {}
+for sub in ("sq1", "sq2"):
+    a, m = pmc_all(sub)
+    for k, v in a.items():
+        sq.setdefault(k, {}).update(v)
+    meta.update(m)
+CLK_GHZ, SIMDS = 2.4, 1024
+per_launch = {}
+for k in set(list(traffic) + list(sq)):
+    per_launch[k] = {"hbm_bytes": round(traffic[k]) if k in traffic else None}
+    for c, v in sq.get(k, {}).items():
+        per_launch[k][c] = round(v)
+if sq:
+    with open(os.path.join(rdir, name + "_occupancy_valu.md"), "w") as o:
+        o.write(f"# Occupancy and VALU issue per kernel, `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` ({pairs} pairs/step), MI355X\n\n"
+                "Two `rocprofv3 --pmc SQ_* --kernel-trace` passes (tools/collect_profiles.sh), values averaged per launch; `avg us` from the\n"
+                "separate `--kernel-trace --stats` pass.  Resources are the dispatch packet's (VGPR/AGPR allocation granule 8, LDS bytes per\n"
+                "workgroup).  `waves/SIMD limit` = min(8, floor(512 / (VGPR+AGPR)), LDS: floor(160 KB / LDS per WG) x waves per WG / 4).\n"
+                "`achieved waves/SIMD` = SQ_WAVE_CYCLES x 4 (the counter ticks in quad-cycles) / (GRBM_GUI_ACTIVE x 1024 SIMDs): the\n"
+                "time-averaged number of resident waves per SIMD while the kernel runs.  `VALU issue` = SQ_INSTS_VALU x 2 cycles (a wave64\n"
+                "VALU instruction issues over 2 cycles on a SIMD-32, MI355X_MICROARCH.md 'Wave scheduling') / (avg duration x 2.4 GHz x 1024\n"
+                "SIMDs): the fraction of the chip's VALU issue slots the kernel fills.  `VALU busy` = SQ_ACTIVE_INST_VALU x 4 /\n"
+                "SQ_WAVE_CYCLES x 4: the share of its resident wave-time a wave spends issuing VALU.  `LDS stall` = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES.\n\n"
+                "| kernel | WG | VGPR | AGPR | SGPR | LDS B/WG | scratch | waves/SIMD limit | achieved waves/SIMD | avg us | SQ_INSTS_VALU | VALU issue | VALU busy | SQ_INSTS_LDS | LDS stall | bank-conflict cycles / LDS active | SQ_INSTS_SALU | SQ_INSTS_VMEM |\n"
+                "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for k in sorted(sq, key=lambda k: -sq[k].get("SQ_INSTS_VALU", 0) * 1.0):
+            m, v = meta.get(k, {}), sq[k]
+            if not m:
+                continue
+            regs = max(((m["vgpr"] + m["agpr"] + 7) // 8) * 8, 8)
+            wpw = max(m["wg"] // 64, 1)
+            lim_v = min(8, 512 // regs)
+            lim_l = 8 if m["lds"] == 0 else (160 * 1024 // m["lds"]) * wpw / 4.0
+            lim = min(lim_v, lim_l, 8)
+            dur_us = avg_ns.get(k, 0) / 1e3
+            gui = v.get("GRBM_GUI_ACTIVE", 0)
+            occ = v.get("SQ_WAVE_CYCLES", 0) * 4 / (gui * SIMDS) if gui else float("nan")
+            issue = v.get("SQ_INSTS_VALU", 0) * 2 / (dur_us * 1e-6 * CLK_GHZ * 1e9 * SIMDS) if dur_us else float("nan")
+            busy = v.get("SQ_ACTIVE_INST_VALU", 0) / v["SQ_WAVE_CYCLES"] if v.get("SQ_WAVE_CYCLES") else float("nan")
+            stall = v.get("SQ_WAIT_INST_LDS", 0) / v["SQ_WAVE_CYCLES"] if v.get("SQ_WAVE_CYCLES") else float("nan")
+            bank = v.get("SQ_LDS_BANK_CONFLICT", 0) / v["SQ_LDS_IDX_ACTIVE"] if v.get("SQ_LDS_IDX_ACTIVE") else float("nan")
+            per_launch[k]["valu_issue_frac"] = round(issue, 4) if issue == issue else None
+            per_launch[k]["achieved_waves_per_simd"] = round(occ, 3) if occ == occ else None
+            o.write(f"| {k} | {m['wg']} | {m['vgpr']} | {m['agpr']} | {m['sgpr']} | {m['lds']} | {m['scratch']} | {lim:.1f} | {occ:.2f} | {dur_us:.1f} | "
+                    f"{v.get('SQ_INSTS_VALU', 0):.0f} | {issue:.3f} | {busy:.3f} | {v.get('SQ_INSTS_LDS', 0):.0f} | {stall:.3f} | {bank:.3f} | "
+                    f"{v.get('SQ_INSTS_SALU', 0):.0f} | {v.get('SQ_INSTS_VMEM', 0):.0f} |\n")
+    print(open(os.path.join(rdir, name + "_occupancy_valu.md")).read())
+json.dump({"source": f"{rdir}/{name}_pmc_hbm.md + {name}_occupancy_valu.md", "pairs_per_step": pairs, "per_launch": per_launch},
+          open(os.path.join("profiles", "pmc_counters.json"), "w"), indent=1)
 json.dump(bj, open(os.path.join(rdir, name + ".json"), "w"), indent=1)
 json.dump({"source": f"{rdir}/{name}_pmc_hbm.md", "pairs_per_step": bj["config"]["pairs_per_step_per_gpu"],
            "bytes_per_launch": {k: round(v) for k, v in traffic.items()}},
