@@ -99,6 +99,7 @@ typedef struct {
 } ssx_ba_problem;
 
 typedef enum { SSX_JAC_ANALYTIC = 0, SSX_JAC_NUMERIC_G2O = 1 } ssx_jac_mode;
+typedef enum { SSX_LARGE_SOLVER_AUTO = 0, SSX_LARGE_SOLVER_TILES = 1, SSX_LARGE_SOLVER_BAND = 2 } ssx_large_solver;
 
 /* Sum-all-reduce hook for landmark-sharded multi-GPU BA.  `buf_dev` is a DEVICE pointer to `count`
  * doubles on the ctx's device; the callee must enqueue an in-place sum over all ranks ordered after
@@ -141,6 +142,11 @@ typedef struct {
    * the communicator's.  The callback above stays for hosts with their own collective layer and for tests. */
   ssx_comm* comm;
   int32_t collect_stats;    /* 1 = time every phase with HIP events (fills ssx_ba_result.ms_*; a few us per launch) */
+  /* windows with more than 16 free keyframes, the reduced pose system: SSX_LARGE_SOLVER_AUTO picks the band solver
+   * (sliding-window block Cholesky + nested dissection along the trajectory) when every keyframe shares landmarks only
+   * with keyframes within 6 positions along the (possibly closed) trajectory, else the 64x64-tile sparse Cholesky;
+   * _TILES / _BAND force one (BAND fails with SSX_ERR_UNSUPPORTED on a wider co-visibility). */
+  int32_t large_solver;
 } ssx_ba_options;
 
 #define SSX_BA_MAX_STATS 128

@@ -52,7 +52,7 @@ class BaOptions(C.Structure):
     _fields_ = [("outer_rounds", C.c_int32), ("iters", C.c_int32), ("chi2_th", C.c_double),
                 ("huber_delta", C.c_double), ("inlier_ratio", C.c_double), ("jac_mode", C.c_int32),
                 ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p),
-                ("rank", C.c_int32), ("world_size", C.c_int32), ("comm", C.c_void_p), ("collect_stats", C.c_int32)]
+                ("rank", C.c_int32), ("world_size", C.c_int32), ("comm", C.c_void_p), ("collect_stats", C.c_int32), ("large_solver", C.c_int32)]
 
 
 class BaResult(C.Structure):

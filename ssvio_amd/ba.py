@@ -42,7 +42,7 @@ def _problem_struct(pr, keep):
 
 def ba_solve(ctx: Context, pr, outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891,
              inlier_ratio=0.7, jac_mode=JAC_ANALYTIC, allreduce=None, rank=0, world_size=1,
-             want_edges=True, comm=None, collect_stats=False):
+             want_edges=True, comm=None, collect_stats=False, large_solver=0):
     """Backend::OptimizeActiveMap's optimisation (defaults = backend.cpp:109,163,175,178,195).
     comm = an ssx_comm handle (dist_ba.init_native_comm): landmark shard of a multi-GPU solve over RCCL."""
     keep = []
@@ -59,6 +59,7 @@ def ba_solve(ctx: Context, pr, outer_rounds=5, iters=10, chi2_th=5.891, huber_de
     if comm is not None:
         opt.comm = comm
     opt.collect_stats = 1 if collect_stats else 0
+    opt.large_solver = int(large_solver)                  # 0 auto, 1 tiles, 2 band (windows beyond 16 free keyframes)
     res = BaResult()
     poses = np.zeros((s.P, 7)); points = np.zeros((s.L, 3))
     chi2 = np.zeros(s.E) if want_edges else None

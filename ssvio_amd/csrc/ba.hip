@@ -899,6 +899,7 @@ __global__ void k_publish_trial(BaDev d, int lm)
 }
 
 #include "ba_big.inc"
+#include "ba_band.inc"
 
 }  // namespace
 
@@ -936,6 +937,7 @@ struct HostPrep {
   // large-window path
   bool big = false;
   std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr, spair_a, spair_b;
+  int band_w = -1;          // cyclic block bandwidth of this rank's part of the reduced system (max over its non-zero blocks)
 };
 
 ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
@@ -1069,6 +1071,12 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
       }
     }
     h.nBlk = 0;
+    // cyclic block bandwidth: pose p is coupled to poses within band_w positions along the (closed) trajectory
+    h.band_w = 0;
+    for (size_t q = 0; q < h.sblk_pa.size(); ++q) {
+      const int dd = h.sblk_pb[q] - h.sblk_pa[q];
+      h.band_w = std::max(h.band_w, std::min(dd, nP - dd));
+    }
     return SSX_OK;
   }
   // per-chunk index lists: edges grouped by free pose; leader pairs grouped by reduced-system block
@@ -1126,8 +1134,37 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
 }
 
 // carve the arena and upload the problem
+// Segment plan of the band solver (ba_band.inc): w > 0 switches it on.  K interiors of >= w poses separated by w poses.
+struct BandPlan {
+  int w = 0, K = 1;
+  std::vector<int> seg_p0, seg_m;
+};
+
+void plan_band(int nP, int w, BandPlan& bp)
+{
+  bp.w = w; bp.K = 1; bp.seg_p0.assign(1, 0); bp.seg_m.assign(1, nP - w);
+  if (w <= 0) return;
+  if (nP >= 48) {
+    // dependent chain ~ nP / K interior pivots + 1.5 K w separator pivots (the top window is wider)
+    int K = (int)std::lround(std::sqrt((double)nP / (1.5 * w)));
+    K = std::max(2, std::min(K, 64));
+    while (K > 1 && (nP - K * w) / K < w) --K;                      // every interior must hold >= w poses
+    while ((nP - K * w + K - 1) / K > 480) ++K;                     // LDS of the back-substitution
+    bp.K = K;
+  }
+  if (bp.K == 1) return;
+  const int K = bp.K, inner = nP - K * w, base = inner / K, rem = inner % K;
+  bp.seg_p0.resize(K); bp.seg_m.resize(K);
+  int p = 0;
+  for (int k = 0; k < K; ++k) {
+    bp.seg_p0[k] = p;
+    bp.seg_m[k] = base + (k < rem ? 1 : 0);
+    p += bp.seg_m[k] + w;
+  }
+}
+
 ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, double huber_delta, double chi2_th,
-                  int world, int rank, BaDev& d, BigDev& bd)
+                  int world, int rank, BaDev& d, BigDev& bd, const BandPlan& bp, BandDev& bnd)
 {
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
@@ -1163,6 +1200,9 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_spair_ptr = in.take(sizeof(int) * (h.spair_ptr.size() + 1));
   const size_t o_spair_a = in.take(sizeof(int) * (nSPairs + 1));
   const size_t o_spair_b = in.take(sizeof(int) * (nSPairs + 1));
+  const bool band = big && bp.w > 0;
+  const size_t o_seg_p0 = in.take(sizeof(int) * (bp.seg_p0.size() + 1));
+  const size_t o_seg_m = in.take(sizeof(int) * (bp.seg_m.size() + 1));
   const size_t o_pose0 = in.take(sizeof(double) * 7 * P);
   const size_t o_point0 = in.take(sizeof(double) * 3 * (L + 1));
   const size_t in_bytes = in.off;
@@ -1183,7 +1223,20 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_BDa = all.take(big ? sizeof(double) * 18 * (size_t)(E + 1) : 256);
   const size_t o_Wma = all.take(big ? sizeof(double) * 18 * (size_t)(E + 1) : 256);
   const size_t o_Cv = all.take(big ? sizeof(double) * 6 * (size_t)(E + 1) : 256);
-  const size_t o_S = all.take(big ? sizeof(double) * (size_t)(n_pad + NB) * n_pad : 256);
+  const size_t o_S = all.take((big && !band) ? sizeof(double) * (size_t)(n_pad + NB) * n_pad : 256);
+  // band solver: band + rhs, segment updates, factors of both levels, the separator system
+  const int bw = bp.w, bK = bp.K, bnPr = bK * bw, bwr = 2 * bw - 1;
+  const int NW0 = 6 * (2 * bw + 1) + 1, LS0 = 36 + NW0 * 6;
+  const int w1 = bK == 1 ? bw : bwr, NW1 = 6 * (w1 + 1 + bw) + 1, LS1 = 36 + NW1 * 6;
+  const int NU = 12 * bw + 1;
+  const size_t sb_count = band ? (size_t)nP * (bw + 1) * 36 + (size_t)n : 0;
+  const size_t sr_count = (band && bK > 1) ? (size_t)bnPr * (bwr + 1) * 36 + 6 * (size_t)bnPr : 0;
+  const size_t o_Sb = all.take(sizeof(double) * (sb_count + 1));
+  const size_t o_U = all.take(band ? sizeof(double) * (size_t)bK * NU * NU : 256);
+  const size_t o_Ls0 = all.take((band && bK > 1) ? sizeof(double) * (size_t)nP * LS0 : 256);
+  const size_t o_Sr = all.take(sizeof(double) * (sr_count + 1));
+  const size_t o_Ls1 = all.take(band ? sizeof(double) * (size_t)(bK > 1 ? bnPr : nP) * LS1 : 256);
+  const size_t o_xr = all.take(sizeof(double) * (6 * (size_t)bnPr + 8));
   const size_t o_x = all.take(sizeof(double) * (n_pad + 8));
   const size_t o_Ld = all.take(sizeof(double) * NB * NB);
   const size_t o_invd = all.take(sizeof(double) * (n_pad + 8));
@@ -1234,6 +1287,10 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_spair_a, h.spair_a.data(), sizeof(int) * h.spair_a.size());
     memcpy(hs + o_spair_b, h.spair_b.data(), sizeof(int) * h.spair_b.size());
   }
+  if (band) {
+    memcpy(hs + o_seg_p0, bp.seg_p0.data(), sizeof(int) * bp.seg_p0.size());
+    memcpy(hs + o_seg_m, bp.seg_m.data(), sizeof(int) * bp.seg_m.size());
+  }
   memcpy(hs + o_pose0, pr->poses, sizeof(double) * 7 * P);
   if (L) memcpy(hs + o_point0, pr->points, sizeof(double) * 3 * L);
   char* base = ws->arena.as<char>();
@@ -1282,12 +1339,21 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.scal = (double*)(base + o_scal);
   d.lm_stat = (double*)(base + o_lmstat);
   bd = BigDev{};
+  bnd = BandDev{};
   if (big) {
     bd.n = n; bd.n_pad = n_pad; bd.ld = n_pad; bd.T = n_pad / NB; bd.nBlkS = (int)nBlkS;
     bd.pe_ptr = (const int*)(base + o_pe_ptr); bd.pe_edge = (const int*)(base + o_pe_edge);
     bd.sblk_pa = (const int*)(base + o_sblk_pa); bd.sblk_pb = (const int*)(base + o_sblk_pb);
     bd.spair_ptr = (const int*)(base + o_spair_ptr); bd.spair_a = (const int*)(base + o_spair_a); bd.spair_b = (const int*)(base + o_spair_b);
     bd.BDa = (double*)(base + o_BDa); bd.Wma = (double*)(base + o_Wma); bd.Cv = (double*)(base + o_Cv);
+    bnd = BandDev{};
+    if (band) {
+      bnd.on = 1; bnd.w = bw; bnd.K = bK; bnd.nP = nP; bnd.nPr = bnPr; bnd.wr = bwr;
+      bnd.Sb = (double*)(base + o_Sb); bnd.bsv = bnd.Sb + (size_t)nP * (bw + 1) * 36;
+      bnd.seg_p0 = (const int*)(base + o_seg_p0); bnd.seg_m = (const int*)(base + o_seg_m);
+      bnd.U = (double*)(base + o_U); bnd.Ls0 = (double*)(base + o_Ls0); bnd.Sr = (double*)(base + o_Sr);
+      bnd.Ls1 = (double*)(base + o_Ls1); bnd.xr = (double*)(base + o_xr); bnd.LS0 = LS0; bnd.LS1 = LS1;
+    }
     bd.S = (double*)(base + o_S); bd.x = (double*)(base + o_x); bd.Ld = (double*)(base + o_Ld); bd.invd = (double*)(base + o_invd); bd.Ninv = (double*)(base + o_Ninv); bd.scale_part = (double*)(base + o_scale_part);
   }
   return SSX_OK;
@@ -1458,7 +1524,9 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
   if (st != SSX_OK) return st;
   BaDev d;
   BigDev bd;
-  st = upload(ctx, prob, h, huber_delta, 5.891, 1, 0, d, bd);
+  BandPlan no_band;
+  BandDev bnd;
+  st = upload(ctx, prob, h, huber_delta, 5.891, 1, 0, d, bd, no_band, bnd);
   if (st != SSX_OK) return st;
   Comm cm;
   st = launch_linearize(ctx, d, bd, cm, jac_mode, 0, 1);
@@ -1545,7 +1613,35 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   res->ms_linearize = res->ms_schur = res->ms_linear_solution = res->ms_update = res->ms_reduce = 0.f;
   BaDev d;
   BigDev bd;
-  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd);
+  // large windows: trajectory-shaped co-visibility (cyclic block band) -> the sliding-window / nested-dissection solver
+  // of ba_band.inc; anything else -> the 64x64-tile sparse Cholesky of ba_big.inc.  With several ranks the decision
+  // must be common: the ranks exchange which bandwidth class their shard falls in (one tiny all-reduce).
+  BandPlan bp;
+  if (h.big && opt.large_solver != SSX_LARGE_SOLVER_TILES) {
+    int w = std::max(h.band_w, 1);
+    if (w > BAND_WMAX) w = BAND_WMAX + 1;
+    if (cm.fn) {
+      if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+      BaWorkspace* w0 = ctx->ba;
+      double hist[BAND_WMAX + 2] = {0};
+      hist[w] = 1.0;
+      SSX_HIP_TRY(ctx, w0->tiles.reserve(sizeof(hist)));
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(w0->tiles.p, hist, sizeof(hist), hipMemcpyHostToDevice, ctx->stream));
+      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      st = allreduce(ctx, cm, w0->tiles.as<double>(), BAND_WMAX + 2);
+      if (st != SSX_OK) return st;
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(hist, w0->tiles.p, sizeof(hist), hipMemcpyDeviceToHost, ctx->stream));
+      SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      for (int i = 1; i <= BAND_WMAX + 1; ++i) if (hist[i] != 0.0) w = i;
+    }
+    if (w <= BAND_WMAX && h.nP >= 2 * w + 2) plan_band(h.nP, w, bp);
+  }
+  if (h.big && opt.large_solver == SSX_LARGE_SOLVER_BAND && bp.w == 0) {
+    ctx->set_error("ssx_ba_solve: the band solver was requested but the co-visibility bandwidth is %d poses (> %d)", h.band_w, BAND_WMAX);
+    return SSX_ERR_UNSUPPORTED;
+  }
+  BandDev bnd;
+  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd);
   if (st != SSX_OK) return st;
   BaWorkspace* ws = ctx->ba;
   double* hscal = ws->scal.as<double>();
@@ -1561,13 +1657,47 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   }
   std::vector<int> tl_row_cnt, tl_pair_cnt;
   std::vector<uint8_t> tl_next_diag;
-  if (d.big) {
+  if (d.big && !bnd.on) {
     st = build_tile_lists(ctx, ws, h.sblk_pa, h.sblk_pb, cm, bd, tl_row_cnt, tl_pair_cnt, tl_next_diag);
     if (st != SSX_OK) return st;
+  }
+  size_t lds_seg = 0, lds_top = 0, lds_back = 0;
+  if (bnd.on) {
+    const int w1 = bnd.K == 1 ? bnd.w : bnd.wr, n1 = bnd.K == 1 ? bnd.nP : bnd.nPr;
+    int m_max = 0;
+    for (int m : bp.seg_m) m_max = std::max(m_max, m);
+    lds_seg = band_lds_elim(bnd.w, bnd.w);
+    lds_top = std::max(band_lds_elim(w1, bnd.w), band_lds_back(w1, bnd.w, n1));
+    lds_back = band_lds_back(bnd.w, bnd.w, m_max + 2 * bnd.w);
+    static size_t set_seg = 0, set_top = 0, set_back = 0;            // raise the dynamic-LDS limits once per size class
+    if (lds_seg > set_seg) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_seg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg); set_seg = lds_seg; }
+    if (lds_top > set_top) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_top), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_top); set_top = lds_top; }
+    if (lds_back > set_back) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_back), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back); set_back = lds_back; }
   }
   // large windows: Schur blocks -> dense S (+ rhs row) -> all-reduce -> blocked Cholesky (MFMA) -> back-substitution
   auto big_trial = [&](double lambda, int dev_lambda, int cur_) -> ssx_status {
     hipStream_t s = ctx->stream;
+    if (bnd.on) {
+      // Schur blocks straight into the band layout -> (all-reduce) -> segments || -> separator system -> segments ||
+      const size_t band_doubles = (size_t)bnd.nP * (bnd.w + 1) * 36;
+      SSX_HIP_TRY(ctx, hipMemsetAsync(bnd.Sb, 0, sizeof(double) * band_doubles, s));
+      if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_prep, dim3(nCh), dim3(CH), lds_prep, s, d, bd, lambda, dev_lambda));
+      SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_blocks_band, dim3((bd.nBlkS + 3) / 4), dim3(CH), 0, s, d, bd, bnd));
+      SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_bs_band, dim3(d.nP), dim3(CH), 0, s, d, bd, bnd));
+      ssx_status st2 = allreduce(ctx, cm, bnd.Sb, band_doubles + (size_t)bd.n);
+      if (st2 != SSX_OK) return st2;
+      if (bnd.K > 1) {
+        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_seg, dim3(bnd.K), dim3(BAND_T), lds_seg, s, d, bnd, lambda, dev_lambda));
+        const int total = bnd.nPr * (bnd.wr + 1) * 36 + 6 * bnd.nPr;
+        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_assemble, dim3(std::min(64, (total + BAND_T - 1) / BAND_T)), dim3(BAND_T), 0, s, d, bnd, lambda, dev_lambda));
+      }
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_top, dim3(1), dim3(BAND_T), lds_top, s, d, bnd, bd, lambda, dev_lambda));
+      if (bnd.K > 1) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_back, dim3(bnd.K), dim3(BAND_T), lds_back, s, d, bnd, bd));
+      const int nparts = std::min(32, (d.P + CH - 1) / CH);
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_pose_update_big, dim3(nparts), dim3(CH), 0, s, d, bd, cur_, lambda, dev_lambda));
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_scale_finish, dim3(1), dim3(64), 0, s, d, bd, nparts));
+      return SSX_OK;
+    }
     SSX_HIP_TRY(ctx, hipMemsetAsync(bd.S, 0, sizeof(double) * (size_t)(bd.n_pad + 1) * bd.ld, s));
     if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_prep, dim3(nCh), dim3(CH), lds_prep, s, d, bd, lambda, dev_lambda));
     SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_blocks, dim3((bd.nBlkS + 3) / 4), dim3(CH), 0, s, d, bd));

@@ -56,12 +56,16 @@ def stereo_cam_ext(baseline=KITTI_BASELINE):
 
 def make_ba_problem(P=10, L=4000, obs_per_lm=5, seed=1, frac_fixed=0.15, frac_gross=0.03,
                     pix_sigma=0.5, gross_sigma=30.0, pose_t_noise=0.02, pose_r_noise=0.002,
-                    point_noise=0.0, loop=False, fix_first_pose=False, K=KITTI_K):
+                    point_noise=0.0, loop=False, fix_first_pose=False, K=KITTI_K, wrap=False, shuffle_poses=False):
     """Synthetic BA graph of SURVEY.md section 8-D.
 
     C3 (local BA): P=10, L=4000, obs_per_lm=5 -> E=20000, 15 % fixed landmarks, no pose fixed
     (as Backend::OptimizeActiveMap, backend.cpp:93-103).  C4 (global BA): P=500, L=80000,
     obs_per_lm=6, loop=True, fix_first_pose=True.
+
+    wrap=True (with loop=True): landmarks near the end of the loop are also seen by the first keyframes -- a closed
+    loop, the co-visibility band wraps around.  shuffle_poses=True renumbers the keyframes at random (same graph, no
+    band structure left in the pose order).
 
     Returns a dict of flat arrays in the layout of ssx_ba_problem (include/ssx.h).
     """
@@ -87,7 +91,7 @@ def make_ba_problem(P=10, L=4000, obs_per_lm=5, seed=1, frac_fixed=0.15, frac_gr
         gt[i, :4] = q_cw
         gt[i, 4:] = -quat_rot(q_cw, centers[i])
 
-    first = rng.integers(0, max(P - obs_per_lm + 1, 1), size=L)
+    first = rng.integers(0, P if wrap else max(P - obs_per_lm + 1, 1), size=L)
     local = np.stack([rng.uniform(-15, 15, L), rng.uniform(-3, 3, L), rng.uniform(6, 46, L)], 1)
     pts = np.zeros((L, 3))
     for j in range(L):
@@ -127,6 +131,11 @@ def make_ba_problem(P=10, L=4000, obs_per_lm=5, seed=1, frac_fixed=0.15, frac_gr
     pose_fixed = np.zeros(P, dtype=np.uint8)
     if fix_first_pose:
         pose_fixed[0] = 1
+    if shuffle_poses:
+        perm = np.random.default_rng(seed + 7919).permutation(P)       # new index of old keyframe i
+        inv = np.argsort(perm)
+        poses, gt, pose_fixed = poses[inv], gt[inv], pose_fixed[inv]
+        edge_pose = perm[edge_pose].astype(np.int32)
     return dict(P=P, L=L, E=E, poses=np.ascontiguousarray(poses), pose_fixed=pose_fixed,
                 points=np.ascontiguousarray(points), point_fixed=point_fixed,
                 edge_pose=edge_pose, edge_point=edge_point, edge_uv=np.ascontiguousarray(edge_uv),

@@ -352,3 +352,68 @@ def test_phase_statistics(ctx):
     assert sum(ph.values()) <= r["ms_total"] * 1.05
     plain = ba.ba_solve(ctx, pr)
     assert plain["phase_ms"] is None and np.array_equal(plain["poses"], r["poses"])
+
+
+# ---- large windows, the two reduced-system solvers (ssx_ba_options.large_solver) ------------------------------------------
+BAND_CASES = {
+    "chain_K1": dict(P=30, L=1500, obs_per_lm=5, seed=51, fix_first_pose=True),                       # 29 free poses: one workgroup
+    "chain_dissected": dict(P=120, L=4000, obs_per_lm=6, seed=52, fix_first_pose=True),               # segments + separator system
+    "closed_loop": dict(P=90, L=3500, obs_per_lm=5, seed=53, loop=True, wrap=True, fix_first_pose=True),   # the band wraps around
+    "closed_loop_gauge_free": dict(P=64, L=2500, obs_per_lm=4, seed=54, loop=True, wrap=True),        # no fixed pose (as the reference)
+    "narrow_band": dict(P=70, L=2000, obs_per_lm=2, seed=55, fix_first_pose=True),                    # w = 1
+}
+
+
+@pytest.mark.parametrize("name", list(BAND_CASES))
+def test_band_solver_matches_oracle_and_tile_solver(ctx, po, name):
+    """trajectory-shaped windows: the sliding-window block Cholesky with nested dissection (ba_band.inc) against the CPU
+    oracle (dense Cholesky) and against the 64x64-tile solver of the same library."""
+    pr = make_ba_problem(**BAND_CASES[name])
+    kw = dict(outer_rounds=1, iters=6)
+    g = ba.ba_solve(ctx, pr, large_solver=2, **kw)                   # 2 = band: fails if the structure is not banded
+    t = ba.ba_solve(ctx, pr, large_solver=1, **kw)                   # 1 = tiles
+    a = ba.ba_solve(ctx, pr, **kw)                                   # auto must pick the band solver: same bits
+    assert np.array_equal(a["poses"], g["poses"]) and np.array_equal(a["chi2"], g["chi2"])
+    o = po.ba_solve(pr, "oracle", jac_mode=0, **kw)
+    act = ~(pr["pose_fixed"][pr["edge_pose"]].astype(bool) & pr["point_fixed"][pr["edge_point"]].astype(bool))
+    gauged = bool(pr["pose_fixed"].any())
+    for r, tag in ((g, "band"), (t, "tiles")):
+        assert r["n_iters"] == len(o["chi2"]), tag
+        assert (r["trials"] == o["trials"]).all(), tag
+        # a gauge-free window has 7 unobservable directions, along which the step is set by rounding: three correct
+        # solvers then drift apart by ~1e-6 relative in the cost after a few iterations (oracle vs tiles just the same)
+        np.testing.assert_allclose(r["chi2"], o["chi2"], rtol=1e-7 if gauged else 2e-5, err_msg=tag)
+        np.testing.assert_allclose(r["lam"], o["lam"], rtol=1e-5 if gauged else 1e-3, err_msg=tag)
+        if gauged:
+            assert np.abs(np.sqrt(r["edge_chi2"]) - np.sqrt(o["edge_chi2"]))[act].max() < RESID_TOL, tag
+    if gauged:
+        assert np.abs(g["poses"] - o["poses"]).max() < 1e-6 and np.abs(g["poses"] - t["poses"]).max() < 1e-7
+    b = ba.ba_solve(ctx, pr, large_solver=2, **kw)
+    assert np.array_equal(b["poses"], g["poses"]) and np.array_equal(b["points"], g["points"])       # deterministic
+
+
+def test_unordered_keyframes_fall_back_to_the_tile_solver(ctx, po):
+    """the same kind of graph with the keyframes numbered at random: no band in the pose order -> auto takes the tile
+    solver, and asking for the band solver is refused"""
+    import ssvio_amd
+    pr = make_ba_problem(P=48, L=2000, obs_per_lm=5, seed=57, fix_first_pose=True, shuffle_poses=True)
+    kw = dict(outer_rounds=1, iters=5)
+    a = ba.ba_solve(ctx, pr, **kw)
+    t = ba.ba_solve(ctx, pr, large_solver=1, **kw)
+    assert np.array_equal(a["poses"], t["poses"]) and np.array_equal(a["chi2"], t["chi2"])
+    o = po.ba_solve(pr, "oracle", jac_mode=0, **kw)
+    assert (a["trials"] == o["trials"]).all()
+    np.testing.assert_allclose(a["chi2"], o["chi2"], rtol=1e-7)
+    with pytest.raises(ssvio_amd.SsxError):
+        ba.ba_solve(ctx, pr, large_solver=2, **kw)
+
+
+def test_c4_shape_band_equals_tiles(ctx):
+    """BASELINE configs[3] shape (500 keyframes on a loop, pose 0 fixed) at 12 000 landmarks: both reduced-system solvers
+    take the same LM decisions and end at the same poses"""
+    pr = make_ba_problem(P=500, L=12000, obs_per_lm=6, seed=43, loop=True, fix_first_pose=True)
+    g = ba.ba_solve(ctx, pr, outer_rounds=1, iters=5, want_edges=False, large_solver=2)
+    t = ba.ba_solve(ctx, pr, outer_rounds=1, iters=5, want_edges=False, large_solver=1)
+    assert np.array_equal(g["trials"], t["trials"])
+    np.testing.assert_allclose(g["chi2"], t["chi2"], rtol=1e-9)
+    assert np.abs(g["poses"] - t["poses"]).max() < 1e-8

@@ -13,7 +13,11 @@ pytestmark = pytest.mark.gpu
 
 CASES = {
     "small": dict(cfg=dict(P=10, L=900, seed=4), kw=dict()),
+    # large windows: the band solver (one workgroup / dissected into segments: the ranks all-reduce the band + rhs, then
+    # every rank factors it redundantly) and the 64x64-tile solver (tile-pattern exchange + packed tile all-reduce)
     "large": dict(cfg=dict(P=40, L=1500, obs_per_lm=5, seed=9, loop=False, fix_first_pose=True), kw=dict(outer_rounds=1, iters=6)),
+    "large_dissected": dict(cfg=dict(P=130, L=4000, obs_per_lm=6, seed=10, loop=True, wrap=True, fix_first_pose=True), kw=dict(outer_rounds=1, iters=5)),
+    "large_tiles": dict(cfg=dict(P=40, L=1500, obs_per_lm=5, seed=9, loop=False, fix_first_pose=True), kw=dict(outer_rounds=1, iters=6, large_solver=1)),
 }
 
 

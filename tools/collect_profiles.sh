@@ -25,3 +25,11 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 cd "$R"
 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
+# the raw per-dispatch tables are hundreds of MB (gpurun merges <= 64 MiB back): summarise HERE, keep the summaries
+python tools/summarize_profiles.py "$TAG" "$OUT/summary" "${2:-bench}" > "$OUT/summary.log" 2>&1
+cp profiles/pmc_counters.json "$OUT/summary/" 2>/dev/null
+for d in stats fetch write sq1 sq2; do
+  find "$OUT/$d" -name "*_agent_info.csv" -exec cp {} "$OUT/summary/agent_info_$d.csv" \; 2>/dev/null
+  rm -rf "$OUT/$d"
+done
+ls -la "$OUT/summary"

@@ -103,8 +103,10 @@ if sq:
                 "Two `rocprofv3 --pmc SQ_* --kernel-trace` passes (tools/collect_profiles.sh), values averaged per launch; `avg us` from the\n"
                 "separate `--kernel-trace --stats` pass.  Resources are the dispatch packet's (VGPR/AGPR allocation granule 8, LDS bytes per\n"
                 "workgroup).  `waves/SIMD limit` = min(8, floor(512 / (VGPR+AGPR)), LDS: floor(160 KB / LDS per WG) x waves per WG / 4).\n"
-                "`achieved waves/SIMD` = SQ_WAVE_CYCLES x 4 (the counter ticks in quad-cycles) / (GRBM_GUI_ACTIVE x 1024 SIMDs): the\n"
-                "time-averaged number of resident waves per SIMD while the kernel runs.  `VALU issue` = SQ_INSTS_VALU x 2 cycles (a wave64\n"
+                "`achieved waves/SIMD` = SQ_WAVE_CYCLES x 4 (the counter ticks in quad-cycles) / (avg duration x 2.4 GHz x 1024 SIMDs): the\n"
+                "time-averaged number of resident waves per SIMD while the kernel runs (GRBM_GUI_ACTIVE spans the profiler's dispatch envelope,\n"
+                "~0.4 ms even for a 5 us kernel, and is not used; LDS_Block_Size of the dispatch row misses static __shared__ arrays: the LDS\n"
+                "column of kernel_resources.csv, from the compiler, is authoritative).  `VALU issue` = SQ_INSTS_VALU x 2 cycles (a wave64\n"
                 "VALU instruction issues over 2 cycles on a SIMD-32, MI355X_MICROARCH.md 'Wave scheduling') / (avg duration x 2.4 GHz x 1024\n"
                 "SIMDs): the fraction of the chip's VALU issue slots the kernel fills.  `VALU busy` = SQ_ACTIVE_INST_VALU x 4 /\n"
                 "SQ_WAVE_CYCLES x 4: the share of its resident wave-time a wave spends issuing VALU.  `LDS stall` = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES.\n\n"
@@ -120,8 +122,7 @@ if sq:
             lim_l = 8 if m["lds"] == 0 else (160 * 1024 // m["lds"]) * wpw / 4.0
             lim = min(lim_v, lim_l, 8)
             dur_us = avg_ns.get(k, 0) / 1e3
-            gui = v.get("GRBM_GUI_ACTIVE", 0)
-            occ = v.get("SQ_WAVE_CYCLES", 0) * 4 / (gui * SIMDS) if gui else float("nan")
+            occ = v.get("SQ_WAVE_CYCLES", 0) * 4 / (dur_us * 1e-6 * CLK_GHZ * 1e9 * SIMDS) if dur_us else float("nan")
             issue = v.get("SQ_INSTS_VALU", 0) * 2 / (dur_us * 1e-6 * CLK_GHZ * 1e9 * SIMDS) if dur_us else float("nan")
             busy = v.get("SQ_ACTIVE_INST_VALU", 0) / v["SQ_WAVE_CYCLES"] if v.get("SQ_WAVE_CYCLES") else float("nan")
             stall = v.get("SQ_WAIT_INST_LDS", 0) / v["SQ_WAVE_CYCLES"] if v.get("SQ_WAVE_CYCLES") else float("nan")
