@@ -1691,7 +1691,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
         const int total = bnd.nPr * (bnd.wr + 1) * 36 + 6 * bnd.nPr;
         SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_assemble, dim3(std::min(64, (total + BAND_T - 1) / BAND_T)), dim3(BAND_T), 0, s, d, bnd, lambda, dev_lambda));
       }
-      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_top, dim3(1), dim3(BAND_T), lds_top, s, d, bnd, bd, lambda, dev_lambda));
+      SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_top, dim3(1), dim3(BAND_TOP_T), lds_top, s, d, bnd, bd, lambda, dev_lambda));
       if (bnd.K > 1) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_back, dim3(bnd.K), dim3(BAND_T), lds_back, s, d, bnd, bd));
       const int nparts = std::min(32, (d.P + CH - 1) / CH);
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_pose_update_big, dim3(nparts), dim3(CH), 0, s, d, bd, cur_, lambda, dev_lambda));
