@@ -176,6 +176,14 @@ SSX_API void ssx_ba_default_options(ssx_ba_options* opt);
 SSX_API ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_options* opt,
                         ssx_ba_result* res);
 
+/* n windows in one call: what a batch of stereo pairs / a set of concurrent streams hands to its backends together.
+ * Per window the arithmetic and the result are those of ssx_ba_solve (bit-identical); the kernels run once for all
+ * windows (one grid dimension is the window), each window's device-driven LM loop advances on its own, one upload and
+ * one download carry all of them, and the host marshalling runs on several threads.  Windows with more than 16 free
+ * keyframes, a collective in `opt`, or n == 1 are solved one after the other.  `opt` applies to every window. */
+SSX_API ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt,
+                                      ssx_ba_result* results);
+
 /* One linearisation of the problem at its current state (no update): the blocks the kernels build,
  * for kernel-level parity tests and profiling.  Any output may be NULL.
  *   Hpp P x 36 (row-major 6x6), bp P x 6, Hll L x 9, bl L x 3, Hpl E x 18 (6x3 row-major, per edge),

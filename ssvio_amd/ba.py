@@ -141,28 +141,44 @@ def pose_graph_opt(ctx, pr, iters=20):
 
 
 class BaBatch:
-    """Many local windows per call (one window per stereo pair of a batch / per stream of BASELINE configs[4]).
-    Marshals the problems once; solve() uploads, optimises and downloads ALL of them."""
+    """Many local windows per call -- ssx_ba_solve_batch (include/ssx.h): one window per stereo pair of a batch / per
+    stream of BASELINE configs[4].  The problems are marshalled into ctypes once; solve() uploads, optimises and downloads
+    ALL of them in one library call (the kernels run once for all windows)."""
 
-    def __init__(self, ctx: Context, problems, n_workers=8, **solve_kwargs):
-        import concurrent.futures as cf
-        self.ctx, self.problems, self.kw = ctx, list(problems), solve_kwargs
-        self._ctxs = [Context(ctx.device) for _ in range(max(1, min(n_workers, len(self.problems))))]
-        self._pool = cf.ThreadPoolExecutor(max_workers=len(self._ctxs))
+    def __init__(self, ctx: Context, problems, outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891, inlier_ratio=0.7,
+                 jac_mode=JAC_ANALYTIC):
+        self.ctx = ctx
+        self.n = len(problems)
+        self._keep = []
+        self.structs = (BaProblem * self.n)()
+        for i, pr in enumerate(problems):
+            self.structs[i] = _problem_struct(pr, self._keep)
+        self.opt = BaOptions()
+        ctx.lib.ssx_ba_default_options(C.byref(self.opt))
+        self.opt.outer_rounds = outer_rounds; self.opt.iters = iters; self.opt.chi2_th = chi2_th
+        self.opt.huber_delta = huber_delta; self.opt.inlier_ratio = inlier_ratio; self.opt.jac_mode = jac_mode
+        self.res = (BaResult * self.n)()
+        self.poses = [np.zeros((s.P, 7)) for s in self.structs]
+        self.points = [np.zeros((s.L, 3)) for s in self.structs]
+        self.chi2 = [np.zeros(s.E) for s in self.structs]
+        self.outl = [np.zeros(s.E, dtype=np.uint8) for s in self.structs]
 
     def solve(self, want_edges=True):
-        n = len(self._ctxs)
-
-        def work(k):
-            return [ba_solve(self._ctxs[k], self.problems[i], want_edges=want_edges, **self.kw) for i in range(k, len(self.problems), n)]
-        parts = list(self._pool.map(work, range(n)))
-        res = [None] * len(self.problems)
-        for k, part in enumerate(parts):
-            for j, r in enumerate(part):
-                res[k + j * n] = r
-        return dict(results=res, n_iters_total=int(sum(r["n_iters"] for r in res)))
+        for i in range(self.n):
+            r = self.res[i]
+            r.poses_out = ptr(self.poses[i], dbl_p); r.points_out = ptr(self.points[i], dbl_p)
+            r.edge_chi2 = ptr(self.chi2[i], dbl_p) if want_edges else None
+            r.edge_outlier = ptr(self.outl[i], u8_p) if want_edges else None
+        self.ctx.check(self.ctx.lib.ssx_ba_solve_batch(self.ctx.handle, self.n, self.structs, C.byref(self.opt), self.res))
+        out = []
+        for i in range(self.n):
+            r = self.res[i]
+            k = min(r.n_iters, _lib.SSX_BA_MAX_STATS)
+            out.append(dict(rounds=r.rounds, n_iters=r.n_iters, poses=self.poses[i], points=self.points[i],
+                            edge_chi2=self.chi2[i] if want_edges else None, edge_outlier=self.outl[i] if want_edges else None,
+                            chi2=np.array(r.iter_chi2[:k]), lam=np.array(r.iter_lambda[:k]), trials=np.array(r.iter_trials[:k]),
+                            n_inliers=r.n_inliers, n_outliers=r.n_outliers, ms_total=r.ms_total))
+        return dict(results=out, n_iters_total=int(sum(o["n_iters"] for o in out)))
 
     def close(self):
-        self._pool.shutdown()
-        for c in self._ctxs:
-            c.close()
+        pass

@@ -40,6 +40,7 @@
 #include <cmath>
 #include <limits>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "ctx.hpp"
@@ -158,7 +159,7 @@ __device__ __forceinline__ double block_max_256(double v, double* s)
 // BaseBinaryEdge::constructQuadraticForm (base_binary_edge.hpp:61-134) for EdgeProjection.
 // ------------------------------------------------------------------------------------------------
 template <int JAC>
-__global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
+__device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur)
 {
   __shared__ double sJi[12][CH + 1];  // Jacobian wrt pose, [component][edge]; odd pitch: rows land on different banks
   __shared__ double sW1[CH], sR0[CH], sR1[CH];
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   __shared__ uint8_t sOrd[CH];
   __shared__ uint16_t sPptr[SSX_BA_SMALL_P + 1];
 
-  const int c = blockIdx.x, t = threadIdx.x;
+  const int c = bx, t = threadIdx.x;
   if (cur < 0) {                                   // device-driven LM: skip when stopped or when the linearisation at the
     if (d.scal[SC_STOP] != 0.0 || d.scal[SC_NEEDLIN] == 0.0) return;   // kept state is still valid (rejected trial)
     cur = (int)d.scal[SC_CUR];
@@ -275,17 +276,28 @@ __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur)
   }
 }
 
+template <int JAC>
+__global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur) { k_linearize_body<JAC>(d, blockIdx.x, cur); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+template <int JAC>
+__global__ __launch_bounds__(CH) void k_linearize_b(const BaDev* dv, int cur)
+{
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= (d.nCh)) return;
+  k_linearize_body<JAC>(d, blockIdx.x, cur);
+}
+
 // slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|: 16 chunk-lanes per entry, 16 entries per 256-thread
 // workgroup, combined by a fixed tree (deterministic for a given nCh); workgroup 0 also reduces chi2 / max-diagonal.
 // (computeLambdaInit, optimization_algorithm_levenberg.cpp:152-166, wants the max over pose AND landmark
 // diagonals; with several ranks the pose diagonals need the all-reduced Hpp, see k_lambda_init.)
-__global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d)
+__device__ __forceinline__ void k_reduce_lin_body(const BaDev& d, const int bx)
 {
   __shared__ double sAcc[CH];
   const int t = threadIdx.x;
   const int n = d.nP * 27;
   const int stride = n + 2;
-  const int ent = blockIdx.x * 16 + (t >> 4), ln = t & 15;
+  const int ent = bx * 16 + (t >> 4), ln = t & 15;
   double acc = 0.0;
   if (ent < n)
     for (int c = ln; c < d.nCh; c += 16) acc += d.lin_slab[(size_t)c * stride + ent];
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d)
     if (k < UPPER6) { d.Hpp[p * UPPER6 + k] = v; d.iter_comm[p * UPPER6 + k] = v; }
     else { d.bp[p * 6 + (k - UPPER6)] = v; d.iter_comm[d.nP * UPPER6 + p * 6 + (k - UPPER6)] = v; }
   }
-  if (blockIdx.x != 0) return;
+  if (bx != 0) return;
   __syncthreads();
   double chi = 0.0, md = 0.0;
   for (int c = t; c < d.nCh; c += CH) {
@@ -315,10 +327,19 @@ __global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d)
   }
 }
 
-// after the (optional) all-reduce of iter_comm: chi2, max diagonal, and lambda_0 = 1e-5 * max on iteration 0
-__global__ void k_lambda_init(BaDev d, int first_iteration)
+__global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d) { k_reduce_lin_body(d, blockIdx.x); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+__global__ __launch_bounds__(CH) void k_reduce_lin_b(const BaDev* dv)
 {
-  if (blockIdx.x != 0) return;
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= ((d.nP * 27 + 15) / 16 > 0 ? (d.nP * 27 + 15) / 16 : 1)) return;
+  k_reduce_lin_body(d, blockIdx.x);
+}
+
+// after the (optional) all-reduce of iter_comm: chi2, max diagonal, and lambda_0 = 1e-5 * max on iteration 0
+__device__ __forceinline__ void k_lambda_init_body(const BaDev& d, const int bx, int first_iteration)
+{
+  if (bx != 0) return;
   const int t = threadIdx.x;                       // one wave
   const double* tail = d.iter_comm + d.nP * 27;
   const int diag[6] = {0, 6, 11, 15, 18, 20};
@@ -333,13 +354,31 @@ __global__ void k_lambda_init(BaDev d, int first_iteration)
   if (first_iteration) d.scal[SC_LAMBDA] = 1e-5 * m;
 }
 
-// Device-driven LM: start of one optimize(iters) at state buffer `cur` (stop = 1: nothing to optimise on any rank)
-__global__ void k_lm_begin(BaDev d, int cur, int iters, int nstat, int stop)
+__global__ __launch_bounds__(64) void k_lambda_init(BaDev d, int first_iteration) { k_lambda_init_body(d, blockIdx.x, first_iteration); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+__global__ __launch_bounds__(64) void k_lambda_init_b(const BaDev* dv, int first_iteration)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= (1)) return;
+  k_lambda_init_body(d, blockIdx.x, first_iteration);
+}
+
+// Device-driven LM: start of one optimize(iters) at state buffer `cur` (stop = 1: nothing to optimise on any rank)
+__device__ __forceinline__ void k_lm_begin_body(const BaDev& d, const int bx, int cur, int iters, int nstat, int stop)
+{
+  if (threadIdx.x != 0 || bx != 0) return;
   d.scal[SC_NI] = 2.0; d.scal[SC_CUR] = (double)cur; d.scal[SC_IT] = 0.0; d.scal[SC_QMAX] = 0.0;
   d.scal[SC_STOP] = (stop || iters <= 0) ? 1.0 : 0.0; d.scal[SC_NEEDLIN] = 1.0; d.scal[SC_ITERS] = (double)iters;
   d.scal[SC_NSTAT] = (double)nstat; d.scal[SC_CURCHI] = 0.0; d.scal[SC_TRIALS_RUN] = 0.0;
+}
+
+__global__ __launch_bounds__(64) void k_lm_begin(BaDev d, int cur, int iters, int nstat, int stop) { k_lm_begin_body(d, blockIdx.x, cur, iters, nstat, stop); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+__global__ __launch_bounds__(64) void k_lm_begin_b(const BaDev* dv, int cur, int iters, int nstat, int stop)
+{
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= (1)) return;
+  k_lm_begin_body(d, blockIdx.x, cur, iters, nstat, stop);
 }
 
 // The bookkeeping of one LM trial (OptimizationAlgorithmLevenberg::solve, optimization_algorithm_levenberg.cpp:99-140)
@@ -403,7 +442,7 @@ __global__ void k_set_lambda(BaDev d, double lambda)
 // restates the marginalisation loop of BlockSolver::solve (block_solver.hpp:342-393):
 //   Dinv = (Hll + lambda I)^-1 ; c_i += W_i Dinv bl ; S_ij -= (W_i Dinv) W_j^T  (upper blocks)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int use_dev_lambda)
+__device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, double lambda_arg, int use_dev_lambda)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // pitch PW = CH + 1 doubles: the owned-entry loops read [component][edge] with the component varying across
@@ -421,7 +460,7 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int us
   uint8_t* sPa = reinterpret_cast<uint8_t*>(sBptr + MAX_BLK + 1);    // [MAX_PAIRS]
   uint8_t* sPb = sPa + MAX_PAIRS;                                    // [MAX_PAIRS]
 
-  const int c = blockIdx.x, t = threadIdx.x;
+  const int c = bx, t = threadIdx.x;
   if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
@@ -532,16 +571,25 @@ __global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int us
   }
 }
 
+__global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int use_dev_lambda) { k_schur_body(d, blockIdx.x, lambda_arg, use_dev_lambda); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+__global__ __launch_bounds__(CH) void k_schur_b(const BaDev* dv, double lambda_arg, int use_dev_lambda)
+{
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= (d.nCh)) return;
+  k_schur_body(d, blockIdx.x, lambda_arg, use_dev_lambda);
+}
+
 // slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c).
 // 16 chunk-lanes per entry (16 entries per 256-thread workgroup), fixed tree: deterministic.
-__global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d)
+__device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx)
 {
   __shared__ double sAcc[CH];
   const int nS = d.nBlk * 36;
   const int stride = nS + d.nP * 6;
   const int n = 6 * d.nP;
   const int t = threadIdx.x;
-  const int ent = blockIdx.x * 16 + (t >> 4), ln = t & 15;
+  const int ent = bx * 16 + (t >> 4), ln = t & 15;
   double acc = 0.0;
   if (ent < stride)
     for (int c = ln; c < d.nCh; c += 16) acc += d.schur_slab[(size_t)c * stride + ent];
@@ -571,6 +619,15 @@ __global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d)
   }
 }
 
+__global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d) { k_reduce_schur_body(d, blockIdx.x); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+__global__ __launch_bounds__(CH) void k_reduce_schur_b(const BaDev* dv)
+{
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= ((d.nBlk * 36 + d.nP * 6 + 15) / 16)) return;
+  k_reduce_schur_body(d, blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_solve: (S + lambda I) x = bs, the role of LinearSolverCSparse::solve
 // (thirdparty/g2o/g2o/solvers/csparse/linear_solver_csparse.h:106-142: false when not positive definite),
@@ -586,7 +643,7 @@ __global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d)
 // The backward substitution L^T x = w is done by ONE wave with the running solution in registers and
 // v_readlane broadcasts (no barrier in the dependent chain).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_solve(BaDev d, int cur, double lambda_arg, int use_dev_lambda)
+__device__ __forceinline__ void k_solve_body(const BaDev& d, const int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
   constexpr int BS = 6;
   __shared__ double sPan[(NMAX + 2) * BS];      // raw panel rows j0..n
@@ -780,16 +837,25 @@ __global__ __launch_bounds__(256) void k_solve(BaDev d, int cur, double lambda_a
   }
 }
 
+__global__ __launch_bounds__(256) void k_solve(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_solve_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+__global__ __launch_bounds__(256) void k_solve_b(const BaDev* dv, int cur, double lambda_arg, int use_dev_lambda)
+{
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= ((6 * d.nP > 64) ? 1 : 0)) return;
+  k_solve_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_backsub_residual: landmark back-substitution (block_solver.hpp:422-442), landmark update, and the
 // residuals / robust chi2 of the TRIAL state (computeActiveErrors + activeRobustChi2,
 // sparse_optimizer.cpp:63-116).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, double lambda_arg, int use_dev_lambda)
+__device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
   __shared__ double sPt[3][CH];
   __shared__ double sRed[CH];
-  const int c = blockIdx.x, t = threadIdx.x;
+  const int c = bx, t = threadIdx.x;
   if (cur < 0) {
     if (d.scal[SC_STOP] != 0.0) return;
     cur = (int)d.scal[SC_CUR];
@@ -863,7 +929,16 @@ __global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, doubl
   }
 }
 
-__global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d, int lm)
+__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_backsub_residual_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+__global__ __launch_bounds__(CH) void k_backsub_residual_b(const BaDev* dv, int cur, double lambda_arg, int use_dev_lambda)
+{
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= (d.nCh)) return;
+  k_backsub_residual_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
+}
+
+__device__ __forceinline__ void k_reduce_trial_body(const BaDev& d, const int bx, int lm)
 {
   __shared__ double sRed[CH];
   double chi = 0.0, sl = 0.0, no = 0.0;
@@ -887,6 +962,15 @@ __global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d, int lm)
   }
 }
 
+__global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d, int lm) { k_reduce_trial_body(d, blockIdx.x, lm); }
+// batched: blockIdx.y = window; every window brings its own BaDev (device array)
+__global__ __launch_bounds__(CH) void k_reduce_trial_b(const BaDev* dv, int lm)
+{
+  const BaDev d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= (1)) return;
+  k_reduce_trial_body(d, blockIdx.x, lm);
+}
+
 // copy the (all-reduced) trial scalars next to the others so that ONE 64-byte download returns everything
 __global__ void k_publish_trial(BaDev d, int lm)
 {
@@ -895,6 +979,44 @@ __global__ void k_publish_trial(BaDev d, int lm)
     d.scal[SC_SCALE_L] = d.scal_comm[1];
     d.scal[SC_NOUT] = d.scal_comm[2];
     if (lm) lm_step(d);                            // every rank takes the same decision from the all-reduced scalars
+  }
+}
+
+// ---- batched small windows (ssx_ba_solve_batch): per-window control words live in one int array [3 n] = cur | nstat | stop
+__global__ __launch_bounds__(64) void k_lm_begin_batch(const BaDev* dv, const int* ctrl, int n, int iters)
+{
+  const int w = blockIdx.x;
+  if (w >= n) return;
+  const BaDev d = dv[w];
+  k_lm_begin_body(d, 0, ctrl[w], iters, ctrl[n + w], ctrl[2 * n + w]);
+}
+
+// control blocks (what = 0: SC_N scalars) or LM statistics (what = 1: 3 x SSX_BA_MAX_STATS) of every window, contiguous
+__global__ __launch_bounds__(CH) void k_gather_scal_b(const BaDev* dv, int n, double* out, int what)
+{
+  const int w = blockIdx.x;
+  if (w >= n) return;
+  const BaDev d = dv[w];
+  const int cnt = what ? 3 * SSX_BA_MAX_STATS : SC_N;
+  const double* src = what ? d.lm_stat : d.scal;
+  for (int i = threadIdx.x; i < cnt; i += CH) out[(size_t)w * cnt + i] = src[i];
+}
+
+// results of every window into one contiguous buffer (one download): [poses 7P | points 3L | errors 2E] at out_off[w]
+__global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* dv, const int* ctrl, int n, const size_t* out_off, double* out, int want_err)
+{
+  const int w = blockIdx.y;
+  const BaDev d = dv[w];
+  const int cur = ctrl[w], trial_err = ctrl[n + w];
+  double* o = out + out_off[w];
+  const size_t nP7 = 7 * (size_t)d.P, nL3 = 3 * (size_t)d.L, nE2 = want_err ? 2 * (size_t)d.E : 0;
+  const double* err = trial_err ? d.err_trial : d.err_lin;
+  for (size_t i = (size_t)blockIdx.x * CH + threadIdx.x; i < nP7 + nL3 + nE2; i += (size_t)gridDim.x * CH) {
+    double v;
+    if (i < nP7) v = d.pose[cur][i];
+    else if (i < nP7 + nL3) v = d.point[cur][i - nP7];
+    else v = err[i - nP7 - nL3];
+    o[i] = v;
   }
 }
 
@@ -1163,11 +1285,20 @@ void plan_band(int nP, int w, BandPlan& bp)
   }
 }
 
+struct UploadPlace {          // where a window of a batch lives (nullptr = a single window in the ctx arena)
+  bool dry = false;            // sizing pass: only in_bytes / rest_bytes are computed
+  size_t in_bytes = 0, rest_bytes = 0;
+  char* in_dev = nullptr;      // uploaded blob on the device
+  char* rest_dev = nullptr;    // scratch on the device
+  char* in_host = nullptr;     // pinned mirror of the blob
+};
+
 ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, double huber_delta, double chi2_th,
-                  int world, int rank, BaDev& d, BigDev& bd, const BandPlan& bp, BandDev& bnd)
+                  int world, int rank, BaDev& d, BigDev& bd, const BandPlan& bp, BandDev& bnd, UploadPlace* place = nullptr)
 {
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
+  const bool dup_state = place != nullptr;       // batched windows: the second state buffer is part of the uploaded blob
   const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm, nCh = h.nCh, nBlk = h.nBlk;
   const int n = 6 * nP;
   const size_t nPairs = h.pair_a.size();
@@ -1205,10 +1336,12 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_seg_m = in.take(sizeof(int) * (bp.seg_m.size() + 1));
   const size_t o_pose0 = in.take(sizeof(double) * 7 * P);
   const size_t o_point0 = in.take(sizeof(double) * 3 * (L + 1));
+  const size_t o_pose1_in = dup_state ? in.take(sizeof(double) * 7 * P) : 0;
+  const size_t o_point1_in = dup_state ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
   const size_t in_bytes = in.off;
   Layout all = in;
-  const size_t o_pose1 = all.take(sizeof(double) * 7 * P);
-  const size_t o_point1 = all.take(sizeof(double) * 3 * (L + 1));
+  const size_t o_pose1 = dup_state ? o_pose1_in : all.take(sizeof(double) * 7 * P);
+  const size_t o_point1 = dup_state ? o_point1_in : all.take(sizeof(double) * 3 * (L + 1));
   const size_t o_W = all.take(sizeof(double) * 18 * (size_t)E);
   const size_t o_err_lin = all.take(sizeof(double) * 2 * (size_t)E);
   const size_t o_err_trial = all.take(sizeof(double) * 2 * (size_t)E);
@@ -1248,11 +1381,18 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_scal = all.take(sizeof(double) * SC_N);
   const size_t o_lmstat = all.take(sizeof(double) * 3 * SSX_BA_MAX_STATS);
 
+  if (place && place->dry) {                     // sizing pass of a batch
+    place->in_bytes = in_bytes;
+    place->rest_bytes = all.off - in_bytes;
+    return SSX_OK;
+  }
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  SSX_HIP_TRY(ctx, ws->arena.reserve(all.off));
-  SSX_HIP_TRY(ctx, ws->stage.reserve(std::max(in_bytes, sizeof(double) * (7 * (size_t)P + 3 * (size_t)L + 2 * (size_t)E))));
-  SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * (SC_N + 3 * SSX_BA_MAX_STATS)));
-  char* hs = ws->stage.as<char>();
+  if (!place) {
+    SSX_HIP_TRY(ctx, ws->arena.reserve(all.off));
+    SSX_HIP_TRY(ctx, ws->stage.reserve(std::max(in_bytes, sizeof(double) * (7 * (size_t)P + 3 * (size_t)L + 2 * (size_t)E))));
+    SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * (SC_N + 3 * SSX_BA_MAX_STATS)));
+  }
+  char* hs = place ? place->in_host : ws->stage.as<char>();
   memcpy(hs + o_pose_free, h.pose_free.data(), sizeof(int) * P);
   if (nLm) {
     memcpy(hs + o_lm_fixed, h.lm_fixed.data(), nLm);
@@ -1293,68 +1433,77 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   }
   memcpy(hs + o_pose0, pr->poses, sizeof(double) * 7 * P);
   if (L) memcpy(hs + o_point0, pr->points, sizeof(double) * 3 * L);
-  char* base = ws->arena.as<char>();
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-  // the second state buffer starts as a copy (landmarks without edges are never rewritten)
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_pose1, base + o_pose0, sizeof(double) * 7 * P, hipMemcpyDeviceToDevice, ctx->stream));
-  if (L)
-    SSX_HIP_TRY(ctx, hipMemcpyAsync(base + o_point1, base + o_point0, sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, ctx->stream));
+  // device addresses: the uploaded blob and the scratch behind it (one arena; a batch keeps all blobs together so that
+  // ONE copy uploads every window)
+  char* base_in = place ? place->in_dev : ws->arena.as<char>();
+  char* base_rest = place ? place->rest_dev : base_in + in_bytes;
+  auto at = [&](size_t o) -> char* { return o < in_bytes ? base_in + o : base_rest + (o - in_bytes); };
+  if (!place) {
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(base_in, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // the second state buffer starts as a copy (landmarks without edges are never rewritten)
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(at(o_pose1), at(o_pose0), sizeof(double) * 7 * P, hipMemcpyDeviceToDevice, ctx->stream));
+    if (L)
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(at(o_point1), at(o_point0), sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    memcpy(hs + o_pose1, pr->poses, sizeof(double) * 7 * P);
+    if (L) memcpy(hs + o_point1, pr->points, sizeof(double) * 3 * L);
+  }
 
   d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
   d.big = big ? 1 : 0; d.lin_stride = lin_stride;
-  d.pose_free = (const int*)(base + o_pose_free);
-  d.lm_fixed = (const uint8_t*)(base + o_lm_fixed);
-  d.lm_id = (const int*)(base + o_lm_id);
-  d.lm_ptr = (const int*)(base + o_lm_ptr);
-  d.ch_lm = (const int*)(base + o_ch_lm);
-  d.e_pose = (const int*)(base + o_e_pose);
-  d.e_lmc = (const int*)(base + o_e_lmc);
-  d.e_cam = (const uint8_t*)(base + o_e_cam);
-  d.e_dup = (const uint8_t*)(base + o_e_dup);
-  d.e_uv = (const double*)(base + o_e_uv);
-  d.blk_pa = (const int8_t*)(base + o_blk_pa);
-  d.blk_pb = (const int8_t*)(base + o_blk_pb);
-  d.porder = (const uint8_t*)(base + o_porder);
-  d.pptr = (const uint16_t*)(base + o_pptr);
-  d.pair_a = (const uint8_t*)(base + o_pair_a);
-  d.pair_b = (const uint8_t*)(base + o_pair_b);
-  d.pair_ptr = (const int*)(base + o_pair_ptr);
+  d.pose_free = (const int*)(at(o_pose_free));
+  d.lm_fixed = (const uint8_t*)(at(o_lm_fixed));
+  d.lm_id = (const int*)(at(o_lm_id));
+  d.lm_ptr = (const int*)(at(o_lm_ptr));
+  d.ch_lm = (const int*)(at(o_ch_lm));
+  d.e_pose = (const int*)(at(o_e_pose));
+  d.e_lmc = (const int*)(at(o_e_lmc));
+  d.e_cam = (const uint8_t*)(at(o_e_cam));
+  d.e_dup = (const uint8_t*)(at(o_e_dup));
+  d.e_uv = (const double*)(at(o_e_uv));
+  d.blk_pa = (const int8_t*)(at(o_blk_pa));
+  d.blk_pb = (const int8_t*)(at(o_blk_pb));
+  d.porder = (const uint8_t*)(at(o_porder));
+  d.pptr = (const uint16_t*)(at(o_pptr));
+  d.pair_a = (const uint8_t*)(at(o_pair_a));
+  d.pair_b = (const uint8_t*)(at(o_pair_b));
+  d.pair_ptr = (const int*)(at(o_pair_ptr));
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
-  d.pose[0] = (double*)(base + o_pose0); d.pose[1] = (double*)(base + o_pose1);
-  d.point[0] = (double*)(base + o_point0); d.point[1] = (double*)(base + o_point1);
-  d.W = (double*)(base + o_W);
-  d.err_lin = (double*)(base + o_err_lin);
-  d.err_trial = (double*)(base + o_err_trial);
-  d.Hll = (double*)(base + o_Hll); d.bl = (double*)(base + o_bl);
-  d.lin_slab = (double*)(base + o_lin_slab);
-  d.Hpp = (double*)(base + o_Hpp); d.bp = (double*)(base + o_bp);
-  d.iter_comm = (double*)(base + o_iter);
-  d.schur_slab = (double*)(base + o_schur);
-  d.trial_comm = (double*)(base + o_trial_comm);
-  d.xp = (double*)(base + o_xp);
-  d.trial_slab = (double*)(base + o_trial);
-  d.scal_comm = (double*)(base + o_scal_comm);
-  d.scal = (double*)(base + o_scal);
-  d.lm_stat = (double*)(base + o_lmstat);
+  d.pose[0] = (double*)(at(o_pose0)); d.pose[1] = (double*)(at(o_pose1));
+  d.point[0] = (double*)(at(o_point0)); d.point[1] = (double*)(at(o_point1));
+  d.W = (double*)(at(o_W));
+  d.err_lin = (double*)(at(o_err_lin));
+  d.err_trial = (double*)(at(o_err_trial));
+  d.Hll = (double*)(at(o_Hll)); d.bl = (double*)(at(o_bl));
+  d.lin_slab = (double*)(at(o_lin_slab));
+  d.Hpp = (double*)(at(o_Hpp)); d.bp = (double*)(at(o_bp));
+  d.iter_comm = (double*)(at(o_iter));
+  d.schur_slab = (double*)(at(o_schur));
+  d.trial_comm = (double*)(at(o_trial_comm));
+  d.xp = (double*)(at(o_xp));
+  d.trial_slab = (double*)(at(o_trial));
+  d.scal_comm = (double*)(at(o_scal_comm));
+  d.scal = (double*)(at(o_scal));
+  d.lm_stat = (double*)(at(o_lmstat));
   bd = BigDev{};
   bnd = BandDev{};
   if (big) {
     bd.n = n; bd.n_pad = n_pad; bd.ld = n_pad; bd.T = n_pad / NB; bd.nBlkS = (int)nBlkS;
-    bd.pe_ptr = (const int*)(base + o_pe_ptr); bd.pe_edge = (const int*)(base + o_pe_edge);
-    bd.sblk_pa = (const int*)(base + o_sblk_pa); bd.sblk_pb = (const int*)(base + o_sblk_pb);
-    bd.spair_ptr = (const int*)(base + o_spair_ptr); bd.spair_a = (const int*)(base + o_spair_a); bd.spair_b = (const int*)(base + o_spair_b);
-    bd.BDa = (double*)(base + o_BDa); bd.Wma = (double*)(base + o_Wma); bd.Cv = (double*)(base + o_Cv);
+    bd.pe_ptr = (const int*)(at(o_pe_ptr)); bd.pe_edge = (const int*)(at(o_pe_edge));
+    bd.sblk_pa = (const int*)(at(o_sblk_pa)); bd.sblk_pb = (const int*)(at(o_sblk_pb));
+    bd.spair_ptr = (const int*)(at(o_spair_ptr)); bd.spair_a = (const int*)(at(o_spair_a)); bd.spair_b = (const int*)(at(o_spair_b));
+    bd.BDa = (double*)(at(o_BDa)); bd.Wma = (double*)(at(o_Wma)); bd.Cv = (double*)(at(o_Cv));
     bnd = BandDev{};
     if (band) {
       bnd.on = 1; bnd.w = bw; bnd.K = bK; bnd.nP = nP; bnd.nPr = bnPr; bnd.wr = bwr;
-      bnd.Sb = (double*)(base + o_Sb); bnd.bsv = bnd.Sb + (size_t)nP * (bw + 1) * 36;
-      bnd.seg_p0 = (const int*)(base + o_seg_p0); bnd.seg_m = (const int*)(base + o_seg_m);
-      bnd.U = (double*)(base + o_U); bnd.Ls0 = (double*)(base + o_Ls0); bnd.Sr = (double*)(base + o_Sr);
-      bnd.Ls1 = (double*)(base + o_Ls1); bnd.xr = (double*)(base + o_xr); bnd.LS0 = LS0; bnd.LS1 = LS1;
+      bnd.Sb = (double*)(at(o_Sb)); bnd.bsv = bnd.Sb + (size_t)nP * (bw + 1) * 36;
+      bnd.seg_p0 = (const int*)(at(o_seg_p0)); bnd.seg_m = (const int*)(at(o_seg_m));
+      bnd.U = (double*)(at(o_U)); bnd.Ls0 = (double*)(at(o_Ls0)); bnd.Sr = (double*)(at(o_Sr));
+      bnd.Ls1 = (double*)(at(o_Ls1)); bnd.xr = (double*)(at(o_xr)); bnd.LS0 = LS0; bnd.LS1 = LS1;
     }
-    bd.S = (double*)(base + o_S); bd.x = (double*)(base + o_x); bd.Ld = (double*)(base + o_Ld); bd.invd = (double*)(base + o_invd); bd.Ninv = (double*)(base + o_Ninv); bd.scale_part = (double*)(base + o_scale_part);
+    bd.S = (double*)(at(o_S)); bd.x = (double*)(at(o_x)); bd.Ld = (double*)(at(o_Ld)); bd.invd = (double*)(at(o_invd)); bd.Ninv = (double*)(at(o_Ninv)); bd.scale_part = (double*)(at(o_scale_part));
   }
   return SSX_OK;
 }
@@ -1948,6 +2097,221 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
         default: res->ms_reduce += t; break;
       }
     }
+  return SSX_OK;
+}
+
+// Many small windows in one call (one window per stereo pair of a batch, per stream of BASELINE configs[4], ...): every
+// kernel of the small-window path runs ONCE for all windows (blockIdx.y = window), the device-driven LM loop of each
+// window advances independently, one upload and one download carry all windows.  Same arithmetic as n calls of
+// ssx_ba_solve -- identical bits per window.  Windows with more than 16 free keyframes (or a collective) make the call
+// fall back to one ssx_ba_solve per window.
+ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt_in, ssx_ba_result* results)
+{
+  if (!ctx || n < 0 || (n > 0 && (!probs || !results))) return SSX_ERR_INVALID_ARG;
+  if (n == 0) return SSX_OK;
+  ssx_ba_options opt;
+  if (opt_in) opt = *opt_in; else ssx_ba_default_options(&opt);
+  auto sequential = [&]() -> ssx_status {
+    for (int w = 0; w < n; ++w) {
+      const ssx_status st = ssx_ba_solve(ctx, &probs[w], &opt, &results[w]);
+      if (st != SSX_OK) return st;
+    }
+    return SSX_OK;
+  };
+  if (opt.comm || opt.allreduce || n == 1) return sequential();
+  // (kept per calling thread between calls; a thread_local named inside a lambda would be the WORKER thread's instance:
+  // the workers go through this reference)
+  static thread_local std::vector<HostPrep> preps_tls;
+  if ((int)preps_tls.size() < n) preps_tls.resize(n);
+  std::vector<HostPrep>& preps = preps_tls;
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min({n, 16, hw > 1 ? hw / 2 : 1}));
+  // ---- 1. host marshalling of every window (edge sort, chunks, index lists), T threads
+  std::vector<ssx_status> sts(n, SSX_OK);
+  auto par_for = [&](auto&& fn) {
+    if (T == 1) { for (int w = 0; w < n; ++w) fn(w); return; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < T; ++k) th.emplace_back([&, k] { for (int w = k; w < n; w += T) fn(w); });
+    for (auto& x : th) x.join();
+  };
+  par_for([&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w]); });
+  for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
+  for (int w = 0; w < n; ++w) if (preps[w].big) return sequential();
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+  BaWorkspace* ws = ctx->ba;
+  // ---- 2. sizes, one arena: [blobs of all windows | BaDev[n] | ctrl int[3n] | out offsets | scratch of all windows | packed outputs]
+  std::vector<UploadPlace> place(n);
+  std::vector<BaDev> devs(n);
+  BandPlan no_band;
+  size_t in_total = 0, rest_total = 0, out_total = 0;
+  const bool want_err = [&] { for (int w = 0; w < n; ++w) if (results[w].edge_chi2 || results[w].edge_outlier) return true; return false; }();
+  std::vector<size_t> in_off(n), rest_off(n), out_off(n);
+  for (int w = 0; w < n; ++w) {
+    BigDev bd; BandDev bnd;
+    place[w].dry = true;
+    ssx_status st = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, devs[w], bd, no_band, bnd, &place[w]);
+    if (st != SSX_OK) return st;
+    in_off[w] = in_total; in_total += place[w].in_bytes;
+    rest_off[w] = rest_total; rest_total += place[w].rest_bytes;
+    out_off[w] = out_total;
+    out_total += 7 * (size_t)preps[w].P + 3 * (size_t)preps[w].L + (want_err ? 2 * (size_t)preps[w].E : 0);
+  }
+  Layout tail;
+  const size_t o_dv = tail.take(sizeof(BaDev) * n), o_ctrl = tail.take(sizeof(int) * 3 * n), o_ooff = tail.take(sizeof(size_t) * n);
+  const size_t head_bytes = in_total + tail.off;                     // everything that is uploaded
+  Layout arena;
+  const size_t a_head = arena.take(head_bytes), a_rest = arena.take(rest_total), a_out = arena.take(sizeof(double) * (out_total + 1));
+  const size_t a_gather = arena.take(sizeof(double) * (size_t)n * (3 * SSX_BA_MAX_STATS));
+  SSX_HIP_TRY(ctx, ws->arena.reserve(arena.off));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(std::max(head_bytes, sizeof(double) * (out_total + 1))));
+  SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS) + sizeof(int) * 3 * n + 64));
+  char* dev_base = ws->arena.as<char>();
+  char* hst = ws->stage.as<char>();
+  // ---- 3. fill the pinned mirror (T threads), one upload
+  par_for([&](int w) {
+    BigDev bd; BandDev bnd;
+    place[w].dry = false;
+    place[w].in_dev = dev_base + a_head + in_off[w];
+    place[w].rest_dev = dev_base + a_rest + rest_off[w];
+    place[w].in_host = hst + in_off[w];
+    sts[w] = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, devs[w], bd, no_band, bnd, &place[w]);
+  });
+  for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
+  memcpy(hst + in_total + o_dv, devs.data(), sizeof(BaDev) * n);
+  int* h_ctrl_up = reinterpret_cast<int*>(hst + in_total + o_ctrl);
+  memcpy(hst + in_total + o_ooff, out_off.data(), sizeof(size_t) * n);
+  const BaDev* dv = reinterpret_cast<const BaDev*>(dev_base + a_head + in_total + o_dv);
+  int* d_ctrl = reinterpret_cast<int*>(dev_base + a_head + in_total + o_ctrl);
+  const size_t* d_ooff = reinterpret_cast<const size_t*>(dev_base + a_head + in_total + o_ooff);
+  double* d_out = reinterpret_cast<double*>(dev_base + a_out);
+  double* d_gather = reinterpret_cast<double*>(dev_base + a_gather);
+  // per-window host state of Backend::OptimizeActiveMap's outer loop (backend.cpp:175-203)
+  struct WinState { int cur = 0, round = 0; bool done = false, active = false, trial_err = false; double n_out = 0; };
+  std::vector<WinState> wsn(n);
+  int max_ch = 1, max_rl = 1, max_rs = 1;
+  bool any_solve64 = false, any_solve = false;
+  for (int w = 0; w < n; ++w) {
+    const BaDev& d = devs[w];
+    wsn[w].active = d.nCh > 0;
+    wsn[w].done = !(d.nCh > 0) || opt.outer_rounds <= 0;
+    max_ch = std::max(max_ch, d.nCh);
+    max_rl = std::max(max_rl, (d.nP * 27 + 15) / 16);
+    max_rs = std::max(max_rs, (d.nBlk * 36 + d.nP * 6 + 15) / 16);
+    if (6 * d.nP <= NB) any_solve64 = true; else any_solve = true;
+    results[w].rounds = 0; results[w].n_iters = 0; results[w].n_inliers = 0; results[w].n_outliers = 0;
+    results[w].ms_linearize = results[w].ms_schur = results[w].ms_linear_solution = results[w].ms_update = results[w].ms_reduce = 0.f;
+    h_ctrl_up[w] = 0; h_ctrl_up[n + w] = 0; h_ctrl_up[2 * n + w] = wsn[w].done ? 1 : 0;
+  }
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + a_head, hst, head_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const size_t lds_schur = schur_lds_bytes();
+  static bool attr_set_b = false;
+  if (!attr_set_b) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur);
+    attr_set_b = true;
+  }
+  double* hscal = ws->scal.as<double>();                              // n x SC_N, then n x 3 x MAX_STATS, then the ctrl words of later rounds
+  int* h_ctrl = reinterpret_cast<int*>(hscal + (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS));
+  hipStream_t s = ctx->stream;
+  const dim3 gCh(max_ch, n), gRl(max_rl, n), gRs(max_rs, n), gOne(1, n);
+  auto all_done = [&] { for (int w = 0; w < n; ++w) if (!wsn[w].done) return false; return true; };
+  bool first_round = true;
+  while (!all_done() && opt.iters > 0) {
+    if (!first_round) {
+      for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = results[w].n_iters; h_ctrl[2 * n + w] = wsn[w].done ? 1 : 0; }
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(int) * 3 * n, hipMemcpyHostToDevice, s));
+    }
+    first_round = false;
+    hipLaunchKernelGGL(k_lm_begin_batch, dim3(n), dim3(64), 0, s, dv, (const int*)d_ctrl, n, opt.iters);
+    int slots_total = 0;
+    bool first_slot = true;
+    for (;;) {
+      int slots = opt.iters;
+      if (slots_total > 0) {
+        slots = 1;
+        for (int w = 0; w < n; ++w)
+          if (!wsn[w].done && hscal[(size_t)w * SC_N + SC_STOP] == 0.0) slots = std::max(slots, opt.iters - (int)hscal[(size_t)w * SC_N + SC_IT]);
+      }
+      for (int sidx = 0; sidx < slots; ++sidx) {
+        if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_NUMERIC_G2O>, gCh, dim3(CH), 0, s, dv, -1));
+        else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_ANALYTIC>, gCh, dim3(CH), 0, s, dv, -1));
+        SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_b, gRl, dim3(CH), 0, s, dv));
+        if (first_slot) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init_b, gOne, dim3(64), 0, s, dv, 1));
+        first_slot = false;
+        SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gCh, dim3(CH), lds_schur, s, dv, 0.0, 2));
+        SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, s, dv));
+        if (any_solve64) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, s, dv, -1, 0.0, 1));
+        if (any_solve) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(256), 0, s, dv, -1, 0.0, 1));
+        SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual_b, gCh, dim3(CH), 0, s, dv, -1, 0.0, 1));
+        SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial_b, gOne, dim3(CH), 0, s, dv, 1));
+      }
+      slots_total += slots;
+      SSX_HIP_TRY(ctx, hipGetLastError());
+      hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 0);
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d_gather, sizeof(double) * (size_t)n * SC_N, hipMemcpyDeviceToHost, s));
+      SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+      bool stopped = true;
+      for (int w = 0; w < n; ++w) if (!wsn[w].done && hscal[(size_t)w * SC_N + SC_STOP] == 0.0) stopped = false;
+      if (stopped) break;
+    }
+    for (int w = 0; w < n; ++w) {
+      WinState& st = wsn[w];
+      if (st.done) continue;
+      const double* sc = hscal + (size_t)w * SC_N;
+      st.cur = (int)sc[SC_CUR];
+      st.n_out = sc[SC_NOUT];
+      if (sc[SC_TRIALS_RUN] > 0.0) st.trial_err = true;
+      results[w].n_iters = std::max(results[w].n_iters, (int)sc[SC_NSTAT]);
+      results[w].rounds++;
+      const double n_edges = (double)devs[w].E, cnt_in = n_edges - st.n_out;
+      results[w].n_outliers = (int)st.n_out;
+      results[w].n_inliers = (int)cnt_in;
+      const double ratio = n_edges > 0 ? cnt_in / (cnt_in + st.n_out) : 1.0;
+      if (ratio > opt.inlier_ratio) st.done = true;
+      if (++st.round >= opt.outer_rounds) st.done = true;
+    }
+  }
+  // ---- 4. statistics + results: one packing kernel, one download
+  for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = wsn[w].trial_err ? 1 : 0; h_ctrl[2 * n + w] = 1; }
+  hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 1);
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal + (size_t)n * SC_N, d_gather, sizeof(double) * (size_t)n * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(int) * 3 * n, hipMemcpyHostToDevice, s));
+  if (want_err)                                                       // windows that never ran a trial: errors of the input state
+    for (int w = 0; w < n; ++w)
+      if (!wsn[w].trial_err && devs[w].nCh > 0)
+        hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(devs[w].nCh), dim3(CH), 0, s, devs[w], wsn[w].cur);
+  hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, d_ooff, d_out, want_err ? 1 : 0);
+  double* h_out = ws->stage.as<double>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * out_total, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  par_for([&](int w) {
+    ssx_ba_result& r = results[w];
+    const HostPrep& h = preps[w];
+    const double* o = h_out + out_off[w];
+    if (r.poses_out) memcpy(r.poses_out, o, sizeof(double) * 7 * h.P);
+    if (r.points_out && h.L) memcpy(r.points_out, o + 7 * (size_t)h.P, sizeof(double) * 3 * h.L);
+    if (want_err && (r.edge_chi2 || r.edge_outlier)) {
+      const double* e = o + 7 * (size_t)h.P + 3 * (size_t)h.L;
+      for (int sidx = 0; sidx < h.E; ++sidx) {
+        const int eo = h.perm[sidx];
+        const double c2 = e[sidx] * e[sidx] + e[(size_t)h.E + sidx] * e[(size_t)h.E + sidx];
+        if (r.edge_chi2) r.edge_chi2[eo] = c2;
+        if (r.edge_outlier) r.edge_outlier[eo] = c2 > opt.chi2_th;
+      }
+    }
+    const double* hstat = hscal + (size_t)n * SC_N + (size_t)w * 3 * SSX_BA_MAX_STATS;
+    for (int k = 0; k < r.n_iters && k < SSX_BA_MAX_STATS; ++k) {
+      r.iter_chi2[k] = hstat[k];
+      r.iter_lambda[k] = hstat[SSX_BA_MAX_STATS + k];
+      r.iter_trials[k] = (int)hstat[2 * SSX_BA_MAX_STATS + k];
+    }
+    r.ms_total = ms;
+    r.ms_setup = 0.f;
+  });
   return SSX_OK;
 }
 

@@ -417,3 +417,33 @@ def test_c4_shape_band_equals_tiles(ctx):
     assert np.array_equal(g["trials"], t["trials"])
     np.testing.assert_allclose(g["chi2"], t["chi2"], rtol=1e-9)
     assert np.abs(g["poses"] - t["poses"]).max() < 1e-8
+
+
+def test_batched_windows_equal_single_calls(ctx):
+    """ssx_ba_solve_batch: many small windows in one call (one grid dimension = the window) give, per window, exactly
+    the bits of ssx_ba_solve -- different sizes, a window that needs several outer rounds, rejected LM trials, a fixed
+    pose, numeric Jacobians."""
+    probs = [make_ba_problem(P=10, L=800, seed=21), make_ba_problem(P=7, L=300, obs_per_lm=4, seed=22),
+             make_ba_problem(P=12, L=900, obs_per_lm=4, seed=23),                       # 72 unknowns: the k_solve path
+             make_ba_problem(P=10, L=600, seed=24, frac_gross=0.45),                    # inlier ratio < 0.7: several rounds
+             make_ba_problem(P=6, L=200, obs_per_lm=3, seed=25, fix_first_pose=True),
+             make_ba_problem(P=10, L=2000, seed=26, pose_t_noise=0.3, pose_r_noise=0.03),   # far start: rejected trials
+             make_ba_problem(P=4, L=60, obs_per_lm=4, seed=27)]
+    for jac in (ba.JAC_ANALYTIC, ba.JAC_NUMERIC_G2O):
+        batch = ba.BaBatch(ctx, probs, jac_mode=jac)
+        out = batch.solve()
+        assert max(o["rounds"] for o in out["results"]) >= 2 and max(o["trials"].max() for o in out["results"]) >= 2
+        for pr, b in zip(probs, out["results"]):
+            one = ba.ba_solve(ctx, pr, jac_mode=jac)
+            assert b["rounds"] == one["rounds"] and b["n_iters"] == one["n_iters"]
+            assert np.array_equal(b["trials"], one["trials"]) and np.array_equal(b["chi2"], one["chi2"]) and np.array_equal(b["lam"], one["lam"])
+            assert np.array_equal(b["poses"], one["poses"]) and np.array_equal(b["points"], one["points"])
+            assert np.array_equal(b["edge_chi2"], one["edge_chi2"]) and np.array_equal(b["edge_outlier"], one["edge_outlier"])
+            assert (b["n_inliers"], b["n_outliers"]) == (one["n_inliers"], one["n_outliers"])
+    # without per-edge outputs, and a batch that contains a large window (falls back to one call per window)
+    again = ba.BaBatch(ctx, probs[:3]).solve(want_edges=False)
+    assert all(np.array_equal(a["poses"], ba.ba_solve(ctx, p)["poses"]) for a, p in zip(again["results"], probs[:3]))
+    mixed = [probs[0], make_ba_problem(P=30, L=1200, obs_per_lm=5, seed=28, fix_first_pose=True)]
+    mo = ba.BaBatch(ctx, mixed, outer_rounds=1, iters=4).solve()
+    for pr, b in zip(mixed, mo["results"]):
+        assert np.array_equal(b["poses"], ba.ba_solve(ctx, pr, outer_rounds=1, iters=4)["poses"])
