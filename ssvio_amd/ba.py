@@ -146,8 +146,11 @@ class BaBatch:
     ALL of them in one library call (the kernels run once for all windows)."""
 
     def __init__(self, ctx: Context, problems, outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891, inlier_ratio=0.7,
-                 jac_mode=JAC_ANALYTIC):
+                 jac_mode=JAC_ANALYTIC, resident=False, with_edge_errors=True):
+        """resident=True: ssx_ba_batch_create -- the windows are uploaded once and stay in HBM; solve() re-optimises them
+        from the uploaded state (solve(download=False) moves nothing but the LM control words across PCIe)."""
         self.ctx = ctx
+        self.handle = None
         self.n = len(problems)
         self._keep = []
         self.structs = (BaProblem * self.n)()
@@ -162,14 +165,27 @@ class BaBatch:
         self.points = [np.zeros((s.L, 3)) for s in self.structs]
         self.chi2 = [np.zeros(s.E) for s in self.structs]
         self.outl = [np.zeros(s.E, dtype=np.uint8) for s in self.structs]
+        self.with_edge_errors = with_edge_errors
+        if resident:
+            h = C.c_void_p()
+            ctx.check(ctx.lib.ssx_ba_batch_create(ctx.handle, self.n, self.structs, C.byref(self.opt), 1 if with_edge_errors else 0, C.byref(h)))
+            self.handle = h
 
-    def solve(self, want_edges=True):
+    def solve(self, want_edges=True, download=True):
+        if self.handle is not None and not download:
+            tot = C.c_int32(0)
+            self.ctx.check(self.ctx.lib.ssx_ba_batch_solve(self.handle, None, C.byref(tot)))
+            return dict(results=None, n_iters_total=tot.value)
+        want_edges = want_edges and (self.handle is None or self.with_edge_errors)
         for i in range(self.n):
             r = self.res[i]
             r.poses_out = ptr(self.poses[i], dbl_p); r.points_out = ptr(self.points[i], dbl_p)
             r.edge_chi2 = ptr(self.chi2[i], dbl_p) if want_edges else None
             r.edge_outlier = ptr(self.outl[i], u8_p) if want_edges else None
-        self.ctx.check(self.ctx.lib.ssx_ba_solve_batch(self.ctx.handle, self.n, self.structs, C.byref(self.opt), self.res))
+        if self.handle is not None:
+            self.ctx.check(self.ctx.lib.ssx_ba_batch_solve(self.handle, self.res, None))
+        else:
+            self.ctx.check(self.ctx.lib.ssx_ba_solve_batch(self.ctx.handle, self.n, self.structs, C.byref(self.opt), self.res))
         out = []
         for i in range(self.n):
             r = self.res[i]
@@ -181,4 +197,7 @@ class BaBatch:
         return dict(results=out, n_iters_total=int(sum(o["n_iters"] for o in out)))
 
     def close(self):
-        pass
+        if self.handle is not None:
+            self.ctx.lib.ssx_ba_batch_destroy.restype = None
+            self.ctx.lib.ssx_ba_batch_destroy(self.handle)
+            self.handle = None

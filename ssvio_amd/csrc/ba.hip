@@ -93,6 +93,8 @@ struct BaDev {
   // state
   double* pose[2];          // [P*7]
   double* point[2];         // [L*3]
+  const double* pose_init;  // batched windows: the uploaded state, kept pristine so that a resident batch can be solved again
+  const double* point_init;
   // linearisation
   double* W;                // [18][E]
   double* err_lin;          // [2][E]
@@ -991,6 +993,17 @@ __global__ __launch_bounds__(64) void k_lm_begin_batch(const BaDev* dv, const in
   k_lm_begin_body(d, 0, ctrl[w], iters, ctrl[n + w], ctrl[2 * n + w]);
 }
 
+// a resident batch is solved again: both state buffers of every window back to the uploaded state
+__global__ __launch_bounds__(CH) void k_reset_state_b(const BaDev* dv)
+{
+  const BaDev d = dv[blockIdx.y];
+  const size_t nP7 = 7 * (size_t)d.P, nL3 = 3 * (size_t)d.L;
+  for (size_t i = (size_t)blockIdx.x * CH + threadIdx.x; i < nP7 + nL3; i += (size_t)gridDim.x * CH) {
+    if (i < nP7) { const double v = d.pose_init[i]; d.pose[0][i] = v; d.pose[1][i] = v; }
+    else { const double v = d.point_init[i - nP7]; d.point[0][i - nP7] = v; d.point[1][i - nP7] = v; }
+  }
+}
+
 // control blocks (what = 0: SC_N scalars) or LM statistics (what = 1: 3 x SSX_BA_MAX_STATS) of every window, contiguous
 __global__ __launch_bounds__(CH) void k_gather_scal_b(const BaDev* dv, int n, double* out, int what)
 {
@@ -1338,6 +1351,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_point0 = in.take(sizeof(double) * 3 * (L + 1));
   const size_t o_pose1_in = dup_state ? in.take(sizeof(double) * 7 * P) : 0;
   const size_t o_point1_in = dup_state ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
+  const size_t o_pose_init = dup_state ? in.take(sizeof(double) * 7 * P) : 0;
+  const size_t o_point_init = dup_state ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
   const size_t in_bytes = in.off;
   Layout all = in;
   const size_t o_pose1 = dup_state ? o_pose1_in : all.take(sizeof(double) * 7 * P);
@@ -1446,7 +1461,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
       SSX_HIP_TRY(ctx, hipMemcpyAsync(at(o_point1), at(o_point0), sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, ctx->stream));
   } else {
     memcpy(hs + o_pose1, pr->poses, sizeof(double) * 7 * P);
-    if (L) memcpy(hs + o_point1, pr->points, sizeof(double) * 3 * L);
+    memcpy(hs + o_pose_init, pr->poses, sizeof(double) * 7 * P);
+    if (L) { memcpy(hs + o_point1, pr->points, sizeof(double) * 3 * L); memcpy(hs + o_point_init, pr->points, sizeof(double) * 3 * L); }
   }
 
   d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
@@ -1471,6 +1487,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
+  d.pose_init = dup_state ? (const double*)(at(o_pose_init)) : nullptr;
+  d.point_init = dup_state ? (const double*)(at(o_point_init)) : nullptr;
   d.pose[0] = (double*)(at(o_pose0)); d.pose[1] = (double*)(at(o_pose1));
   d.point[0] = (double*)(at(o_point0)); d.point[1] = (double*)(at(o_point1));
   d.W = (double*)(at(o_W));
@@ -2100,25 +2118,43 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   return SSX_OK;
 }
 
-// Many small windows in one call (one window per stereo pair of a batch, per stream of BASELINE configs[4], ...): every
+// ---- batches of small windows ----------------------------------------------------------------------------------------------
+// Many small windows together (one window per stereo pair of a batch, per stream of BASELINE configs[4], ...): every
 // kernel of the small-window path runs ONCE for all windows (blockIdx.y = window), the device-driven LM loop of each
 // window advances independently, one upload and one download carry all windows.  Same arithmetic as n calls of
-// ssx_ba_solve -- identical bits per window.  Windows with more than 16 free keyframes (or a collective) make the call
-// fall back to one ssx_ba_solve per window.
-ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt_in, ssx_ba_result* results)
-{
-  if (!ctx || n < 0 || (n > 0 && (!probs || !results))) return SSX_ERR_INVALID_ARG;
-  if (n == 0) return SSX_OK;
+// ssx_ba_solve -- identical bits per window.
+}  // extern "C"
+
+struct ssx_ba_batch {
+  ssx_ctx* ctx = nullptr;
+  int n = 0;
   ssx_ba_options opt;
-  if (opt_in) opt = *opt_in; else ssx_ba_default_options(&opt);
-  auto sequential = [&]() -> ssx_status {
-    for (int w = 0; w < n; ++w) {
-      const ssx_status st = ssx_ba_solve(ctx, &probs[w], &opt, &results[w]);
-      if (st != SSX_OK) return st;
-    }
-    return SSX_OK;
-  };
-  if (opt.comm || opt.allreduce || n == 1) return sequential();
+  DevBuf arena_own; HostBuf stage_own, scal_own;     // a resident batch owns its memory; the one-call path borrows the ctx workspace
+  DevBuf* arena = nullptr; HostBuf* stage = nullptr; HostBuf* scal = nullptr;
+  std::vector<BaDev> devs;
+  std::vector<std::vector<int>> perm;                // sorted edge -> caller's edge, per window
+  std::vector<int> P, L, E;
+  std::vector<size_t> out_off;
+  size_t out_total = 0, a_out = 0, a_gather = 0, a_head = 0, in_total = 0, o_dv = 0, o_ctrl = 0, o_ooff = 0;
+  int max_ch = 1, max_rl = 1, max_rs = 1;
+  bool any_solve64 = false, any_solve = false, with_err = false, fresh = false;
+  int threads = 1;
+};
+
+namespace {
+
+template <class F>
+void batch_par_for(int n, int T, F&& fn)
+{
+  if (T <= 1) { for (int w = 0; w < n; ++w) fn(w); return; }
+  std::vector<std::thread> th;
+  for (int k = 0; k < T; ++k) th.emplace_back([&, k] { for (int w = k; w < n; w += T) fn(w); });
+  for (auto& x : th) x.join();
+}
+
+// marshal + upload n small windows; SSX_ERR_UNSUPPORTED when one of them is a large window (> 16 free keyframes)
+ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const ssx_ba_options& opt, bool with_err, bool own, ssx_ba_batch* B)
+{
   // (kept per calling thread between calls; a thread_local named inside a lambda would be the WORKER thread's instance:
   // the workers go through this reference)
   static thread_local std::vector<HostPrep> preps_tls;
@@ -2126,103 +2162,111 @@ ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* pro
   std::vector<HostPrep>& preps = preps_tls;
   const int hw = (int)std::thread::hardware_concurrency();
   const int T = std::max(1, std::min({n, 16, hw > 1 ? hw / 2 : 1}));
+  B->ctx = ctx; B->n = n; B->opt = opt; B->threads = T; B->with_err = with_err;
   // ---- 1. host marshalling of every window (edge sort, chunks, index lists), T threads
   std::vector<ssx_status> sts(n, SSX_OK);
-  auto par_for = [&](auto&& fn) {
-    if (T == 1) { for (int w = 0; w < n; ++w) fn(w); return; }
-    std::vector<std::thread> th;
-    for (int k = 0; k < T; ++k) th.emplace_back([&, k] { for (int w = k; w < n; w += T) fn(w); });
-    for (auto& x : th) x.join();
-  };
-  par_for([&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w]); });
+  batch_par_for(n, T, [&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w]); });
   for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
-  for (int w = 0; w < n; ++w) if (preps[w].big) return sequential();
+  for (int w = 0; w < n; ++w) if (preps[w].big) return SSX_ERR_UNSUPPORTED;
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
-  // ---- 2. sizes, one arena: [blobs of all windows | BaDev[n] | ctrl int[3n] | out offsets | scratch of all windows | packed outputs]
+  B->arena = own ? &B->arena_own : &ws->arena;
+  B->stage = own ? &B->stage_own : &ws->stage;
+  B->scal = own ? &B->scal_own : &ws->scal;
+  // ---- 2. sizes, one arena: [blobs of all windows | BaDev[n] | ctrl int[3n] | out offsets | scratch of all windows | packed outputs | gather]
   std::vector<UploadPlace> place(n);
-  std::vector<BaDev> devs(n);
+  B->devs.assign(n, BaDev{});
   BandPlan no_band;
   size_t in_total = 0, rest_total = 0, out_total = 0;
-  const bool want_err = [&] { for (int w = 0; w < n; ++w) if (results[w].edge_chi2 || results[w].edge_outlier) return true; return false; }();
-  std::vector<size_t> in_off(n), rest_off(n), out_off(n);
+  std::vector<size_t> in_off(n), rest_off(n);
+  B->out_off.assign(n, 0); B->P.resize(n); B->L.resize(n); B->E.resize(n); B->perm.resize(n);
   for (int w = 0; w < n; ++w) {
     BigDev bd; BandDev bnd;
     place[w].dry = true;
-    ssx_status st = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, devs[w], bd, no_band, bnd, &place[w]);
+    ssx_status st = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w]);
     if (st != SSX_OK) return st;
     in_off[w] = in_total; in_total += place[w].in_bytes;
     rest_off[w] = rest_total; rest_total += place[w].rest_bytes;
-    out_off[w] = out_total;
-    out_total += 7 * (size_t)preps[w].P + 3 * (size_t)preps[w].L + (want_err ? 2 * (size_t)preps[w].E : 0);
+    B->out_off[w] = out_total;
+    B->P[w] = preps[w].P; B->L[w] = preps[w].L; B->E[w] = preps[w].E;
+    out_total += 7 * (size_t)preps[w].P + 3 * (size_t)preps[w].L + (with_err ? 2 * (size_t)preps[w].E : 0);
   }
   Layout tail;
-  const size_t o_dv = tail.take(sizeof(BaDev) * n), o_ctrl = tail.take(sizeof(int) * 3 * n), o_ooff = tail.take(sizeof(size_t) * n);
+  B->o_dv = tail.take(sizeof(BaDev) * n); B->o_ctrl = tail.take(sizeof(int) * 3 * n); B->o_ooff = tail.take(sizeof(size_t) * n);
   const size_t head_bytes = in_total + tail.off;                     // everything that is uploaded
   Layout arena;
-  const size_t a_head = arena.take(head_bytes), a_rest = arena.take(rest_total), a_out = arena.take(sizeof(double) * (out_total + 1));
-  const size_t a_gather = arena.take(sizeof(double) * (size_t)n * (3 * SSX_BA_MAX_STATS));
-  SSX_HIP_TRY(ctx, ws->arena.reserve(arena.off));
-  SSX_HIP_TRY(ctx, ws->stage.reserve(std::max(head_bytes, sizeof(double) * (out_total + 1))));
-  SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS) + sizeof(int) * 3 * n + 64));
-  char* dev_base = ws->arena.as<char>();
-  char* hst = ws->stage.as<char>();
+  B->a_head = arena.take(head_bytes);
+  const size_t a_rest = arena.take(rest_total);
+  B->a_out = arena.take(sizeof(double) * (out_total + 1));
+  B->a_gather = arena.take(sizeof(double) * (size_t)n * (3 * SSX_BA_MAX_STATS));
+  B->in_total = in_total; B->out_total = out_total;
+  SSX_HIP_TRY(ctx, B->arena->reserve(arena.off));
+  SSX_HIP_TRY(ctx, B->stage->reserve(std::max(head_bytes, sizeof(double) * (out_total + 1))));
+  SSX_HIP_TRY(ctx, B->scal->reserve(sizeof(double) * (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS) + sizeof(int) * 3 * n + 64));
+  char* dev_base = B->arena->as<char>();
+  char* hst = B->stage->as<char>();
   // ---- 3. fill the pinned mirror (T threads), one upload
-  par_for([&](int w) {
+  batch_par_for(n, T, [&](int w) {
     BigDev bd; BandDev bnd;
     place[w].dry = false;
-    place[w].in_dev = dev_base + a_head + in_off[w];
+    place[w].in_dev = dev_base + B->a_head + in_off[w];
     place[w].rest_dev = dev_base + a_rest + rest_off[w];
     place[w].in_host = hst + in_off[w];
-    sts[w] = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, devs[w], bd, no_band, bnd, &place[w]);
+    sts[w] = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w]);
+    if (with_err) B->perm[w] = preps[w].perm;
   });
   for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
-  memcpy(hst + in_total + o_dv, devs.data(), sizeof(BaDev) * n);
-  int* h_ctrl_up = reinterpret_cast<int*>(hst + in_total + o_ctrl);
-  memcpy(hst + in_total + o_ooff, out_off.data(), sizeof(size_t) * n);
-  const BaDev* dv = reinterpret_cast<const BaDev*>(dev_base + a_head + in_total + o_dv);
-  int* d_ctrl = reinterpret_cast<int*>(dev_base + a_head + in_total + o_ctrl);
-  const size_t* d_ooff = reinterpret_cast<const size_t*>(dev_base + a_head + in_total + o_ooff);
-  double* d_out = reinterpret_cast<double*>(dev_base + a_out);
-  double* d_gather = reinterpret_cast<double*>(dev_base + a_gather);
-  // per-window host state of Backend::OptimizeActiveMap's outer loop (backend.cpp:175-203)
-  struct WinState { int cur = 0, round = 0; bool done = false, active = false, trial_err = false; double n_out = 0; };
-  std::vector<WinState> wsn(n);
-  int max_ch = 1, max_rl = 1, max_rs = 1;
-  bool any_solve64 = false, any_solve = false;
+  memcpy(hst + in_total + B->o_dv, B->devs.data(), sizeof(BaDev) * n);
+  memset(hst + in_total + B->o_ctrl, 0, sizeof(int) * 3 * n);
+  memcpy(hst + in_total + B->o_ooff, B->out_off.data(), sizeof(size_t) * n);
   for (int w = 0; w < n; ++w) {
-    const BaDev& d = devs[w];
-    wsn[w].active = d.nCh > 0;
-    wsn[w].done = !(d.nCh > 0) || opt.outer_rounds <= 0;
-    max_ch = std::max(max_ch, d.nCh);
-    max_rl = std::max(max_rl, (d.nP * 27 + 15) / 16);
-    max_rs = std::max(max_rs, (d.nBlk * 36 + d.nP * 6 + 15) / 16);
-    if (6 * d.nP <= NB) any_solve64 = true; else any_solve = true;
-    results[w].rounds = 0; results[w].n_iters = 0; results[w].n_inliers = 0; results[w].n_outliers = 0;
-    results[w].ms_linearize = results[w].ms_schur = results[w].ms_linear_solution = results[w].ms_update = results[w].ms_reduce = 0.f;
-    h_ctrl_up[w] = 0; h_ctrl_up[n + w] = 0; h_ctrl_up[2 * n + w] = wsn[w].done ? 1 : 0;
+    const BaDev& d = B->devs[w];
+    B->max_ch = std::max(B->max_ch, d.nCh);
+    B->max_rl = std::max(B->max_rl, (d.nP * 27 + 15) / 16);
+    B->max_rs = std::max(B->max_rs, (d.nBlk * 36 + d.nP * 6 + 15) / 16);
+    if (6 * d.nP <= NB) B->any_solve64 = true; else B->any_solve = true;
   }
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + a_head, hst, head_bytes, hipMemcpyHostToDevice, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + B->a_head, hst, head_bytes, hipMemcpyHostToDevice, ctx->stream));
+  B->fresh = true;                                                   // the state buffers hold the uploaded state
   const size_t lds_schur = schur_lds_bytes();
   static bool attr_set_b = false;
   if (!attr_set_b) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur);
     attr_set_b = true;
   }
-  double* hscal = ws->scal.as<double>();                              // n x SC_N, then n x 3 x MAX_STATS, then the ctrl words of later rounds
-  int* h_ctrl = reinterpret_cast<int*>(hscal + (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS));
+  return SSX_OK;
+}
+
+// optimise every window of a built batch; results may be null (nothing is downloaded then, counters only in `summary`)
+ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterations_total)
+{
+  ssx_ctx* ctx = B->ctx;
+  const int n = B->n;
+  const ssx_ba_options& opt = B->opt;
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  char* dev_base = B->arena->as<char>();
+  const BaDev* dv = reinterpret_cast<const BaDev*>(dev_base + B->a_head + B->in_total + B->o_dv);
+  int* d_ctrl = reinterpret_cast<int*>(dev_base + B->a_head + B->in_total + B->o_ctrl);
+  const size_t* d_ooff = reinterpret_cast<const size_t*>(dev_base + B->a_head + B->in_total + B->o_ooff);
+  double* d_out = reinterpret_cast<double*>(dev_base + B->a_out);
+  double* d_gather = reinterpret_cast<double*>(dev_base + B->a_gather);
   hipStream_t s = ctx->stream;
-  const dim3 gCh(max_ch, n), gRl(max_rl, n), gRs(max_rs, n), gOne(1, n);
+  if (!B->fresh) hipLaunchKernelGGL(k_reset_state_b, dim3(16, n), dim3(CH), 0, s, dv);
+  B->fresh = false;
+  // per-window host state of Backend::OptimizeActiveMap's outer loop (backend.cpp:175-203)
+  struct WinState { int cur = 0, round = 0, rounds = 0, n_iters = 0, n_in = 0, n_outl = 0; bool done = false, trial_err = false; double n_out = 0; };
+  std::vector<WinState> wsn(n);
+  double* hscal = B->scal->as<double>();                             // n x SC_N, then n x 3 x MAX_STATS, then the ctrl words
+  int* h_ctrl = reinterpret_cast<int*>(hscal + (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS));
+  for (int w = 0; w < n; ++w) wsn[w].done = !(B->devs[w].nCh > 0) || opt.outer_rounds <= 0;
+  const size_t lds_schur = schur_lds_bytes();
+  const dim3 gCh(B->max_ch, n), gRl(B->max_rl, n), gRs(B->max_rs, n), gOne(1, n);
   auto all_done = [&] { for (int w = 0; w < n; ++w) if (!wsn[w].done) return false; return true; };
-  bool first_round = true;
   while (!all_done() && opt.iters > 0) {
-    if (!first_round) {
-      for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = results[w].n_iters; h_ctrl[2 * n + w] = wsn[w].done ? 1 : 0; }
-      SSX_HIP_TRY(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(int) * 3 * n, hipMemcpyHostToDevice, s));
-    }
-    first_round = false;
+    for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = wsn[w].n_iters; h_ctrl[2 * n + w] = wsn[w].done ? 1 : 0; }
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(int) * 3 * n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_lm_begin_batch, dim3(n), dim3(64), 0, s, dv, (const int*)d_ctrl, n, opt.iters);
     int slots_total = 0;
     bool first_slot = true;
@@ -2241,8 +2285,8 @@ ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* pro
         first_slot = false;
         SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gCh, dim3(CH), lds_schur, s, dv, 0.0, 2));
         SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, s, dv));
-        if (any_solve64) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, s, dv, -1, 0.0, 1));
-        if (any_solve) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(256), 0, s, dv, -1, 0.0, 1));
+        if (B->any_solve64) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, s, dv, -1, 0.0, 1));
+        if (B->any_solve) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(256), 0, s, dv, -1, 0.0, 1));
         SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual_b, gCh, dim3(CH), 0, s, dv, -1, 0.0, 1));
         SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial_b, gOne, dim3(CH), 0, s, dv, 1));
       }
@@ -2262,43 +2306,53 @@ ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* pro
       st.cur = (int)sc[SC_CUR];
       st.n_out = sc[SC_NOUT];
       if (sc[SC_TRIALS_RUN] > 0.0) st.trial_err = true;
-      results[w].n_iters = std::max(results[w].n_iters, (int)sc[SC_NSTAT]);
-      results[w].rounds++;
-      const double n_edges = (double)devs[w].E, cnt_in = n_edges - st.n_out;
-      results[w].n_outliers = (int)st.n_out;
-      results[w].n_inliers = (int)cnt_in;
+      st.n_iters = std::max(st.n_iters, (int)sc[SC_NSTAT]);
+      st.rounds++;
+      const double n_edges = (double)B->devs[w].E, cnt_in = n_edges - st.n_out;
+      st.n_outl = (int)st.n_out; st.n_in = (int)cnt_in;
       const double ratio = n_edges > 0 ? cnt_in / (cnt_in + st.n_out) : 1.0;
       if (ratio > opt.inlier_ratio) st.done = true;
       if (++st.round >= opt.outer_rounds) st.done = true;
     }
   }
-  // ---- 4. statistics + results: one packing kernel, one download
+  if (lm_iterations_total) { int t = 0; for (int w = 0; w < n; ++w) t += wsn[w].n_iters; *lm_iterations_total = t; }
+  if (!results) {                                                    // nothing to download: the caller only wants the work done
+    SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+    SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+    return SSX_OK;
+  }
+  // ---- statistics + results: one packing kernel, one download
+  const bool want_err = B->with_err;
   for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = wsn[w].trial_err ? 1 : 0; h_ctrl[2 * n + w] = 1; }
   hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 1);
   SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal + (size_t)n * SC_N, d_gather, sizeof(double) * (size_t)n * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, s));
   SSX_HIP_TRY(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(int) * 3 * n, hipMemcpyHostToDevice, s));
   if (want_err)                                                       // windows that never ran a trial: errors of the input state
     for (int w = 0; w < n; ++w)
-      if (!wsn[w].trial_err && devs[w].nCh > 0)
-        hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(devs[w].nCh), dim3(CH), 0, s, devs[w], wsn[w].cur);
+      if (!wsn[w].trial_err && B->devs[w].nCh > 0)
+        hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(B->devs[w].nCh), dim3(CH), 0, s, B->devs[w], wsn[w].cur);
   hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, d_ooff, d_out, want_err ? 1 : 0);
-  double* h_out = ws->stage.as<double>();
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * out_total, hipMemcpyDeviceToHost, s));
+  double* h_out = B->stage->as<double>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * B->out_total, hipMemcpyDeviceToHost, s));
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-  par_for([&](int w) {
+  batch_par_for(n, B->threads, [&](int w) {
     ssx_ba_result& r = results[w];
-    const HostPrep& h = preps[w];
-    const double* o = h_out + out_off[w];
-    if (r.poses_out) memcpy(r.poses_out, o, sizeof(double) * 7 * h.P);
-    if (r.points_out && h.L) memcpy(r.points_out, o + 7 * (size_t)h.P, sizeof(double) * 3 * h.L);
+    const WinState& st = wsn[w];
+    const int P = B->P[w], L = B->L[w], E = B->E[w];
+    r.rounds = st.rounds; r.n_iters = st.n_iters; r.n_inliers = st.n_in; r.n_outliers = st.n_outl;
+    r.ms_linearize = r.ms_schur = r.ms_linear_solution = r.ms_update = r.ms_reduce = 0.f;
+    const double* o = h_out + B->out_off[w];
+    if (r.poses_out) memcpy(r.poses_out, o, sizeof(double) * 7 * P);
+    if (r.points_out && L) memcpy(r.points_out, o + 7 * (size_t)P, sizeof(double) * 3 * L);
     if (want_err && (r.edge_chi2 || r.edge_outlier)) {
-      const double* e = o + 7 * (size_t)h.P + 3 * (size_t)h.L;
-      for (int sidx = 0; sidx < h.E; ++sidx) {
-        const int eo = h.perm[sidx];
-        const double c2 = e[sidx] * e[sidx] + e[(size_t)h.E + sidx] * e[(size_t)h.E + sidx];
+      const double* e = o + 7 * (size_t)P + 3 * (size_t)L;
+      const std::vector<int>& perm = B->perm[w];
+      for (int sidx = 0; sidx < E; ++sidx) {
+        const int eo = perm[sidx];
+        const double c2 = e[sidx] * e[sidx] + e[(size_t)E + sidx] * e[(size_t)E + sidx];
         if (r.edge_chi2) r.edge_chi2[eo] = c2;
         if (r.edge_outlier) r.edge_outlier[eo] = c2 > opt.chi2_th;
       }
@@ -2313,6 +2367,70 @@ ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* pro
     r.ms_setup = 0.f;
   });
   return SSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt_in, ssx_ba_result* results)
+{
+  if (!ctx || n < 0 || (n > 0 && (!probs || !results))) return SSX_ERR_INVALID_ARG;
+  if (n == 0) return SSX_OK;
+  ssx_ba_options opt;
+  if (opt_in) opt = *opt_in; else ssx_ba_default_options(&opt);
+  auto sequential = [&]() -> ssx_status {
+    for (int w = 0; w < n; ++w) {
+      const ssx_status st = ssx_ba_solve(ctx, &probs[w], &opt, &results[w]);
+      if (st != SSX_OK) return st;
+    }
+    return SSX_OK;
+  };
+  if (opt.comm || opt.allreduce || n == 1) return sequential();
+  bool with_err = false;
+  for (int w = 0; w < n; ++w) if (results[w].edge_chi2 || results[w].edge_outlier) with_err = true;
+  ssx_ba_batch B;
+  ssx_status st = batch_build(ctx, n, probs, opt, with_err, false, &B);
+  if (st == SSX_ERR_UNSUPPORTED) return sequential();                 // a large window in the batch
+  if (st != SSX_OK) return st;
+  return batch_run(&B, results, nullptr);
+}
+
+// A RESIDENT batch: the windows are marshalled and uploaded once and stay in HBM; every ssx_ba_batch_solve optimises
+// them again from the uploaded state (bench.py times this with nothing crossing PCIe but the LM control words).
+ssx_status ssx_ba_batch_create(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt_in, int32_t with_edge_errors,
+                               ssx_ba_batch** out)
+{
+  if (!ctx || n <= 0 || !probs || !out) return SSX_ERR_INVALID_ARG;
+  *out = nullptr;
+  ssx_ba_options opt;
+  if (opt_in) opt = *opt_in; else ssx_ba_default_options(&opt);
+  if (opt.comm || opt.allreduce) { ctx->set_error("ssx_ba_batch_create: batches do not take a collective"); return SSX_ERR_UNSUPPORTED; }
+  ssx_ba_batch* B = new ssx_ba_batch();
+  const ssx_status st = batch_build(ctx, n, probs, opt, with_edge_errors != 0, true, B);
+  if (st != SSX_OK) {
+    if (st == SSX_ERR_UNSUPPORTED) ctx->set_error("ssx_ba_batch_create: a window has more than %d free keyframes (use ssx_ba_solve)", SSX_BA_SMALL_P);
+    ssx_ba_batch_destroy(B);
+    return st;
+  }
+  *out = B;
+  return SSX_OK;
+}
+
+ssx_status ssx_ba_batch_solve(ssx_ba_batch* batch, ssx_ba_result* results, int32_t* lm_iterations_total)
+{
+  if (!batch) return SSX_ERR_INVALID_ARG;
+  return batch_run(batch, results, lm_iterations_total);
+}
+
+int32_t ssx_ba_batch_size(const ssx_ba_batch* batch) { return batch ? batch->n : 0; }
+
+void ssx_ba_batch_destroy(ssx_ba_batch* batch)
+{
+  if (!batch) return;
+  if (batch->ctx) (void)hipSetDevice(batch->ctx->device);
+  batch->arena_own.release(); batch->stage_own.release(); batch->scal_own.release();
+  delete batch;
 }
 
 }  // extern "C"

@@ -440,6 +440,17 @@ def test_batched_windows_equal_single_calls(ctx):
             assert np.array_equal(b["poses"], one["poses"]) and np.array_equal(b["points"], one["points"])
             assert np.array_equal(b["edge_chi2"], one["edge_chi2"]) and np.array_equal(b["edge_outlier"], one["edge_outlier"])
             assert (b["n_inliers"], b["n_outliers"]) == (one["n_inliers"], one["n_outliers"])
+    # a RESIDENT batch (uploaded once): solved twice from the uploaded state, same bits both times; solve without download
+    res = ba.BaBatch(ctx, probs, resident=True)
+    r1 = res.solve(); p1 = [o["poses"].copy() for o in r1["results"]]; c1 = [o["edge_chi2"].copy() for o in r1["results"]]
+    nd = res.solve(download=False)
+    assert nd["results"] is None and nd["n_iters_total"] == r1["n_iters_total"]
+    r2 = res.solve()
+    for pr, a, pa, ca in zip(probs, r2["results"], p1, c1):
+        one = ba.ba_solve(ctx, pr)
+        assert np.array_equal(a["poses"], pa) and np.array_equal(a["poses"], one["poses"]) and np.array_equal(a["edge_chi2"], ca)
+        assert np.array_equal(a["edge_chi2"], one["edge_chi2"]) and np.array_equal(a["trials"], one["trials"])
+    res.close()
     # without per-edge outputs, and a batch that contains a large window (falls back to one call per window)
     again = ba.BaBatch(ctx, probs[:3]).solve(want_edges=False)
     assert all(np.array_equal(a["poses"], ba.ba_solve(ctx, p)["poses"]) for a, p in zip(again["results"], probs[:3]))
