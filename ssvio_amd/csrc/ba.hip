@@ -55,6 +55,8 @@ using ssx::Cam;
 constexpr int CH = 256;            // threads per chunk workgroup
 constexpr int PW = CH + 1;         // padded LDS pitch (doubles) of [component][edge] tiles
 constexpr int CH_E = 255;          // max edges per chunk (chunk-local edge indices fit a byte)
+constexpr int CH_L = 128;          // max landmarks per chunk (per-landmark LDS arrays of k_schur)
+constexpr int PL = CH_L + 1;       // their padded pitch
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
 constexpr int NMAX = 6 * SSX_BA_SMALL_P;   // 96 unknowns of the reduced system
@@ -447,14 +449,15 @@ __global__ void k_set_lambda(BaDev d, double lambda)
 __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, double lambda_arg, int use_dev_lambda)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // With D = Hll + lambda I = L L^T (3x3 Cholesky) and Y_e = W_e L^-T, the Schur term of an edge pair is
+  // W_a D^-1 W_b^T = Y_a Y_b^T and W D^-1 bl = Y (L^-1 bl): ONE 6x3 array per edge in LDS instead of W and W D^-1
+  // (37 KB per chunk instead of 74; with <= 128 landmarks per chunk the whole workgroup needs 53 KB: three per CU).
   // pitch PW = CH + 1 doubles: the owned-entry loops read [component][edge] with the component varying across
   // lanes -- an even pitch would put all components on the same LDS bank
-  double* sW = reinterpret_cast<double*>(smem);            // [18][PW]
-  double* sBD = sW + 18 * PW;                              // [18][PW]
-  double* sC = sBD + 18 * PW;                              // [6][PW]
-  double* sDinv = sC + 6 * PW;                             // [9][PW] per landmark
-  double* sDb = sDinv + 9 * PW;                            // [3][PW]
-  int* sLm = reinterpret_cast<int*>(sDb + 3 * PW);         // [CH] local landmark of each edge
+  double* sY = reinterpret_cast<double*>(smem);            // [18][PW]   Y = W L^-T of the leader edges
+  double* sG = sY + 18 * PW;                               // [6][PL] per landmark: 1/l00, l10, l20, 1/l11, l21, 1/l22
+  double* sGb = sG + 6 * PL;                               // [3][PL] per landmark: L^-1 bl
+  int* sLm = reinterpret_cast<int*>(sGb + 3 * PL);         // [CH] local landmark of each edge
   uint8_t* sLeader = reinterpret_cast<uint8_t*>(sLm + CH); // [CH]
   uint8_t* sOrd = sLeader + CH;                            // [CH]
   uint16_t* sPptr = reinterpret_cast<uint16_t*>(sOrd + CH);// [SSX_BA_SMALL_P + 2]
@@ -471,6 +474,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, doubl
   const int nP = d.nP;
 
   bool leader = false;
+  double Wm[18];
   if (t < ne) sOrd[t] = d.porder[e0 + t];
   if (t <= nP) sPptr[t] = d.pptr[(size_t)c * (nP + 1) + t];
   {
@@ -482,43 +486,53 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, doubl
   }
   if (t < ne) {
     const int e = e0 + t;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) sW[k * PW + t] = d.W[(size_t)k * d.E + e];
     const int lc = d.e_lmc[e];
     sLm[t] = lc - lm0;
     const int pf = d.pose_free[d.e_pose[e]];
     leader = (pf >= 0) && !d.lm_fixed[lc] && !d.e_dup[e];
+    if (leader) {
+#pragma unroll
+      for (int k = 0; k < 18; ++k) Wm[k] = d.W[(size_t)k * d.E + e];
+      // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
+      for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j)
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Wm[k] += d.W[(size_t)k * d.E + e0 + j];
+    }
   }
   sLeader[t] = leader ? 1 : 0;
   if (t < nl) {
     const int lc = lm0 + t;
-    double D[6], Di[9];
+    double D[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) D[k] = d.Hll[(size_t)k * d.nLm + lc];
     D[0] += lambda; D[3] += lambda; D[5] += lambda;
-    ssx::inv3_sym(D, Di);
+    // D = (d00 d01 d02 d11 d12 d22); a non-positive pivot yields NaN, the reduced solve then reports failure and the
+    // LM step is rejected (g2o: Cholesky failure)
+    const double i00 = 1.0 / sqrt(D[0]);
+    const double l10 = D[1] * i00, l20 = D[2] * i00;
+    const double i11 = 1.0 / sqrt(D[3] - l10 * l10);
+    const double l21 = (D[4] - l20 * l10) * i11;
+    const double i22 = 1.0 / sqrt(D[5] - l20 * l20 - l21 * l21);
+    sG[t] = i00; sG[PL + t] = l10; sG[2 * PL + t] = l20; sG[3 * PL + t] = i11; sG[4 * PL + t] = l21; sG[5 * PL + t] = i22;
     const double b0 = d.bl[lc], b1 = d.bl[(size_t)d.nLm + lc], b2 = d.bl[(size_t)2 * d.nLm + lc];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) sDinv[k * PW + t] = Di[k];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) sDb[r * PW + t] = Di[r * 3] * b0 + Di[r * 3 + 1] * b1 + Di[r * 3 + 2] * b2;
+    const double g0 = b0 * i00, g1 = (b1 - l10 * g0) * i11, g2 = (b2 - l20 * g0 - l21 * g1) * i22;
+    sGb[t] = g0; sGb[PL + t] = g1; sGb[2 * PL + t] = g2;
   }
   __syncthreads();
-  if (leader) {
-    // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
-    for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j)
+  if (t < ne) {
+    if (leader) {
+      const int l = sLm[t];
+      const double i00 = sG[l], l10 = sG[PL + l], l20 = sG[2 * PL + l], i11 = sG[3 * PL + l], l21 = sG[4 * PL + l], i22 = sG[5 * PL + l];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) sW[k * PW + t] += sW[k * PW + j];
-    const int l = sLm[t];
-    double Di[9];
+      for (int a = 0; a < 6; ++a) {
+        const double y0 = Wm[a * 3] * i00;
+        const double y1 = (Wm[a * 3 + 1] - y0 * l10) * i11;
+        const double y2 = (Wm[a * 3 + 2] - y0 * l20 - y1 * l21) * i22;
+        sY[(a * 3) * PW + t] = y0; sY[(a * 3 + 1) * PW + t] = y1; sY[(a * 3 + 2) * PW + t] = y2;
+      }
+    } else {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Di[k] = sDinv[k * PW + l];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double w0 = sW[(a * 3) * PW + t], w1 = sW[(a * 3 + 1) * PW + t], w2 = sW[(a * 3 + 2) * PW + t];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) sBD[(a * 3 + b) * PW + t] = w0 * Di[b] + w1 * Di[3 + b] + w2 * Di[6 + b];
-      sC[a * PW + t] = w0 * sDb[l] + w1 * sDb[PW + l] + w2 * sDb[2 * PW + l];
+      for (int k = 0; k < 18; ++k) sY[k * PW + t] = 0.0;
     }
   }
   __syncthreads();
@@ -536,8 +550,8 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, doubl
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[i][j] = 0.0;
-    const double* bdp = sBD + (qr * 9) * PW;                             // component (row r, m) of W Dinv = r * 3 + m
-    const double* wp = sW + (qc * 9) * PW;
+    const double* bdp = sY + (qr * 9) * PW;                              // component (row r, m) of Y = r * 3 + m
+    const double* wp = sY + (qc * 9) * PW;
     for (int q = q0; q < q1; ++q) {
       const int ea = sPa[q], eb = sPb[q];
       double bd[3][3], w[3][3];
@@ -565,7 +579,10 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, doubl
     if (on)
       for (int s = sPptr[p] + part; s < sPptr[p + 1]; s += 4) {
         const int j = sOrd[s];
-        if (sLeader[j]) acc += sC[a * PW + j];
+        if (sLeader[j]) {
+          const int l = sLm[j];
+          acc += sY[(a * 3) * PW + j] * sGb[l] + sY[(a * 3 + 1) * PW + j] * sGb[PL + l] + sY[(a * 3 + 2) * PW + j] * sGb[2 * PL + l];
+        }
       }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
@@ -856,6 +873,7 @@ __global__ __launch_bounds__(256) void k_solve_b(const BaDev* dv, int cur, doubl
 __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
   __shared__ double sPt[3][CH];
+  __shared__ double sPart[3][CH];
   __shared__ double sRed[CH];
   const int c = bx, t = threadIdx.x;
   if (cur < 0) {
@@ -868,6 +886,23 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
   const int ne = e1 - e0, nl = lm1 - lm0;
   const double* pt_src = d.point[cur];
   double* pt_dst = d.point[cur ^ 1];
+  // W_e^T x_p of every edge (one thread per edge: the 18 component loads are coalesced), summed per landmark below
+  if (t < ne) {
+    const int e = e0 + t;
+    const int pf = d.pose_free[d.e_pose[e]];
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+    if (pf >= 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double xa = d.xp[pf * 6 + a];
+        p0 = fma(d.W[(size_t)(a * 3) * d.E + e], xa, p0);
+        p1 = fma(d.W[(size_t)(a * 3 + 1) * d.E + e], xa, p1);
+        p2 = fma(d.W[(size_t)(a * 3 + 2) * d.E + e], xa, p2);
+      }
+    }
+    sPart[0][t] = p0; sPart[1][t] = p1; sPart[2][t] = p2;
+  }
+  __syncthreads();
   double scale_l = 0.0;
   if (t < nl) {
     const int lc = lm0 + t;
@@ -881,16 +916,7 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
       ssx::inv3_sym(D, Di);
       const double b[3] = {d.bl[lc], d.bl[(size_t)d.nLm + lc], d.bl[(size_t)2 * d.nLm + lc]};
       double cl[3] = {b[0], b[1], b[2]};
-      for (int e = d.lm_ptr[lc]; e < d.lm_ptr[lc + 1]; ++e) {
-        const int pf = d.pose_free[d.e_pose[e]];
-        if (pf < 0) continue;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const double xa = d.xp[pf * 6 + a];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) cl[k] -= d.W[(size_t)(a * 3 + k) * d.E + e] * xa;
-        }
-      }
+      for (int j = d.lm_ptr[lc] - e0; j < d.lm_ptr[lc + 1] - e0; ++j) { cl[0] -= sPart[0][j]; cl[1] -= sPart[1][j]; cl[2] -= sPart[2][j]; }
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
@@ -1137,13 +1163,13 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     h.e_uv[(size_t)E + s] = pr->edge_uv[2 * (size_t)e + 1];
     if (s > 0 && h.e_lmc[s] == h.e_lmc[s - 1] && h.e_pose[s] == h.e_pose[s - 1]) h.e_dup[s] = 1;
   }
-  // chunks of whole landmarks, <= CH_E edges and <= CH landmarks each
+  // chunks of whole landmarks, <= CH_E edges and <= CH_L landmarks each
   h.ch_lm.clear();
   h.ch_lm.push_back(0);
   int acc_e = 0, acc_l = 0;
   for (int lc = 0; lc < h.nLm; ++lc) {
     const int k = h.lm_ptr[lc + 1] - h.lm_ptr[lc];
-    if (acc_e + k > CH_E || acc_l + 1 > CH) {
+    if (acc_e + k > CH_E || acc_l + 1 > CH_L) {
       h.ch_lm.push_back(lc);
       acc_e = 0; acc_l = 0;
     }
@@ -1528,7 +1554,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
 
 size_t schur_lds_bytes()
 {
-  return sizeof(double) * (18 + 18 + 6 + 9 + 3) * PW + sizeof(int) * CH + 2 * CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) +
+  return sizeof(double) * (18 * PW + 9 * PL) + sizeof(int) * CH + 2 * CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) +
          sizeof(int) * (MAX_BLK + 1) + 2 * MAX_PAIRS + 64;
 }
 
