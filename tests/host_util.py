@@ -78,8 +78,35 @@ def parse_runner_log(text):
     return out
 
 
+def _build_sanitized(kind):
+    """SSX_SANITIZE=asan|tsan (tools/sanitize.sh): test_units and oracle_runner with the WHOLE host layer and the CPU
+    oracle compiled in from source under -fsanitize=address,undefined / thread (libssx.so stays a plain shared object:
+    these tests run on the oracle, the HIP library is never called).  Separate build directory."""
+    from ssvio_amd import build as b
+    b.build()
+    out = os.path.join(OUT, kind)
+    os.makedirs(out, exist_ok=True)
+    san = {"asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], "tsan": ["-fsanitize=thread"]}[kind]
+    flags = [f for f in b.HOST_FLAGS if f != "-O2"] + ["-O1", "-g", "-fno-omit-frame-pointer", *san, "-I", ROOT]
+    host_src = [os.path.join(b.HOST, f) for f in b.HOST_LIB_SRCS]
+    orc_src = sorted(os.path.join(ROOT, "oracle", "src", f) for f in os.listdir(os.path.join(ROOT, "oracle", "src")) if f.endswith(".cpp"))
+    rpath = ["-Wl,-rpath," + os.path.dirname(b.LIB), "-Wl,-rpath,/opt/rocm/lib"]
+    src = os.path.join(ROOT, "tests", "host")
+    units, runner = os.path.join(out, "test_units"), os.path.join(out, "oracle_runner")
+    deps = host_src + orc_src + [os.path.join(src, f) for f in ("test_units.cpp", "oracle_runner.cpp", "oracle_compute.hpp")]
+    newest = max(os.path.getmtime(p) for p in deps)
+    if not (os.path.exists(units) and os.path.getmtime(units) >= newest):
+        subprocess.check_call(["g++", *flags, os.path.join(src, "test_units.cpp"), *host_src, b.LIB, "-lz", "-lpthread", *rpath, "-o", units])
+    if not (os.path.exists(runner) and os.path.getmtime(runner) >= newest):
+        subprocess.check_call(["g++", *flags, "-ffp-contract=off", os.path.join(src, "oracle_runner.cpp"), *host_src, *orc_src, b.LIB, "-lz", "-lpthread",
+                               *rpath, "-o", runner])
+    return dict(units=units, oracle_runner=runner, run_kitti=None, host_lib=None)
+
+
 def build_test_binaries():
     """tests/host/build/{test_units, oracle_runner}; the product pieces come from ssvio_amd.build.build_host()"""
+    if os.environ.get("SSX_SANITIZE") in ("asan", "tsan"):
+        return _build_sanitized(os.environ["SSX_SANITIZE"])
     from oracle import pyoracle
     from ssvio_amd import build as b
     host_lib, host_exe = b.build_host()
