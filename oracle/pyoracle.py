@@ -460,10 +460,14 @@ def voc_transform_features(voc, feat):
     return word, w
 
 
-def bow_vector(word, weight, weighting=0):
+def bow_vector(word, weight, weighting=0, which="oracle"):
+    """which = "ref": the reference's own DBoW2::BowVector (BowVector.cpp compiled into oracle/_ref)"""
     word = np.ascontiguousarray(word, dtype=np.int32); weight = np.ascontiguousarray(weight, dtype=np.float64)
     cap = max(len(word), 1)
     ids = np.zeros(cap, np.int32); vals = np.zeros(cap, np.float64)
+    if which == "ref":
+        m = ref_lib().ref_bow_vector(len(word), _p(word, i32_p), _p(weight, dbl_p), int(weighting), cap, _p(ids, i32_p), _p(vals, dbl_p))
+        return ids[:m].copy(), vals[:m].copy()
     m = oracle_lib().orc_bow_vector(len(word), _p(word, i32_p), _p(weight, dbl_p), int(weighting), cap, _p(ids, i32_p), _p(vals, dbl_p))
     return ids[:m].copy(), vals[:m].copy()
 

@@ -18,6 +18,10 @@
 //   ref_edge_eval     EdgeProjection error + g2o numeric Jacobian + Huber weights for ONE edge.
 //   ref_pose_graph    LoopClosing::PoseGraphOptimization (/root/reference/src/ssvio/loopclosing.cpp:458-539):
 //                     VertexPose + EdgePoseGraph, BlockSolver<6,6>, LinearSolverEigen, LM, optimize(20).
+//   ref_bow_vector    the BowVector a TemplatedVocabulary::transform builds from per-feature (word, weight) pairs
+//                     (/root/reference/thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1083-1122), on the reference's OWN
+//                     DBoW2::BowVector (BowVector.cpp:30-84 compiled where it lies: addWeight / addIfNotExist / normalize).
+//                     TemplatedVocabulary.h itself includes OpenCV and cannot be compiled: the tree descent stays unpinned.
 //
 // backend.cpp / frontend.cpp themselves cannot be compiled here (they need OpenCV + Pangolin), so the
 // graph assembly is restated from the cited lines; all arithmetic is the reference's.
@@ -25,6 +29,7 @@
 #include <map>
 #include <vector>
 
+#include "DBoW2/BowVector.h"
 #include "ssvio/algorithm.hpp"
 #include "ssvio/g2otypes.hpp"
 #include "g2o/solvers/eigen/linear_solver_eigen.h"
@@ -403,6 +408,26 @@ void ref_pg_edge_eval(const double* meas7, const double* T0, const double* T1, d
       if (Ji36) Ji36[r * 6 + c] = e.jacobianOplusXi()(r, c);
       if (Jj36) Jj36[r * 6 + c] = e.jacobianOplusXj()(r, c);
     }
+}
+
+// TemplatedVocabulary::transform after the tree descent (TemplatedVocabulary.h:1083-1122): weighting 0 TF_IDF / 1 TF ->
+// addWeight + division by the feature count unless the scoring normalises (L1_NORM: it does); 2 IDF / 3 BINARY ->
+// addIfNotExist; then normalize(L1).  -> number of entries (ids ascending: std::map order)
+int ref_bow_vector(int n, const int32_t* word, const double* weight, int weighting, int cap, int32_t* ids_out, double* vals_out)
+{
+  DBoW2::BowVector v;
+  for (int i = 0; i < n; ++i) {
+    if (!(weight[i] > 0)) continue;
+    if (weighting == 0 || weighting == 1) v.addWeight((DBoW2::WordId)word[i], weight[i]);
+    else v.addIfNotExist((DBoW2::WordId)word[i], weight[i]);
+  }
+  v.normalize(DBoW2::L1);
+  int m = 0;
+  for (const auto& kv : v) {
+    if (m < cap) { ids_out[m] = (int32_t)kv.first; vals_out[m] = kv.second; }
+    ++m;
+  }
+  return m;
 }
 
 }  // extern "C"

@@ -69,6 +69,30 @@ def make_pose_graph_golden():
     print("ref_pg.npz:", os.path.getsize(os.path.join(OUT, "ref_pg.npz")), "bytes,", len(g), "arrays")
 
 
+def bow_inputs(case):
+    """per-feature (word, weight) pairs as a tree descent would deliver them: repeated words, zero weights (stop words)"""
+    rng = np.random.default_rng(900 + case)
+    n = [1500, 40, 1, 700][case]
+    word = rng.integers(0, [1000, 25, 5, 100000][case], n).astype(np.int32)
+    weight = rng.uniform(0.0, 3.0, n)
+    weight[rng.random(n) < 0.1] = 0.0
+    return word, weight
+
+
+def make_bow_golden():
+    """ref_bow.npz: the BowVector of TemplatedVocabulary::transform (TemplatedVocabulary.h:1083-1122) built on the
+    reference's OWN DBoW2::BowVector (BowVector.cpp compiled into oracle/_ref): ids ascending, L1-normalised values, for
+    the four weighting types.  The tree descent and L1Scoring::score include OpenCV headers and stay unpinned."""
+    g = {}
+    for case in range(4):
+        word, weight = bow_inputs(case)
+        for weighting in range(4):
+            ids, vals = po.bow_vector(word, weight, weighting, which="ref")
+            g[f"bow{case}_w{weighting}_ids"] = ids; g[f"bow{case}_w{weighting}_vals"] = vals
+    np.savez_compressed(os.path.join(OUT, "ref_bow.npz"), **g)
+    print("ref_bow.npz:", os.path.getsize(os.path.join(OUT, "ref_bow.npz")), "bytes,", len(g), "arrays")
+
+
 def main():
     assert po.have_ref(), "needs /root/reference (or a prebuilt oracle/_ref/libssvio_ref.so)"
     rng = np.random.default_rng(1234)
@@ -142,6 +166,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "ref_golden.npz"), **g)
     print("ref_golden.npz:", os.path.getsize(os.path.join(OUT, "ref_golden.npz")), "bytes,", len(g), "arrays")
     make_pose_graph_golden()
+    make_bow_golden()
 
     # ---- self pins of the ORB restatement ----
     s = {}

@@ -87,3 +87,24 @@ def test_random_vocabulary_properties():
     other = po.voc_transform(voc, feats[::-1][:150])
     s = po.bow_score_l1((ids, vals), other)
     assert 0.0 < s < 1.0 and abs(s - po.bow_score_l1(other, (ids, vals))) < 1e-15
+
+
+def test_bow_vector_matches_the_reference_bowvector(po):
+    """the BowVector half of transform() against vectors produced by the reference's OWN DBoW2::BowVector (BowVector.cpp
+    compiled into oracle/_ref; tests/golden/ref_bow.npz by make_golden.py): same ids, bit-identical values for TF_IDF / TF
+    (addWeight, input order) and IDF / BINARY (addIfNotExist), L1 normalisation.  The GPU path's BowVector is compared
+    bit-for-bit with this oracle function in tests/test_voc_gpu.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import bow_inputs
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_bow.npz"))
+    for case in range(4):
+        word, weight = bow_inputs(case)
+        for weighting in range(4):
+            ids, vals = po.bow_vector(word, weight, weighting)
+            assert np.array_equal(ids, G[f"bow{case}_w{weighting}_ids"]), (case, weighting)
+            assert vals.tobytes() == G[f"bow{case}_w{weighting}_vals"].tobytes(), (case, weighting)
+            if po.have_ref() and os.path.exists(os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libssvio_ref.so")):
+                li, lv = po.bow_vector(word, weight, weighting, which="ref")
+                assert np.array_equal(li, ids) and lv.tobytes() == vals.tobytes()
