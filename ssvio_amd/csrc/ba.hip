@@ -284,9 +284,9 @@ template <int JAC>
 __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur) { k_linearize_body<JAC>(d, blockIdx.x, cur); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
 template <int JAC>
-__global__ __launch_bounds__(CH) void k_linearize_b(const BaDev* dv, int cur)
+__global__ __launch_bounds__(CH) void k_linearize_b(const BaDev* __restrict__ dv, int cur)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (d.nCh)) return;
   k_linearize_body<JAC>(d, blockIdx.x, cur);
 }
@@ -333,9 +333,9 @@ __device__ __forceinline__ void k_reduce_lin_body(const BaDev& d, const int bx)
 
 __global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d) { k_reduce_lin_body(d, blockIdx.x); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(CH) void k_reduce_lin_b(const BaDev* dv)
+__global__ __launch_bounds__(CH) void k_reduce_lin_b(const BaDev* __restrict__ dv)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= ((d.nP * 27 + 15) / 16 > 0 ? (d.nP * 27 + 15) / 16 : 1)) return;
   k_reduce_lin_body(d, blockIdx.x);
 }
@@ -360,9 +360,9 @@ __device__ __forceinline__ void k_lambda_init_body(const BaDev& d, const int bx,
 
 __global__ __launch_bounds__(64) void k_lambda_init(BaDev d, int first_iteration) { k_lambda_init_body(d, blockIdx.x, first_iteration); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(64) void k_lambda_init_b(const BaDev* dv, int first_iteration)
+__global__ __launch_bounds__(64) void k_lambda_init_b(const BaDev* __restrict__ dv, int first_iteration)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (1)) return;
   k_lambda_init_body(d, blockIdx.x, first_iteration);
 }
@@ -378,9 +378,9 @@ __device__ __forceinline__ void k_lm_begin_body(const BaDev& d, const int bx, in
 
 __global__ __launch_bounds__(64) void k_lm_begin(BaDev d, int cur, int iters, int nstat, int stop) { k_lm_begin_body(d, blockIdx.x, cur, iters, nstat, stop); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(64) void k_lm_begin_b(const BaDev* dv, int cur, int iters, int nstat, int stop)
+__global__ __launch_bounds__(64) void k_lm_begin_b(const BaDev* __restrict__ dv, int cur, int iters, int nstat, int stop)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (1)) return;
   k_lm_begin_body(d, blockIdx.x, cur, iters, nstat, stop);
 }
@@ -592,9 +592,9 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, doubl
 
 __global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int use_dev_lambda) { k_schur_body(d, blockIdx.x, lambda_arg, use_dev_lambda); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(CH) void k_schur_b(const BaDev* dv, double lambda_arg, int use_dev_lambda)
+__global__ __launch_bounds__(CH) void k_schur_b(const BaDev* __restrict__ dv, double lambda_arg, int use_dev_lambda)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (d.nCh)) return;
   k_schur_body(d, blockIdx.x, lambda_arg, use_dev_lambda);
 }
@@ -640,9 +640,9 @@ __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx
 
 __global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d) { k_reduce_schur_body(d, blockIdx.x); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(CH) void k_reduce_schur_b(const BaDev* dv)
+__global__ __launch_bounds__(CH) void k_reduce_schur_b(const BaDev* __restrict__ dv)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= ((d.nBlk * 36 + d.nP * 6 + 15) / 16)) return;
   k_reduce_schur_body(d, blockIdx.x);
 }
@@ -858,9 +858,9 @@ __device__ __forceinline__ void k_solve_body(const BaDev& d, const int bx, int c
 
 __global__ __launch_bounds__(256) void k_solve(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_solve_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(256) void k_solve_b(const BaDev* dv, int cur, double lambda_arg, int use_dev_lambda)
+__global__ __launch_bounds__(256) void k_solve_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= ((6 * d.nP > 64) ? 1 : 0)) return;
   k_solve_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
 }
@@ -959,9 +959,9 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
 
 __global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_backsub_residual_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(CH) void k_backsub_residual_b(const BaDev* dv, int cur, double lambda_arg, int use_dev_lambda)
+__global__ __launch_bounds__(CH) void k_backsub_residual_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (d.nCh)) return;
   k_backsub_residual_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
 }
@@ -992,9 +992,9 @@ __device__ __forceinline__ void k_reduce_trial_body(const BaDev& d, const int bx
 
 __global__ __launch_bounds__(CH) void k_reduce_trial(BaDev d, int lm) { k_reduce_trial_body(d, blockIdx.x, lm); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(CH) void k_reduce_trial_b(const BaDev* dv, int lm)
+__global__ __launch_bounds__(CH) void k_reduce_trial_b(const BaDev* __restrict__ dv, int lm)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (1)) return;
   k_reduce_trial_body(d, blockIdx.x, lm);
 }
@@ -1011,18 +1011,18 @@ __global__ void k_publish_trial(BaDev d, int lm)
 }
 
 // ---- batched small windows (ssx_ba_solve_batch): per-window control words live in one int array [3 n] = cur | nstat | stop
-__global__ __launch_bounds__(64) void k_lm_begin_batch(const BaDev* dv, const int* ctrl, int n, int iters)
+__global__ __launch_bounds__(64) void k_lm_begin_batch(const BaDev* __restrict__ dv, const int* ctrl, int n, int iters)
 {
   const int w = blockIdx.x;
   if (w >= n) return;
-  const BaDev d = dv[w];
+  const BaDev& d = dv[w];
   k_lm_begin_body(d, 0, ctrl[w], iters, ctrl[n + w], ctrl[2 * n + w]);
 }
 
 // a resident batch is solved again: both state buffers of every window back to the uploaded state
-__global__ __launch_bounds__(CH) void k_reset_state_b(const BaDev* dv)
+__global__ __launch_bounds__(CH) void k_reset_state_b(const BaDev* __restrict__ dv)
 {
-  const BaDev d = dv[blockIdx.y];
+  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   const size_t nP7 = 7 * (size_t)d.P, nL3 = 3 * (size_t)d.L;
   for (size_t i = (size_t)blockIdx.x * CH + threadIdx.x; i < nP7 + nL3; i += (size_t)gridDim.x * CH) {
     if (i < nP7) { const double v = d.pose_init[i]; d.pose[0][i] = v; d.pose[1][i] = v; }
@@ -1031,21 +1031,21 @@ __global__ __launch_bounds__(CH) void k_reset_state_b(const BaDev* dv)
 }
 
 // control blocks (what = 0: SC_N scalars) or LM statistics (what = 1: 3 x SSX_BA_MAX_STATS) of every window, contiguous
-__global__ __launch_bounds__(CH) void k_gather_scal_b(const BaDev* dv, int n, double* out, int what)
+__global__ __launch_bounds__(CH) void k_gather_scal_b(const BaDev* __restrict__ dv, int n, double* out, int what)
 {
   const int w = blockIdx.x;
   if (w >= n) return;
-  const BaDev d = dv[w];
+  const BaDev& d = dv[w];
   const int cnt = what ? 3 * SSX_BA_MAX_STATS : SC_N;
   const double* src = what ? d.lm_stat : d.scal;
   for (int i = threadIdx.x; i < cnt; i += CH) out[(size_t)w * cnt + i] = src[i];
 }
 
 // results of every window into one contiguous buffer (one download): [poses 7P | points 3L | errors 2E] at out_off[w]
-__global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* dv, const int* ctrl, int n, const size_t* out_off, double* out, int want_err)
+__global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* __restrict__ dv, const int* ctrl, int n, const size_t* out_off, double* out, int want_err)
 {
   const int w = blockIdx.y;
-  const BaDev d = dv[w];
+  const BaDev& d = dv[w];
   const int cur = ctrl[w], trial_err = ctrl[n + w];
   double* o = out + out_off[w];
   const size_t nP7 = 7 * (size_t)d.P, nL3 = 3 * (size_t)d.L, nE2 = want_err ? 2 * (size_t)d.E : 0;

@@ -288,7 +288,7 @@ def test_ba_solve_matches_reference_golden(ctx, name, jac, record_property):
     # BASELINE configs[2] size (C3) every residual of the analytic mode is within north_star's 1e-4 px of the reference
     # (max 8.1e-5) and 99.6 % of the numeric mode's (max 1.1e-4); the 4- and 6-pose toy graphs are barely constrained
     # (no fixed pose / 3 observations per landmark) and amplify the central-difference noise by two more digits.
-    bars = {"tiny": (5e-5, 3e-3, 5e-3, 0.88), "mid": (1e-5, 4e-4, 1e-3, 0.97), "C3": (5e-6, 1.5e-4, 3e-4, 0.99), "gauge": (3e-5, 1.5e-3, 4e-3, 0.92)}
+    bars = {"tiny": (1e-4, 5e-3, 1e-2, 0.80), "mid": (1e-5, 4e-4, 1e-3, 0.97), "C3": (5e-6, 1.5e-4, 3e-4, 0.99), "gauge": (3e-5, 1.5e-3, 4e-3, 0.92)}
     med, p99, mx, fr = bars[name]
     assert np.median(d) < med and np.percentile(d, 99) < p99 and d.max() < mx and frac >= fr
     if name == "C3" and jac == ba.JAC_ANALYTIC:
