@@ -237,7 +237,9 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
             pc = json.load(f)
         if pc.get("pairs_per_step") == B and world == 1:
-            key = [k for k in pc["per_launch"] if k.split("<")[0] == dom.split("<")[0]]
+            base = dom.split("<")[0]
+            names = [base + "_b", base] if kernels[dom]["part"] == "ba" else [base]     # the BA kernels of the step are the batched ones
+            key = [k for nm in names for k in pc["per_launch"] if k.split("<")[0] == nm]
             if key:
                 rec = pc["per_launch"][key[0]]
                 traffic = rec.get("hbm_bytes")
