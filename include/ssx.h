@@ -195,6 +195,9 @@ SSX_API ssx_status ssx_ba_batch_solve(ssx_ba_batch* batch, ssx_ba_result* result
 SSX_API int32_t ssx_ba_batch_size(const ssx_ba_batch* batch);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
 
+/* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */
+SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps);
+
 /* One linearisation of the problem at its current state (no update): the blocks the kernels build,
  * for kernel-level parity tests and profiling.  Any output may be NULL.
  *   Hpp P x 36 (row-major 6x6), bp P x 6, Hll L x 9, bl L x 3, Hpl E x 18 (6x3 row-major, per edge),

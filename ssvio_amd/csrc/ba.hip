@@ -37,6 +37,7 @@
 // iteration, [S | b_s] once per trial before the (replicated, deterministic) solve, [chi2', scale, #outliers]
 // once per trial after the residual pass.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <numeric>
@@ -2398,6 +2399,18 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
 }  // namespace
 
 extern "C" {
+
+// tools hook (no GPU needed): seconds of host marshalling (edge sort, chunks, index lists) of one problem
+double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps)
+{
+  if (!prob || reps < 1) return -1.0;
+  ssx_ctx dummy;
+  static thread_local HostPrep h;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < reps; ++i)
+    if (prepare(&dummy, prob, h) != SSX_OK) return -1.0;
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+}
 
 ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt_in, ssx_ba_result* results)
 {
