@@ -72,6 +72,9 @@ struct BaDev {
   // problem (uploaded once per ssx_ba_solve)
   int P, L, E, nP, nLm, nCh, nBlk, world, rank;
   int big;                  // large-window path (free poses > SSX_BA_SMALL_P): pose blocks / Schur / solve in ba_big.inc
+  int store_w;              // 1: k_linearize stores W = Ji^T w Jj (144 B per edge) for the later kernels (large windows, numeric
+                            // Jacobians, the linearize hook); 0: small windows with analytic Jacobians RECOMPUTE it where needed --
+                            // 150 flops per edge instead of one 144-byte write and two reads
   int lin_stride;           // doubles per chunk in lin_slab: nP*27 + 2 (small) or 2 (big)
   const int* pose_free;     // P: free index or -1
   const uint8_t* lm_fixed;  // nLm (compact landmarks = landmarks that have edges)
@@ -216,11 +219,13 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     const double r0 = -er[0] * w, r1 = -er[1] * w;
     // W = Ji^T w Jj  (6x3), only when both vertices are free (block_solver.hpp:196-222)
     const bool both = (pf >= 0) && lfree;
+    if (d.store_w) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+      for (int a = 0; a < 6; ++a)
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
-        d.W[(size_t)(a * 3 + b) * d.E + e] = both ? (Ji[a] * w * Jj[b] + Ji[6 + a] * w * Jj[3 + b]) : 0.0;
+        for (int b = 0; b < 3; ++b)
+          d.W[(size_t)(a * 3 + b) * d.E + e] = both ? (Ji[a] * w * Jj[b] + Ji[6 + a] * w * Jj[3 + b]) : 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < 12; ++k) sJi[k][t] = Ji[k];
     sW1[t] = w; sR0[t] = r0; sR1[t] = r1;
@@ -442,12 +447,43 @@ __global__ void k_set_lambda(BaDev d, double lambda)
   if (threadIdx.x == 0 && blockIdx.x == 0) d.scal[SC_LAMBDA] = lambda;
 }
 
+// W_e = Ji^T w Jj (6x3) of sorted edge e at the linearisation state `cur`: what k_linearize computes, recomputed by the
+// kernels that need it when d.store_w == 0 (analytic Jacobians: the same instruction sequence, the same bits)
+__device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W)
+{
+  const int p = d.e_pose[e];
+  const int lc = d.e_lmc[e];
+  const int lid = d.lm_id[lc];
+  const bool both = d.pose_free[p] >= 0 && !d.lm_fixed[lc];
+  if (!both) {
+#pragma unroll
+    for (int k = 0; k < 18; ++k) W[k] = 0.0;
+    return;
+  }
+  const double* pose = d.pose[cur];
+  const double* point = d.point[cur];
+  double T[7], X[3];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) T[k] = pose[p * 7 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) X[k] = point[lid * 3 + k];
+  const double* ext = d.ext + 7 * d.e_cam[e];
+  double er[2], p1[3], pc[3], Ji[12], Jj[6], rho0, w;
+  ssx::edge_error(T, X, ext, d.K, d.e_uv[e], d.e_uv[d.E + e], er, p1, pc);
+  ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
+  ssx::huber(er[0] * er[0] + er[1] * er[1], d.huber_delta, rho0, w);
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) W[a * 3 + b] = Ji[a] * w * Jj[b] + Ji[6 + a] * w * Jj[3 + b];
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_schur: landmark elimination for one chunk at damping lambda.
 // restates the marginalisation loop of BlockSolver::solve (block_solver.hpp:342-393):
 //   Dinv = (Hll + lambda I)^-1 ; c_i += W_i Dinv bl ; S_ij -= (W_i Dinv) W_j^T  (upper blocks)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, double lambda_arg, int use_dev_lambda)
+__device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // With D = Hll + lambda I = L L^T (3x3 Cholesky) and Y_e = W_e L^-T, the Schur term of an edge pair is
@@ -468,6 +504,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, doubl
 
   const int c = bx, t = threadIdx.x;
   if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
+  if (cur < 0) cur = (int)d.scal[SC_CUR];
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
   const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
@@ -492,12 +529,22 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, doubl
     const int pf = d.pose_free[d.e_pose[e]];
     leader = (pf >= 0) && !d.lm_fixed[lc] && !d.e_dup[e];
     if (leader) {
-#pragma unroll
-      for (int k = 0; k < 18; ++k) Wm[k] = d.W[(size_t)k * d.E + e];
       // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
-      for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j)
+      if (d.store_w) {
 #pragma unroll
-        for (int k = 0; k < 18; ++k) Wm[k] += d.W[(size_t)k * d.E + e0 + j];
+        for (int k = 0; k < 18; ++k) Wm[k] = d.W[(size_t)k * d.E + e];
+        for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j)
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Wm[k] += d.W[(size_t)k * d.E + e0 + j];
+      } else {
+        edge_W(d, cur, e, Wm);
+        for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j) {
+          double Wd[18];
+          edge_W(d, cur, e0 + j, Wd);
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Wm[k] += Wd[k];
+        }
+      }
     }
   }
   sLeader[t] = leader ? 1 : 0;
@@ -591,13 +638,13 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, doubl
   }
 }
 
-__global__ __launch_bounds__(CH) void k_schur(BaDev d, double lambda_arg, int use_dev_lambda) { k_schur_body(d, blockIdx.x, lambda_arg, use_dev_lambda); }
+__global__ __launch_bounds__(CH) void k_schur(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_schur_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(CH) void k_schur_b(const BaDev* __restrict__ dv, double lambda_arg, int use_dev_lambda)
+__global__ __launch_bounds__(CH) void k_schur_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (d.nCh)) return;
-  k_schur_body(d, blockIdx.x, lambda_arg, use_dev_lambda);
+  k_schur_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
 }
 
 // slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c).
@@ -893,12 +940,19 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
     const int pf = d.pose_free[d.e_pose[e]];
     double p0 = 0.0, p1 = 0.0, p2 = 0.0;
     if (pf >= 0) {
+      double Wr[18];
+      if (d.store_w) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Wr[k] = d.W[(size_t)k * d.E + e];
+      } else {
+        edge_W(d, cur, e, Wr);
+      }
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const double xa = d.xp[pf * 6 + a];
-        p0 = fma(d.W[(size_t)(a * 3) * d.E + e], xa, p0);
-        p1 = fma(d.W[(size_t)(a * 3 + 1) * d.E + e], xa, p1);
-        p2 = fma(d.W[(size_t)(a * 3 + 2) * d.E + e], xa, p2);
+        p0 = fma(Wr[a * 3], xa, p0);
+        p1 = fma(Wr[a * 3 + 1], xa, p1);
+        p2 = fma(Wr[a * 3 + 2], xa, p2);
       }
     }
     sPart[0][t] = p0; sPart[1][t] = p1; sPart[2][t] = p2;
@@ -1494,6 +1548,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
 
   d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
   d.big = big ? 1 : 0; d.lin_stride = lin_stride;
+  d.store_w = 1;                                 // the caller clears it for small windows with analytic Jacobians
   d.pose_free = (const int*)(at(o_pose_free));
   d.lm_fixed = (const uint8_t*)(at(o_lm_fixed));
   d.lm_id = (const int*)(at(o_lm_id));
@@ -1837,6 +1892,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   BandDev bnd;
   st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd);
   if (st != SSX_OK) return st;
+  d.store_w = (d.big || opt.jac_mode == SSX_JAC_NUMERIC_G2O) ? 1 : 0;
   BaWorkspace* ws = ctx->ba;
   double* hscal = ws->scal.as<double>();
   const int n = 6 * d.nP;
@@ -1953,7 +2009,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
           if (first_slot || cm.fn) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_slot ? 1 : 0));
           first_slot = false;
           if (n > 0) {
-            if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, 0.0, 2));
+            if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, -1, 0.0, 2));
             SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
             st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
             if (st != SSX_OK) return st;
@@ -2009,7 +2065,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
           if (st != SSX_OK) return st;
         } else {
         if (n > 0) {
-          if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, lambda, dev_lambda));
+          if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, cur, lambda, dev_lambda));
           SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
           st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
           if (st != SSX_OK) return st;
@@ -2241,6 +2297,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     place[w].rest_dev = dev_base + a_rest + rest_off[w];
     place[w].in_host = hst + in_off[w];
     sts[w] = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w]);
+    B->devs[w].store_w = opt.jac_mode == SSX_JAC_NUMERIC_G2O ? 1 : 0;
     if (with_err) B->perm[w] = preps[w].perm;
   });
   for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
@@ -2310,7 +2367,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
         SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_b, gRl, dim3(CH), 0, s, dv));
         if (first_slot) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init_b, gOne, dim3(64), 0, s, dv, 1));
         first_slot = false;
-        SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gCh, dim3(CH), lds_schur, s, dv, 0.0, 2));
+        SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gCh, dim3(CH), lds_schur, s, dv, -1, 0.0, 2));
         SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, s, dv));
         if (B->any_solve64) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, s, dv, -1, 0.0, 1));
         if (B->any_solve) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(256), 0, s, dv, -1, 0.0, 1));
