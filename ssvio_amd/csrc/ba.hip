@@ -88,6 +88,10 @@ struct BaDev {
   const double* e_uv;       // [2][E]
   const int8_t* blk_pa;     // nBlk upper blocks (pa<=pb) of the reduced system
   const int8_t* blk_pb;
+  // packed records: ONE 16-byte load per chunk / edge / landmark instead of a chain of dependent index loads
+  const int4* ch_desc;      // nCh: first sorted edge, #edges, first compact landmark, #landmarks
+  const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bits 8.. chunk-local landmark
+  const int4* l_rec;        // nLm: chunk-local first edge, #edges, landmark id (caller's), fixed
   const uint8_t* porder;    // E: chunk-local edge indices grouped by free pose (fixed-pose edges last)
   const uint16_t* pptr;     // nCh x (nP+1): segment of each pose inside the chunk's porder
   const uint8_t* pair_a;    // nPairs: chunk-local leader edge a (pose pa)
@@ -181,9 +185,8 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     if (d.scal[SC_STOP] != 0.0 || d.scal[SC_NEEDLIN] == 0.0) return;   // kept state is still valid (rejected trial)
     cur = (int)d.scal[SC_CUR];
   }
-  const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
-  const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
-  const int ne = e1 - e0, nl = lm1 - lm0;
+  const int4 cd = d.ch_desc[c];
+  const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const double* pose = d.pose[cur];
   const double* point = d.point[cur];
 
@@ -194,17 +197,15 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
   }
   if (t < ne) {
     const int e = e0 + t;
-    const int p = d.e_pose[e];
-    const int lc = d.e_lmc[e];
-    const int lid = d.lm_id[lc];
-    const int pf = d.pose_free[p];
-    const bool lfree = !d.lm_fixed[lc];
+    const int4 er4 = d.e_rec[e];
+    const int p = er4.x, pf = er4.y, lid = er4.z;
+    const bool lfree = !(er4.w & 4);
     double T[7], X[3];
 #pragma unroll
     for (int k = 0; k < 7; ++k) T[k] = pose[p * 7 + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) X[k] = point[lid * 3 + k];
-    const double* ext = d.ext + 7 * d.e_cam[e];
+    const double* ext = d.ext + 7 * (er4.w & 1);
     const double u = d.e_uv[e], v = d.e_uv[d.E + e];
     double er[2], p1[3], pc[3], Ji[12], Jj[6];
     ssx::edge_error(T, X, ext, d.K, u, v, er, p1, pc);
@@ -244,7 +245,8 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
   double maxd = 0.0;
   if (t < nl) {
     const int lc = lm0 + t;
-    const int a0 = d.lm_ptr[lc] - e0, a1 = d.lm_ptr[lc + 1] - e0;
+    const int4 lr = d.l_rec[lc];
+    const int a0 = lr.x, a1 = lr.x + lr.y;
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = a0; j < a1; ++j)
 #pragma unroll
@@ -451,10 +453,9 @@ __global__ void k_set_lambda(BaDev d, double lambda)
 // kernels that need it when d.store_w == 0 (analytic Jacobians: the same instruction sequence, the same bits)
 __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W)
 {
-  const int p = d.e_pose[e];
-  const int lc = d.e_lmc[e];
-  const int lid = d.lm_id[lc];
-  const bool both = d.pose_free[p] >= 0 && !d.lm_fixed[lc];
+  const int4 er4 = d.e_rec[e];
+  const int p = er4.x, lid = er4.z;
+  const bool both = er4.y >= 0 && !(er4.w & 4);
   if (!both) {
 #pragma unroll
     for (int k = 0; k < 18; ++k) W[k] = 0.0;
@@ -467,7 +468,7 @@ __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W
   for (int k = 0; k < 7; ++k) T[k] = pose[p * 7 + k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) X[k] = point[lid * 3 + k];
-  const double* ext = d.ext + 7 * d.e_cam[e];
+  const double* ext = d.ext + 7 * (er4.w & 1);
   double er[2], p1[3], pc[3], Ji[12], Jj[6], rho0, w;
   ssx::edge_error(T, X, ext, d.K, d.e_uv[e], d.e_uv[d.E + e], er, p1, pc);
   ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
@@ -506,9 +507,8 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
   if (cur < 0) cur = (int)d.scal[SC_CUR];
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
-  const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
-  const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
-  const int ne = e1 - e0, nl = lm1 - lm0;
+  const int4 cd = d.ch_desc[c];
+  const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const int nP = d.nP;
 
   bool leader = false;
@@ -524,10 +524,9 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   }
   if (t < ne) {
     const int e = e0 + t;
-    const int lc = d.e_lmc[e];
-    sLm[t] = lc - lm0;
-    const int pf = d.pose_free[d.e_pose[e]];
-    leader = (pf >= 0) && !d.lm_fixed[lc] && !d.e_dup[e];
+    const int4 er4 = d.e_rec[e];
+    sLm[t] = er4.w >> 8;
+    leader = (er4.y >= 0) && !(er4.w & 6);                    // free pose, free landmark, not a duplicate
     if (leader) {
       // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
       if (d.store_w) {
@@ -600,6 +599,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
       for (int j = 0; j < 3; ++j) acc[i][j] = 0.0;
     const double* bdp = sY + (qr * 9) * PW;                              // component (row r, m) of Y = r * 3 + m
     const double* wp = sY + (qc * 9) * PW;
+#pragma unroll 2
     for (int q = q0; q < q1; ++q) {
       const int ea = sPa[q], eb = sPb[q];
       double bd[3][3], w[3][3];
@@ -929,15 +929,16 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
     cur = (int)d.scal[SC_CUR];
   }
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
-  const int lm0 = d.ch_lm[c], lm1 = d.ch_lm[c + 1];
-  const int e0 = d.lm_ptr[lm0], e1 = d.lm_ptr[lm1];
-  const int ne = e1 - e0, nl = lm1 - lm0;
+  const int4 cd = d.ch_desc[c];
+  const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const double* pt_src = d.point[cur];
   double* pt_dst = d.point[cur ^ 1];
+  int4 er4 = make_int4(0, -1, 0, 0);
+  if (t < ne) er4 = d.e_rec[e0 + t];
   // W_e^T x_p of every edge (one thread per edge: the 18 component loads are coalesced), summed per landmark below
   if (t < ne) {
     const int e = e0 + t;
-    const int pf = d.pose_free[d.e_pose[e]];
+    const int pf = er4.y;
     double p0 = 0.0, p1 = 0.0, p2 = 0.0;
     if (pf >= 0) {
       double Wr[18];
@@ -961,9 +962,10 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
   double scale_l = 0.0;
   if (t < nl) {
     const int lc = lm0 + t;
-    const int lid = d.lm_id[lc];
+    const int4 lr = d.l_rec[lc];
+    const int lid = lr.z;
     double X[3] = {pt_src[lid * 3], pt_src[lid * 3 + 1], pt_src[lid * 3 + 2]};
-    if (!d.lm_fixed[lc]) {
+    if (!lr.w) {
       double D[6], Di[9];
 #pragma unroll
       for (int k = 0; k < 6; ++k) D[k] = d.Hll[(size_t)k * d.nLm + lc];
@@ -971,7 +973,7 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
       ssx::inv3_sym(D, Di);
       const double b[3] = {d.bl[lc], d.bl[(size_t)d.nLm + lc], d.bl[(size_t)2 * d.nLm + lc]};
       double cl[3] = {b[0], b[1], b[2]};
-      for (int j = d.lm_ptr[lc] - e0; j < d.lm_ptr[lc + 1] - e0; ++j) { cl[0] -= sPart[0][j]; cl[1] -= sPart[1][j]; cl[2] -= sPart[2][j]; }
+      for (int j = lr.x; j < lr.x + lr.y; ++j) { cl[0] -= sPart[0][j]; cl[1] -= sPart[1][j]; cl[2] -= sPart[2][j]; }
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const double xl = Di[r * 3] * cl[0] + Di[r * 3 + 1] * cl[1] + Di[r * 3 + 2] * cl[2];
@@ -986,20 +988,20 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
   double rho0 = 0.0, nout = 0.0;
   if (t < ne) {
     const int e = e0 + t;
-    const int p = d.e_pose[e];
-    const int l = d.e_lmc[e] - lm0;
+    const int p = er4.x;
+    const int l = er4.w >> 8;
     const double* pose = d.pose[cur ^ 1];
     double T[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) T[k] = pose[p * 7 + k];
     const double X[3] = {sPt[0][l], sPt[1][l], sPt[2][l]};
     double er[2], p1[3], pc[3], w;
-    ssx::edge_error(T, X, d.ext + 7 * d.e_cam[e], d.K, d.e_uv[e], d.e_uv[d.E + e], er, p1, pc);
+    ssx::edge_error(T, X, d.ext + 7 * (er4.w & 1), d.K, d.e_uv[e], d.e_uv[d.E + e], er, p1, pc);
     d.err_trial[e] = er[0];
     d.err_trial[d.E + e] = er[1];
     const double c2 = er[0] * er[0] + er[1] * er[1];
     ssx::huber(c2, d.huber_delta, rho0, w);
-    if (d.pose_free[p] < 0 && d.lm_fixed[d.e_lmc[e]]) rho0 = 0.0;   // inactive edge (all vertices fixed)
+    if (er4.y < 0 && (er4.w & 4)) rho0 = 0.0;                        // inactive edge (all vertices fixed)
     nout = (c2 > d.chi2_th) ? 1.0 : 0.0;
   }
   const double chi = block_sum_256(rho0, sRed);
@@ -1153,6 +1155,7 @@ struct HostPrep {
   // large-window path
   bool big = false;
   std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr, spair_a, spair_b;
+  std::vector<int> ch_desc, e_rec, l_rec;   // packed records (4 ints each), see BaDev
   int band_w = -1;          // cyclic block bandwidth of this rank's part of the reduced system (max over its non-zero blocks)
 };
 
@@ -1233,6 +1236,21 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   if (h.nLm > 0) h.ch_lm.push_back(h.nLm);
   h.nCh = (int)h.ch_lm.size() - 1;
   if (h.nCh < 0) h.nCh = 0;
+  h.ch_desc.resize(4 * (size_t)std::max(h.nCh, 1)); h.e_rec.resize(4 * (size_t)std::max(E, 1)); h.l_rec.resize(4 * (size_t)std::max(h.nLm, 1));
+  for (int c = 0; c < h.nCh; ++c) {
+    const int lm0 = h.ch_lm[c], lm1 = h.ch_lm[c + 1], e0 = h.lm_ptr[lm0], e1 = h.lm_ptr[lm1];
+    int* cd = &h.ch_desc[4 * (size_t)c];
+    cd[0] = e0; cd[1] = e1 - e0; cd[2] = lm0; cd[3] = lm1 - lm0;
+    for (int lc = lm0; lc < lm1; ++lc) {
+      int* lr = &h.l_rec[4 * (size_t)lc];
+      lr[0] = h.lm_ptr[lc] - e0; lr[1] = h.lm_ptr[lc + 1] - h.lm_ptr[lc]; lr[2] = h.lm_id[lc]; lr[3] = h.lm_fixed[lc];
+      for (int s2 = h.lm_ptr[lc]; s2 < h.lm_ptr[lc + 1]; ++s2) {
+        int* er = &h.e_rec[4 * (size_t)s2];
+        er[0] = h.e_pose[s2]; er[1] = h.pose_free[h.e_pose[s2]]; er[2] = h.lm_id[lc];
+        er[3] = (int)h.e_cam[s2] | ((int)h.e_dup[s2] << 1) | ((int)h.lm_fixed[lc] << 2) | ((lc - lm0) << 8);
+      }
+    }
+  }
   h.blk_pa.clear(); h.blk_pb.clear();
   if (h.nP <= SSX_BA_SMALL_P)
     for (int a = 0; a < h.nP; ++a)
@@ -1411,6 +1429,9 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_e_cam = in.take(E);
   const size_t o_e_dup = in.take(E);
   const size_t o_e_uv = in.take(sizeof(double) * 2 * E);
+  const size_t o_ch_desc = in.take(sizeof(int) * 4 * (size_t)(nCh + 1));
+  const size_t o_e_rec = in.take(sizeof(int) * 4 * (size_t)(E + 1));
+  const size_t o_l_rec = in.take(sizeof(int) * 4 * (size_t)(nLm + 1));
   const size_t o_blk_pa = in.take(nBlk + 1);
   const size_t o_blk_pb = in.take(nBlk + 1);
   const size_t o_porder = in.take(E + 1);
@@ -1495,6 +1516,9 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_lm_id, h.lm_id.data(), sizeof(int) * nLm);
   }
   memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (nLm + 1));
+  if (nCh) memcpy(hs + o_ch_desc, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
+  if (E) memcpy(hs + o_e_rec, h.e_rec.data(), sizeof(int) * 4 * (size_t)E);
+  if (nLm) memcpy(hs + o_l_rec, h.l_rec.data(), sizeof(int) * 4 * (size_t)nLm);
   memcpy(hs + o_ch_lm, h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
   if (E) {
     memcpy(hs + o_e_pose, h.e_pose.data(), sizeof(int) * E);
@@ -1559,6 +1583,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.e_cam = (const uint8_t*)(at(o_e_cam));
   d.e_dup = (const uint8_t*)(at(o_e_dup));
   d.e_uv = (const double*)(at(o_e_uv));
+  d.ch_desc = (const int4*)(at(o_ch_desc)); d.e_rec = (const int4*)(at(o_e_rec)); d.l_rec = (const int4*)(at(o_l_rec));
   d.blk_pa = (const int8_t*)(at(o_blk_pa));
   d.blk_pb = (const int8_t*)(at(o_blk_pb));
   d.porder = (const uint8_t*)(at(o_porder));
