@@ -170,21 +170,25 @@ __device__ __forceinline__ double block_max_256(double v, double* s)
 // restates BlockSolver::buildSystem (thirdparty/g2o/g2o/core/block_solver.hpp:463-521) +
 // BaseBinaryEdge::constructQuadraticForm (base_binary_edge.hpp:61-134) for EdgeProjection.
 // ------------------------------------------------------------------------------------------------
+// LDS of the linearisation (carved from the workgroup's dynamic LDS so that the fused k_lin_schur can reuse the same
+// bytes for the Schur phase)
+constexpr size_t LIN_LDS_BYTES = sizeof(double) * (12 * (CH + 1) + 3 * CH + 9 * CH + CH) + CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) + 64;
+
+// Wout (18, nullable): this thread's edge block W = Ji^T w Jj stays in registers for the caller; lmout (9, nullable):
+// this thread's landmark sums (Hll 6 + bl 3).  cur must be >= 0 (the device-driven checks are the wrappers').
 template <int JAC>
-__device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur)
+__device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur, char* smem, double* Wout, double* lmout)
 {
-  __shared__ double sJi[12][CH + 1];  // Jacobian wrt pose, [component][edge]; odd pitch: rows land on different banks
-  __shared__ double sW1[CH], sR0[CH], sR1[CH];
-  __shared__ double sL[9][CH];        // per-edge landmark contributions (6 Hll + 3 bl)
-  __shared__ double sRed[CH];
-  __shared__ uint8_t sOrd[CH];
-  __shared__ uint16_t sPptr[SSX_BA_SMALL_P + 1];
+  double (*sJi)[CH + 1] = reinterpret_cast<double (*)[CH + 1]>(smem);   // [12]: Jacobian wrt pose, [component][edge]; odd pitch: rows land on different banks
+  double* sW1 = reinterpret_cast<double*>(smem) + 12 * (CH + 1);
+  double* sR0 = sW1 + CH;
+  double* sR1 = sR0 + CH;
+  double (*sL)[CH] = reinterpret_cast<double (*)[CH]>(sR1 + CH);        // [9]: per-edge landmark contributions (6 Hll + 3 bl)
+  double* sRed = sR1 + CH + 9 * CH;
+  uint8_t* sOrd = reinterpret_cast<uint8_t*>(sRed + CH);
+  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sOrd + CH);
 
   const int c = bx, t = threadIdx.x;
-  if (cur < 0) {                                   // device-driven LM: skip when stopped or when the linearisation at the
-    if (d.scal[SC_STOP] != 0.0 || d.scal[SC_NEEDLIN] == 0.0) return;   // kept state is still valid (rejected trial)
-    cur = (int)d.scal[SC_CUR];
-  }
   const int4 cd = d.ch_desc[c];
   const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const double* pose = d.pose[cur];
@@ -220,12 +224,15 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     const double r0 = -er[0] * w, r1 = -er[1] * w;
     // W = Ji^T w Jj  (6x3), only when both vertices are free (block_solver.hpp:196-222)
     const bool both = (pf >= 0) && lfree;
-    if (d.store_w) {
+    if (d.store_w || Wout) {
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
-          d.W[(size_t)(a * 3 + b) * d.E + e] = both ? (Ji[a] * w * Jj[b] + Ji[6 + a] * w * Jj[3 + b]) : 0.0;
+        for (int b = 0; b < 3; ++b) {
+          const double wv = both ? (Ji[a] * w * Jj[b] + Ji[6 + a] * w * Jj[3 + b]) : 0.0;
+          if (d.store_w) d.W[(size_t)(a * 3 + b) * d.E + e] = wv;
+          if (Wout) Wout[a * 3 + b] = wv;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) sJi[k][t] = Ji[k];
@@ -255,6 +262,10 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     for (int k = 0; k < 6; ++k) d.Hll[(size_t)k * d.nLm + lc] = acc[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) d.bl[(size_t)k * d.nLm + lc] = acc[6 + k];
+    if (lmout) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) lmout[k] = acc[k];
+    }
     maxd = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
   }
 
@@ -289,14 +300,24 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
 }
 
 template <int JAC>
-__global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur) { k_linearize_body<JAC>(d, blockIdx.x, cur); }
+__device__ __forceinline__ void k_linearize_entry(const BaDev& d, int bx, int cur)
+{
+  extern __shared__ __attribute__((aligned(16))) char lin_smem[];
+  if (cur < 0) {                                   // device-driven LM: skip when stopped or when the linearisation at the
+    if (d.scal[SC_STOP] != 0.0 || d.scal[SC_NEEDLIN] == 0.0) return;   // kept state is still valid (rejected trial)
+    cur = (int)d.scal[SC_CUR];
+  }
+  k_linearize_body<JAC>(d, bx, cur, lin_smem, nullptr, nullptr);
+}
+template <int JAC>
+__global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur) { k_linearize_entry<JAC>(d, blockIdx.x, cur); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
 template <int JAC>
 __global__ __launch_bounds__(CH) void k_linearize_b(const BaDev* __restrict__ dv, int cur)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (d.nCh)) return;
-  k_linearize_body<JAC>(d, blockIdx.x, cur);
+  k_linearize_entry<JAC>(d, blockIdx.x, cur);
 }
 
 // slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|: 16 chunk-lanes per entry, 16 entries per 256-thread
@@ -484,9 +505,10 @@ __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W
 // restates the marginalisation loop of BlockSolver::solve (block_solver.hpp:342-393):
 //   Dinv = (Hll + lambda I)^-1 ; c_i += W_i Dinv bl ; S_ij -= (W_i Dinv) W_j^T  (upper blocks)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int cur, double lambda_arg, int use_dev_lambda)
+// Win (18, nullable): this thread's edge block W from a linearisation phase that just ran in the same kernel; lmin (9,
+// nullable): this thread's landmark sums (Hll 6 + bl 3).  The stop / state checks are the wrappers'.
+__device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int cur, double lambda, char* smem, const double* Win, const double* lmin)
 {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   // With D = Hll + lambda I = L L^T (3x3 Cholesky) and Y_e = W_e L^-T, the Schur term of an edge pair is
   // W_a D^-1 W_b^T = Y_a Y_b^T and W D^-1 bl = Y (L^-1 bl): ONE 6x3 array per edge in LDS instead of W and W D^-1
   // (37 KB per chunk instead of 74; with <= 128 landmarks per chunk the whole workgroup needs 53 KB: three per CU).
@@ -504,9 +526,6 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   uint8_t* sPb = sPa + MAX_PAIRS;                                    // [MAX_PAIRS]
 
   const int c = bx, t = threadIdx.x;
-  if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
-  if (cur < 0) cur = (int)d.scal[SC_CUR];
-  const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
   const int4 cd = d.ch_desc[c];
   const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const int nP = d.nP;
@@ -529,20 +548,25 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     leader = (er4.y >= 0) && !(er4.w & 6);                    // free pose, free landmark, not a duplicate
     if (leader) {
       // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
-      if (d.store_w) {
+      if (Win) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Wm[k] = Win[k];
+      } else if (d.store_w) {
 #pragma unroll
         for (int k = 0; k < 18; ++k) Wm[k] = d.W[(size_t)k * d.E + e];
-        for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j)
-#pragma unroll
-          for (int k = 0; k < 18; ++k) Wm[k] += d.W[(size_t)k * d.E + e0 + j];
       } else {
         edge_W(d, cur, e, Wm);
-        for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j) {
-          double Wd[18];
-          edge_W(d, cur, e0 + j, Wd);
+      }
+      for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j) {
+        double Wd[18];
+        if (d.store_w) {                                   // (written by this workgroup's linearisation phase, a barrier ago, when fused)
 #pragma unroll
-          for (int k = 0; k < 18; ++k) Wm[k] += Wd[k];
+          for (int k = 0; k < 18; ++k) Wd[k] = d.W[(size_t)k * d.E + e0 + j];
+        } else {
+          edge_W(d, cur, e0 + j, Wd);
         }
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Wm[k] += Wd[k];
       }
     }
   }
@@ -551,7 +575,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     const int lc = lm0 + t;
     double D[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) D[k] = d.Hll[(size_t)k * d.nLm + lc];
+    for (int k = 0; k < 6; ++k) D[k] = lmin ? lmin[k] : d.Hll[(size_t)k * d.nLm + lc];
     D[0] += lambda; D[3] += lambda; D[5] += lambda;
     // D = (d00 d01 d02 d11 d12 d22); a non-positive pivot yields NaN, the reduced solve then reports failure and the
     // LM step is rejected (g2o: Cholesky failure)
@@ -561,7 +585,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     const double l21 = (D[4] - l20 * l10) * i11;
     const double i22 = 1.0 / sqrt(D[5] - l20 * l20 - l21 * l21);
     sG[t] = i00; sG[PL + t] = l10; sG[2 * PL + t] = l20; sG[3 * PL + t] = i11; sG[4 * PL + t] = l21; sG[5 * PL + t] = i22;
-    const double b0 = d.bl[lc], b1 = d.bl[(size_t)d.nLm + lc], b2 = d.bl[(size_t)2 * d.nLm + lc];
+    const double b0 = lmin ? lmin[6] : d.bl[lc], b1 = lmin ? lmin[7] : d.bl[(size_t)d.nLm + lc], b2 = lmin ? lmin[8] : d.bl[(size_t)2 * d.nLm + lc];
     const double g0 = b0 * i00, g1 = (b1 - l10 * g0) * i11, g2 = (b2 - l20 * g0 - l21 * g1) * i22;
     sGb[t] = g0; sGb[PL + t] = g1; sGb[2 * PL + t] = g2;
   }
@@ -638,13 +662,55 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   }
 }
 
-__global__ __launch_bounds__(CH) void k_schur(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_schur_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
+__device__ __forceinline__ void k_schur_entry(const BaDev& d, int bx, int cur, double lambda_arg, int use_dev_lambda)
+{
+  extern __shared__ __attribute__((aligned(16))) char schur_smem[];
+  if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
+  if (cur < 0) cur = (int)d.scal[SC_CUR];
+  const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
+  k_schur_body(d, bx, cur, lambda, schur_smem, nullptr, nullptr);
+}
+__global__ __launch_bounds__(CH) void k_schur(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_schur_entry(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
 __global__ __launch_bounds__(CH) void k_schur_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (d.nCh)) return;
-  k_schur_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
+  k_schur_entry(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
+}
+
+// k_lin_schur: one slot of the device-driven LM loop whose damping is already known (every slot but the first of an
+// optimize()): (re)linearise the chunk if the last trial was accepted, then eliminate its landmarks at the current
+// lambda -- ONE kernel, one pass over the chunk's edges: the edge blocks W and the landmark sums go from the
+// linearisation to the Schur phase in registers, the LDS is reused.
+template <int JAC>
+__device__ __forceinline__ void k_lin_schur_entry(const BaDev& d, int bx)
+{
+  extern __shared__ __attribute__((aligned(16))) char fused_smem[];
+  if (d.scal[SC_STOP] != 0.0) return;
+  const int cur = (int)d.scal[SC_CUR];
+  const double lambda = d.scal[SC_LAMBDA];
+  if (d.scal[SC_NEEDLIN] != 0.0) {
+    double W[18], lm[9];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) W[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) lm[k] = 0.0;
+    k_linearize_body<JAC>(d, bx, cur, fused_smem, W, lm);
+    __syncthreads();                                               // the linearisation's LDS is dead: the Schur phase takes it over
+    k_schur_body(d, bx, cur, lambda, fused_smem, W, lm);
+  } else {
+    k_schur_body(d, bx, cur, lambda, fused_smem, nullptr, nullptr);
+  }
+}
+template <int JAC>
+__global__ __launch_bounds__(CH, 3) void k_lin_schur(BaDev d) { k_lin_schur_entry<JAC>(d, blockIdx.x); }
+template <int JAC>
+__global__ __launch_bounds__(CH, 3) void k_lin_schur_b(const BaDev* __restrict__ dv)
+{
+  const BaDev& d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= (d.nCh)) return;
+  k_lin_schur_entry<JAC>(d, blockIdx.x);
 }
 
 // slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c).
@@ -1658,8 +1724,8 @@ ssx_status allreduce(ssx_ctx* ctx, const Comm& cm, double* buf, size_t count)
 ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, const BigDev& bd, const Comm& cm, int jac, int cur, int first_iteration)
 {
   if (d.nCh > 0) {
-    if (jac == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
-    else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(d.nCh), dim3(CH), 0, ctx->stream, d, cur));
+    if (jac == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(d.nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, cur));
+    else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(d.nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, cur));
   }
   if (d.big) {
     if (jac == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_pose_blocks<SSX_JAC_NUMERIC_G2O>, dim3(d.nP), dim3(CH), 0, ctx->stream, d, bd, cur));
@@ -1923,9 +1989,14 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   const int n = 6 * d.nP;
   const int nCh = d.nCh;
   const size_t lds_schur = schur_lds_bytes();
+  const size_t lds_fused = std::max(lds_schur, LIN_LDS_BYTES);
   const size_t lds_prep = sizeof(double) * (18 + 9 + 3) * PW + 64;
   static bool attr_set = false;
   if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lin_schur<SSX_JAC_ANALYTIC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lin_schur<SSX_JAC_NUMERIC_G2O>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize<SSX_JAC_ANALYTIC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize<SSX_JAC_NUMERIC_G2O>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
     attr_set = true;
@@ -2024,9 +2095,15 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
       while (active && opt.iters > 0) {
         int slots = slots_total == 0 ? opt.iters : std::max(1, opt.iters - (int)hscal[SC_IT]);
         for (int sidx = 0; sidx < slots; ++sidx) {
-          if (nCh > 0) {
-            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1));
-            else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1));
+          // the first slot of an optimize() needs lambda_0 between the linearisation and the Schur complement; every
+          // later slot (and every slot with a collective between the two) knows its damping: one fused kernel
+          const bool fused = !first_slot && !cm.fn && nCh > 0 && n > 0;
+          if (fused) {
+            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), lds_fused, ctx->stream, d));
+            else SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), lds_fused, ctx->stream, d));
+          } else if (nCh > 0) {
+            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
+            else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
           }
           SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 15) / 16)), dim3(CH), 0, ctx->stream, d));
           st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
@@ -2034,7 +2111,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
           if (first_slot || cm.fn) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_slot ? 1 : 0));
           first_slot = false;
           if (n > 0) {
-            if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, -1, 0.0, 2));
+            if (nCh > 0 && !fused) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, -1, 0.0, 2));
             SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
             st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
             if (st != SSX_OK) return st;
@@ -2342,6 +2419,11 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   static bool attr_set_b = false;
   if (!attr_set_b) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur);
+    const int lf = (int)std::max(lds_schur, LIN_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lin_schur_b<SSX_JAC_ANALYTIC>), hipFuncAttributeMaxDynamicSharedMemorySize, lf);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lin_schur_b<SSX_JAC_NUMERIC_G2O>), hipFuncAttributeMaxDynamicSharedMemorySize, lf);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_b<SSX_JAC_ANALYTIC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_b<SSX_JAC_NUMERIC_G2O>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_LDS_BYTES);
     attr_set_b = true;
   }
   return SSX_OK;
@@ -2371,6 +2453,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   int* h_ctrl = reinterpret_cast<int*>(hscal + (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS));
   for (int w = 0; w < n; ++w) wsn[w].done = !(B->devs[w].nCh > 0) || opt.outer_rounds <= 0;
   const size_t lds_schur = schur_lds_bytes();
+  const size_t lds_fused = std::max(lds_schur, LIN_LDS_BYTES);
   const dim3 gCh(B->max_ch, n), gRl(B->max_rl, n), gRs(B->max_rs, n), gOne(1, n);
   auto all_done = [&] { for (int w = 0; w < n; ++w) if (!wsn[w].done) return false; return true; };
   while (!all_done() && opt.iters > 0) {
@@ -2387,12 +2470,18 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
           if (!wsn[w].done && hscal[(size_t)w * SC_N + SC_STOP] == 0.0) slots = std::max(slots, opt.iters - (int)hscal[(size_t)w * SC_N + SC_IT]);
       }
       for (int sidx = 0; sidx < slots; ++sidx) {
-        if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_NUMERIC_G2O>, gCh, dim3(CH), 0, s, dv, -1));
-        else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_ANALYTIC>, gCh, dim3(CH), 0, s, dv, -1));
+        const bool fused = !first_slot;                                // see ssx_ba_solve: lambda is known after the first slot
+        if (fused) {
+          if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_NUMERIC_G2O>, gCh, dim3(CH), lds_fused, s, dv));
+          else SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_ANALYTIC>, gCh, dim3(CH), lds_fused, s, dv));
+        } else {
+          if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_NUMERIC_G2O>, gCh, dim3(CH), LIN_LDS_BYTES, s, dv, -1));
+          else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_ANALYTIC>, gCh, dim3(CH), LIN_LDS_BYTES, s, dv, -1));
+        }
         SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_b, gRl, dim3(CH), 0, s, dv));
         if (first_slot) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init_b, gOne, dim3(64), 0, s, dv, 1));
         first_slot = false;
-        SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gCh, dim3(CH), lds_schur, s, dv, -1, 0.0, 2));
+        if (!fused) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gCh, dim3(CH), lds_schur, s, dv, -1, 0.0, 2));
         SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, s, dv));
         if (B->any_solve64) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, s, dv, -1, 0.0, 1));
         if (B->any_solve) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(256), 0, s, dv, -1, 0.0, 1));
@@ -2439,7 +2528,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   if (want_err)                                                       // windows that never ran a trial: errors of the input state
     for (int w = 0; w < n; ++w)
       if (!wsn[w].trial_err && B->devs[w].nCh > 0)
-        hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(B->devs[w].nCh), dim3(CH), 0, s, B->devs[w], wsn[w].cur);
+        hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(B->devs[w].nCh), dim3(CH), LIN_LDS_BYTES, s, B->devs[w], wsn[w].cur);
   hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, d_ooff, d_out, want_err ? 1 : 0);
   double* h_out = B->stage->as<double>();
   SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * B->out_total, hipMemcpyDeviceToHost, s));
