@@ -208,11 +208,16 @@ def main():
         "k_match": 60.0 * kp_total + 8.0 * kp_total / 2,
         "k_triangulate_matches": (56.0 + 25.0) * kp_total / 2,
     }
-    # BA kernels: bytes per LAUNCH of the batched kernels (B windows): SURVEY 8-D terms of bytes_iter split by kernel
+    # BA kernels: algorithmic bytes per LAUNCH of the batched kernels (B windows), the terms of SURVEY.md 8-D's bytes_iter
+    # (24 B per edge, 24 B per landmark state + 72 B of Hll / bl, 56 B per pose, 288 B per non-zero block of S) by kernel.
+    # The edge blocks W = Ji^T w Jj are NOT materialised any more (recomputed where needed), so they do not count.
+    # "k_schur" is the profiling id of BOTH the stand-alone Schur kernel (first slot of an optimize) and the fused
+    # linearise + Schur kernel k_lin_schur (every later slot): 9 of the 10 launches per step are the fused one.
+    lin_b = 24.0 * E3 + 24.0 * L3 + 56.0 * P3 + 72.0 * L3
     algo_launch_ba = {
-        "k_linearize": B * (24.0 * E3 + 24.0 * L3 + 56.0 * P3 + 18 * 8.0 * E3),       # edges + state in, W out
-        "k_schur": B * (18 * 8.0 * E3 + 72.0 * L3 + 288.0 * 55),
-        "k_backsub_residual": B * (18 * 8.0 * E3 + 24.0 * E3 + 48.0 * L3),
+        "k_linearize": B * lin_b,
+        "k_schur": B * (lin_b + 72.0 * L3 + 288.0 * 55),
+        "k_backsub_residual": B * (24.0 * E3 + 72.0 * L3 + 24.0 * L3 + 56.0 * P3 + 16.0 * E3),   # edges, Hll / bl, new points, poses, trial errors
         "k_solve64": B * (8.0 * 61 * 60 + 56.0 * 2 * P3),
     }
     kernels = {}
@@ -239,6 +244,8 @@ def main():
         if pc.get("pairs_per_step") == B and world == 1:
             base = dom.split("<")[0]
             names = [base + "_b", base] if kernels[dom]["part"] == "ba" else [base]     # the BA kernels of the step are the batched ones
+            if base == "k_schur":
+                names = ["k_lin_schur_b"] + names                                     # 9 of its 10 launches per step
             key = [k for nm in names for k in pc["per_launch"] if k.split("<")[0] == nm]
             if key:
                 rec = pc["per_launch"][key[0]]
