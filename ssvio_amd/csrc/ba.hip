@@ -44,6 +44,11 @@
 #include <thread>
 #include <vector>
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
 #include "ctx.hpp"
 #include "se3.hpp"
 
@@ -1196,6 +1201,8 @@ struct BaWorkspace {
   HostBuf scal;      // pinned scalars read back per trial
   DevBuf tiles;      // large windows: tile-sparsity lists of the factor
   HostBuf tiles_h;
+  DevBuf pairs_a, pairs_b, pairs_c;   // large windows: device-built pair lists (inputs + scan | sort buffers | final lists)
+  HostBuf pairs_h;
 };
 
 static void ssx_ba_workspace_free(BaWorkspace* w)
@@ -1206,6 +1213,7 @@ static void ssx_ba_workspace_free(BaWorkspace* w)
   w->scal.release();
   w->tiles.release();
   w->tiles_h.release();
+  w->pairs_a.release(); w->pairs_b.release(); w->pairs_c.release(); w->pairs_h.release();
   delete w;
 }
 
@@ -1220,8 +1228,9 @@ struct HostPrep {
   std::vector<int8_t> blk_pa, blk_pb;
   // large-window path
   bool big = false;
-  std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr, spair_a, spair_b;
+  std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr;
   std::vector<int> ch_desc, e_rec, l_rec;   // packed records (4 ints each), see BaDev
+  std::vector<int> lm_chunk;                // compact landmark -> chunk (large windows: the device-side pair builder)
   int band_w = -1;          // cyclic block bandwidth of this rank's part of the reduced system (max over its non-zero blocks)
 };
 
@@ -1303,11 +1312,13 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   h.nCh = (int)h.ch_lm.size() - 1;
   if (h.nCh < 0) h.nCh = 0;
   h.ch_desc.resize(4 * (size_t)std::max(h.nCh, 1)); h.e_rec.resize(4 * (size_t)std::max(E, 1)); h.l_rec.resize(4 * (size_t)std::max(h.nLm, 1));
+  h.lm_chunk.resize((size_t)std::max(h.nLm, 1));
   for (int c = 0; c < h.nCh; ++c) {
     const int lm0 = h.ch_lm[c], lm1 = h.ch_lm[c + 1], e0 = h.lm_ptr[lm0], e1 = h.lm_ptr[lm1];
     int* cd = &h.ch_desc[4 * (size_t)c];
     cd[0] = e0; cd[1] = e1 - e0; cd[2] = lm0; cd[3] = lm1 - lm0;
     for (int lc = lm0; lc < lm1; ++lc) {
+      h.lm_chunk[lc] = c;
       int* lr = &h.l_rec[4 * (size_t)lc];
       lr[0] = h.lm_ptr[lc] - e0; lr[1] = h.lm_ptr[lc + 1] - h.lm_ptr[lc]; lr[2] = h.lm_id[lc]; lr[3] = h.lm_fixed[lc];
       for (int s2 = h.lm_ptr[lc]; s2 < h.lm_ptr[lc + 1]; ++s2) {
@@ -1335,48 +1346,10 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
       std::vector<int> fill(h.pe_ptr.begin(), h.pe_ptr.end() - 1);
       for (int s = 0; s < E; ++s) { const int pf = h.pose_free[h.e_pose[s]]; if (pf >= 0) h.pe_edge[fill[pf]++] = s; }
     }
-    // non-zero upper blocks of the reduced system (co-visibility) and the (leader, leader) pairs feeding each
-    std::vector<int> blk_id((size_t)nP * nP, -1);
-    h.sblk_pa.clear(); h.sblk_pb.clear();
-    for (int p = 0; p < nP; ++p) { blk_id[(size_t)p * nP + p] = p; h.sblk_pa.push_back(p); h.sblk_pb.push_back(p); }
-    std::vector<int> cntb;
-    std::vector<int> leaders;
-    for (int pass = 0; pass < 2; ++pass) {
-      for (int lc = 0; lc < h.nLm; ++lc) {
-        if (h.lm_fixed[lc]) continue;
-        leaders.clear();
-        for (int s = h.lm_ptr[lc]; s < h.lm_ptr[lc + 1]; ++s)
-          if (h.pose_free[h.e_pose[s]] >= 0 && !h.e_dup[s]) leaders.push_back(s);
-        for (size_t i = 0; i < leaders.size(); ++i)
-          for (size_t j = i; j < leaders.size(); ++j) {
-            const int pa = h.pose_free[h.e_pose[leaders[i]]], pb = h.pose_free[h.e_pose[leaders[j]]];
-            int& id = blk_id[(size_t)pa * nP + pb];
-            if (pass == 0) {
-              if (id < 0) { id = (int)h.sblk_pa.size(); h.sblk_pa.push_back(pa); h.sblk_pb.push_back(pb); }
-              if ((int)cntb.size() <= id) cntb.resize(id + 1, 0);
-              cntb[id]++;
-            } else {
-              const int q = cntb[id]++;
-              h.spair_a[q] = leaders[i]; h.spair_b[q] = leaders[j];
-            }
-          }
-      }
-      if (pass == 0) {
-        const int nb = (int)h.sblk_pa.size();
-        cntb.resize(nb, 0);
-        h.spair_ptr.assign(nb + 1, 0);
-        for (int b = 0; b < nb; ++b) h.spair_ptr[b + 1] = h.spair_ptr[b] + cntb[b];
-        h.spair_a.assign(std::max(h.spair_ptr[nb], 1), 0); h.spair_b.assign(std::max(h.spair_ptr[nb], 1), 0);
-        for (int b = 0; b < nb; ++b) cntb[b] = h.spair_ptr[b];
-      }
-    }
+    // the non-zero blocks of the reduced system and their (edge, edge) pair lists are built on the device (build_pairs)
+    h.sblk_pa.clear(); h.sblk_pb.clear(); h.spair_ptr.assign(1, 0);
     h.nBlk = 0;
-    // cyclic block bandwidth: pose p is coupled to poses within band_w positions along the (closed) trajectory
-    h.band_w = 0;
-    for (size_t q = 0; q < h.sblk_pa.size(); ++q) {
-      const int dd = h.sblk_pb[q] - h.sblk_pa[q];
-      h.band_w = std::max(h.band_w, std::min(dd, nP - dd));
-    }
+    h.band_w = -1;
     return SSX_OK;
   }
   // per-chunk index lists: edges grouped by free pose; leader pairs grouped by reduced-system block
@@ -1483,7 +1456,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const bool big = h.big;
   const int lin_stride = big ? 2 : nP * 27 + 2;
   const int n_pad = big ? ((n + NB - 1) / NB) * NB : 0;
-  const size_t nBlkS = h.sblk_pa.size(), nSPairs = big ? (size_t)h.spair_ptr.back() : 0;
+  const size_t nBlkS = h.sblk_pa.size();
   Layout in;   // input blob (mirrored in pinned staging)
   const size_t o_pose_free = in.take(sizeof(int) * P);
   const size_t o_lm_fixed = in.take(nLm);
@@ -1510,8 +1483,6 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_sblk_pa = in.take(sizeof(int) * (nBlkS + 1));
   const size_t o_sblk_pb = in.take(sizeof(int) * (nBlkS + 1));
   const size_t o_spair_ptr = in.take(sizeof(int) * (h.spair_ptr.size() + 1));
-  const size_t o_spair_a = in.take(sizeof(int) * (nSPairs + 1));
-  const size_t o_spair_b = in.take(sizeof(int) * (nSPairs + 1));
   const bool band = big && bp.w > 0;
   const size_t o_seg_p0 = in.take(sizeof(int) * (bp.seg_p0.size() + 1));
   const size_t o_seg_m = in.take(sizeof(int) * (bp.seg_m.size() + 1));
@@ -1610,8 +1581,6 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_sblk_pa, h.sblk_pa.data(), sizeof(int) * nBlkS);
     memcpy(hs + o_sblk_pb, h.sblk_pb.data(), sizeof(int) * nBlkS);
     memcpy(hs + o_spair_ptr, h.spair_ptr.data(), sizeof(int) * h.spair_ptr.size());
-    memcpy(hs + o_spair_a, h.spair_a.data(), sizeof(int) * h.spair_a.size());
-    memcpy(hs + o_spair_b, h.spair_b.data(), sizeof(int) * h.spair_b.size());
   }
   if (band) {
     memcpy(hs + o_seg_p0, bp.seg_p0.data(), sizeof(int) * bp.seg_p0.size());
@@ -1684,7 +1653,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     bd.n = n; bd.n_pad = n_pad; bd.ld = n_pad; bd.T = n_pad / NB; bd.nBlkS = (int)nBlkS;
     bd.pe_ptr = (const int*)(at(o_pe_ptr)); bd.pe_edge = (const int*)(at(o_pe_edge));
     bd.sblk_pa = (const int*)(at(o_sblk_pa)); bd.sblk_pb = (const int*)(at(o_sblk_pb));
-    bd.spair_ptr = (const int*)(at(o_spair_ptr)); bd.spair_a = (const int*)(at(o_spair_a)); bd.spair_b = (const int*)(at(o_spair_b));
+    bd.spair_ptr = (const int*)(at(o_spair_ptr)); bd.spair_ab = nullptr;   // the pair lists live in the workspace of build_pairs
     bd.BDa = (double*)(at(o_BDa)); bd.Wma = (double*)(at(o_Wma)); bd.Cv = (double*)(at(o_Cv));
     bnd = BandDev{};
     if (band) {
@@ -1696,6 +1665,111 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     }
     bd.S = (double*)(at(o_S)); bd.x = (double*)(at(o_x)); bd.Ld = (double*)(at(o_Ld)); bd.invd = (double*)(at(o_invd)); bd.Ninv = (double*)(at(o_Ninv)); bd.scale_part = (double*)(at(o_scale_part));
   }
+  return SSX_OK;
+}
+
+// Large windows: the non-zero blocks of the reduced system and their pair lists, on the device (kernels in ba_big.inc).
+// Fills h.sblk_pa / h.sblk_pb / h.spair_ptr (sorted by (pa, pb); every diagonal block present, possibly with an empty
+// list) and h.band_w; the lists themselves stay in the workspace: *ab_dev.
+ssx_status build_pairs(ssx_ctx* ctx, HostPrep& h, const unsigned long long** ab_dev)
+{
+  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+  BaWorkspace* ws = ctx->ba;
+  hipStream_t s = ctx->stream;
+  const int nLm = h.nLm, nP = h.nP, E = h.E, nCh = h.nCh;
+  *ab_dev = nullptr;
+  h.sblk_pa.clear(); h.sblk_pb.clear();
+  auto add_diagonals_only = [&] {
+    for (int p = 0; p < nP; ++p) { h.sblk_pa.push_back(p); h.sblk_pb.push_back(p); }
+    h.spair_ptr.assign((size_t)nP + 1, 0);
+    h.band_w = 0;
+  };
+  if (nLm == 0 || E == 0) { add_diagonals_only(); return SSX_OK; }
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // ---- stage A: records in, count + scan
+  size_t scan_tmp = 0;
+  (void)rocprim::exclusive_scan(nullptr, scan_tmp, (int*)nullptr, (int*)nullptr, 0, (size_t)nLm + 1, rocprim::plus<int>(), s);
+  Layout la;
+  const size_t a_erec = la.take(sizeof(int) * 4 * (size_t)E), a_lrec = la.take(sizeof(int) * 4 * (size_t)nLm), a_cd = la.take(sizeof(int) * 4 * (size_t)nCh);
+  const size_t a_lmc = la.take(sizeof(int) * (size_t)nLm);
+  const size_t a_in_bytes = la.off;
+  const size_t a_cnt = la.take(sizeof(int) * ((size_t)nLm + 1)), a_off = la.take(sizeof(int) * ((size_t)nLm + 1)), a_scal = la.take(64), a_tmp = la.take(scan_tmp + 256);
+  SSX_HIP_TRY(ctx, ws->pairs_a.reserve(la.off));
+  SSX_HIP_TRY(ctx, ws->pairs_h.reserve(std::max(a_in_bytes, sizeof(int) * 2 * ((size_t)nP * (nP + 1) / 2 + 8))));
+  char* da = ws->pairs_a.as<char>();
+  char* hh = ws->pairs_h.as<char>();
+  memcpy(hh + a_erec, h.e_rec.data(), sizeof(int) * 4 * (size_t)E);
+  memcpy(hh + a_lrec, h.l_rec.data(), sizeof(int) * 4 * (size_t)nLm);
+  memcpy(hh + a_cd, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
+  memcpy(hh + a_lmc, h.lm_chunk.data(), sizeof(int) * (size_t)nLm);
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(da, hh, a_in_bytes, hipMemcpyHostToDevice, s));
+  SSX_HIP_TRY(ctx, hipMemsetAsync(da + a_cnt, 0, sizeof(int) * ((size_t)nLm + 1), s));
+  SSX_HIP_TRY(ctx, hipMemsetAsync(da + a_scal, 0, 64, s));
+  const int4* d_erec = (const int4*)(da + a_erec); const int4* d_lrec = (const int4*)(da + a_lrec); const int4* d_cd = (const int4*)(da + a_cd);
+  const int* d_lmc = (const int*)(da + a_lmc);
+  int* d_cnt = (int*)(da + a_cnt); int* d_off = (int*)(da + a_off); int* d_scal = (int*)(da + a_scal);
+  hipLaunchKernelGGL(k_pairs_count, dim3((nLm + CH - 1) / CH), dim3(CH), 0, s, d_erec, d_lrec, d_cd, d_lmc, nLm, nP, d_cnt, d_scal);
+  if (rocprim::exclusive_scan(da + a_tmp, scan_tmp, d_cnt, d_off, 0, (size_t)nLm + 1, rocprim::plus<int>(), s) != hipSuccess) {
+    ctx->set_error("ssx_ba: rocprim::exclusive_scan failed"); return SSX_ERR_HIP;
+  }
+  int h_np_w[2] = {0, 0};
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(&h_np_w[0], d_off + nLm, sizeof(int), hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(&h_np_w[1], d_scal, sizeof(int), hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  const size_t NP = (size_t)h_np_w[0];
+  if (NP == 0) { add_diagonals_only(); return SSX_OK; }
+  // ---- stage B: emit, sort by block key, run-length encode
+  int key_bits = 1;
+  while ((1ull << key_bits) < (unsigned long long)nP * nP) ++key_bits;
+  size_t sort_tmp = 0, rle_tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr, NP, 0,
+                                  key_bits, s);
+  (void)rocprim::run_length_encode(nullptr, rle_tmp, (unsigned int*)nullptr, (unsigned int)NP, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned int*)nullptr, s);
+  const size_t max_blk = std::min((size_t)nP * (nP + 1) / 2, NP);
+  Layout lb;
+  const size_t b_k0 = lb.take(sizeof(unsigned int) * NP), b_k1 = lb.take(sizeof(unsigned int) * NP), b_v0 = lb.take(sizeof(unsigned long long) * NP);
+  const size_t b_uq = lb.take(sizeof(unsigned int) * (max_blk + 1)), b_ct = lb.take(sizeof(unsigned int) * (max_blk + 1)), b_nr = lb.take(64);
+  const size_t b_tmp = lb.take(std::max(sort_tmp, rle_tmp) + 256);
+  SSX_HIP_TRY(ctx, ws->pairs_b.reserve(lb.off));
+  SSX_HIP_TRY(ctx, ws->pairs_c.reserve(sizeof(unsigned long long) * NP + 64));
+  char* db = ws->pairs_b.as<char>();
+  unsigned int* d_k0 = (unsigned int*)(db + b_k0); unsigned int* d_k1 = (unsigned int*)(db + b_k1);
+  unsigned long long* d_v0 = (unsigned long long*)(db + b_v0);
+  unsigned long long* d_v1 = ws->pairs_c.as<unsigned long long>();   // the sorted values = the final lists
+  unsigned int* d_uq = (unsigned int*)(db + b_uq); unsigned int* d_ct = (unsigned int*)(db + b_ct); unsigned int* d_nr = (unsigned int*)(db + b_nr);
+  hipLaunchKernelGGL(k_pairs_emit, dim3((nLm + CH - 1) / CH), dim3(CH), 0, s, d_erec, d_lrec, d_cd, d_lmc, nLm, nP, (const int*)d_off, d_k0, d_v0);
+  if (rocprim::radix_sort_pairs(db + b_tmp, sort_tmp, d_k0, d_k1, d_v0, d_v1, NP, 0, key_bits, s) != hipSuccess ||
+      rocprim::run_length_encode(db + b_tmp, rle_tmp, d_k1, (unsigned int)NP, d_uq, d_ct, d_nr, s) != hipSuccess) {
+    ctx->set_error("ssx_ba: rocprim radix_sort_pairs / run_length_encode failed"); return SSX_ERR_HIP;
+  }
+  unsigned int n_runs = 0;
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(&n_runs, d_nr, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  unsigned int* h_uq = reinterpret_cast<unsigned int*>(hh);
+  unsigned int* h_ct = h_uq + n_runs;
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(h_uq, d_uq, sizeof(unsigned int) * n_runs, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(h_ct, d_ct, sizeof(unsigned int) * n_runs, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  // ---- the block list: the runs (sorted by key) merged with the diagonal blocks that have no pair (a pose whose
+  // landmarks are all fixed still owns its Hpp block)
+  h.spair_ptr.clear(); h.spair_ptr.push_back(0);
+  unsigned int r = 0;
+  int run_sum = 0;
+  for (int p = 0; p < nP; ++p) {
+    const unsigned int diag = (unsigned int)p * nP + p;
+    bool have_diag = false;
+    while (r < n_runs && h_uq[r] / (unsigned int)nP == (unsigned int)p) {      // the blocks of block-row p, ascending pb
+      if (h_uq[r] > diag && !have_diag) { h.sblk_pa.push_back(p); h.sblk_pb.push_back(p); h.spair_ptr.push_back(run_sum); have_diag = true; }
+      if (h_uq[r] == diag) have_diag = true;
+      h.sblk_pa.push_back(p); h.sblk_pb.push_back((int)(h_uq[r] % (unsigned int)nP));
+      run_sum += (int)h_ct[r];
+      h.spair_ptr.push_back(run_sum);
+      ++r;
+    }
+    if (!have_diag) { h.sblk_pa.push_back(p); h.sblk_pb.push_back(p); h.spair_ptr.push_back(run_sum); }
+  }
+  h.band_w = h_np_w[1];
+  *ab_dev = d_v1;
   return SSX_OK;
 }
 
@@ -1956,6 +2030,11 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   // large windows: trajectory-shaped co-visibility (cyclic block band) -> the sliding-window / nested-dissection solver
   // of ba_band.inc; anything else -> the 64x64-tile sparse Cholesky of ba_big.inc.  With several ranks the decision
   // must be common: the ranks exchange which bandwidth class their shard falls in (one tiny all-reduce).
+  const unsigned long long* pairs_dev = nullptr;
+  if (h.big) {
+    st = build_pairs(ctx, h, &pairs_dev);
+    if (st != SSX_OK) return st;
+  }
   BandPlan bp;
   if (h.big && opt.large_solver != SSX_LARGE_SOLVER_TILES) {
     int w = std::max(h.band_w, 1);
@@ -1984,6 +2063,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd);
   if (st != SSX_OK) return st;
   d.store_w = (d.big || opt.jac_mode == SSX_JAC_NUMERIC_G2O) ? 1 : 0;
+  bd.spair_ab = pairs_dev;
   BaWorkspace* ws = ctx->ba;
   double* hscal = ws->scal.as<double>();
   const int n = 6 * d.nP;
