@@ -88,6 +88,7 @@ struct OrbWorkspace {
   DevBuf input;        // uploaded host images (host-pointer entry points)
   DevBuf stereo;       // match / triangulation results of the batch entry points
   HostBuf stage;       // pinned staging
+  HostBuf fetch;       // pinned: everything ssx_stereo_frame returns, fetched with ONE synchronisation
   ssxorb::OrbDev dev{};
   // plan key
   int rows = 0, cols = 0, I = 0, nlevels = 0, nfeatures = 0, ini_th = 0, min_th = 0, has_mask = 0, detect_only = 0;

@@ -399,6 +399,50 @@ ssx_status fetch_pair(ssx_ctx* ctx, int pair, ssx_stereo_frame_out* out)
   return SSX_OK;
 }
 
+// One stereo pair's results with ONE stream synchronisation: every array at its full capacity into pinned memory (0.6 MB
+// at 2000 features: 12 us on PCIe 5), the counts with it, unpacked on the host.  (fetch_pair takes five synchronisations
+// and copies into the caller's pageable buffers: a third of the latency of a single frame.)
+ssx_status fetch_frame_fast(ssx_ctx* ctx, ssx_stereo_frame_out* out)
+{
+  OrbWorkspace* ws = get_ws(ctx);
+  const OrbDev& d = ws->dev;
+  const size_t cap = d.out_cap;
+  Layout lay;
+  const size_t o_cnt = lay.take(sizeof(int) * 8);
+  const size_t o_k = lay.take(sizeof(ssx_keypoint) * 2 * cap), o_d = lay.take((size_t)64 * cap);
+  const size_t o_idx = lay.take(sizeof(int) * cap), o_dist = lay.take(sizeof(int) * cap), o_xyz = lay.take(sizeof(double) * 3 * cap), o_ok = lay.take(cap);
+  SSX_HIP_TRY(ctx, ws->fetch.reserve(lay.off));
+  char* hf = ws->fetch.as<char>();
+  hipStream_t s = ctx->stream;
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_cnt, ws->pair_counts, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_cnt + 16, d.out_n, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_cnt + 24, d.status, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+  if (out->kpsL || out->kpsR) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_k, d.out_kps, sizeof(ssx_keypoint) * 2 * cap, hipMemcpyDeviceToHost, s));
+  if (out->descL || out->descR) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_d, d.out_desc, (size_t)64 * cap, hipMemcpyDeviceToHost, s));
+  if (out->match_idx) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_idx, ws->match_idx, sizeof(int) * cap, hipMemcpyDeviceToHost, s));
+  if (out->match_dist) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_dist, ws->match_dist, sizeof(int) * cap, hipMemcpyDeviceToHost, s));
+  if (out->xyz) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_xyz, ws->xyz, sizeof(double) * 3 * cap, hipMemcpyDeviceToHost, s));
+  if (out->ok) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_ok, ws->tri_ok, cap, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  const int* c = reinterpret_cast<const int*>(hf + o_cnt);
+  const int nL = c[4], nR = c[5];
+  if (c[6] != 0 || c[7] != 0) {
+    ctx->set_error("ssx_orb: internal capacity exceeded (status bits %d / %d: 1=candidates 2=octree nodes 4=outputs)", c[6], c[7]);
+    return SSX_ERR_CAPACITY;
+  }
+  out->nL = nL; out->nR = nR; out->n_matched = c[2]; out->n_triangulated = c[3];
+  if (nL > out->cap || nR > out->cap) { ctx->set_error("ssx_orb: %d / %d keypoints but capacity %d", nL, nR, out->cap); return SSX_ERR_CAPACITY; }
+  if (out->kpsL) memcpy(out->kpsL, hf + o_k, sizeof(ssx_keypoint) * nL);
+  if (out->kpsR) memcpy(out->kpsR, hf + o_k + sizeof(ssx_keypoint) * cap, sizeof(ssx_keypoint) * nR);
+  if (out->descL) memcpy(out->descL, hf + o_d, (size_t)32 * nL);
+  if (out->descR) memcpy(out->descR, hf + o_d + (size_t)32 * cap, (size_t)32 * nR);
+  if (out->match_idx) memcpy(out->match_idx, hf + o_idx, sizeof(int) * nL);
+  if (out->match_dist) memcpy(out->match_dist, hf + o_dist, sizeof(int) * nL);
+  if (out->xyz) memcpy(out->xyz, hf + o_xyz, sizeof(double) * 3 * nL);
+  if (out->ok) memcpy(out->ok, hf + o_ok, nL);
+  return SSX_OK;
+}
+
 }  // namespace
 }  // namespace ssxorb
 
@@ -551,7 +595,7 @@ ssx_status ssx_stereo_frame(ssx_ctx* ctx, const uint8_t* imgL, const uint8_t* im
   if (st != SSX_OK) return st;
   st = launch_stereo(ctx, m);
   if (st != SSX_OK) return st;
-  return fetch_pair(ctx, 0, out);
+  return fetch_frame_fast(ctx, out);
 }
 
 ssx_status ssx_stereo_batch_enqueue(ssx_ctx* ctx)
