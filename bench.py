@@ -183,6 +183,31 @@ def main():
     barrier()
     ba1_elapsed = max_over_ranks(time.perf_counter() - t0)
 
+    # ---------------- single-pair latency: ssx_stereo_frame, HOST images in, host results out ----------------
+    # (a live front-end is single-stream: the dependent-launch chain of ONE pair, PCIe both ways; never `value`)
+    lat = None
+    if rank == 0:
+        import ctypes as C
+        from ssvio_amd._lib import ptr, u8_p, dbl_p
+        ctx_lat = ssvio_amd.Context(dev_index)
+        Lh, Rh, _ = make_stereo_pair(seed=0)
+        o_ = orb.OrbParams(2000, 1.2, 8, 20, 7); mp_ = orb.match_params(scale_factor=o_.scale_factor); rig_ = orb.stereo_rig()
+        fb = orb._FrameBuffers(o_.nfeatures + 260 * o_.nlevels + 64)
+        a_ = (ctx_lat.handle, ptr(Lh, u8_p), ptr(Rh, u8_p), Lh.strides[0], Lh.shape[0], Lh.shape[1], C.byref(o_), C.byref(mp_),
+              C.byref(rig_), ptr(None, dbl_p), C.byref(fb.out))
+        for _ in range(5):
+            ctx_lat.check(ctx_lat.lib.ssx_stereo_frame(*a_))
+        LAT_REP = 40
+        t0 = time.perf_counter()
+        for _ in range(LAT_REP):
+            ctx_lat.lib.ssx_stereo_frame(*a_)
+        lat_s = (time.perf_counter() - t0) / LAT_REP
+        lat = {"ms_per_pair": round(lat_s * 1e3, 4), "pairs_per_s": round(1.0 / lat_s, 1),
+               "what": "ssx_stereo_frame, one 1241x376 pair at a time: pageable host images in (pinned staging, level 0 built over PCIe), "
+                       "18 dependent launches on one stream, results written to pinned memory by the last kernel, one synchronisation, "
+                       "host arrays out; arguments marshalled once (a C caller's cost)"}
+        ctx_lat.close()
+
     # ---------------- per-kernel time with HIP events (same workload, profiling on) ----------------
     PROF_STEPS = 3
     _lib.profile_begin(ctx)
@@ -396,7 +421,8 @@ def main():
             "roofline": roofline,
             "frontend": {"metric": "stereo frames/s (ORB extract + row-band match + triangulate), no BA", "value": round(fe_value, 2),
                          "ms_per_step": round(fe_elapsed / args.steps * 1e3, 4),
-                         "pipeline_algorithmic_GBps_per_gpu": round(pipeline_gbs, 3)},
+                         "pipeline_algorithmic_GBps_per_gpu": round(pipeline_gbs, 3),
+                         "single_pair_latency": lat},
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "ba": {"workload": "C3: local BA, 10 KF x 4000 landmarks x 20000 edges, analytic Jacobians, f64",
                    "batched": {"windows_per_call": B, "windows_per_s": round(world * B * BA_REP / bab_elapsed, 1),

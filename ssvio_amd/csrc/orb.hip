@@ -123,9 +123,16 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
   if (x >= cols || y >= rows) return;
   const uint8_t* srow = in + (size_t)blockIdx.z * in_img_bytes + (size_t)y * in_stride;
   uint32_t w[2] = {0u, 0u};
+  if (((in_stride | in_img_bytes | reinterpret_cast<uintptr_t>(in)) & 7) == 0) {   // 8-byte rows (may run into the row's padding)
+    const uint2 v = *reinterpret_cast<const uint2*>(srow + x);
+    w[0] = v.x; w[1] = v.y;
+    const int valid = cols - x;   // >= 1
+    if (valid < 8) { const uint64_t keep = (~0ull) >> (8 * (8 - valid)); w[0] &= (uint32_t)keep; w[1] &= (uint32_t)(keep >> 32); }
+  } else {
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (x + k < cols) w[k >> 2] |= (uint32_t)srow[x + k] << (8 * (k & 3));
+    for (int k = 0; k < 8; ++k)
+      if (x + k < cols) w[k >> 2] |= (uint32_t)srow[x + k] << (8 * (k & 3));
+  }
   *reinterpret_cast<uint2*>(dst_base + (size_t)blockIdx.z * img_stride_bytes + (size_t)y * dpitch + x) = make_uint2(w[0], w[1]);
 }
 
@@ -1123,7 +1130,9 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   // level 0 of the detection (a third of the cells) runs beside it on the auxiliary stream; the blur only needs
   // the pyramid and runs beside the detection of the upper levels and the octree.  Joined before the octree
   // (level-0 candidates) and before the descriptors (blur).
-  const bool fork = !d.detect_only && ctx->aux != nullptr;
+  // (One or two images: the chain is latency bound either way and the event hand-offs cost more than the overlap
+  // returns -- 0.319 against 0.312 ms for a single stereo pair -- so a single frame stays on one stream.)
+  const bool fork = !d.detect_only && ctx->aux != nullptr && d.I > 2;
   if (fork) {
     SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
     SSX_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));

@@ -328,6 +328,51 @@ __global__ __launch_bounds__(256) void k_pair_counts(MatchDev m)
   }
 }
 
+// Single-frame path: the counts of k_pair_counts (workgroup 0) and, beside it, every result array of pair 0 written
+// straight into pinned host memory -- one launch instead of k_pair_counts + nine device-to-host copies (5 us against 73).
+struct FrameSlots { size_t cnt, kps, desc, idx, dist, xyz, ok; };   // byte offsets in the pinned block, capacity based
+
+__device__ __forceinline__ void copy_words(uint32_t* dst, const uint32_t* src, int words, int tid, int nthr)
+{
+  for (int i = tid; i < words; i += nthr) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_pack_frame(MatchDev m, const int* status, char* host, FrameSlots o)
+{
+  const int t = threadIdx.x;
+  const int nL = min(m.n[0], m.out_cap), nR = min(m.n[1], m.out_cap);
+  if (blockIdx.x == 0) {
+    __shared__ int s[2];
+    if (t < 2) s[t] = 0;
+    __syncthreads();
+    int nm = 0, nt = 0;
+    for (int i = t; i < nL; i += 256) { nm += m.match_idx[i] >= 0; nt += m.ok[i] != 0; }
+    atomicAdd(&s[0], nm);
+    atomicAdd(&s[1], nt);
+    __syncthreads();
+    if (t == 0) {
+      int* c = m.counts;
+      c[0] = nL; c[1] = nR; c[2] = s[0]; c[3] = s[1];
+      int* h = reinterpret_cast<int*>(host + o.cnt);
+      h[0] = nL; h[1] = nR; h[2] = s[0]; h[3] = s[1]; h[4] = m.n[0]; h[5] = m.n[1]; h[6] = status[0]; h[7] = status[1];
+    }
+    return;
+  }
+  const int tid = (blockIdx.x - 1) * 256 + t, nthr = (gridDim.x - 1) * 256;
+  const size_t cap = m.out_cap;
+  const uint32_t* kps = reinterpret_cast<const uint32_t*>(m.kps);
+  const uint32_t* desc = reinterpret_cast<const uint32_t*>(m.desc);
+  copy_words(reinterpret_cast<uint32_t*>(host + o.kps), kps, nL * 7, tid, nthr);
+  copy_words(reinterpret_cast<uint32_t*>(host + o.kps) + cap * 7, kps + cap * 7, nR * 7, tid, nthr);
+  copy_words(reinterpret_cast<uint32_t*>(host + o.desc), desc, nL * 8, tid, nthr);
+  copy_words(reinterpret_cast<uint32_t*>(host + o.desc) + cap * 8, desc + cap * 8, nR * 8, tid, nthr);
+  copy_words(reinterpret_cast<uint32_t*>(host + o.idx), reinterpret_cast<const uint32_t*>(m.match_idx), nL, tid, nthr);
+  copy_words(reinterpret_cast<uint32_t*>(host + o.dist), reinterpret_cast<const uint32_t*>(m.match_dist), nL, tid, nthr);
+  copy_words(reinterpret_cast<uint32_t*>(host + o.xyz), reinterpret_cast<const uint32_t*>(m.xyz), nL * 6, tid, nthr);
+  copy_words(reinterpret_cast<uint32_t*>(host + o.ok), reinterpret_cast<const uint32_t*>(m.ok), (nL + 3) / 4, tid, nthr);
+}
+static_assert(sizeof(ssx_keypoint) == 28, "k_pack_frame copies keypoints as seven words");
+
 void fill_scale(MatchDev& m)
 {
   m.scale[0] = 1.0f;
@@ -365,9 +410,17 @@ ssx_status make_match_dev(ssx_ctx* ctx, int pairs, const ssx_match_params& mp, c
   return SSX_OK;
 }
 
-ssx_status launch_stereo(ssx_ctx* ctx, const MatchDev& m)
+ssx_status launch_stereo(ssx_ctx* ctx, const MatchDev& m, char* frame_host = nullptr, const FrameSlots* slots = nullptr)
 {
   hipStream_t s = ctx->stream;
+  if (frame_host) {
+    SSX_PROF(ctx, KID_ST_BUCKET, hipLaunchKernelGGL(k_row_bucket, dim3(m.pairs), dim3(1024), 0, s, m));
+    SSX_PROF(ctx, KID_ST_MATCH, hipLaunchKernelGGL(k_match, dim3((m.out_cap + 3) / 4, m.pairs), dim3(256), 0, s, m));
+    SSX_PROF(ctx, KID_ST_TRIANGULATE, hipLaunchKernelGGL(k_triangulate_matches, dim3((m.out_cap + 255) / 256, m.pairs), dim3(256), 0, s, m));
+    SSX_PROF(ctx, KID_ST_MISC, hipLaunchKernelGGL(k_pack_frame, dim3(1 + 128), dim3(256), 0, s, m, get_ws(ctx)->dev.status, frame_host, *slots));
+    SSX_HIP_TRY(ctx, hipGetLastError());
+    return SSX_OK;
+  }
   SSX_PROF(ctx, KID_ST_BUCKET, hipLaunchKernelGGL(k_row_bucket, dim3(m.pairs), dim3(1024), 0, s, m));
   SSX_PROF(ctx, KID_ST_MATCH, hipLaunchKernelGGL(k_match, dim3((m.out_cap + 3) / 4, m.pairs), dim3(256), 0, s, m));
   SSX_PROF(ctx, KID_ST_TRIANGULATE, hipLaunchKernelGGL(k_triangulate_matches, dim3((m.out_cap + 255) / 256, m.pairs), dim3(256), 0, s, m));
@@ -399,32 +452,26 @@ ssx_status fetch_pair(ssx_ctx* ctx, int pair, ssx_stereo_frame_out* out)
   return SSX_OK;
 }
 
-// One stereo pair's results with ONE stream synchronisation: every array at its full capacity into pinned memory (0.6 MB
-// at 2000 features: 12 us on PCIe 5), the counts with it, unpacked on the host.  (fetch_pair takes five synchronisations
-// and copies into the caller's pageable buffers: a third of the latency of a single frame.)
-ssx_status fetch_frame_fast(ssx_ctx* ctx, ssx_stereo_frame_out* out)
+// One stereo pair's results with ONE stream synchronisation: k_pack_frame has written them into pinned memory; wait, check,
+// and hand them to the caller's (pageable) arrays.  (fetch_pair takes five synchronisations and nine copies.)
+FrameSlots frame_slots(size_t cap, size_t* total)
+{
+  Layout lay;
+  FrameSlots o;
+  o.cnt = lay.take(sizeof(int) * 8);
+  o.kps = lay.take(sizeof(ssx_keypoint) * 2 * cap); o.desc = lay.take((size_t)64 * cap);
+  o.idx = lay.take(sizeof(int) * cap); o.dist = lay.take(sizeof(int) * cap); o.xyz = lay.take(sizeof(double) * 3 * cap); o.ok = lay.take(cap + 4);
+  *total = lay.off;
+  return o;
+}
+
+ssx_status fetch_frame_fast(ssx_ctx* ctx, const FrameSlots& o, ssx_stereo_frame_out* out)
 {
   OrbWorkspace* ws = get_ws(ctx);
-  const OrbDev& d = ws->dev;
-  const size_t cap = d.out_cap;
-  Layout lay;
-  const size_t o_cnt = lay.take(sizeof(int) * 8);
-  const size_t o_k = lay.take(sizeof(ssx_keypoint) * 2 * cap), o_d = lay.take((size_t)64 * cap);
-  const size_t o_idx = lay.take(sizeof(int) * cap), o_dist = lay.take(sizeof(int) * cap), o_xyz = lay.take(sizeof(double) * 3 * cap), o_ok = lay.take(cap);
-  SSX_HIP_TRY(ctx, ws->fetch.reserve(lay.off));
-  char* hf = ws->fetch.as<char>();
-  hipStream_t s = ctx->stream;
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_cnt, ws->pair_counts, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_cnt + 16, d.out_n, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_cnt + 24, d.status, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
-  if (out->kpsL || out->kpsR) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_k, d.out_kps, sizeof(ssx_keypoint) * 2 * cap, hipMemcpyDeviceToHost, s));
-  if (out->descL || out->descR) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_d, d.out_desc, (size_t)64 * cap, hipMemcpyDeviceToHost, s));
-  if (out->match_idx) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_idx, ws->match_idx, sizeof(int) * cap, hipMemcpyDeviceToHost, s));
-  if (out->match_dist) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_dist, ws->match_dist, sizeof(int) * cap, hipMemcpyDeviceToHost, s));
-  if (out->xyz) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_xyz, ws->xyz, sizeof(double) * 3 * cap, hipMemcpyDeviceToHost, s));
-  if (out->ok) SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + o_ok, ws->tri_ok, cap, hipMemcpyDeviceToHost, s));
-  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
-  const int* c = reinterpret_cast<const int*>(hf + o_cnt);
+  const size_t cap = ws->dev.out_cap;
+  const char* hf = ws->fetch.as<char>();
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int* c = reinterpret_cast<const int*>(hf + o.cnt);
   const int nL = c[4], nR = c[5];
   if (c[6] != 0 || c[7] != 0) {
     ctx->set_error("ssx_orb: internal capacity exceeded (status bits %d / %d: 1=candidates 2=octree nodes 4=outputs)", c[6], c[7]);
@@ -432,14 +479,14 @@ ssx_status fetch_frame_fast(ssx_ctx* ctx, ssx_stereo_frame_out* out)
   }
   out->nL = nL; out->nR = nR; out->n_matched = c[2]; out->n_triangulated = c[3];
   if (nL > out->cap || nR > out->cap) { ctx->set_error("ssx_orb: %d / %d keypoints but capacity %d", nL, nR, out->cap); return SSX_ERR_CAPACITY; }
-  if (out->kpsL) memcpy(out->kpsL, hf + o_k, sizeof(ssx_keypoint) * nL);
-  if (out->kpsR) memcpy(out->kpsR, hf + o_k + sizeof(ssx_keypoint) * cap, sizeof(ssx_keypoint) * nR);
-  if (out->descL) memcpy(out->descL, hf + o_d, (size_t)32 * nL);
-  if (out->descR) memcpy(out->descR, hf + o_d + (size_t)32 * cap, (size_t)32 * nR);
-  if (out->match_idx) memcpy(out->match_idx, hf + o_idx, sizeof(int) * nL);
-  if (out->match_dist) memcpy(out->match_dist, hf + o_dist, sizeof(int) * nL);
-  if (out->xyz) memcpy(out->xyz, hf + o_xyz, sizeof(double) * 3 * nL);
-  if (out->ok) memcpy(out->ok, hf + o_ok, nL);
+  if (out->kpsL) memcpy(out->kpsL, hf + o.kps, sizeof(ssx_keypoint) * nL);
+  if (out->kpsR) memcpy(out->kpsR, hf + o.kps + sizeof(ssx_keypoint) * cap, sizeof(ssx_keypoint) * nR);
+  if (out->descL) memcpy(out->descL, hf + o.desc, (size_t)32 * nL);
+  if (out->descR) memcpy(out->descR, hf + o.desc + (size_t)32 * cap, (size_t)32 * nR);
+  if (out->match_idx) memcpy(out->match_idx, hf + o.idx, sizeof(int) * nL);
+  if (out->match_dist) memcpy(out->match_dist, hf + o.dist, sizeof(int) * nL);
+  if (out->xyz) memcpy(out->xyz, hf + o.xyz, sizeof(double) * 3 * nL);
+  if (out->ok) memcpy(out->ok, hf + o.ok, nL);
   return SSX_OK;
 }
 
@@ -577,25 +624,28 @@ ssx_status ssx_stereo_frame(ssx_ctx* ctx, const uint8_t* imgL, const uint8_t* im
   ssx_status st = plan(ctx, rows, cols, 2, *orb, false, false);
   if (st != SSX_OK) return st;
   OrbWorkspace* ws = get_ws(ctx);
-  const size_t bytes = (size_t)rows * cols;
-  SSX_HIP_TRY(ctx, ws->input.reserve(2 * bytes + 512));
+  const int pitch = (cols + 7) & ~7;   // 8-byte rows: k_copy_level0 reads the staging copy with one load per 8 pixels
+  const size_t bytes = (size_t)rows * pitch;
   SSX_HIP_TRY(ctx, ws->stage.reserve(2 * bytes + 512));
   uint8_t* hs = ws->stage.as<uint8_t>();
   for (int y = 0; y < rows; ++y) {
-    memcpy(hs + (size_t)y * cols, imgL + (size_t)y * stride, cols);
-    memcpy(hs + bytes + (size_t)y * cols, imgR + (size_t)y * stride, cols);
+    memcpy(hs + (size_t)y * pitch, imgL + (size_t)y * stride, cols);
+    memcpy(hs + bytes + (size_t)y * pitch, imgR + (size_t)y * stride, cols);
   }
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->input.p, hs, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
-  st = stage_level0(ctx, ws->input.as<uint8_t>(), cols, bytes, nullptr, 0, 0);
+  // level 0 is built straight from the pinned staging copy (k_copy_level0 reads it over PCIe once): no separate upload
+  st = stage_level0(ctx, hs, pitch, bytes, nullptr, 0, 0);
   if (st != SSX_OK) return st;
   st = run_pipeline(ctx);
   if (st != SSX_OK) return st;
   MatchDev m{};
   st = make_match_dev(ctx, 1, *mp, *rig, T_wc, m);
   if (st != SSX_OK) return st;
-  st = launch_stereo(ctx, m);
+  size_t fetch_bytes = 0;
+  const FrameSlots slots = frame_slots(ws->dev.out_cap, &fetch_bytes);
+  SSX_HIP_TRY(ctx, ws->fetch.reserve(fetch_bytes));
+  st = launch_stereo(ctx, m, ws->fetch.as<char>(), &slots);
   if (st != SSX_OK) return st;
-  return fetch_frame_fast(ctx, out);
+  return fetch_frame_fast(ctx, slots, out);
 }
 
 ssx_status ssx_stereo_batch_enqueue(ssx_ctx* ctx)

@@ -137,10 +137,11 @@ def triangulate(ctx: Context, uvL, uvR, rig=None, T_wc=None):
 
 class _FrameBuffers:
     def __init__(self, cap):
-        self.kL = np.zeros(cap, dtype=KP_DTYPE); self.kR = np.zeros(cap, dtype=KP_DTYPE)
-        self.dL = np.zeros((cap, 32), np.uint8); self.dR = np.zeros((cap, 32), np.uint8)
-        self.idx = np.zeros(cap, np.int32); self.dist = np.zeros(cap, np.int32)
-        self.xyz = np.zeros((cap, 3)); self.ok = np.zeros(cap, np.uint8)
+        # (np.empty: the library writes the first nL / nR entries and result() returns exactly those)
+        self.kL = np.empty(cap, dtype=KP_DTYPE); self.kR = np.empty(cap, dtype=KP_DTYPE)
+        self.dL = np.empty((cap, 32), np.uint8); self.dR = np.empty((cap, 32), np.uint8)
+        self.idx = np.empty(cap, np.int32); self.dist = np.empty(cap, np.int32)
+        self.xyz = np.empty((cap, 3)); self.ok = np.empty(cap, np.uint8)
         o = StereoFrameOut()
         o.cap = cap
         o.kpsL = self.kL.ctypes.data_as(C.c_void_p); o.kpsR = self.kR.ctypes.data_as(C.c_void_p)
