@@ -51,7 +51,7 @@ def _newest_dep() -> float:
 
 def _compile(cc, src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    cmd = [cc, *COMMON, *PER_FILE.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [cc, *COMMON, *PER_FILE.get(src, []), *os.environ.get("SSX_EXTRA_HIPCC_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")

@@ -65,13 +65,10 @@ constexpr int CH_L = 128;          // max landmarks per chunk (per-landmark LDS 
 constexpr int PL = CH_L + 1;       // their padded pitch
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
+constexpr int BSEG_PARTS = 4;      // a block's pair list is cut into at most this many parts (k_schur's block phase) ...
+constexpr int BSEG_MIN = 8;        // ... of at least this many pairs
 constexpr int NMAX = 6 * SSX_BA_SMALL_P;   // 96 unknowns of the reduced system
-constexpr int MAX_BLK = SSX_BA_SMALL_P * (SSX_BA_SMALL_P + 1) / 2;   // 136 upper blocks
 constexpr int MAX_PAIRS = CH_E * (SSX_BA_SMALL_P + 1) / 2 + 8;       // leader pairs of one chunk (sum k(k+1)/2, k <= 16)
-
-// upper-triangular (r<=c) index tables of a 6x6 block
-__constant__ int8_t c_u6_r[UPPER6] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-__constant__ int8_t c_u6_c[UPPER6] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
 
 struct BaDev {
   // problem (uploaded once per ssx_ba_solve)
@@ -95,13 +92,15 @@ struct BaDev {
   const int8_t* blk_pb;
   // packed records: ONE 16-byte load per chunk / edge / landmark instead of a chain of dependent index loads
   const int4* ch_desc;      // nCh: first sorted edge, #edges, first compact landmark, #landmarks
-  const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bits 8.. chunk-local landmark
+  const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bits 8..15 chunk-local landmark, bits 16..23 position in the chunk's pose-major order (porder^-1)
   const int4* l_rec;        // nLm: chunk-local first edge, #edges, landmark id (caller's), fixed
   const uint8_t* porder;    // E: chunk-local edge indices grouped by free pose (fixed-pose edges last)
   const uint16_t* pptr;     // nCh x (nP+1): segment of each pose inside the chunk's porder
   const uint8_t* pair_a;    // nPairs: chunk-local leader edge a (pose pa)
   const uint8_t* pair_b;    // nPairs: chunk-local leader edge b (pose pb)
   const int* pair_ptr;      // nCh x (nBlk+1): absolute offsets into pair_a/pair_b
+  const int4* bseg;         // work items of k_schur's block phase: (block or -1, first pair, end pair [chunk-relative], part | parts << 4)
+  const int* bseg_ptr;      // nCh + 1: the chunk's items in bseg
   Cam K;
   double ext[14];
   double huber_delta, chi2_th;
@@ -177,38 +176,85 @@ __device__ __forceinline__ double block_max_256(double v, double* s)
 // ------------------------------------------------------------------------------------------------
 // LDS of the linearisation (carved from the workgroup's dynamic LDS so that the fused k_lin_schur can reuse the same
 // bytes for the Schur phase)
-constexpr size_t LIN_LDS_BYTES = sizeof(double) * (12 * (CH + 1) + 3 * CH + 9 * CH + CH) + CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) + 64;
+// -DSSX_PHASE_CLOCK (tools/ba_phase_clock.py): shader-clock stamps of one workgroup at the phase boundaries of the
+// linearise / Schur bodies, read back through ssx_debug_phase_clock -- how the per-phase cycle counts in DESIGN.md were taken
+#ifdef SSX_PHASE_CLOCK
+__device__ long long g_ph[16];
+#define PH(i) do { if (threadIdx.x == 0 && bx == 7 && blockIdx.y == 0) g_ph[i] = clock64(); } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
+constexpr int LIN_VA = 14;           // pose-block entries per round: 27 = 14 + 13
+constexpr size_t LIN_LDS_BYTES = sizeof(double) * (9 * CH + LIN_VA * PW + CH) + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) + 64;
+
+// the 27 owned entries of a pose (21 upper entries of Hpp, row-major, + 6 of bp): this edge's term of entries
+// [K0, K0 + N).  (Ji w) Ji and Ji r in the same association as ever, so that the sums keep their bits.
+template <int K0, int N>
+__device__ __forceinline__ void pose_terms(const double* Ji, double w, double r0, double r1, double* V)
+{
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int cc = r; cc < 6; ++cc) {
+      if (k >= K0 && k < K0 + N) V[k - K0] = Ji[r] * w * Ji[cc] + Ji[6 + r] * w * Ji[6 + cc];
+      ++k;
+    }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    if (k >= K0 && k < K0 + N) V[k - K0] = Ji[a] * r0 + Ji[6 + a] * r1;
+    ++k;
+  }
+}
+
+// sum of row[s0 .. s1): the chunk's edges of one pose sit next to each other (pose-major positions), so the loads of
+// several iterations are in flight together -- the former loop chased an index list with one dependent LDS round trip
+// per edge and dominated the kernel (12 000 + 9 600 waiting of 44 000 cycles per workgroup)
+__device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
+{
+  double acc = 0.0;
+  int s = s0;
+  for (; s + 8 <= s1; s += 8) {
+    double v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = row[s + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += v[i];
+  }
+  for (; s < s1; ++s) acc += row[s];
+  return acc;
+}
 
 // Wout (18, nullable): this thread's edge block W = Ji^T w Jj stays in registers for the caller; lmout (9, nullable):
 // this thread's landmark sums (Hll 6 + bl 3).  cur must be >= 0 (the device-driven checks are the wrappers').
 template <int JAC>
 __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur, char* smem, double* Wout, double* lmout)
 {
-  double (*sJi)[CH + 1] = reinterpret_cast<double (*)[CH + 1]>(smem);   // [12]: Jacobian wrt pose, [component][edge]; odd pitch: rows land on different banks
-  double* sW1 = reinterpret_cast<double*>(smem) + 12 * (CH + 1);
-  double* sR0 = sW1 + CH;
-  double* sR1 = sR0 + CH;
-  double (*sL)[CH] = reinterpret_cast<double (*)[CH]>(sR1 + CH);        // [9]: per-edge landmark contributions (6 Hll + 3 bl)
-  double* sRed = sR1 + CH + 9 * CH;
-  uint8_t* sOrd = reinterpret_cast<uint8_t*>(sRed + CH);
-  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sOrd + CH);
+  double (*sL)[CH] = reinterpret_cast<double (*)[CH]>(smem);            // [9]: per-edge landmark contributions (6 Hll + 3 bl), edge order
+  double* sV = reinterpret_cast<double*>(smem) + 9 * CH;                // [LIN_VA][PW]: per-edge pose-block terms, POSE-MAJOR order
+  double* sRed = sV + LIN_VA * PW;
+  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sRed + CH);
 
   const int c = bx, t = threadIdx.x;
   const int4 cd = d.ch_desc[c];
   const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const double* pose = d.pose[cur];
   const double* point = d.point[cur];
+  const bool small = !d.big;
 
   double rho0 = 0.0;
-  if (!d.big) {
-    if (t < ne) sOrd[t] = d.porder[e0 + t];
-    if (t <= d.nP) sPptr[t] = d.pptr[(size_t)c * (d.nP + 1) + t];
-  }
+  PH(0);
+  if (small && t <= d.nP) sPptr[t] = d.pptr[(size_t)c * (d.nP + 1) + t];
+  double Ji[12], wq = 0.0, r0 = 0.0, r1 = 0.0;
+  int pos = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Ji[k] = 0.0;
   if (t < ne) {
     const int e = e0 + t;
     const int4 er4 = d.e_rec[e];
     const int p = er4.x, pf = er4.y, lid = er4.z;
     const bool lfree = !(er4.w & 4);
+    pos = (er4.w >> 16) & 0xFF;
     double T[7], X[3];
 #pragma unroll
     for (int k = 0; k < 7; ++k) T[k] = pose[p * 7 + k];
@@ -216,7 +262,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     for (int k = 0; k < 3; ++k) X[k] = point[lid * 3 + k];
     const double* ext = d.ext + 7 * (er4.w & 1);
     const double u = d.e_uv[e], v = d.e_uv[d.E + e];
-    double er[2], p1[3], pc[3], Ji[12], Jj[6];
+    double er[2], p1[3], pc[3], Jj[6];
     ssx::edge_error(T, X, ext, d.K, u, v, er, p1, pc);
     if (JAC == SSX_JAC_NUMERIC_G2O) ssx::edge_jac_numeric(T, X, ext, d.K, u, v, Ji, Jj);
     else ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
@@ -226,7 +272,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     d.err_lin[d.E + e] = er[1];
     // an edge whose vertices are both fixed is not active in g2o (sparse_optimizer.cpp:237): no chi2 term
     if (pf < 0 && !lfree) rho0 = 0.0;
-    const double r0 = -er[0] * w, r1 = -er[1] * w;
+    wq = w; r0 = -er[0] * w; r1 = -er[1] * w;
     // W = Ji^T w Jj  (6x3), only when both vertices are free (block_solver.hpp:196-222)
     const bool both = (pf >= 0) && lfree;
     if (d.store_w || Wout) {
@@ -239,9 +285,6 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
           if (Wout) Wout[a * 3 + b] = wv;
         }
     }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) sJi[k][t] = Ji[k];
-    sW1[t] = w; sR0[t] = r0; sR1[t] = r1;
     // landmark contributions: Hll (6 unique) + bl
     int q = 0;
 #pragma unroll
@@ -250,8 +293,15 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
       for (int b = a; b < 3; ++b) sL[q++][t] = lfree ? (Jj[a] * w * Jj[b] + Jj[3 + a] * w * Jj[3 + b]) : 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) sL[6 + a][t] = lfree ? (Jj[a] * r0 + Jj[3 + a] * r1) : 0.0;
+    if (small) {
+      double V[LIN_VA];
+      pose_terms<0, LIN_VA>(Ji, wq, r0, r1, V);
+#pragma unroll
+      for (int k = 0; k < LIN_VA; ++k) sV[k * PW + pos] = V[k];
+    }
   }
   __syncthreads();
+  PH(1);
 
   // per-landmark sums in edge order (one thread per landmark of the chunk)
   double maxd = 0.0;
@@ -273,31 +323,34 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     }
     maxd = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
   }
+  PH(2);
 
-  // pose blocks: owned entries; each walks only the chunk's edges of ITS pose, in the host-prepared order
-  // (large windows build the pose blocks pose-major instead: k_pose_blocks)
+  // pose blocks: owned entries, each the sum of ITS pose's run of the pose-major term rows, in two rounds of 14 and 13
+  // entries per pose (large windows build the pose blocks pose-major instead: k_pose_blocks)
   double* slab = d.lin_slab + (size_t)c * d.lin_stride;
-  for (int idx = t; idx < (d.big ? 0 : d.nP * 27); idx += CH) {
-    const int p = idx / 27, k = idx - p * 27;
-    const int s0 = sPptr[p], s1 = sPptr[p + 1];
-    double acc = 0.0;
-    if (k < UPPER6) {
-      const int r = c_u6_r[k], cc = c_u6_c[k];
-      for (int s = s0; s < s1; ++s) {
-        const int j = sOrd[s];
-        acc += sJi[r][j] * sW1[j] * sJi[cc][j] + sJi[6 + r][j] * sW1[j] * sJi[6 + cc][j];
-      }
-    } else {
-      const int a = k - UPPER6;
-      for (int s = s0; s < s1; ++s) {
-        const int j = sOrd[s];
-        acc += sJi[a][j] * sR0[j] + sJi[6 + a][j] * sR1[j];
-      }
+  if (small) {
+    const int nP = d.nP;
+    for (int i = t; i < nP * LIN_VA; i += CH) {
+      const int p = i / LIN_VA, k = i - p * LIN_VA;
+      slab[p * 27 + k] = run_sum(sV + k * PW, sPptr[p], sPptr[p + 1]);
     }
-    slab[idx] = acc;
+    __syncthreads();
+    if (t < ne) {
+      double V[27 - LIN_VA];
+      pose_terms<LIN_VA, 27 - LIN_VA>(Ji, wq, r0, r1, V);
+#pragma unroll
+      for (int k = 0; k < 27 - LIN_VA; ++k) sV[k * PW + pos] = V[k];
+    }
+    __syncthreads();
+    for (int i = t; i < nP * (27 - LIN_VA); i += CH) {
+      const int p = i / (27 - LIN_VA), k = i - p * (27 - LIN_VA);
+      slab[p * 27 + LIN_VA + k] = run_sum(sV + k * PW, sPptr[p], sPptr[p + 1]);
+    }
   }
+  PH(3);
   const double chi = block_sum_256(rho0, sRed);
   const double md = block_max_256(maxd, sRed);
+  PH(4);
   if (t == 0) {
     slab[d.lin_stride - 2] = chi;
     slab[d.lin_stride - 1] = md;
@@ -523,12 +576,8 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   double* sG = sY + 18 * PW;                               // [6][PL] per landmark: 1/l00, l10, l20, 1/l11, l21, 1/l22
   double* sGb = sG + 6 * PL;                               // [3][PL] per landmark: L^-1 bl
   int* sLm = reinterpret_cast<int*>(sGb + 3 * PL);         // [CH] local landmark of each edge
-  uint8_t* sLeader = reinterpret_cast<uint8_t*>(sLm + CH); // [CH]
-  uint8_t* sOrd = sLeader + CH;                            // [CH]
-  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sOrd + CH);// [SSX_BA_SMALL_P + 2]
-  int* sBptr = reinterpret_cast<int*>(sPptr + SSX_BA_SMALL_P + 2);   // [MAX_BLK + 1] pair offsets of each block
-  uint8_t* sPa = reinterpret_cast<uint8_t*>(sBptr + MAX_BLK + 1);    // [MAX_PAIRS]
-  uint8_t* sPb = sPa + MAX_PAIRS;                                    // [MAX_PAIRS]
+  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sLm + CH); // [SSX_BA_SMALL_P + 2]
+  uint16_t* sPab = sPptr + SSX_BA_SMALL_P + 2;             // [MAX_PAIRS] edge a | edge b << 8 of the chunk's pairs, grouped by block
 
   const int c = bx, t = threadIdx.x;
   const int4 cd = d.ch_desc[c];
@@ -537,19 +586,24 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
 
   bool leader = false;
   double Wm[18];
-  if (t < ne) sOrd[t] = d.porder[e0 + t];
+  double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // this edge's term of c = sum W D^-1 bl: Y (L^-1 bl)
+  int zpos = 0;                                  // its position in the chunk's pose-major order
+  PH(5);
+  // this lane's first work item of the block phase (see there): fetched now, used after the barriers
+  const int it0 = d.bseg_ptr[c], n_items = 4 * (d.bseg_ptr[c + 1] - it0);
+  int4 item_rec = t < n_items ? d.bseg[it0 + (t >> 2)] : make_int4(-1, 0, 0, 1 << 4);
   if (t <= nP) sPptr[t] = d.pptr[(size_t)c * (nP + 1) + t];
   {
     // the chunk's (edge a, edge b) pairs grouped by block: global -> LDS once, coalesced
     const int* gp = d.pair_ptr + (size_t)c * (d.nBlk + 1);
     const int q_base = gp[0], q_end = gp[d.nBlk];
-    for (int i = t; i <= d.nBlk; i += CH) sBptr[i] = gp[i] - q_base;
-    for (int q = t; q < q_end - q_base; q += CH) { sPa[q] = d.pair_a[q_base + q]; sPb[q] = d.pair_b[q_base + q]; }
+    for (int q = t; q < q_end - q_base; q += CH) sPab[q] = (uint16_t)(d.pair_a[q_base + q] | (d.pair_b[q_base + q] << 8));
   }
   if (t < ne) {
     const int e = e0 + t;
     const int4 er4 = d.e_rec[e];
-    sLm[t] = er4.w >> 8;
+    sLm[t] = (er4.w >> 8) & 0xFF;
+    zpos = (er4.w >> 16) & 0xFF;
     leader = (er4.y >= 0) && !(er4.w & 6);                    // free pose, free landmark, not a duplicate
     if (leader) {
       // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
@@ -575,7 +629,6 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
       }
     }
   }
-  sLeader[t] = leader ? 1 : 0;
   if (t < nl) {
     const int lc = lm0 + t;
     double D[6];
@@ -595,16 +648,19 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     sGb[t] = g0; sGb[PL + t] = g1; sGb[2 * PL + t] = g2;
   }
   __syncthreads();
+  PH(6);
   if (t < ne) {
     if (leader) {
       const int l = sLm[t];
       const double i00 = sG[l], l10 = sG[PL + l], l20 = sG[2 * PL + l], i11 = sG[3 * PL + l], l21 = sG[4 * PL + l], i22 = sG[5 * PL + l];
+      const double g0 = sGb[l], g1 = sGb[PL + l], g2 = sGb[2 * PL + l];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const double y0 = Wm[a * 3] * i00;
         const double y1 = (Wm[a * 3 + 1] - y0 * l10) * i11;
         const double y2 = (Wm[a * 3 + 2] - y0 * l20 - y1 * l21) * i22;
         sY[(a * 3) * PW + t] = y0; sY[(a * 3 + 1) * PW + t] = y1; sY[(a * 3 + 2) * PW + t] = y2;
+        z[a] = y0 * g0 + y1 * g1 + y2 * g2;
       }
     } else {
 #pragma unroll
@@ -613,14 +669,22 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   }
   __syncthreads();
 
-  // The reduced system's blocks: FOUR threads per block, each owning a 3x3 quarter of the 6x6 -- it walks the (edge a,
-  // edge b) pairs of the block in landmark order with 9 independent accumulators: 18 LDS doubles per pair feed 27
-  // fused multiply-adds (the former one-thread-per-entry loop read 6 doubles for 3 and ran as one dependent chain).
+  // The reduced system's blocks: FOUR lanes per work item, each owning a 3x3 quarter of the 6x6 -- it walks (a part of)
+  // the block's (edge a, edge b) pairs in landmark order with 9 independent accumulators: 18 LDS doubles per pair feed
+  // 27 fused multiply-adds.  A wave takes as long as its longest list and nine tenths of the kernel's VALU
+  // instructions are issued here, so the host cuts the lists (0 .. 40 pairs) into parts of equal length, sorts the
+  // items by length and keeps the parts of one block in one wave (d.bseg): the first part collects the partial sums
+  // through wave shuffles, in part order.
+  // (Tried and slower: reading only one 3x3 operand per lane and passing the other between the lanes of the quad
+  // through DPP -- half the LDS traffic; an explicit software pipeline of index / operands / multiply.)
+  PH(7);
   double* slab = d.schur_slab + (size_t)c * (d.nBlk * 36 + nP * 6);
   const int nS = d.nBlk * 36;
-  for (int item = t; item < 4 * d.nBlk; item += CH) {
-    const int blk = item >> 2, qr = (item >> 1) & 1, qc = item & 1;      // rows 3 qr .. 3 qr + 2, columns 3 qc .. 3 qc + 2
-    const int q0 = sBptr[blk], q1 = sBptr[blk + 1];
+  for (int base = 0; base < n_items; base += CH) {
+    const int4 ir = item_rec;
+    if (base + CH < n_items) item_rec = base + CH + t < n_items ? d.bseg[it0 + ((base + CH + t) >> 2)] : make_int4(-1, 0, 0, 1 << 4);
+    const int blk = ir.x, qr = (t >> 1) & 1, qc = t & 1;                 // rows 3 qr .. 3 qr + 2, columns 3 qc .. 3 qc + 2
+    const int q0 = ir.y, q1 = ir.z, part = ir.w & 15, parts = ir.w >> 4;
     double acc[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -630,7 +694,8 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     const double* wp = sY + (qc * 9) * PW;
 #pragma unroll 2
     for (int q = q0; q < q1; ++q) {
-      const int ea = sPa[q], eb = sPb[q];
+      const int ab = sPab[q];
+      const int ea = ab & 0xFF, eb = ab >> 8;
       double bd[3][3], w[3][3];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -641,12 +706,36 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] += bd[i][0] * w[j][0] + bd[i][1] * w[j][1] + bd[i][2] * w[j][2];
     }
+    if (__any(parts > 1)) {                                              // wave-uniform: every lane takes part in the shuffles
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j] = acc[i][j];
+        for (int j = 0; j < 3; ++j) {
+          const double v1 = __shfl_down(acc[i][j], 4), v2 = __shfl_down(acc[i][j], 8), v3 = __shfl_down(acc[i][j], 12);
+          if (part == 0) {
+            if (parts > 1) acc[i][j] += v1;
+            if (parts > 2) acc[i][j] += v2;
+            if (parts > 3) acc[i][j] += v3;
+          }
+        }
+    }
+    if (blk >= 0 && part == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j] = acc[i][j];
+    }
   }
-  // c: four threads per entry share the pose's edge list, partial sums folded inside the quad
+  PH(8);
+  // c: the per-edge terms z go to LDS in POSE-MAJOR positions (Y is dead), four threads per entry share the pose's run,
+  // partial sums folded inside the quad (the former loop chased the pose's edge list: three dependent LDS round trips
+  // per edge)
+  __syncthreads();
+  if (t < ne) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) sY[a * PW + zpos] = z[a];
+  }
+  __syncthreads();
   for (int base = 0; base < nP * 6 * 4; base += CH) {
     const int item = base + t;
     const bool on = item < nP * 6 * 4;
@@ -654,18 +743,16 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     const int p = idx / 6, a = idx - p * 6;
     double acc = 0.0;
     if (on)
-      for (int s = sPptr[p] + part; s < sPptr[p + 1]; s += 4) {
-        const int j = sOrd[s];
-        if (sLeader[j]) {
-          const int l = sLm[j];
-          acc += sY[(a * 3) * PW + j] * sGb[l] + sY[(a * 3 + 1) * PW + j] * sGb[PL + l] + sY[(a * 3 + 2) * PW + j] * sGb[2 * PL + l];
-        }
-      }
+      for (int s = sPptr[p] + part; s < sPptr[p + 1]; s += 4) acc += sY[a * PW + s];
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     if (on && part == 0) slab[nS + idx] = acc;
   }
+  PH(9);
 }
+#ifdef SSX_PHASE_CLOCK
+extern "C" __attribute__((visibility("default"))) void ssx_debug_phase_clock(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ph), sizeof(long long) * 16); }
+#endif
 
 __device__ __forceinline__ void k_schur_entry(const BaDev& d, int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
@@ -1060,7 +1147,7 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
   if (t < ne) {
     const int e = e0 + t;
     const int p = er4.x;
-    const int l = er4.w >> 8;
+    const int l = (er4.w >> 8) & 0xFF;
     const double* pose = d.pose[cur ^ 1];
     double T[7];
 #pragma unroll
@@ -1229,6 +1316,7 @@ struct HostPrep {
   // large-window path
   bool big = false;
   std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr;
+  std::vector<int> bseg, bseg_ptr;   // see BaDev
   std::vector<int> ch_desc, e_rec, l_rec;   // packed records (4 ints each), see BaDev
   std::vector<int> lm_chunk;                // compact landmark -> chunk (large windows: the device-side pair builder)
   int band_w = -1;          // cyclic block bandwidth of this rank's part of the reduced system (max over its non-zero blocks)
@@ -1350,6 +1438,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     h.sblk_pa.clear(); h.sblk_pb.clear(); h.spair_ptr.assign(1, 0);
     h.nBlk = 0;
     h.band_w = -1;
+    h.bseg.clear(); h.bseg_ptr.clear();
     return SSX_OK;
   }
   // per-chunk index lists: edges grouped by free pose; leader pairs grouped by reduced-system block
@@ -1358,6 +1447,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   h.pptr.assign((size_t)h.nCh * (nP + 1) + 1, 0);
   h.pair_ptr.assign((size_t)h.nCh * (nBlk + 1) + 1, 0);
   h.pair_a.clear(); h.pair_b.clear();
+  h.bseg.clear(); h.bseg_ptr.assign((size_t)h.nCh + 1, 0);
   std::vector<int> blk_of((size_t)std::max(nP, 1) * std::max(nP, 1), -1);
   for (int b = 0; b < nBlk; ++b) blk_of[(size_t)h.blk_pa[b] * nP + h.blk_pb[b]] = b;
   std::vector<int> pc(nP + 1), bc(nBlk + 1);
@@ -1374,8 +1464,9 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     int tail = pc[nP];
     for (int s = e0; s < e1; ++s) {
       const int pf = h.pose_free[h.e_pose[s]];
-      if (pf >= 0) h.porder[e0 + pc[pf]++] = (uint8_t)(s - e0);
-      else h.porder[e0 + tail++] = (uint8_t)(s - e0);
+      const int pos = pf >= 0 ? pc[pf]++ : tail++;
+      h.porder[e0 + pos] = (uint8_t)(s - e0);
+      h.e_rec[4 * (size_t)s + 3] = (h.e_rec[4 * (size_t)s + 3] & 0xFFFF) | (pos << 16);   // the inverse map, for the kernels that store pose-major
     }
     // --- pairs by block: two passes (count, fill) over the landmarks of the chunk ---
     std::fill(bc.begin(), bc.end(), 0);
@@ -1401,6 +1492,34 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
         for (int b = 0; b <= nBlk; ++b) bp[b] = bc[b];
         h.pair_a.resize(bc[nBlk]); h.pair_b.resize(bc[nBlk]);
       }
+    }
+    // --- work items of the block phase.  A lane walks ONE pair list and a wave takes as long as its longest list, so
+    // the lists (0 .. 40 pairs in a local window) are cut into parts of about the same length, the parts sorted by
+    // length, and the parts of one block kept inside one wave (their partial sums meet through wave shuffles).
+    {
+      const int* bp = &h.pair_ptr[(size_t)c * (nBlk + 1)];
+      const int base = bp[0];
+      int maxlen = 0;
+      for (int b = 0; b < nBlk; ++b) maxlen = std::max(maxlen, bp[b + 1] - bp[b]);
+      const int seg = std::max(BSEG_MIN, (maxlen + BSEG_PARTS - 1) / BSEG_PARTS);
+      std::vector<std::pair<int, int>> order;   // (-part length, block)
+      order.reserve(nBlk);
+      for (int b = 0; b < nBlk; ++b) {
+        const int n = bp[b + 1] - bp[b], k = std::max(1, (n + seg - 1) / seg);
+        order.push_back({-((n + k - 1) / k), b});
+      }
+      std::stable_sort(order.begin(), order.end());
+      int pos = 0;                                // in items (16 per wave: four lanes each)
+      for (const auto& ob : order) {
+        const int b = ob.second, n = bp[b + 1] - bp[b], k = std::max(1, (n + seg - 1) / seg), len = (n + k - 1) / k;
+        while ((pos & 15) + k > 16) { h.bseg.insert(h.bseg.end(), {-1, 0, 0, 1 << 4}); ++pos; }
+        for (int i = 0; i < k; ++i) {
+          const int q0 = bp[b] - base + std::min(n, i * len), q1 = bp[b] - base + std::min(n, (i + 1) * len);
+          h.bseg.insert(h.bseg.end(), {b, q0, q1, i | (k << 4)});
+          ++pos;
+        }
+      }
+      h.bseg_ptr[c + 1] = (int)(h.bseg.size() / 4);
     }
   }
   return SSX_OK;
@@ -1478,6 +1597,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_pair_a = in.take(nPairs + 1);
   const size_t o_pair_b = in.take(nPairs + 1);
   const size_t o_pair_ptr = in.take(sizeof(int) * (h.pair_ptr.size() + 1));
+  const size_t o_bseg = in.take(sizeof(int) * (h.bseg.size() + 4));
+  const size_t o_bseg_ptr = in.take(sizeof(int) * (h.bseg_ptr.size() + 1));
   const size_t o_pe_ptr = in.take(sizeof(int) * (h.pe_ptr.size() + 1));
   const size_t o_pe_edge = in.take(sizeof(int) * (h.pe_edge.size() + 1));
   const size_t o_sblk_pa = in.take(sizeof(int) * (nBlkS + 1));
@@ -1575,6 +1696,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_pair_b, h.pair_b.data(), nPairs);
   }
   if (!h.pair_ptr.empty()) memcpy(hs + o_pair_ptr, h.pair_ptr.data(), sizeof(int) * h.pair_ptr.size());
+  if (!h.bseg.empty()) memcpy(hs + o_bseg, h.bseg.data(), sizeof(int) * h.bseg.size());
+  if (!h.bseg_ptr.empty()) memcpy(hs + o_bseg_ptr, h.bseg_ptr.data(), sizeof(int) * h.bseg_ptr.size());
   if (big) {
     memcpy(hs + o_pe_ptr, h.pe_ptr.data(), sizeof(int) * h.pe_ptr.size());
     memcpy(hs + o_pe_edge, h.pe_edge.data(), sizeof(int) * h.pe_edge.size());
@@ -1626,6 +1749,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.pair_a = (const uint8_t*)(at(o_pair_a));
   d.pair_b = (const uint8_t*)(at(o_pair_b));
   d.pair_ptr = (const int*)(at(o_pair_ptr));
+  d.bseg = (const int4*)(at(o_bseg)); d.bseg_ptr = (const int*)(at(o_bseg_ptr));
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
@@ -1775,8 +1899,7 @@ ssx_status build_pairs(ssx_ctx* ctx, HostPrep& h, const unsigned long long** ab_
 
 size_t schur_lds_bytes()
 {
-  return sizeof(double) * (18 * PW + 9 * PL) + sizeof(int) * CH + 2 * CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) +
-         sizeof(int) * (MAX_BLK + 1) + 2 * MAX_PAIRS + 64;
+  return sizeof(double) * (18 * PW + 9 * PL) + sizeof(int) * CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) + 2 * MAX_PAIRS + 64;
 }
 
 struct Comm {
