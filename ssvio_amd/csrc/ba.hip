@@ -138,35 +138,52 @@ enum { SC_CHI2_CUR = 0, SC_MAXDIAG = 1, SC_SOLVE_OK = 2, SC_SCALE_P = 3, SC_TEMP
        SC_NI = 8, SC_CUR = 9, SC_IT = 10, SC_QMAX = 11, SC_STOP = 12, SC_NEEDLIN = 13, SC_ITERS = 14, SC_NSTAT = 15,
        SC_CURCHI = 16, SC_TRIALS_RUN = 17, SC_N = 32 };
 
+// Workgroup reductions (256 threads), fixed shape, hence deterministic: an xor tree inside each wave, then the four wave
+// results in wave order.  `s` needs 16 doubles; two barriers per call (the tree of barriers it replaces took ten).
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
 __device__ __forceinline__ double block_sum_256(double v, double* s)
 {
-  // fixed-shape tree: deterministic
   const int t = threadIdx.x;
-  s[t] = v;
+  v = wave_sum(v);
+  if ((t & 63) == 0) s[t >> 6] = v;
   __syncthreads();
-#pragma unroll
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) s[t] += s[t + o];
-    __syncthreads();
-  }
-  const double r = s[0];
+  const double r = ((s[0] + s[1]) + s[2]) + s[3];
   __syncthreads();
   return r;
 }
-
 __device__ __forceinline__ double block_max_256(double v, double* s)
 {
   const int t = threadIdx.x;
-  s[t] = v;
+  v = wave_max(v);
+  if ((t & 63) == 0) s[t >> 6] = v;
   __syncthreads();
-#pragma unroll
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) s[t] = fmax(s[t], s[t + o]);
-    __syncthreads();
-  }
-  const double r = s[0];
+  const double r = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
   __syncthreads();
   return r;
+}
+// a, b, c summed and m maximised over the workgroup in one pass (one pair of barriers)
+__device__ __forceinline__ void block_sum3_max_256(double& a, double& b, double& c, double& m, double* s)
+{
+  const int t = threadIdx.x;
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); m = wave_max(m);
+  if ((t & 63) == 0) { const int w = t >> 6; s[w] = a; s[4 + w] = b; s[8 + w] = c; s[12 + w] = m; }
+  __syncthreads();
+  a = ((s[0] + s[1]) + s[2]) + s[3];
+  b = ((s[4] + s[5]) + s[6]) + s[7];
+  c = ((s[8] + s[9]) + s[10]) + s[11];
+  m = fmax(fmax(s[12], s[13]), fmax(s[14], s[15]));
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,14 +231,13 @@ __device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
 {
   double acc = 0.0;
   int s = s0;
-  for (; s + 8 <= s1; s += 8) {
+  for (; s < s1; s += 8) {      // the last round reads past the run (inside the row or its neighbour) and adds zeros instead
     double v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = row[s + i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc += v[i];
+    for (int i = 0; i < 8; ++i) acc += (s + i < s1) ? v[i] : 0.0;
   }
-  for (; s < s1; ++s) acc += row[s];
   return acc;
 }
 
@@ -348,8 +364,8 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     }
   }
   PH(3);
-  const double chi = block_sum_256(rho0, sRed);
-  const double md = block_max_256(maxd, sRed);
+  double chi = rho0, md = maxd, z0 = 0.0, z1 = 0.0;
+  block_sum3_max_256(chi, z0, z1, md, sRed);
   PH(4);
   if (t == 0) {
     slab[d.lin_stride - 2] = chi;
@@ -1162,9 +1178,8 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
     if (er4.y < 0 && (er4.w & 4)) rho0 = 0.0;                        // inactive edge (all vertices fixed)
     nout = (c2 > d.chi2_th) ? 1.0 : 0.0;
   }
-  const double chi = block_sum_256(rho0, sRed);
-  const double sl = block_sum_256(scale_l, sRed);
-  const double no = block_sum_256(nout, sRed);
+  double chi = rho0, sl = scale_l, no = nout, unused_max = 0.0;
+  block_sum3_max_256(chi, sl, no, unused_max, sRed);
   if (t == 0) {
     d.trial_slab[c * 3] = chi;
     d.trial_slab[c * 3 + 1] = sl;
