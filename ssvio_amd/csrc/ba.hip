@@ -92,7 +92,7 @@ struct BaDev {
   const int8_t* blk_pb;
   // packed records: ONE 16-byte load per chunk / edge / landmark instead of a chain of dependent index loads
   const int4* ch_desc;      // nCh: first sorted edge, #edges, first compact landmark, #landmarks
-  const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bits 8..15 chunk-local landmark, bits 16..23 position in the chunk's pose-major order (porder^-1)
+  const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bit3 next edge is a dup, bit5 pose fixed, bits 8..15 chunk-local landmark, bits 16..23 position in the chunk's pose-major order (porder^-1)
   const int4* l_rec;        // nLm: chunk-local first edge, #edges, landmark id (caller's), fixed
   const uint8_t* porder;    // E: chunk-local edge indices grouped by free pose (fixed-pose edges last)
   const uint16_t* pptr;     // nCh x (nP+1): segment of each pose inside the chunk's porder
@@ -202,7 +202,44 @@ __device__ long long g_ph[16];
 #define PH(i) do {} while (0)
 #endif
 constexpr int LIN_VA = 14;           // pose-block entries per round: 27 = 14 + 13
-constexpr size_t LIN_LDS_BYTES = sizeof(double) * (9 * CH + LIN_VA * PW + CH) + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) + 64;
+// One LDS layout for k_linearize, k_schur and the fused k_lin_schur: [0, BA_PHASE_BYTES) belongs to the running phase
+// (linearise: sL 9 x CH + sV 14 x PW doubles; Schur: sY 18 x PW + sG, sGb 9 x PL doubles + sLm CH ints), the lists above
+// it (pose segments, pair list) are loaded ONCE at the top of the kernel and survive the change of phase.
+constexpr size_t BA_PHASE_BYTES = 47360;
+static_assert(sizeof(double) * (9 * CH + LIN_VA * PW) <= BA_PHASE_BYTES, "linearise phase LDS");
+static_assert(sizeof(double) * (18 * PW + 9 * PL) + sizeof(int) * CH <= BA_PHASE_BYTES, "Schur phase LDS");
+constexpr size_t BA_OFF_PPTR = BA_PHASE_BYTES;                                   // uint16 [SSX_BA_SMALL_P + 2]
+constexpr size_t BA_OFF_PAB = BA_OFF_PPTR + 64;                                  // uint16 [MAX_PAIRS]
+constexpr size_t BA_LDS_BYTES = BA_OFF_PAB + ((2 * MAX_PAIRS + 63) & ~size_t(63));   // 51 776 B: three workgroups per CU
+constexpr size_t LIN_LDS_BYTES = BA_LDS_BYTES;
+static_assert(2 * (SSX_BA_SMALL_P + 2) <= 64 && 3 * BA_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// What a chunk's workgroup fetches before it looks at the LM state: nothing here depends on it, and the loads are in
+// flight while the state words arrive (the kernel is a chain of dependent global loads: window -> state -> chunk ->
+// edge records -> poses / points; every hop taken off the chain is ~1 us per workgroup).
+struct ChunkLists {
+  int4 cd;          // ch_desc
+  int it0, n_items; // work items of the Schur block phase (BaDev::bseg)
+  int4 item_rec;    // this lane's first work item
+};
+__device__ __forceinline__ void chunk_lists_load(const BaDev& d, int c, char* smem, bool want_pairs, ChunkLists& cl)
+{
+  const int t = threadIdx.x;
+  uint16_t* sPptr = reinterpret_cast<uint16_t*>(smem + BA_OFF_PPTR);
+  uint16_t* sPab = reinterpret_cast<uint16_t*>(smem + BA_OFF_PAB);
+  cl.cd = d.ch_desc[c];
+  cl.it0 = 0; cl.n_items = 0; cl.item_rec = make_int4(-1, 0, 0, 1 << 4);
+  if (d.big) return;
+  if (t <= d.nP) sPptr[t] = d.pptr[(size_t)c * (d.nP + 1) + t];
+  if (!want_pairs) return;
+  cl.it0 = d.bseg_ptr[c];
+  cl.n_items = 4 * (d.bseg_ptr[c + 1] - cl.it0);
+  if (t < cl.n_items) cl.item_rec = d.bseg[cl.it0 + (t >> 2)];
+  // the chunk's (edge a, edge b) pairs grouped by block: global -> LDS once, coalesced
+  const int* gp = d.pair_ptr + (size_t)c * (d.nBlk + 1);
+  const int q_base = gp[0], q_end = gp[d.nBlk];
+  for (int q = t; q < q_end - q_base; q += CH) sPab[q] = (uint16_t)(d.pair_a[q_base + q] | (d.pair_b[q_base + q] << 8));
+}
 
 // the 27 owned entries of a pose (21 upper entries of Hpp, row-major, + 6 of bp): this edge's term of entries
 // [K0, K0 + N).  (Ji w) Ji and Ji r in the same association as ever, so that the sums keep their bits.
@@ -243,16 +280,18 @@ __device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
 
 // Wout (18, nullable): this thread's edge block W = Ji^T w Jj stays in registers for the caller; lmout (9, nullable):
 // this thread's landmark sums (Hll 6 + bl 3).  cur must be >= 0 (the device-driven checks are the wrappers').
+// erw_out (nullable): the flag word of this thread's edge record, for the Schur phase of the fused kernel.
 template <int JAC>
-__device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur, char* smem, double* Wout, double* lmout)
+__device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur, char* smem, const ChunkLists& cl, double* Wout, double* lmout,
+                                                 int* erw_out)
 {
   double (*sL)[CH] = reinterpret_cast<double (*)[CH]>(smem);            // [9]: per-edge landmark contributions (6 Hll + 3 bl), edge order
   double* sV = reinterpret_cast<double*>(smem) + 9 * CH;                // [LIN_VA][PW]: per-edge pose-block terms, POSE-MAJOR order
-  double* sRed = sV + LIN_VA * PW;
-  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sRed + CH);
+  double* sRed = reinterpret_cast<double*>(smem);                       // 16 doubles over sL, which is dead by then
+  const uint16_t* sPptr = reinterpret_cast<const uint16_t*>(smem + BA_OFF_PPTR);
 
   const int c = bx, t = threadIdx.x;
-  const int4 cd = d.ch_desc[c];
+  const int4 cd = cl.cd;
   const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const double* pose = d.pose[cur];
   const double* point = d.point[cur];
@@ -260,7 +299,6 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
 
   double rho0 = 0.0;
   PH(0);
-  if (small && t <= d.nP) sPptr[t] = d.pptr[(size_t)c * (d.nP + 1) + t];
   double Ji[12], wq = 0.0, r0 = 0.0, r1 = 0.0;
   int pos = 0;
 #pragma unroll
@@ -271,6 +309,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     const int p = er4.x, pf = er4.y, lid = er4.z;
     const bool lfree = !(er4.w & 4);
     pos = (er4.w >> 16) & 0xFF;
+    if (erw_out) *erw_out = er4.w;
     double T[7], X[3];
 #pragma unroll
     for (int k = 0; k < 7; ++k) T[k] = pose[p * 7 + k];
@@ -364,6 +403,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     }
   }
   PH(3);
+  if (!small) __syncthreads();                   // sRed lies over sL: every landmark sum must have been read
   double chi = rho0, md = maxd, z0 = 0.0, z1 = 0.0;
   block_sum3_max_256(chi, z0, z1, md, sRed);
   PH(4);
@@ -377,11 +417,13 @@ template <int JAC>
 __device__ __forceinline__ void k_linearize_entry(const BaDev& d, int bx, int cur)
 {
   extern __shared__ __attribute__((aligned(16))) char lin_smem[];
+  ChunkLists cl;
+  chunk_lists_load(d, bx, lin_smem, false, cl);
   if (cur < 0) {                                   // device-driven LM: skip when stopped or when the linearisation at the
     if (d.scal[SC_STOP] != 0.0 || d.scal[SC_NEEDLIN] == 0.0) return;   // kept state is still valid (rejected trial)
     cur = (int)d.scal[SC_CUR];
   }
-  k_linearize_body<JAC>(d, bx, cur, lin_smem, nullptr, nullptr);
+  k_linearize_body<JAC>(d, bx, cur, lin_smem, cl, nullptr, nullptr, nullptr);
 }
 template <int JAC>
 __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur) { k_linearize_entry<JAC>(d, blockIdx.x, cur); }
@@ -581,7 +623,9 @@ __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W
 // ------------------------------------------------------------------------------------------------
 // Win (18, nullable): this thread's edge block W from a linearisation phase that just ran in the same kernel; lmin (9,
 // nullable): this thread's landmark sums (Hll 6 + bl 3).  The stop / state checks are the wrappers'.
-__device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int cur, double lambda, char* smem, const double* Win, const double* lmin)
+// erw_in (nullable): this thread's edge flag word from the linearisation phase (fused kernel).
+__device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int cur, double lambda, char* smem, const ChunkLists& cl, const double* Win,
+                                             const double* lmin, const int* erw_in)
 {
   // With D = Hll + lambda I = L L^T (3x3 Cholesky) and Y_e = W_e L^-T, the Schur term of an edge pair is
   // W_a D^-1 W_b^T = Y_a Y_b^T and W D^-1 bl = Y (L^-1 bl): ONE 6x3 array per edge in LDS instead of W and W D^-1
@@ -592,11 +636,11 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   double* sG = sY + 18 * PW;                               // [6][PL] per landmark: 1/l00, l10, l20, 1/l11, l21, 1/l22
   double* sGb = sG + 6 * PL;                               // [3][PL] per landmark: L^-1 bl
   int* sLm = reinterpret_cast<int*>(sGb + 3 * PL);         // [CH] local landmark of each edge
-  uint16_t* sPptr = reinterpret_cast<uint16_t*>(sLm + CH); // [SSX_BA_SMALL_P + 2]
-  uint16_t* sPab = sPptr + SSX_BA_SMALL_P + 2;             // [MAX_PAIRS] edge a | edge b << 8 of the chunk's pairs, grouped by block
+  const uint16_t* sPptr = reinterpret_cast<const uint16_t*>(smem + BA_OFF_PPTR);   // [SSX_BA_SMALL_P + 2]   (chunk_lists_load)
+  const uint16_t* sPab = reinterpret_cast<const uint16_t*>(smem + BA_OFF_PAB);     // [MAX_PAIRS] edge a | edge b << 8, grouped by block
 
   const int c = bx, t = threadIdx.x;
-  const int4 cd = d.ch_desc[c];
+  const int4 cd = cl.cd;
   const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const int nP = d.nP;
 
@@ -605,22 +649,14 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // this edge's term of c = sum W D^-1 bl: Y (L^-1 bl)
   int zpos = 0;                                  // its position in the chunk's pose-major order
   PH(5);
-  // this lane's first work item of the block phase (see there): fetched now, used after the barriers
-  const int it0 = d.bseg_ptr[c], n_items = 4 * (d.bseg_ptr[c + 1] - it0);
-  int4 item_rec = t < n_items ? d.bseg[it0 + (t >> 2)] : make_int4(-1, 0, 0, 1 << 4);
-  if (t <= nP) sPptr[t] = d.pptr[(size_t)c * (nP + 1) + t];
-  {
-    // the chunk's (edge a, edge b) pairs grouped by block: global -> LDS once, coalesced
-    const int* gp = d.pair_ptr + (size_t)c * (d.nBlk + 1);
-    const int q_base = gp[0], q_end = gp[d.nBlk];
-    for (int q = t; q < q_end - q_base; q += CH) sPab[q] = (uint16_t)(d.pair_a[q_base + q] | (d.pair_b[q_base + q] << 8));
-  }
+  const int it0 = cl.it0, n_items = cl.n_items;
+  int4 item_rec = cl.item_rec;
   if (t < ne) {
     const int e = e0 + t;
-    const int4 er4 = d.e_rec[e];
-    sLm[t] = (er4.w >> 8) & 0xFF;
-    zpos = (er4.w >> 16) & 0xFF;
-    leader = (er4.y >= 0) && !(er4.w & 6);                    // free pose, free landmark, not a duplicate
+    const int erw = erw_in ? *erw_in : d.e_rec[e].w;
+    sLm[t] = (erw >> 8) & 0xFF;
+    zpos = (erw >> 16) & 0xFF;
+    leader = !(erw & (6 | 32));                              // free pose (bit 5 clear), free landmark, not a duplicate
     if (leader) {
       // merge duplicates (several edges of the same (landmark,pose) pair share one Hpl block in g2o)
       if (Win) {
@@ -632,7 +668,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
       } else {
         edge_W(d, cur, e, Wm);
       }
-      for (int j = t + 1; j < ne && d.e_dup[e0 + j]; ++j) {
+      for (int j = t + 1; (erw & 8) && j < ne && d.e_dup[e0 + j]; ++j) {   // bit 3: the next edge is a duplicate of this one (rare)
         double Wd[18];
         if (d.store_w) {                                   // (written by this workgroup's linearisation phase, a barrier ago, when fused)
 #pragma unroll
@@ -773,10 +809,12 @@ extern "C" __attribute__((visibility("default"))) void ssx_debug_phase_clock(lon
 __device__ __forceinline__ void k_schur_entry(const BaDev& d, int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
   extern __shared__ __attribute__((aligned(16))) char schur_smem[];
+  ChunkLists cl;
+  chunk_lists_load(d, bx, schur_smem, true, cl);
   if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
   if (cur < 0) cur = (int)d.scal[SC_CUR];
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
-  k_schur_body(d, bx, cur, lambda, schur_smem, nullptr, nullptr);
+  k_schur_body(d, bx, cur, lambda, schur_smem, cl, nullptr, nullptr, nullptr);
 }
 __global__ __launch_bounds__(CH) void k_schur(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_schur_entry(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
@@ -795,20 +833,23 @@ template <int JAC>
 __device__ __forceinline__ void k_lin_schur_entry(const BaDev& d, int bx)
 {
   extern __shared__ __attribute__((aligned(16))) char fused_smem[];
-  if (d.scal[SC_STOP] != 0.0) return;
-  const int cur = (int)d.scal[SC_CUR];
-  const double lambda = d.scal[SC_LAMBDA];
-  if (d.scal[SC_NEEDLIN] != 0.0) {
+  const double stop = d.scal[SC_STOP], curd = d.scal[SC_CUR], lambda = d.scal[SC_LAMBDA], needlin = d.scal[SC_NEEDLIN];
+  ChunkLists cl;
+  chunk_lists_load(d, bx, fused_smem, true, cl);                   // issued beside the state words, not after them
+  if (stop != 0.0) return;
+  const int cur = (int)curd;
+  if (needlin != 0.0) {
     double W[18], lm[9];
+    int erw = 0;
 #pragma unroll
     for (int k = 0; k < 18; ++k) W[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) lm[k] = 0.0;
-    k_linearize_body<JAC>(d, bx, cur, fused_smem, W, lm);
+    k_linearize_body<JAC>(d, bx, cur, fused_smem, cl, W, lm, &erw);
     __syncthreads();                                               // the linearisation's LDS is dead: the Schur phase takes it over
-    k_schur_body(d, bx, cur, lambda, fused_smem, W, lm);
+    k_schur_body(d, bx, cur, lambda, fused_smem, cl, W, lm, &erw);
   } else {
-    k_schur_body(d, bx, cur, lambda, fused_smem, nullptr, nullptr);
+    k_schur_body(d, bx, cur, lambda, fused_smem, cl, nullptr, nullptr, nullptr);
   }
 }
 template <int JAC>
@@ -1427,7 +1468,9 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
       for (int s2 = h.lm_ptr[lc]; s2 < h.lm_ptr[lc + 1]; ++s2) {
         int* er = &h.e_rec[4 * (size_t)s2];
         er[0] = h.e_pose[s2]; er[1] = h.pose_free[h.e_pose[s2]]; er[2] = h.lm_id[lc];
-        er[3] = (int)h.e_cam[s2] | ((int)h.e_dup[s2] << 1) | ((int)h.lm_fixed[lc] << 2) | ((lc - lm0) << 8);
+        const int next_dup = (s2 + 1 < h.lm_ptr[lc + 1] && h.e_dup[s2 + 1]) ? 1 : 0;   // duplicates are of the same landmark
+        er[3] = (int)h.e_cam[s2] | ((int)h.e_dup[s2] << 1) | ((int)h.lm_fixed[lc] << 2) | (next_dup << 3) |
+                ((h.pose_free[h.e_pose[s2]] < 0 ? 1 : 0) << 5) | ((lc - lm0) << 8);
       }
     }
   }
@@ -1914,7 +1957,7 @@ ssx_status build_pairs(ssx_ctx* ctx, HostPrep& h, const unsigned long long** ab_
 
 size_t schur_lds_bytes()
 {
-  return sizeof(double) * (18 * PW + 9 * PL) + sizeof(int) * CH + sizeof(uint16_t) * (SSX_BA_SMALL_P + 2) + 2 * MAX_PAIRS + 64;
+  return BA_LDS_BYTES;
 }
 
 struct Comm {
