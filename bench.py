@@ -238,12 +238,15 @@ def main():
     # The edge blocks W = Ji^T w Jj are NOT materialised any more (recomputed where needed), so they do not count.
     # "k_schur" is the profiling id of BOTH the stand-alone Schur kernel (first slot of an optimize) and the fused
     # linearise + Schur kernel k_lin_schur (every later slot): 9 of the 10 launches per step are the fused one.
+    # The library runs the batch in `groups` groups of windows side by side, each batched kernel once per group: a launch
+    # covers B / groups windows.
     lin_b = 24.0 * E3 + 24.0 * L3 + 56.0 * P3 + 72.0 * L3
+    Bl = B / max(batch.groups, 1)
     algo_launch_ba = {
-        "k_linearize": B * lin_b,
-        "k_schur": B * (lin_b + 72.0 * L3 + 288.0 * 55),
-        "k_backsub_residual": B * (24.0 * E3 + 72.0 * L3 + 24.0 * L3 + 56.0 * P3 + 16.0 * E3),   # edges, Hll / bl, new points, poses, trial errors
-        "k_solve64": B * (8.0 * 61 * 60 + 56.0 * 2 * P3),
+        "k_linearize": Bl * lin_b,
+        "k_schur": Bl * (lin_b + 72.0 * L3 + 288.0 * 55),
+        "k_backsub_residual": Bl * (24.0 * E3 + 72.0 * L3 + 24.0 * L3 + 56.0 * P3 + 16.0 * E3),   # edges, Hll / bl, new points, poses, trial errors
+        "k_solve64": Bl * (8.0 * 61 * 60 + 56.0 * 2 * P3),
     }
     kernels = {}
     dom = None
@@ -266,7 +269,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
             pc = json.load(f)
-        if pc.get("pairs_per_step") == B and world == 1:
+        if pc.get("pairs_per_step") == B and pc.get("ba_groups", 1) == batch.groups and world == 1:
             base = dom.split("<")[0]
             names = [base + "_b", base] if kernels[dom]["part"] == "ba" else [base]     # the BA kernels of the step are the batched ones
             if base == "k_schur":
@@ -409,7 +412,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (front-end) + f64 (BA)", "data": "synthetic",
             "config": {"workload": "C2 + C3: 1241x376 synthetic stereo, 2000 ORB feats/img, 8 levels, extract+match+triangulate, then one "
                                    "local BA (10 KF x 4000 landmarks x 20000 edges, <= 5 x optimize(10), analytic Jacobians) per pair",
-                       "pairs_per_step_per_gpu": B, "ba_windows_per_step_per_gpu": B,
+                       "pairs_per_step_per_gpu": B, "ba_windows_per_step_per_gpu": B, "ba_groups": batch.groups,
                        "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
                        "avg_keypoints_per_image": round(kp_total / I, 1),
                        "avg_matches_per_pair": round(float(counts[:, 2].mean()), 1),

@@ -193,6 +193,9 @@ SSX_API ssx_status ssx_ba_batch_create(ssx_ctx* ctx, int32_t n, const ssx_ba_pro
                                        int32_t with_edge_errors, ssx_ba_batch** out);
 SSX_API ssx_status ssx_ba_batch_solve(ssx_ba_batch* batch, ssx_ba_result* results, int32_t* lm_iterations_total);
 SSX_API int32_t ssx_ba_batch_size(const ssx_ba_batch* batch);
+/* groups of windows ssx_ba_batch_solve runs side by side, each on its own stream (every batched kernel is launched once
+   per group; 1 for fewer than 8 windows; SSX_BA_GROUPS in the environment overrides the default of 2) */
+SSX_API int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
 
 /* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */

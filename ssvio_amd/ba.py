@@ -171,6 +171,15 @@ class BaBatch:
             ctx.check(ctx.lib.ssx_ba_batch_create(ctx.handle, self.n, self.structs, C.byref(self.opt), 1 if with_edge_errors else 0, C.byref(h)))
             self.handle = h
 
+    @property
+    def groups(self):
+        """groups of windows the library runs side by side (each batched kernel is launched once per group)"""
+        if self.handle is None:
+            return 1
+        self.ctx.lib.ssx_ba_batch_groups.restype = C.c_int32
+        self.ctx.lib.ssx_ba_batch_groups.argtypes = [C.c_void_p]
+        return int(self.ctx.lib.ssx_ba_batch_groups(self.handle))
+
     def solve(self, want_edges=True, download=True):
         if self.handle is not None and not download:
             tot = C.c_int32(0)

@@ -69,6 +69,10 @@ void ssx_ctx_destroy(ssx_ctx* ctx)
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
   if (ctx->ev_spec) (void)hipEventDestroy(ctx->ev_spec);
+  for (int g = 0; g < 3; ++g) {
+    if (ctx->grp[g]) { (void)hipStreamSynchronize(ctx->grp[g]); (void)hipStreamDestroy(ctx->grp[g]); }
+    if (ctx->grp_ev[g]) (void)hipEventDestroy(ctx->grp_ev[g]);
+  }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_pyr) (void)hipEventDestroy(ctx->ev_pyr);

@@ -131,6 +131,8 @@ struct ssx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_spec = nullptr;
   hipStream_t aux = nullptr;                 // second stream: independent stages overlap (blur || detect)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pyr = nullptr, ev_fast0 = nullptr;
+  hipStream_t grp[3] = {nullptr, nullptr, nullptr};   // batched BA: the groups of windows beside the main stream (created on first use)
+  hipEvent_t grp_ev[3] = {nullptr, nullptr, nullptr};
   SsxProf prof;
   DevBuf po_arena;                           // pose-only optimisation scratch
   HostBuf po_stage;

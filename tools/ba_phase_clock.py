@@ -18,6 +18,7 @@ def dump(tag):
     print(tag, "total", v[9] - v[0], "cycles")
     for i, n in enumerate(names):
         print(f"   {n:28s} {v[i+1]-v[i]:8d}")
+    print("   k_solve: load S", v[11]-v[10], " factor", v[12]-v[11], " back substitution", v[13]-v[12], " update + scale", v[14]-v[13])
 for _ in range(2): ba.ba_solve(ctx, pr, want_edges=False)
 dump("single window (79 WGs)")
 wins = [make_ba_problem(seed=10 + i) for i in range(64)]
