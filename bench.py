@@ -214,10 +214,14 @@ def main():
     for _ in range(PROF_STEPS):
         orb.stereo_batch_enqueue(ctx)
     kt = _lib.profile_end(ctx)
+    ba_groups = batch.groups
+    batch.set_groups(1)                  # per-kernel figures: every kernel alone on the chip, one launch for the whole batch
+    batch.solve(download=False)
     _lib.profile_begin(ctx_ba)
     for _ in range(PROF_STEPS):
         batch.solve(download=False)
     kt_ba = _lib.profile_end(ctx_ba)
+    batch.set_groups(0)
     px = level_pixels(KITTI_H, KITTI_W)
     I = 2 * B
     kp_total = int(counts[:, 0].sum() + counts[:, 1].sum())
@@ -238,10 +242,10 @@ def main():
     # The edge blocks W = Ji^T w Jj are NOT materialised any more (recomputed where needed), so they do not count.
     # "k_schur" is the profiling id of BOTH the stand-alone Schur kernel (first slot of an optimize) and the fused
     # linearise + Schur kernel k_lin_schur (every later slot): 9 of the 10 launches per step are the fused one.
-    # The library runs the batch in `groups` groups of windows side by side, each batched kernel once per group: a launch
-    # covers B / groups windows.
+    # (The timed regions run the batch in `ba_groups` groups of windows side by side on as many streams; the per-kernel
+    # pass above runs it as ONE group, so that a launch covers the B windows and has the chip to itself.)
     lin_b = 24.0 * E3 + 24.0 * L3 + 56.0 * P3 + 72.0 * L3
-    Bl = B / max(batch.groups, 1)
+    Bl = B
     algo_launch_ba = {
         "k_linearize": Bl * lin_b,
         "k_schur": Bl * (lin_b + 72.0 * L3 + 288.0 * 55),
@@ -269,7 +273,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
             pc = json.load(f)
-        if pc.get("pairs_per_step") == B and pc.get("ba_groups", 1) == batch.groups and world == 1:
+        if pc.get("pairs_per_step") == B and pc.get("ba_groups", 1) == 1 and world == 1:
             base = dom.split("<")[0]
             names = [base + "_b", base] if kernels[dom]["part"] == "ba" else [base]     # the BA kernels of the step are the batched ones
             if base == "k_schur":
@@ -287,11 +291,18 @@ def main():
                 "algorithmic_bytes_per_launch": int(dom_bytes), "traffic": traffic, "hbm": hbm}
     if valu_insts:
         va = valu_insts / dom_avg_s / 1e9
-        roofline["valu"] = {"achieved": round(va, 2), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": round(va / VALU_PEAK_GWIPS, 5),
-                            "wave_instructions_per_launch": int(valu_insts),
-                            "definition": "SQ_INSTS_VALU per launch (PMC) / live launch duration; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}
+        # issue cycles of a wave64 VALU instruction on a SIMD-32: 2, but 4 for f64 (tools/microbench/f64_rate.hip: 36.5 T
+        # lane-FMA/s chip-wide, 73 TFLOP/s).  The BA kernels are f64 kernels: 72 of the 83 VALU instructions of the loop
+        # that issues nine tenths of k_lin_schur's instructions are f64 (profiles/r02/k_lin_schur_b_block_loop.s),
+        # a mean of 3.73 cycles per instruction; the front-end kernels are integer / f32: 2 cycles.
+        cyc = 3.73 if kernels[dom]["part"] == "ba" else 2.0
+        peak = 1024 * 2.4 / cyc
+        roofline["valu"] = {"achieved": round(va, 2), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(va / peak, 5),
+                            "wave_instructions_per_launch": int(valu_insts), "issue_cycles_per_instruction": cyc,
+                            "definition": "SQ_INSTS_VALU per launch (PMC) / live launch duration; peak = 1024 SIMD-32 x 2.4 GHz / mean issue "
+                                          "cycles per wave64 instruction (2; 4 for f64, measured)"}
     if valu_insts and roofline["valu"]["frac"] > hbm["frac"]:
-        roofline.update(bound="valu", achieved=roofline["valu"]["achieved"], peak=VALU_PEAK_GWIPS, unit="G wave-instr/s",
+        roofline.update(bound="valu", achieved=roofline["valu"]["achieved"], peak=roofline["valu"]["peak"], unit="G wave-instr/s",
                         frac=roofline["valu"]["frac"])
     else:
         roofline.update(bound="hbm", achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac"])
@@ -412,7 +423,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (front-end) + f64 (BA)", "data": "synthetic",
             "config": {"workload": "C2 + C3: 1241x376 synthetic stereo, 2000 ORB feats/img, 8 levels, extract+match+triangulate, then one "
                                    "local BA (10 KF x 4000 landmarks x 20000 edges, <= 5 x optimize(10), analytic Jacobians) per pair",
-                       "pairs_per_step_per_gpu": B, "ba_windows_per_step_per_gpu": B, "ba_groups": batch.groups,
+                       "pairs_per_step_per_gpu": B, "ba_windows_per_step_per_gpu": B, "ba_groups": ba_groups,
                        "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
                        "avg_keypoints_per_image": round(kp_total / I, 1),
                        "avg_matches_per_pair": round(float(counts[:, 2].mean()), 1),

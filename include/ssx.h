@@ -196,6 +196,9 @@ SSX_API int32_t ssx_ba_batch_size(const ssx_ba_batch* batch);
 /* groups of windows ssx_ba_batch_solve runs side by side, each on its own stream (every batched kernel is launched once
    per group; 1 for fewer than 8 windows; SSX_BA_GROUPS in the environment overrides the default of 2) */
 SSX_API int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch);
+/* 1 .. 4 groups for the following solves; 0 = back to the default (per-kernel profiles want 1: one launch per kernel and
+   LM slot, nothing else on the chip beside it) */
+SSX_API void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
 
 /* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */

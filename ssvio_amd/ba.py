@@ -180,6 +180,13 @@ class BaBatch:
         self.ctx.lib.ssx_ba_batch_groups.argtypes = [C.c_void_p]
         return int(self.ctx.lib.ssx_ba_batch_groups(self.handle))
 
+    def set_groups(self, groups):
+        """1 .. 4 groups of windows side by side for the following solves, 0 = the library's default"""
+        if self.handle is not None:
+            self.ctx.lib.ssx_ba_batch_set_groups.restype = None
+            self.ctx.lib.ssx_ba_batch_set_groups.argtypes = [C.c_void_p, C.c_int32]
+            self.ctx.lib.ssx_ba_batch_set_groups(self.handle, int(groups))
+
     def solve(self, want_edges=True, download=True):
         if self.handle is not None and not download:
             tot = C.c_int32(0)

@@ -2587,6 +2587,7 @@ struct ssx_ba_batch {
   int max_ch = 1, max_rl = 1, max_rs = 1;
   bool any_solve64 = false, any_solve = false, with_err = false, fresh = false;
   int threads = 1;
+  int groups = 0;                                    // ssx_ba_batch_set_groups; 0: batch_groups(n)
 };
 
 namespace {
@@ -2726,7 +2727,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   for (int w = 0; w < n; ++w) wsn[w].done = !(B->devs[w].nCh > 0) || opt.outer_rounds <= 0;
   const size_t lds_schur = schur_lds_bytes();
   const size_t lds_fused = std::max(lds_schur, LIN_LDS_BYTES);
-  int G = batch_groups(n);
+  int G = B->groups > 0 ? std::min(B->groups, 4) : batch_groups(n);
   for (int g = 0; g + 1 < G; ++g) {
     if (!ctx->grp[g] && hipStreamCreateWithFlags(&ctx->grp[g], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G = g + 1; break; }
     if (!ctx->grp_ev[g] && hipEventCreateWithFlags(&ctx->grp_ev[g], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G = g + 1; break; }
@@ -2929,7 +2930,9 @@ ssx_status ssx_ba_batch_solve(ssx_ba_batch* batch, ssx_ba_result* results, int32
 
 int32_t ssx_ba_batch_size(const ssx_ba_batch* batch) { return batch ? batch->n : 0; }
 
-int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch) { return batch ? batch_groups(batch->n) : 0; }
+int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch) { return !batch ? 0 : (batch->groups > 0 ? std::min(batch->groups, 4) : batch_groups(batch->n)); }
+
+void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups) { if (batch) batch->groups = groups > 0 ? groups : 0; }
 
 void ssx_ba_batch_destroy(ssx_ba_batch* batch)
 {

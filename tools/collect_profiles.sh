@@ -14,6 +14,9 @@ OUT=$R/gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
+# one group of BA windows per launch while the counters run: a batched kernel then covers the whole batch and has the chip
+# to itself (the default, two groups on two streams, is what the bench line after the passes is taken with)
+export SSX_BA_GROUPS=1
 CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
@@ -23,6 +26,7 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_BUSY_CU_CYCLES GRBM_COUNT \
     --kernel-trace --output-format csv -d "$OUT/sq2" -- $CMD > "$OUT/sq2.log" 2>&1
 cd "$R"
+unset SSX_BA_GROUPS
 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
 # the raw per-dispatch tables are hundreds of MB (gpurun merges <= 64 MiB back): summarise HERE, keep the summaries

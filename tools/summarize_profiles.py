@@ -134,7 +134,7 @@ if sq:
                     f"{v.get('SQ_INSTS_SALU', 0):.0f} | {v.get('SQ_INSTS_VMEM', 0):.0f} |\n")
     print(open(os.path.join(rdir, name + "_occupancy_valu.md")).read())
 json.dump({"source": f"profiles/r02/{name}_pmc_hbm.md + profiles/r02/{name}_occupancy_valu.md", "pairs_per_step": pairs,
-           "ba_groups": bj["config"].get("ba_groups", 1), "per_launch": per_launch},
+           "ba_groups": 1, "per_launch": per_launch},
           open(os.path.join("profiles", "pmc_counters.json"), "w"), indent=1)
 json.dump(bj, open(os.path.join(rdir, name + ".json"), "w"), indent=1)
 json.dump({"source": f"{rdir}/{name}_pmc_hbm.md", "pairs_per_step": bj["config"]["pairs_per_step_per_gpu"],
