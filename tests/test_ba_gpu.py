@@ -420,6 +420,28 @@ def test_c4_shape_band_equals_tiles(ctx):
     assert np.abs(g["poses"] - t["poses"]).max() < 1e-8
 
 
+def test_batch_groups_do_not_change_the_bits(ctx):
+    """A batch of >= 8 windows runs as groups of windows on several streams (ssx_ba_batch_groups / _set_groups): every
+    grouping returns, per window, the bits of ssx_ba_solve."""
+    probs = [make_ba_problem(P=4 + (k % 7), L=120 + 90 * k, obs_per_lm=3 + (k % 3), seed=300 + k, fix_first_pose=(k % 4 == 0),
+                             frac_gross=0.4 if k == 5 else 0.05) for k in range(11)]
+    ones = [ba.ba_solve(ctx, pr) for pr in probs]
+    res = ba.BaBatch(ctx, probs, resident=True)
+    assert res.groups == 2                                   # the default for 8 or more windows
+    for g in (0, 1, 2, 3, 4, 9):
+        res.set_groups(g)
+        assert res.groups == (2 if g == 0 else min(g, 4))
+        out = res.solve()
+        for b, one in zip(out["results"], ones):
+            assert np.array_equal(b["poses"], one["poses"]) and np.array_equal(b["points"], one["points"])
+            assert np.array_equal(b["chi2"], one["chi2"]) and np.array_equal(b["trials"], one["trials"])
+            assert np.array_equal(b["edge_chi2"], one["edge_chi2"]) and b["rounds"] == one["rounds"]
+    res.close()
+    host = ba.BaBatch(ctx, probs).solve()                     # the one-call form takes the default grouping
+    assert all(np.array_equal(b["poses"], one["poses"]) for b, one in zip(host["results"], ones))
+    assert ba.BaBatch(ctx, probs[:3], resident=True).groups == 1
+
+
 def test_batched_windows_equal_single_calls(ctx):
     """ssx_ba_solve_batch: many small windows in one call (one grid dimension = the window) give, per window, exactly
     the bits of ssx_ba_solve -- different sizes, a window that needs several outer rounds, rejected LM trials, a fixed
