@@ -65,9 +65,9 @@ constexpr int CH_L = 128;          // max landmarks per chunk (per-landmark LDS 
 constexpr int PL = CH_L + 1;       // their padded pitch
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
+constexpr int NMAX = 6 * SSX_BA_SMALL_P;   // 96 unknowns of the reduced system
 constexpr int BSEG_PARTS = 4;      // a block's pair list is cut into at most this many parts (k_schur's block phase) ...
 constexpr int BSEG_MIN = 8;        // ... of at least this many pairs
-constexpr int NMAX = 6 * SSX_BA_SMALL_P;   // 96 unknowns of the reduced system
 constexpr int MAX_PAIRS = CH_E * (SSX_BA_SMALL_P + 1) / 2 + 8;       // leader pairs of one chunk (sum k(k+1)/2, k <= 16)
 
 struct BaDev {
