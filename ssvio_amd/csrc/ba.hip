@@ -65,7 +65,6 @@ constexpr int CH_L = 128;          // max landmarks per chunk (per-landmark LDS 
 constexpr int PL = CH_L + 1;       // their padded pitch
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
-constexpr int NMAX = 6 * SSX_BA_SMALL_P;   // 96 unknowns of the reduced system
 constexpr int BSEG_PARTS = 4;      // a block's pair list is cut into at most this many parts (k_schur's block phase) ...
 constexpr int BSEG_MIN = 8;        // ... of at least this many pairs
 constexpr int MAX_PAIRS = CH_E * (SSX_BA_SMALL_P + 1) / 2 + 8;       // leader pairs of one chunk (sum k(k+1)/2, k <= 16)
@@ -912,223 +911,8 @@ __global__ __launch_bounds__(CH) void k_reduce_schur_b(const BaDev* __restrict__
   k_reduce_schur_body(d, blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_solve: (S + lambda I) x = bs, the role of LinearSolverCSparse::solve
-// (thirdparty/g2o/g2o/solvers/csparse/linear_solver_csparse.h:106-142: false when not positive definite),
-// then the pose update T <- exp(x) T into the trial buffer (SparseOptimizer::update,
-// sparse_optimizer.cpp:433-446) and the pose part of computeScale (optimization_algorithm_levenberg.cpp:168-175).
-//
-// LDL^T, right-looking, BLOCKED by pose (6 columns per step), register-tiled: the 256 threads form a 16x16 grid
-// and thread (ty,tx) keeps the entries (i,k) with i = ty (mod 16), k = tx (mod 16) of the matrix AUGMENTED with
-// the right-hand side as row n, so the elimination also performs the forward substitution (row n ends up holding
-// w = D^-1 L^-1 b).  Per block step: the raw 6-column panel goes to LDS; every thread factors the 6x6 diagonal
-// block redundantly in registers (no communication), one thread per row solves its 6 panel entries; then every
-// thread applies the rank-6 update to its entries.  Two barriers per pose block (instead of one per column).
-// The backward substitution L^T x = w is done by ONE wave with the running solution in registers and
-// v_readlane broadcasts (no barrier in the dependent chain).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void k_solve_body(const BaDev& d, const int bx, int cur, double lambda_arg, int use_dev_lambda)
-{
-  constexpr int BS = 6;
-  __shared__ double sPan[(NMAX + 2) * BS];      // raw panel rows j0..n
-  __shared__ double sLp[(NMAX + 2) * BS];       // L panel
-  __shared__ double sLD[(NMAX + 2) * BS];       // L panel times D
-  __shared__ double sL[NMAX * (NMAX + 1)];      // L (row-major, pitch n+1) for the backward substitution
-  __shared__ double sWv[NMAX + 8];
-  __shared__ double sX[NMAX + 8];
-  const int n = 6 * d.nP;
-  const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-  if (cur < 0) {
-    if (d.scal[SC_STOP] != 0.0) return;
-    cur = (int)d.scal[SC_CUR];
-  }
-  const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
-  const double* S = d.trial_comm;
-  const double* bs = d.trial_comm + (size_t)n * n;
-  constexpr int RA = NMAX / 16 + 1, RB = NMAX / 16;     // rows incl. the rhs row, columns
-  double R[RA][RB];
-#pragma unroll
-  for (int a = 0; a < RA; ++a)
-#pragma unroll
-    for (int b = 0; b < RB; ++b) {
-      const int i = ty + 16 * a, k = tx + 16 * b;
-      double v = 0.0;
-      if (k < n) {
-        if (i < n) v = S[(size_t)i * n + k] + (i == k ? lambda : 0.0);
-        else if (i == n) v = bs[k];
-      }
-      R[a][b] = v;
-    }
-  int ok = 1;
-  for (int bstep = 0; bstep < d.nP; ++bstep) {
-    const int j0 = BS * bstep, j1 = j0 + BS;
-    // 1. publish the raw panel (lower part: i >= k) 
-#pragma unroll
-    for (int b = 0; b < RB; ++b) {
-      const int k = tx + 16 * b;
-      if (k >= j0 && k < j1) {
-#pragma unroll
-        for (int a = 0; a < RA; ++a) {
-          const int i = ty + 16 * a;
-          if (i >= k && i <= n) sPan[i * BS + (k - j0)] = R[a][b];
-        }
-      }
-    }
-    __syncthreads();
-    // 2. factor the diagonal block (every thread, redundantly: identical arithmetic, identical result)
-    double Lb[BS][BS], D[BS], Dinv[BS];
-#pragma unroll
-    for (int c = 0; c < BS; ++c) {
-      double dc = sPan[(j0 + c) * BS + c];
-#pragma unroll
-      for (int m = 0; m < c; ++m) dc -= Lb[c][m] * Lb[c][m] * D[m];
-      D[c] = dc;
-      if (!(dc > 0.0) || !isfinite(dc)) ok = 0;
-      const double rinv = 1.0 / dc;
-      Dinv[c] = rinv;
-#pragma unroll
-      for (int r = c + 1; r < BS; ++r) {
-        double v = sPan[(j0 + r) * BS + c];
-#pragma unroll
-        for (int m = 0; m < c; ++m) v -= Lb[r][m] * Lb[c][m] * D[m];
-        Lb[r][c] = v * rinv;
-      }
-    }
-    if (!ok) break;      // uniform: every thread factored the same block
-    // one thread per row below the diagonal block (incl. the rhs row): its 6 entries of L
-    {
-      const int i = j1 + t;
-      if (i <= n) {
-        double l[BS];
-#pragma unroll
-        for (int c = 0; c < BS; ++c) {
-          double v = sPan[i * BS + c];
-#pragma unroll
-          for (int m = 0; m < c; ++m) v -= l[m] * D[m] * Lb[c][m];
-          l[c] = v * Dinv[c];
-          sLp[i * BS + c] = l[c];
-          sLD[i * BS + c] = l[c] * D[c];
-        }
-      }
-    }
-    __syncthreads();
-    // 3. rank-6 update of the trailing entries; the panel columns become final (store L)
-    double lpk[RB][BS];      // L rows of this thread's columns, loaded once per block step
-#pragma unroll
-    for (int b = 0; b < RB; ++b) {
-      const int k = tx + 16 * b;
-#pragma unroll
-      for (int c = 0; c < BS; ++c) lpk[b][c] = (k >= j1 && k < n) ? sLp[k * BS + c] : 0.0;
-    }
-#pragma unroll
-    for (int a = 0; a < RA; ++a) {
-      const int i = ty + 16 * a;
-      if (i < j0 || i > n) continue;
-      double ld[BS];
-      if (i >= j1) {
-#pragma unroll
-        for (int c = 0; c < BS; ++c) ld[c] = sLD[i * BS + c];
-      }
-#pragma unroll
-      for (int b = 0; b < RB; ++b) {
-        const int k = tx + 16 * b;
-        if (k >= n) continue;
-        if (k >= j1) {
-          if (i >= j1 && k <= i) {
-            double acc = R[a][b];
-#pragma unroll
-            for (int c = 0; c < BS; ++c) acc -= ld[c] * lpk[b][c];
-            R[a][b] = acc;
-          }
-        } else if (k >= j0 && i > k) {
-          // final L entry of the panel
-          double v;
-          if (i >= j1) v = sLp[i * BS + (k - j0)];
-          else {
-            v = 0.0;
-#pragma unroll
-            for (int r = 1; r < BS; ++r)
-#pragma unroll
-              for (int c = 0; c < r; ++c)
-                if (r == i - j0 && c == k - j0) v = Lb[r][c];
-          }
-          R[a][b] = v;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // spill L and w to LDS for the backward substitution
-  const int ld = n + 1;
-#pragma unroll
-  for (int a = 0; a < RA; ++a)
-#pragma unroll
-    for (int b = 0; b < RB; ++b) {
-      const int i = ty + 16 * a, k = tx + 16 * b;
-      if (k < n) {
-        if (i < n && k < i) sL[i * ld + k] = R[a][b];
-        else if (i == n) sWv[k] = R[a][b];
-      }
-    }
-  __syncthreads();
-  if (t < 64) {
-    // lane l holds x[l] and x[l + 64]
-    double x0 = (ok && t < n) ? sWv[t] : 0.0;
-    double x1 = (ok && t + 64 < n) ? sWv[t + 64] : 0.0;
-    if (ok) {
-      for (int i = n - 1; i > 0; --i) {
-        // broadcast the final x_i from its owner lane
-        const double src = (i >= 64) ? x1 : x0;
-        const int sl = i & 63;
-        const int lo = __builtin_amdgcn_readlane(__double2loint(src), sl);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(src), sl);
-        const double xi = __hiloint2double(hi, lo);
-        // x_k -= L[i][k] * x_i for k < i
-        if (t < i) x0 -= sL[i * ld + t] * xi;
-        if (t + 64 < i) x1 -= sL[i * ld + t + 64] * xi;
-      }
-    }
-    if (t < n) { sX[t] = x0; d.xp[t] = x0; }
-    if (t + 64 < n) { sX[t + 64] = x1; d.xp[t + 64] = x1; }
-  }
-  __syncthreads();
-  // pose update into the trial buffer
-  const double* src = d.pose[cur];
-  double* dst = d.pose[cur ^ 1];
-  for (int p = t; p < d.P; p += 256) {
-    const int pf = d.pose_free[p];
-    double T[7], out[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) T[k] = src[p * 7 + k];
-    if (pf >= 0) {
-      double dx[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) dx[k] = sX[pf * 6 + k];
-      ssx::pose_oplus(T, dx, out);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 7; ++k) out[k] = T[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 7; ++k) dst[p * 7 + k] = out[k];
-  }
-  if (t == 0) {
-    const double* bp_g = d.iter_comm + d.nP * UPPER6;   // the (all-reduced) pose part of b
-    double s = 0.0;
-    for (int j = 0; j < n; ++j) s += sX[j] * (lambda * sX[j] + bp_g[j]);
-    d.scal[SC_SOLVE_OK] = ok ? 1.0 : 0.0;
-    d.scal[SC_SCALE_P] = s;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_solve(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_solve_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
-// batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(256) void k_solve_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda)
-{
-  const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
-  if ((int)blockIdx.x >= ((6 * d.nP > 64) ? 1 : 0)) return;
-  k_solve_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
-}
+// (the reduced solve of a small window -- k_solve64 for <= 10 free keyframes, k_solve80 for 11 .. 13, k_solve for 14 .. 16
+// -- is k_solve_tiles in ba_big.inc)
 
 // ------------------------------------------------------------------------------------------------
 // k_backsub_residual: landmark back-substitution (block_solver.hpp:422-442), landmark update, and the
@@ -2380,7 +2164,8 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
             if (st != SSX_OK) return st;
           }
           if (n <= NB) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
-          else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, ctx->stream, d, -1, 0.0, 1));
+          else if (n <= 80) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
+          else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
           if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
           SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, cm.fn ? 0 : 1));
           if (cm.fn) {
@@ -2436,7 +2221,8 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
           if (st != SSX_OK) return st;
         }
         if (n <= NB) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64, dim3(1), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
-        else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, ctx->stream, d, cur, lambda, dev_lambda));
+        else if (n <= 80) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80, dim3(1), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
+        else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
         }
         if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
         SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, 0));
@@ -2585,7 +2371,7 @@ struct ssx_ba_batch {
   std::vector<size_t> out_off;
   size_t out_total = 0, a_out = 0, a_gather = 0, a_head = 0, in_total = 0, o_dv = 0, o_ctrl = 0, o_ooff = 0;
   int max_ch = 1, max_rl = 1, max_rs = 1;
-  bool any_solve64 = false, any_solve = false, with_err = false, fresh = false;
+  bool any_solve64 = false, any_solve80 = false, any_solve = false, with_err = false, fresh = false;
   int threads = 1;
   int groups = 0;                                    // ssx_ba_batch_set_groups; 0: batch_groups(n)
 };
@@ -2684,7 +2470,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     B->max_ch = std::max(B->max_ch, d.nCh);
     B->max_rl = std::max(B->max_rl, (d.nP * 27 + 15) / 16);
     B->max_rs = std::max(B->max_rs, (d.nBlk * 36 + d.nP * 6 + 15) / 16);
-    if (6 * d.nP <= NB) B->any_solve64 = true; else B->any_solve = true;
+    if (6 * d.nP <= NB) B->any_solve64 = true; else if (6 * d.nP <= 80) B->any_solve80 = true; else B->any_solve = true;
   }
   SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + B->a_head, hst, head_bytes, hipMemcpyHostToDevice, ctx->stream));
   B->fresh = true;                                                   // the state buffers hold the uploaded state
@@ -2773,7 +2559,8 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
           if (!fused) SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gCh, dim3(CH), lds_schur, hs, hv, -1, 0.0, 2));
           SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, hs, hv));
           if (B->any_solve64) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
-          if (B->any_solve) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(256), 0, hs, hv, -1, 0.0, 1));
+          if (B->any_solve80) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
+          if (B->any_solve) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           SSX_PROF_ON(ctx, hs, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual_b, gCh, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial_b, gOne, dim3(CH), 0, hs, hv, 1));
         }
