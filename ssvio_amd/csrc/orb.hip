@@ -1127,7 +1127,11 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   const OrbDev& d = ws->dev;
   hipStream_t s = ctx->stream;
   SSX_HIP_TRY(ctx, hipMemsetAsync(d.status, 0, sizeof(int) * d.I, s));
-  constexpr int FAST_WPW = 4;   // cells (waves) per workgroup; 1, 2 and 4 measure the same end to end
+  // cells (waves) per workgroup.  A workgroup keeps its LDS until its slowest cell is done and cells differ 8x in work:
+  // the kernel alone takes 0.615 / 0.430 / 0.410 ms per 128 images with 4 / 2 / 1 cells per workgroup.  The front-end as a
+  // whole does not care (1.16 / 1.19 / 1.20 ms: its two streams hide the difference), the composite step with the BA on
+  // its own streams does a little: 17.96 / 18.36 / 18.20 k frames/s.
+  constexpr int FAST_WPW = 2;
   if (FAST_WPW * (size_t)d.fast_lds_per_wave > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(FAST_WPW * (size_t)d.fast_lds_per_wave));
