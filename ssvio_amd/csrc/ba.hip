@@ -1159,6 +1159,8 @@ struct HostPrep {
   bool big = false;
   std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr;
   std::vector<int> bseg, bseg_ptr;   // see BaDev
+  std::vector<uint32_t> tmp_pairs;   // scratch of prepare(), kept between calls
+  std::vector<std::pair<int, int>> tmp_order;
   std::vector<int> ch_desc, e_rec, l_rec;   // packed records (4 ints each), see BaDev
   std::vector<int> lm_chunk;                // compact landmark -> chunk (large windows: the device-side pair builder)
   int band_w = -1;          // cyclic block bandwidth of this rank's part of the reduced system (max over its non-zero blocks)
@@ -1295,7 +1297,9 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   std::vector<int> blk_of((size_t)std::max(nP, 1) * std::max(nP, 1), -1);
   for (int b = 0; b < nBlk; ++b) blk_of[(size_t)h.blk_pa[b] * nP + h.blk_pb[b]] = b;
   std::vector<int> pc(nP + 1), bc(nBlk + 1);
-  std::vector<uint8_t> leaders;
+  std::vector<uint32_t>& tmp_pairs = h.tmp_pairs;
+  std::vector<std::pair<int, int>>& order = h.tmp_order;   // (-part length, block)
+  h.bseg.reserve(4 * ((size_t)h.nCh * (nBlk + 8)));
   for (int c = 0; c < h.nCh; ++c) {
     const int lm0 = h.ch_lm[c], lm1 = h.ch_lm[c + 1];
     const int e0 = h.lm_ptr[lm0], e1 = h.lm_ptr[lm1];
@@ -1312,29 +1316,37 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
       h.porder[e0 + pos] = (uint8_t)(s - e0);
       h.e_rec[4 * (size_t)s + 3] = (h.e_rec[4 * (size_t)s + 3] & 0xFFFF) | (pos << 16);   // the inverse map, for the kernels that store pose-major
     }
-    // --- pairs by block: two passes (count, fill) over the landmarks of the chunk ---
+    // --- pairs by block: one pass over the landmarks of the chunk lists (block, edge a, edge b), a counting sort by
+    // block keeps the landmark order inside a block ---
     std::fill(bc.begin(), bc.end(), 0);
-    for (int pass = 0; pass < 2; ++pass) {
-      for (int lc = lm0; lc < lm1; ++lc) {
-        if (h.lm_fixed[lc]) continue;
-        leaders.clear();
-        for (int s = h.lm_ptr[lc]; s < h.lm_ptr[lc + 1]; ++s)
-          if (h.pose_free[h.e_pose[s]] >= 0 && !h.e_dup[s]) leaders.push_back((uint8_t)(s - e0));
-        for (size_t i = 0; i < leaders.size(); ++i)
-          for (size_t j = i; j < leaders.size(); ++j) {
-            const int pa = h.pose_free[h.e_pose[e0 + leaders[i]]], pb = h.pose_free[h.e_pose[e0 + leaders[j]]];
-            const int b = blk_of[(size_t)pa * nP + pb];   // pa <= pb: edges of a landmark are sorted by pose
-            if (pass == 0) bc[b + 1]++;
-            else { const int q = bc[b]++; h.pair_a[q] = leaders[i]; h.pair_b[q] = leaders[j]; }
-          }
+    tmp_pairs.clear();
+    for (int lc = lm0; lc < lm1; ++lc) {
+      if (h.lm_fixed[lc]) continue;
+      int nl = 0;
+      uint8_t led[CH_E]; int16_t lpf[CH_E];
+      for (int s = h.lm_ptr[lc]; s < h.lm_ptr[lc + 1]; ++s) {
+        const int pf = h.pose_free[h.e_pose[s]];
+        if (pf >= 0 && !h.e_dup[s]) { led[nl] = (uint8_t)(s - e0); lpf[nl] = (int16_t)pf; ++nl; }
       }
-      if (pass == 0) {
-        const int base = (int)h.pair_a.size();
-        bc[0] = base;
-        for (int b = 0; b < nBlk; ++b) bc[b + 1] += bc[b];
-        int* bp = &h.pair_ptr[(size_t)c * (nBlk + 1)];
-        for (int b = 0; b <= nBlk; ++b) bp[b] = bc[b];
-        h.pair_a.resize(bc[nBlk]); h.pair_b.resize(bc[nBlk]);
+      for (int i = 0; i < nl; ++i) {
+        const int* row = &blk_of[(size_t)lpf[i] * nP];
+        for (int j = i; j < nl; ++j) {
+          const int b = row[lpf[j]];                        // pa <= pb: edges of a landmark are sorted by pose
+          bc[b + 1]++;
+          tmp_pairs.push_back((uint32_t)b << 16 | (uint32_t)led[i] << 8 | led[j]);
+        }
+      }
+    }
+    {
+      const int base = (int)h.pair_a.size();
+      bc[0] = base;
+      for (int b = 0; b < nBlk; ++b) bc[b + 1] += bc[b];
+      int* bp = &h.pair_ptr[(size_t)c * (nBlk + 1)];
+      for (int b = 0; b <= nBlk; ++b) bp[b] = bc[b];
+      h.pair_a.resize(bc[nBlk]); h.pair_b.resize(bc[nBlk]);
+      for (const uint32_t k : tmp_pairs) {
+        const int q = bc[k >> 16]++;
+        h.pair_a[q] = (uint8_t)(k >> 8); h.pair_b[q] = (uint8_t)k;
       }
     }
     // --- work items of the block phase.  A lane walks ONE pair list and a wave takes as long as its longest list, so
@@ -1346,8 +1358,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
       int maxlen = 0;
       for (int b = 0; b < nBlk; ++b) maxlen = std::max(maxlen, bp[b + 1] - bp[b]);
       const int seg = std::max(BSEG_MIN, (maxlen + BSEG_PARTS - 1) / BSEG_PARTS);
-      std::vector<std::pair<int, int>> order;   // (-part length, block)
-      order.reserve(nBlk);
+      order.clear();
       for (int b = 0; b < nBlk; ++b) {
         const int n = bp[b + 1] - bp[b], k = std::max(1, (n + seg - 1) / seg);
         order.push_back({-((n + k - 1) / k), b});
@@ -1356,10 +1367,10 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
       int pos = 0;                                // in items (16 per wave: four lanes each)
       for (const auto& ob : order) {
         const int b = ob.second, n = bp[b + 1] - bp[b], k = std::max(1, (n + seg - 1) / seg), len = (n + k - 1) / k;
-        while ((pos & 15) + k > 16) { h.bseg.insert(h.bseg.end(), {-1, 0, 0, 1 << 4}); ++pos; }
+        while ((pos & 15) + k > 16) { h.bseg.push_back(-1); h.bseg.push_back(0); h.bseg.push_back(0); h.bseg.push_back(1 << 4); ++pos; }
         for (int i = 0; i < k; ++i) {
           const int q0 = bp[b] - base + std::min(n, i * len), q1 = bp[b] - base + std::min(n, (i + 1) * len);
-          h.bseg.insert(h.bseg.end(), {b, q0, q1, i | (k << 4)});
+          h.bseg.push_back(b); h.bseg.push_back(q0); h.bseg.push_back(q1); h.bseg.push_back(i | (k << 4));
           ++pos;
         }
       }
