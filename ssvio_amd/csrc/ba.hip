@@ -1963,7 +1963,12 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
   for (int s = 0; s < E; ++s) {
     const int e = h.perm[s];
     if (Hpl) for (int k = 0; k < 18; ++k) Hpl[18 * (size_t)e + k] = hW[(size_t)k * E + s];
-    if (err) { err[2 * (size_t)e] = herr[s]; err[2 * (size_t)e + 1] = herr[(size_t)E + s]; }
+    if (err) {
+      // an edge whose vertices are both fixed is not active in g2o (sparse_optimizer.cpp:237): its error is never computed
+      const bool inactive = h.pose_free[h.e_pose[s]] < 0 && h.lm_fixed[h.e_lmc[s]];
+      err[2 * (size_t)e] = inactive ? 0.0 : herr[s];
+      err[2 * (size_t)e + 1] = inactive ? 0.0 : herr[(size_t)E + s];
+    }
   }
   if (chi2) *chi2 = hscal[SC_CHI2_CUR];
   return SSX_OK;

@@ -18,7 +18,9 @@ CASES = {
     "tiny": dict(P=4, L=60, obs_per_lm=4, seed=2),
     "mid": dict(P=10, L=400, seed=3),
     "C3": dict(P=10, L=4000, seed=1),
-    "window12": dict(P=12, L=1500, obs_per_lm=4, seed=5),
+    "window12": dict(P=12, L=1500, obs_per_lm=4, seed=5),          # 72 unknowns: k_solve80 (5x5 tiles)
+    "window16": dict(P=16, L=1200, obs_per_lm=5, seed=6),          # 96 unknowns: k_solve (6x6 tiles), the largest small window
+    "window14fix": dict(P=15, L=900, obs_per_lm=4, seed=7, fix_first_pose=True),   # 84 unknowns
 }
 
 
