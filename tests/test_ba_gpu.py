@@ -444,6 +444,25 @@ def test_batch_groups_do_not_change_the_bits(ctx):
     assert ba.BaBatch(ctx, probs[:3], resident=True).groups == 1
 
 
+def test_bench_size_batch_equals_single_calls(ctx):
+    """The bench's own configuration (BASELINE configs[2]: 10 keyframes x 4000 landmarks x 20 000 edges per window), eight
+    windows resident in two groups: every window returns the bits of ssx_ba_solve, and solving again from the uploaded
+    state returns them again."""
+    probs = [make_ba_problem(P=10, L=4000, seed=500 + k) for k in range(8)]
+    res = ba.BaBatch(ctx, probs, resident=True)
+    assert res.groups == 2
+    first = res.solve()
+    again = res.solve()
+    for pr, a, b in zip(probs, first["results"], again["results"]):
+        one = ba.ba_solve(ctx, pr)
+        assert one["n_iters"] == 10 and a["n_iters"] == 10
+        for k in ("poses", "points", "chi2", "lam", "trials", "edge_chi2", "edge_outlier"):
+            assert np.array_equal(a[k], one[k]), k
+            assert np.array_equal(b[k], one[k]), k
+        assert a["chi2"][-1] < a["chi2"][0]
+    res.close()
+
+
 def test_batched_windows_equal_single_calls(ctx):
     """ssx_ba_solve_batch: many small windows in one call (one grid dimension = the window) give, per window, exactly
     the bits of ssx_ba_solve -- different sizes, a window that needs several outer rounds, rejected LM trials, a fixed
