@@ -443,19 +443,29 @@ __global__ __launch_bounds__(CH) void k_linearize_b(const BaDev* __restrict__ dv
 // diagonals; with several ranks the pose diagonals need the all-reduced Hpp, see k_lambda_init.)
 __device__ __forceinline__ void k_reduce_lin_body(const BaDev& d, const int bx)
 {
+  // 64 entries x 4 groups of chunks per workgroup, as k_reduce_schur
   __shared__ double sAcc[CH];
   const int t = threadIdx.x;
   const int n = d.nP * 27;
   const int stride = n + 2;
-  const int ent = bx * 16 + (t >> 4), ln = t & 15;
+  const int ent = bx * 64 + (t & 63), grp = t >> 6;
   double acc = 0.0;
-  if (ent < n)
-    for (int c = ln; c < d.nCh; c += 16) acc += d.lin_slab[(size_t)c * stride + ent];
+  if (ent < n) {
+    const double* col = d.lin_slab + ent;
+    int c = grp;
+    for (; c + 28 < d.nCh; c += 32) {
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = col[(size_t)(c + 4 * i) * stride];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += v[i];
+    }
+    for (; c < d.nCh; c += 4) acc += col[(size_t)c * stride];
+  }
   sAcc[t] = acc;
   __syncthreads();
-  for (int o = 8; o > 0; o >>= 1) { if (ln < o) sAcc[t] += sAcc[t + o]; __syncthreads(); }
-  if (ent < n && ln == 0) {
-    const double v = sAcc[t];
+  if (ent < n && grp == 0) {
+    const double v = ((sAcc[t] + sAcc[t + 64]) + sAcc[t + 128]) + sAcc[t + 192];
     const int p = ent / 27, k = ent - p * 27;
     if (k < UPPER6) { d.Hpp[p * UPPER6 + k] = v; d.iter_comm[p * UPPER6 + k] = v; }
     else { d.bp[p * 6 + (k - UPPER6)] = v; d.iter_comm[d.nP * UPPER6 + p * 6 + (k - UPPER6)] = v; }
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(CH) void k_reduce_lin(BaDev d) { k_reduce_lin_body(
 __global__ __launch_bounds__(CH) void k_reduce_lin_b(const BaDev* __restrict__ dv)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
-  if ((int)blockIdx.x >= ((d.nP * 27 + 15) / 16 > 0 ? (d.nP * 27 + 15) / 16 : 1)) return;
+  if ((int)blockIdx.x >= ((d.nP * 27 + 63) / 64 > 0 ? (d.nP * 27 + 63) / 64 : 1)) return;
   k_reduce_lin_body(d, blockIdx.x);
 }
 
@@ -869,20 +879,32 @@ __global__ __launch_bounds__(CH, 3) void k_lin_schur_b(const BaDev* __restrict__
 // 16 chunk-lanes per entry (16 entries per 256-thread workgroup), fixed tree: deterministic.
 __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx)
 {
-  __shared__ double sAcc[CH];
+  // 64 entries x 4 groups of chunks per workgroup: a wave reads 64 CONSECUTIVE entries of one chunk's slab (512 bytes in one
+  // piece; the former 16 entries x 16 chunk lanes read 32-byte pieces of 16 different slabs), eight loads in flight, the
+  // four group sums added in group order
+  __shared__ double sAcc[3][64];
   const int nS = d.nBlk * 36;
   const int stride = nS + d.nP * 6;
   const int n = 6 * d.nP;
   const int t = threadIdx.x;
-  const int ent = bx * 16 + (t >> 4), ln = t & 15;
+  const int ent = bx * 64 + (t & 63), grp = t >> 6;
   double acc = 0.0;
-  if (ent < stride)
-    for (int c = ln; c < d.nCh; c += 16) acc += d.schur_slab[(size_t)c * stride + ent];
-  sAcc[t] = acc;
+  if (ent < stride) {
+    const double* col = d.schur_slab + ent;
+    int c = grp;
+    for (; c + 28 < d.nCh; c += 32) {
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = col[(size_t)(c + 4 * i) * stride];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += v[i];
+    }
+    for (; c < d.nCh; c += 4) acc += col[(size_t)c * stride];
+  }
+  if (grp > 0) sAcc[grp - 1][t & 63] = acc;
   __syncthreads();
-  for (int o = 8; o > 0; o >>= 1) { if (ln < o) sAcc[t] += sAcc[t + o]; __syncthreads(); }
-  if (ln != 0 || ent >= stride) return;
-  acc = sAcc[t];
+  if (grp != 0 || ent >= stride) return;
+  acc = ((acc + sAcc[0][t]) + sAcc[1][t]) + sAcc[2][t];
   double* S = d.trial_comm;
   double* bs = d.trial_comm + (size_t)n * n;
   if (ent < nS) {
@@ -909,7 +931,7 @@ __global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d) { k_reduce_schur_b
 __global__ __launch_bounds__(CH) void k_reduce_schur_b(const BaDev* __restrict__ dv)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
-  if ((int)blockIdx.x >= ((d.nBlk * 36 + d.nP * 6 + 15) / 16)) return;
+  if ((int)blockIdx.x >= ((d.nBlk * 36 + d.nP * 6 + 63) / 64)) return;
   k_reduce_schur_body(d, blockIdx.x);
 }
 
@@ -1786,7 +1808,7 @@ ssx_status launch_linearize(ssx_ctx* ctx, const BaDev& d, const BigDev& bd, cons
     else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_pose_blocks<SSX_JAC_ANALYTIC>, dim3(d.nP), dim3(CH), 0, ctx->stream, d, bd, cur));
     SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_big, dim3(1), dim3(CH), 0, ctx->stream, d));
   } else
-  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 15) / 16)), dim3(CH), 0, ctx->stream, d));
+  SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 63) / 64)), dim3(CH), 0, ctx->stream, d));
   ssx_status st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
   if (st != SSX_OK) return st;
   // lambda_0 (first iteration of a round) and, after a collective, the global chi2
@@ -2170,14 +2192,14 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
             else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
           }
-          SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 15) / 16)), dim3(CH), 0, ctx->stream, d));
+          SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 63) / 64)), dim3(CH), 0, ctx->stream, d));
           st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
           if (st != SSX_OK) return st;
           if (first_slot || cm.fn) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_slot ? 1 : 0));
           first_slot = false;
           if (n > 0) {
             if (nCh > 0 && !fused) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, -1, 0.0, 2));
-            SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
+            SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 63) / 64), dim3(CH), 0, ctx->stream, d));
             st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
             if (st != SSX_OK) return st;
           }
@@ -2234,7 +2256,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
         } else {
         if (n > 0) {
           if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, cur, lambda, dev_lambda));
-          SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 15) / 16), dim3(CH), 0, ctx->stream, d));
+          SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 63) / 64), dim3(CH), 0, ctx->stream, d));
           st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
           if (st != SSX_OK) return st;
         }
@@ -2486,8 +2508,8 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   for (int w = 0; w < n; ++w) {
     const BaDev& d = B->devs[w];
     B->max_ch = std::max(B->max_ch, d.nCh);
-    B->max_rl = std::max(B->max_rl, (d.nP * 27 + 15) / 16);
-    B->max_rs = std::max(B->max_rs, (d.nBlk * 36 + d.nP * 6 + 15) / 16);
+    B->max_rl = std::max(B->max_rl, (d.nP * 27 + 63) / 64);
+    B->max_rs = std::max(B->max_rs, (d.nBlk * 36 + d.nP * 6 + 63) / 64);
     if (6 * d.nP <= NB) B->any_solve64 = true; else if (6 * d.nP <= 80) B->any_solve80 = true; else B->any_solve = true;
   }
   SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + B->a_head, hst, head_bytes, hipMemcpyHostToDevice, ctx->stream));
