@@ -91,10 +91,9 @@ struct BaDev {
   const int8_t* blk_pb;
   // packed records: ONE 16-byte load per chunk / edge / landmark instead of a chain of dependent index loads
   const int4* ch_desc;      // nCh: first sorted edge, #edges, first compact landmark, #landmarks
-  const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bit3 next edge is a dup, bit5 pose fixed, bits 8..15 chunk-local landmark, bits 16..23 position in the chunk's pose-major order (porder^-1)
+  const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bit3 next edge is a dup, bit5 pose fixed, bits 8..15 chunk-local landmark, bits 16..23 position in the chunk's pose-major order (edges grouped by free pose, fixed-pose edges last)
   const int4* l_rec;        // nLm: chunk-local first edge, #edges, landmark id (caller's), fixed
-  const uint8_t* porder;    // E: chunk-local edge indices grouped by free pose (fixed-pose edges last)
-  const uint16_t* pptr;     // nCh x (nP+1): segment of each pose inside the chunk's porder
+  const uint16_t* pptr;     // nCh x (nP+1): segment of each pose inside the chunk's pose-major order
   const uint8_t* pair_a;    // nPairs: chunk-local leader edge a (pose pa)
   const uint8_t* pair_b;    // nPairs: chunk-local leader edge b (pose pb)
   const int* pair_ptr;      // nCh x (nBlk+1): absolute offsets into pair_a/pair_b
@@ -1175,7 +1174,7 @@ namespace {
 struct HostPrep {
   int P, L, E, nP, nLm, nCh, nBlk;
   std::vector<int> pose_free, lm_id, lm_ptr, ch_lm, e_pose, e_lmc, perm, pair_ptr;
-  std::vector<uint8_t> lm_fixed, e_cam, e_dup, porder, pair_a, pair_b;
+  std::vector<uint8_t> lm_fixed, e_cam, e_dup, pair_a, pair_b;
   std::vector<uint16_t> pptr;
   std::vector<double> e_uv;
   std::vector<int8_t> blk_pa, blk_pb;
@@ -1313,7 +1312,6 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   }
   // per-chunk index lists: edges grouped by free pose; leader pairs grouped by reduced-system block
   const int nP = h.nP, nBlk = h.nBlk;
-  h.porder.assign(E, 0);
   h.pptr.assign((size_t)h.nCh * (nP + 1) + 1, 0);
   h.pair_ptr.assign((size_t)h.nCh * (nBlk + 1) + 1, 0);
   h.pair_a.clear(); h.pair_b.clear();
@@ -1337,7 +1335,6 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     for (int s = e0; s < e1; ++s) {
       const int pf = h.pose_free[h.e_pose[s]];
       const int pos = pf >= 0 ? pc[pf]++ : tail++;
-      h.porder[e0 + pos] = (uint8_t)(s - e0);
       h.e_rec[4 * (size_t)s + 3] = (h.e_rec[4 * (size_t)s + 3] & 0xFFFF) | (pos << 16);   // the inverse map, for the kernels that store pose-major
     }
     // --- pairs by block: one pass over the landmarks of the chunk lists (block, edge a, edge b), a counting sort by
@@ -1471,7 +1468,6 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_l_rec = in.take(sizeof(int) * 4 * (size_t)(nLm + 1));
   const size_t o_blk_pa = in.take(nBlk + 1);
   const size_t o_blk_pb = in.take(nBlk + 1);
-  const size_t o_porder = in.take(E + 1);
   const size_t o_pptr = in.take(sizeof(uint16_t) * (h.pptr.size() + 1));
   const size_t o_pair_a = in.take(nPairs + 1);
   const size_t o_pair_b = in.take(nPairs + 1);
@@ -1563,7 +1559,6 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_e_cam, h.e_cam.data(), E);
     memcpy(hs + o_e_dup, h.e_dup.data(), E);
     memcpy(hs + o_e_uv, h.e_uv.data(), sizeof(double) * 2 * E);
-    if (!h.porder.empty()) memcpy(hs + o_porder, h.porder.data(), E);
   }
   if (nBlk) {
     memcpy(hs + o_blk_pa, h.blk_pa.data(), nBlk);
@@ -1623,7 +1618,6 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.ch_desc = (const int4*)(at(o_ch_desc)); d.e_rec = (const int4*)(at(o_e_rec)); d.l_rec = (const int4*)(at(o_l_rec));
   d.blk_pa = (const int8_t*)(at(o_blk_pa));
   d.blk_pb = (const int8_t*)(at(o_blk_pb));
-  d.porder = (const uint8_t*)(at(o_porder));
   d.pptr = (const uint16_t*)(at(o_pptr));
   d.pair_a = (const uint8_t*)(at(o_pair_a));
   d.pair_b = (const uint8_t*)(at(o_pair_b));
