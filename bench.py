@@ -317,13 +317,33 @@ def main():
     # strong-scaling reference point).
     comm_kwargs = {}
     hook_kwargs = {}
+    comm_kind = "none"
     if world > 1:
         from ssvio_amd import dist_ba
         if test_mode:
             hook_kwargs = dict(allreduce=dist_ba.make_allreduce_hook_host_staged(dev), rank=rank, world_size=world)
+            comm_kind = "gloo, host staged (single-GPU test mode)"
         else:
-            comm = dist_ba.init_native_comm(ctx, rank, world)          # ncclCommInitRank inside libssx.so, id broadcast by torch.distributed
-            comm_kwargs = dict(comm=comm, rank=rank, world_size=world)
+            # ncclCommInitRank inside libssx.so, id broadcast by torch.distributed.  If the library cannot bring RCCL up on
+            # this node (every rank agrees on that through one all-reduce), the collective goes through torch.distributed's
+            # own RCCL communicator instead (ssx_allreduce_fn callback) and the line says so.
+            comm = None
+            try:
+                comm = dist_ba.init_native_comm(ctx, rank, world)
+                ok_native = 1.0
+            except Exception as exc:                                   # noqa: BLE001 -- any failure means "use the fallback"
+                print(f"[bench] rank {rank}: native RCCL unavailable ({exc}); falling back to torch.distributed", file=sys.stderr)
+                ok_native = 0.0
+            tn = torch.tensor([ok_native], dtype=torch.float64, device=dev)
+            dist.all_reduce(tn, op=dist.ReduceOp.MIN)
+            if float(tn.item()) > 0.5:
+                comm_kwargs = dict(comm=comm, rank=rank, world_size=world)
+                comm_kind = "RCCL inside libssx.so (ssx_comm_*)"
+            else:
+                if comm is not None:
+                    dist_ba.destroy_native_comm(ctx, comm)
+                hook_kwargs = dict(allreduce=dist_ba.make_allreduce_hook(dev), rank=rank, world_size=world)
+                comm_kind = "torch.distributed all_reduce through the ssx_allreduce_fn callback (native RCCL init failed)"
     dkw = dict(comm_kwargs, **hook_kwargs)
 
     def c4_problem(n_landmarks):
@@ -368,7 +388,8 @@ def main():
     C4_LM_PER_GPU = 10000
     c4 = {"workload": "C4 shape: 500 KF on a loop, 6 observations per landmark, pose 0 fixed, analytic Jacobians, f64",
           "weak": time_c4(C4_LM_PER_GPU * world, 2),
-          "sharding": (f"landmarks l mod {world} + RCCL all-reduce of the banded reduced system" if world > 1 else "none")}
+          "sharding": (f"landmarks l mod {world} + RCCL all-reduce of the banded reduced system" if world > 1 else "none"),
+          "collective": comm_kind}
     if world == 1 or os.environ.get("SSX_BENCH_C4_FULL") == "1":
         c4["full_configs3"] = time_c4(80000, 2)                       # strong-scaling point: the same 480 k edges at every N
 
