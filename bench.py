@@ -292,10 +292,10 @@ def main():
     if valu_insts:
         va = valu_insts / dom_avg_s / 1e9
         # issue cycles of a wave64 VALU instruction on a SIMD-32: 2, but 4 for f64 (tools/microbench/f64_rate.hip: 36.5 T
-        # lane-FMA/s chip-wide, 73 TFLOP/s).  The BA kernels are f64 kernels: 72 of the 83 VALU instructions of the loop
-        # that issues nine tenths of k_lin_schur's instructions are f64 (profiles/r02/k_lin_schur_b_block_loop.s),
-        # a mean of 3.73 cycles per instruction; the front-end kernels are integer / f32: 2 cycles.
-        cyc = 3.73 if kernels[dom]["part"] == "ba" else 2.0
+        # lane-FMA/s chip-wide, 73 TFLOP/s).  The BA kernels are f64 kernels: 54 of the 65 VALU instructions of the loop
+        # that issues most of k_lin_schur's instructions are f64 (profiles/r02/k_lin_schur_b_block_loop.s),
+        # a mean of 3.66 cycles per instruction; the front-end kernels are integer / f32: 2 cycles.
+        cyc = 3.66 if kernels[dom]["part"] == "ba" else 2.0
         peak = 1024 * 2.4 / cyc
         roofline["valu"] = {"achieved": round(va, 2), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(va / peak, 5),
                             "wave_instructions_per_launch": int(valu_insts), "issue_cycles_per_instruction": cyc,
