@@ -153,6 +153,39 @@ def main():
     host_elapsed = max_over_ranks(time.perf_counter() - t0)
     host_value = world * B * HOST_STEPS / host_elapsed
 
+    # ---------------- timed region 1c: host buffers, TWO batches in flight (what a server fed by several streams does) ----------------
+    # two host threads, each with its own context, marshal + upload + solve + download their batch while the other's is
+    # on the GPU; the front-end steps of both are enqueued by this thread
+    import threading
+    pipe_value = None
+    try:
+        ctx_p = [ssvio_amd.Context(dev_index) for _ in range(2)]
+        bh = [ba.BaBatch(c, step_windows) for c in ctx_p]
+        for b_ in bh:
+            b_.solve(want_edges=False)
+        PSTEPS = max(2, args.steps // 4)
+
+        def pipe_worker(k):
+            for _ in range(PSTEPS):
+                bh[k].solve(want_edges=False)
+
+        barrier()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=pipe_worker, args=(k,)) for k in range(2)]
+        for t_ in th:
+            t_.start()
+        for _ in range(2 * PSTEPS):
+            orb.stereo_batch_enqueue(ctx)
+        for t_ in th:
+            t_.join()
+        barrier()
+        pipe_elapsed = max_over_ranks(time.perf_counter() - t0)
+        pipe_value = world * B * 2 * PSTEPS / pipe_elapsed
+        for c in ctx_p:
+            c.close()
+    except Exception as exc:                                           # noqa: BLE001 -- an extra figure, never fatal
+        print(f"[bench] pipelined host-buffer region skipped: {exc}", file=sys.stderr)
+
     # ---------------- timed region 2: the front-end alone (round 1's `value`) ----------------
     barrier()
     t0 = time.perf_counter()
@@ -452,7 +485,8 @@ def main():
                        "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2)},
             "host_buffers_inclusive": {"value": round(host_value, 2), "unit": "stereo frames/s",
                                        "what": "the same step with the B windows handed over as host arrays every step (ssx_ba_solve_batch: host "
-                                               "marshalling on 16 threads + one PCIe upload + one download of poses / points); images still resident"},
+                                               "marshalling on 16 threads + one PCIe upload + one download of poses / points); images still resident",
+                                       "two_batches_in_flight": None if pipe_value is None else round(pipe_value, 2)},
             "roofline": roofline,
             "frontend": {"metric": "stereo frames/s (ORB extract + row-band match + triangulate), no BA", "value": round(fe_value, 2),
                          "ms_per_step": round(fe_elapsed / args.steps * 1e3, 4),
