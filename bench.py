@@ -169,7 +169,8 @@ def main():
             for _ in range(PSTEPS):
                 bh[k].solve(want_edges=False)
 
-        barrier()
+        # (no collective in here: an exception on one rank must not leave the others waiting; rank 0's own clock, times the ranks)
+        torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         th = [threading.Thread(target=pipe_worker, args=(k,)) for k in range(2)]
         for t_ in th:
@@ -178,8 +179,8 @@ def main():
             orb.stereo_batch_enqueue(ctx)
         for t_ in th:
             t_.join()
-        barrier()
-        pipe_elapsed = max_over_ranks(time.perf_counter() - t0)
+        torch.cuda.synchronize(dev)
+        pipe_elapsed = time.perf_counter() - t0
         pipe_value = world * B * 2 * PSTEPS / pipe_elapsed
         for c in ctx_p:
             c.close()
