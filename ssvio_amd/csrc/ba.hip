@@ -1454,13 +1454,15 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t nBlkS = h.sblk_pa.size();
   Layout in;   // input blob (mirrored in pinned staging)
   const size_t o_pose_free = in.take(sizeof(int) * P);
-  const size_t o_lm_fixed = in.take(nLm);
-  const size_t o_lm_id = in.take(sizeof(int) * nLm);
-  const size_t o_lm_ptr = in.take(sizeof(int) * (nLm + 1));
-  const size_t o_ch_lm = in.take(sizeof(int) * (nCh + 1));
-  const size_t o_e_pose = in.take(sizeof(int) * E);
-  const size_t o_e_lmc = in.take(sizeof(int) * E);
-  const size_t o_e_cam = in.take(E);
+  // (the landmark / chunk tables and the structure-of-arrays edge columns are read by the large-window kernels only: the
+  // small-window kernels take everything from the packed records -- a quarter of a C3 window's blob not staged, not sent)
+  const size_t o_lm_fixed = in.take(big ? nLm : 0);
+  const size_t o_lm_id = in.take(big ? sizeof(int) * nLm : 0);
+  const size_t o_lm_ptr = in.take(big ? sizeof(int) * (nLm + 1) : 0);
+  const size_t o_ch_lm = in.take(big ? sizeof(int) * (nCh + 1) : 0);
+  const size_t o_e_pose = in.take(big ? sizeof(int) * E : 0);
+  const size_t o_e_lmc = in.take(big ? sizeof(int) * E : 0);
+  const size_t o_e_cam = in.take(big ? E : 0);
   const size_t o_e_dup = in.take(E);
   const size_t o_e_uv = in.take(sizeof(double) * 2 * E);
   const size_t o_ch_desc = in.take(sizeof(int) * 4 * (size_t)(nCh + 1));
@@ -1544,19 +1546,21 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   }
   char* hs = place ? place->in_host : ws->stage.as<char>();
   memcpy(hs + o_pose_free, h.pose_free.data(), sizeof(int) * P);
-  if (nLm) {
+  if (big && nLm) {
     memcpy(hs + o_lm_fixed, h.lm_fixed.data(), nLm);
     memcpy(hs + o_lm_id, h.lm_id.data(), sizeof(int) * nLm);
   }
-  memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (nLm + 1));
+  if (big) memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (nLm + 1));
   if (nCh) memcpy(hs + o_ch_desc, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
   if (E) memcpy(hs + o_e_rec, h.e_rec.data(), sizeof(int) * 4 * (size_t)E);
   if (nLm) memcpy(hs + o_l_rec, h.l_rec.data(), sizeof(int) * 4 * (size_t)nLm);
-  memcpy(hs + o_ch_lm, h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
+  if (big) memcpy(hs + o_ch_lm, h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
   if (E) {
-    memcpy(hs + o_e_pose, h.e_pose.data(), sizeof(int) * E);
-    memcpy(hs + o_e_lmc, h.e_lmc.data(), sizeof(int) * E);
-    memcpy(hs + o_e_cam, h.e_cam.data(), E);
+    if (big) {
+      memcpy(hs + o_e_pose, h.e_pose.data(), sizeof(int) * E);
+      memcpy(hs + o_e_lmc, h.e_lmc.data(), sizeof(int) * E);
+      memcpy(hs + o_e_cam, h.e_cam.data(), E);
+    }
     memcpy(hs + o_e_dup, h.e_dup.data(), E);
     memcpy(hs + o_e_uv, h.e_uv.data(), sizeof(double) * 2 * E);
   }
