@@ -94,11 +94,14 @@ struct BaDev {
   const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bit3 next edge is a dup, bit5 pose fixed, bits 8..15 chunk-local landmark, bits 16..23 position in the chunk's pose-major order (edges grouped by free pose, fixed-pose edges last)
   const int4* l_rec;        // nLm: chunk-local first edge, #edges, landmark id (caller's), fixed
   const uint16_t* pptr;     // nCh x (nP+1): segment of each pose inside the chunk's pose-major order
-  const uint8_t* pair_a;    // nPairs: chunk-local leader edge a (pose pa)
-  const uint8_t* pair_b;    // nPairs: chunk-local leader edge b (pose pb)
-  const int* pair_ptr;      // nCh x (nBlk+1): absolute offsets into pair_a/pair_b
-  const int4* bseg;         // work items of k_schur's block phase: (block or -1, first pair, end pair [chunk-relative], part | parts << 4)
-  const int* bseg_ptr;      // nCh + 1: the chunk's items in bseg
+  // (the pair lists and the work items are built by the host marshalling OR, the default, by k_build_lists on the device:
+  // the arrays are then scratch with a fixed capacity per chunk)
+  uint8_t* pair_a;          // nPairs: chunk-local leader edge a (pose pa)
+  uint8_t* pair_b;          // nPairs: chunk-local leader edge b (pose pb)
+  int* pair_ptr;            // nCh x (nBlk+1): absolute offsets into pair_a/pair_b
+  int4* bseg;               // work items of k_schur's block phase: (block or -1, first pair, end pair [chunk-relative], part | parts << 4)
+  int* bseg_ptr;            // nCh x 2: first item of the chunk in bseg, number of items
+  int bseg_cap;             // device-built lists: items reserved per chunk (pairs: MAX_PAIRS per chunk)
   Cam K;
   double ext[14];
   double huber_delta, chi2_th;
@@ -232,8 +235,8 @@ __device__ __forceinline__ void chunk_lists_load(const BaDev& d, int c, char* sm
   if (d.big) return;
   if (t <= d.nP) sPptr[t] = d.pptr[(size_t)c * (d.nP + 1) + t];
   if (!want_pairs) return;
-  cl.it0 = d.bseg_ptr[c];
-  cl.n_items = 4 * (d.bseg_ptr[c + 1] - cl.it0);
+  cl.it0 = d.bseg_ptr[2 * c];
+  cl.n_items = 4 * d.bseg_ptr[2 * c + 1];
   if (t < cl.n_items) cl.item_rec = d.bseg[cl.it0 + (t >> 2)];
   // the chunk's (edge a, edge b) pairs grouped by block: global -> LDS once, coalesced
   const int* gp = d.pair_ptr + (size_t)c * (d.nBlk + 1);
@@ -594,6 +597,133 @@ __device__ void lm_step(const BaDev& d)
 __global__ void k_set_lambda(BaDev d, double lambda)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0) d.scal[SC_LAMBDA] = lambda;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_build_lists: the (edge a, edge b) pair lists of the reduced system's blocks and the balanced work items of k_schur's
+// block phase, per chunk, ON THE DEVICE -- what the host marshalling spent 40 % of its time on (0.2 of 0.53 ms per C3
+// window).  Same lists, byte for byte, as prepare() builds with SSX_BA_HOST_LISTS=1 (tests/test_ba_gpu.py compares the
+// solves bit by bit): pairs grouped by block in block order, inside a block in landmark order (a landmark has at most one
+// pair per block: its leaders see distinct poses), items sorted by part length with the parts of a block inside one wave.
+// One workgroup per chunk; the landmarks are the lanes of waves 0 and 1, "which landmarks hold block b" is a ballot.
+// ------------------------------------------------------------------------------------------------
+constexpr int LIST_MAX_BLK = SSX_BA_SMALL_P * (SSX_BA_SMALL_P + 1) / 2;   // 136
+__device__ __forceinline__ void k_build_lists_body(const BaDev& d, const int c)
+{
+  __shared__ uint8_t sEdgeOf[CH_L][SSX_BA_SMALL_P];
+  __shared__ int sCnt[2][LIST_MAX_BLK];
+  __shared__ int sBp[LIST_MAX_BLK + 1];
+  __shared__ int sLen[LIST_MAX_BLK], sK[LIST_MAX_BLK];
+  __shared__ uint8_t sSorted[LIST_MAX_BLK];
+  __shared__ int sMaxLen, sWaveTot[4], sWaveMax[4];
+  __shared__ int sPosR[LIST_MAX_BLK + 1];                                 // first item of the r-th block in sorted order, padding included
+  __shared__ int sKr[LIST_MAX_BLK];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int4 cd = d.ch_desc[c];
+  const int e0 = cd.x, lm0 = cd.z, nl = cd.w;
+  const int nP = d.nP, nBlk = d.nBlk;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // 1. every unfixed landmark: which free poses see it (leader edges: free pose, not a duplicate), and through which edge
+  uint32_t mask = 0;
+  if (t < nl) {
+    const int4 lr = d.l_rec[lm0 + t];
+    if (!lr.w)
+      for (int j = lr.x; j < lr.x + lr.y; ++j) {
+        const int4 er = d.e_rec[e0 + j];
+        if (er.y >= 0 && !(er.w & 2)) { mask |= 1u << er.y; sEdgeOf[t][er.y] = (uint8_t)j; }
+      }
+  }
+  __syncthreads();
+  // 2. pairs per block and wave
+  if (wave < 2) {
+    int pa = 0, pb = 0;
+    for (int b = 0; b < nBlk; ++b) {
+      const bool has = ((mask >> pa) & (mask >> pb) & 1u) != 0;
+      const unsigned long long bal = __ballot(has);
+      if (lane == 0) sCnt[wave][b] = __popcll(bal);
+      if (++pb == nP) { ++pa; pb = pa; }
+    }
+  }
+  __syncthreads();
+  // 3. block offsets inside the chunk's list (block order: an exclusive scan over <= 136 counts), the longest list
+  {
+    const int n = t < nBlk ? sCnt[0][t] + sCnt[1][t] : 0;
+    int inc = n, mx = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 63) { sWaveTot[wave] = inc; sWaveMax[wave] = mx; }
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += sWaveTot[w];
+    if (t < nBlk) sBp[t] = before + inc - n;
+    if (t == nBlk) sBp[nBlk] = before + inc - n;                       // = the total (its own n is 0)
+    if (t == 0) sMaxLen = max(max(sWaveMax[0], sWaveMax[1]), max(sWaveMax[2], sWaveMax[3]));
+  }
+  __syncthreads();
+  const int base = c * MAX_PAIRS;
+  for (int b = t; b <= nBlk; b += CH) d.pair_ptr[(size_t)c * (nBlk + 1) + b] = base + sBp[b];
+  // 4. the pairs: landmark order inside a block = rank of the landmark among the holders of the block
+  if (wave < 2) {
+    int pa = 0, pb = 0;
+    for (int b = 0; b < nBlk; ++b) {
+      const bool has = ((mask >> pa) & (mask >> pb) & 1u) != 0;
+      const unsigned long long bal = __ballot(has);
+      if (has) {
+        const int q = base + sBp[b] + (wave ? sCnt[0][b] : 0) + __popcll(bal & lt_mask);
+        d.pair_a[q] = sEdgeOf[t][pa];
+        d.pair_b[q] = sEdgeOf[t][pb];
+      }
+      if (++pb == nP) { ++pa; pb = pa; }
+    }
+  }
+  // 5. work items of the block phase (prepare()'s rule: parts of at least BSEG_MIN pairs, at most BSEG_PARTS per block, sorted by
+  // part length -- ties in block order --, the parts of one block inside one group of 16 items)
+  const int seg = max(BSEG_MIN, (sMaxLen + BSEG_PARTS - 1) / BSEG_PARTS);
+  if (t < nBlk) {
+    const int n = sBp[t + 1] - sBp[t], k = max(1, (n + seg - 1) / seg);
+    sK[t] = k;
+    sLen[t] = (n + k - 1) / k;
+  }
+  __syncthreads();
+  if (t < nBlk) {
+    const int len = sLen[t];
+    int rank = 0;
+    for (int b = 0; b < nBlk; ++b) { const int lb = sLen[b]; rank += (lb > len) || (lb == len && b < t); }
+    sSorted[rank] = (uint8_t)t;
+  }
+  __syncthreads();
+  if (t < nBlk) sKr[t] = sK[sSorted[t]];
+  __syncthreads();
+  if (t == 0) {
+    // where every block's parts start: the only sequential piece (a block moves to the next group of 16 items when it would
+    // straddle one), the loads do not depend on the running position
+    int pos = 0;
+    for (int r = 0; r < nBlk; ++r) {
+      const int k = sKr[r];
+      if ((pos & 15) + k > 16) pos = (pos + 15) & ~15;
+      sPosR[r] = pos;
+      pos += k;
+    }
+    sPosR[nBlk] = pos;
+    d.bseg_ptr[2 * c] = c * d.bseg_cap;
+    d.bseg_ptr[2 * c + 1] = pos;
+  }
+  __syncthreads();
+  if (t < nBlk) {
+    int4* out = d.bseg + (size_t)c * d.bseg_cap;
+    const int b = sSorted[t], n = sBp[b + 1] - sBp[b], k = sK[b], len = sLen[b], p0 = sPosR[t];
+    for (int i = 0; i < k; ++i) out[p0 + i] = make_int4(b, sBp[b] + min(n, i * len), sBp[b] + min(n, (i + 1) * len), i | (k << 4));
+    for (int q = p0 + k; q < sPosR[t + 1]; ++q) out[q] = make_int4(-1, 0, 0, 1 << 4);   // the padding in front of the next block
+  }
+}
+__global__ __launch_bounds__(CH) void k_build_lists(BaDev d) { k_build_lists_body(d, blockIdx.x); }
+__global__ __launch_bounds__(CH) void k_build_lists_b(const BaDev* __restrict__ dv)
+{
+  const BaDev& d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= d.nCh || d.bseg_cap == 0) return;
+  k_build_lists_body(d, blockIdx.x);
 }
 
 // W_e = Ji^T w Jj (6x3) of sorted edge e at the linearisation state `cur`: what k_linearize computes, recomputed by the
@@ -1182,6 +1312,7 @@ struct HostPrep {
   bool big = false;
   std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr;
   std::vector<int> bseg, bseg_ptr;   // see BaDev
+  bool dev_lists = false;            // small window: pair lists + work items are built by k_build_lists, not here
   std::vector<uint32_t> tmp_pairs;   // scratch of prepare(), kept between calls
   std::vector<std::pair<int, int>> tmp_order;
   std::vector<int> ch_desc, e_rec, l_rec;   // packed records (4 ints each), see BaDev
@@ -1308,14 +1439,17 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     h.nBlk = 0;
     h.band_w = -1;
     h.bseg.clear(); h.bseg_ptr.clear();
+    h.dev_lists = false;
     return SSX_OK;
   }
   // per-chunk index lists: edges grouped by free pose; leader pairs grouped by reduced-system block
+  static const bool host_lists = getenv("SSX_BA_HOST_LISTS") != nullptr;   // the host builder stays as the reference of the tests
+  h.dev_lists = !host_lists;
   const int nP = h.nP, nBlk = h.nBlk;
   h.pptr.assign((size_t)h.nCh * (nP + 1) + 1, 0);
   h.pair_ptr.assign((size_t)h.nCh * (nBlk + 1) + 1, 0);
   h.pair_a.clear(); h.pair_b.clear();
-  h.bseg.clear(); h.bseg_ptr.assign((size_t)h.nCh + 1, 0);
+  h.bseg.clear(); h.bseg_ptr.assign(2 * (size_t)h.nCh + 2, 0);
   std::vector<int> blk_of((size_t)std::max(nP, 1) * std::max(nP, 1), -1);
   for (int b = 0; b < nBlk; ++b) blk_of[(size_t)h.blk_pa[b] * nP + h.blk_pb[b]] = b;
   std::vector<int> pc(nP + 1), bc(nBlk + 1);
@@ -1337,6 +1471,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
       const int pos = pf >= 0 ? pc[pf]++ : tail++;
       h.e_rec[4 * (size_t)s + 3] = (h.e_rec[4 * (size_t)s + 3] & 0xFFFF) | (pos << 16);   // the inverse map, for the kernels that store pose-major
     }
+    if (h.dev_lists) continue;                    // k_build_lists (same lists, on the device)
     // --- pairs by block: one pass over the landmarks of the chunk lists (block, edge a, edge b), a counting sort by
     // block keeps the landmark order inside a block ---
     std::fill(bc.begin(), bc.end(), 0);
@@ -1385,6 +1520,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
         order.push_back({-((n + k - 1) / k), b});
       }
       std::stable_sort(order.begin(), order.end());
+      h.bseg_ptr[2 * c] = (int)(h.bseg.size() / 4);
       int pos = 0;                                // in items (16 per wave: four lanes each)
       for (const auto& ob : order) {
         const int b = ob.second, n = bp[b + 1] - bp[b], k = std::max(1, (n + seg - 1) / seg), len = (n + k - 1) / k;
@@ -1395,7 +1531,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
           ++pos;
         }
       }
-      h.bseg_ptr[c + 1] = (int)(h.bseg.size() / 4);
+      h.bseg_ptr[2 * c + 1] = (int)(h.bseg.size() / 4) - h.bseg_ptr[2 * c];
     }
   }
   return SSX_OK;
@@ -1447,8 +1583,10 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const bool dup_state = place != nullptr;       // batched windows: the second state buffer is part of the uploaded blob
   const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm, nCh = h.nCh, nBlk = h.nBlk;
   const int n = 6 * nP;
-  const size_t nPairs = h.pair_a.size();
   const bool big = h.big;
+  const bool dev_lists = h.dev_lists && !big;
+  const int bseg_cap = dev_lists ? 2 * nBlk * BSEG_PARTS + 16 : 0;
+  const size_t nPairs = dev_lists ? 0 : h.pair_a.size();
   const int lin_stride = big ? 2 : nP * 27 + 2;
   const int n_pad = big ? ((n + NB - 1) / NB) * NB : 0;
   const size_t nBlkS = h.sblk_pa.size();
@@ -1471,11 +1609,12 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_blk_pa = in.take(nBlk + 1);
   const size_t o_blk_pb = in.take(nBlk + 1);
   const size_t o_pptr = in.take(sizeof(uint16_t) * (h.pptr.size() + 1));
-  const size_t o_pair_a = in.take(nPairs + 1);
-  const size_t o_pair_b = in.take(nPairs + 1);
-  const size_t o_pair_ptr = in.take(sizeof(int) * (h.pair_ptr.size() + 1));
-  const size_t o_bseg = in.take(sizeof(int) * (h.bseg.size() + 4));
-  const size_t o_bseg_ptr = in.take(sizeof(int) * (h.bseg_ptr.size() + 1));
+  // (host-built lists travel with the blob; device-built ones are scratch behind it, a fixed capacity per chunk)
+  size_t o_pair_a = dev_lists ? 0 : in.take(nPairs + 1);
+  size_t o_pair_b = dev_lists ? 0 : in.take(nPairs + 1);
+  size_t o_pair_ptr = dev_lists ? 0 : in.take(sizeof(int) * (h.pair_ptr.size() + 1));
+  size_t o_bseg = dev_lists ? 0 : in.take(sizeof(int) * (h.bseg.size() + 4));
+  size_t o_bseg_ptr = dev_lists ? 0 : in.take(sizeof(int) * (h.bseg_ptr.size() + 1));
   const size_t o_pe_ptr = in.take(sizeof(int) * (h.pe_ptr.size() + 1));
   const size_t o_pe_edge = in.take(sizeof(int) * (h.pe_edge.size() + 1));
   const size_t o_sblk_pa = in.take(sizeof(int) * (nBlkS + 1));
@@ -1494,6 +1633,13 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   Layout all = in;
   const size_t o_pose1 = dup_state ? o_pose1_in : all.take(sizeof(double) * 7 * P);
   const size_t o_point1 = dup_state ? o_point1_in : all.take(sizeof(double) * 3 * (L + 1));
+  if (dev_lists) {
+    o_pair_a = all.take((size_t)(nCh + 1) * MAX_PAIRS);
+    o_pair_b = all.take((size_t)(nCh + 1) * MAX_PAIRS);
+    o_pair_ptr = all.take(sizeof(int) * ((size_t)(nCh + 1) * (nBlk + 1) + 1));
+    o_bseg = all.take(sizeof(int) * 4 * ((size_t)(nCh + 1) * bseg_cap + 1));
+    o_bseg_ptr = all.take(sizeof(int) * (2 * (size_t)nCh + 2));
+  }
   const size_t o_W = all.take(sizeof(double) * 18 * (size_t)E);
   const size_t o_err_lin = all.take(sizeof(double) * 2 * (size_t)E);
   const size_t o_err_trial = all.take(sizeof(double) * 2 * (size_t)E);
@@ -1573,9 +1719,11 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_pair_a, h.pair_a.data(), nPairs);
     memcpy(hs + o_pair_b, h.pair_b.data(), nPairs);
   }
-  if (!h.pair_ptr.empty()) memcpy(hs + o_pair_ptr, h.pair_ptr.data(), sizeof(int) * h.pair_ptr.size());
-  if (!h.bseg.empty()) memcpy(hs + o_bseg, h.bseg.data(), sizeof(int) * h.bseg.size());
-  if (!h.bseg_ptr.empty()) memcpy(hs + o_bseg_ptr, h.bseg_ptr.data(), sizeof(int) * h.bseg_ptr.size());
+  if (!dev_lists) {
+    if (!h.pair_ptr.empty()) memcpy(hs + o_pair_ptr, h.pair_ptr.data(), sizeof(int) * h.pair_ptr.size());
+    if (!h.bseg.empty()) memcpy(hs + o_bseg, h.bseg.data(), sizeof(int) * h.bseg.size());
+    if (!h.bseg_ptr.empty()) memcpy(hs + o_bseg_ptr, h.bseg_ptr.data(), sizeof(int) * h.bseg_ptr.size());
+  }
   if (big) {
     memcpy(hs + o_pe_ptr, h.pe_ptr.data(), sizeof(int) * h.pe_ptr.size());
     memcpy(hs + o_pe_edge, h.pe_edge.data(), sizeof(int) * h.pe_edge.size());
@@ -1623,10 +1771,11 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.blk_pa = (const int8_t*)(at(o_blk_pa));
   d.blk_pb = (const int8_t*)(at(o_blk_pb));
   d.pptr = (const uint16_t*)(at(o_pptr));
-  d.pair_a = (const uint8_t*)(at(o_pair_a));
-  d.pair_b = (const uint8_t*)(at(o_pair_b));
-  d.pair_ptr = (const int*)(at(o_pair_ptr));
-  d.bseg = (const int4*)(at(o_bseg)); d.bseg_ptr = (const int*)(at(o_bseg_ptr));
+  d.pair_a = (uint8_t*)(at(o_pair_a));
+  d.pair_b = (uint8_t*)(at(o_pair_b));
+  d.pair_ptr = (int*)(at(o_pair_ptr));
+  d.bseg = (int4*)(at(o_bseg)); d.bseg_ptr = (int*)(at(o_bseg_ptr));
+  d.bseg_cap = bseg_cap;
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
@@ -1665,6 +1814,10 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
       bnd.Ls1 = (double*)(at(o_Ls1)); bnd.xr = (double*)(at(o_xr)); bnd.LS0 = LS0; bnd.LS1 = LS1;
     }
     bd.S = (double*)(at(o_S)); bd.x = (double*)(at(o_x)); bd.Ld = (double*)(at(o_Ld)); bd.invd = (double*)(at(o_invd)); bd.Ninv = (double*)(at(o_Ninv)); bd.scale_part = (double*)(at(o_scale_part));
+  }
+  if (!place && dev_lists && nCh > 0) {            // (a batch builds the lists of all its windows with one launch: batch_build)
+    hipLaunchKernelGGL(k_build_lists, dim3(nCh), dim3(CH), 0, ctx->stream, d);
+    SSX_HIP_TRY(ctx, hipGetLastError());
   }
   return SSX_OK;
 }
@@ -2511,6 +2664,12 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     if (6 * d.nP <= NB) B->any_solve64 = true; else if (6 * d.nP <= 80) B->any_solve80 = true; else B->any_solve = true;
   }
   SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + B->a_head, hst, head_bytes, hipMemcpyHostToDevice, ctx->stream));
+  {
+    // pair lists + work items of every window, on the device (windows marshalled with SSX_BA_HOST_LISTS brought theirs along)
+    const BaDev* dvb = reinterpret_cast<const BaDev*>(dev_base + B->a_head + in_total + B->o_dv);
+    hipLaunchKernelGGL(k_build_lists_b, dim3(B->max_ch, n), dim3(CH), 0, ctx->stream, dvb);
+    SSX_HIP_TRY(ctx, hipGetLastError());
+  }
   B->fresh = true;                                                   // the state buffers hold the uploaded state
   const size_t lds_schur = schur_lds_bytes();
   static bool attr_set_b = false;

@@ -4,6 +4,8 @@ Tolerances: the north_star asks for reprojection residuals within 1e-4 px of the
 path and the oracle run the same algorithm (analytic or numeric Jacobians) in f64 with different
 summation orders, so the bars here are much tighter than that where the arithmetic allows.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -442,6 +444,67 @@ def test_batch_groups_do_not_change_the_bits(ctx):
     host = ba.BaBatch(ctx, probs).solve()                     # the one-call form takes the default grouping
     assert all(np.array_equal(b["poses"], one["poses"]) for b, one in zip(host["results"], ones))
     assert ba.BaBatch(ctx, probs[:3], resident=True).groups == 1
+
+
+_LISTS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import ssvio_amd
+from ssvio_amd import ba
+from ssvio_amd.synth import make_ba_problem
+ctx = ssvio_amd.Context(0)
+out = {}
+def with_duplicates(pr, n):   # right-camera observations of the first n landmarks from the pose of their first edge
+    ep, pt, uv = [], [], []
+    for j in range(n):
+        e = int(np.nonzero(pr["edge_point"] == j)[0][0])
+        u = pr["edge_uv"][e].copy(); u[0] -= pr["K"][0] * 0.537 / 20.0
+        ep.append(pr["edge_pose"][e]); pt.append(j); uv.append(u)
+    pr["edge_pose"] = np.concatenate([pr["edge_pose"], np.array(ep, dtype=np.int32)])
+    pr["edge_point"] = np.concatenate([pr["edge_point"], np.array(pt, dtype=np.int32)])
+    pr["edge_uv"] = np.concatenate([pr["edge_uv"], np.array(uv)])
+    pr["edge_cam"] = np.concatenate([pr["edge_cam"], np.ones(n, dtype=np.uint8)])
+    pr["E"] = len(pr["edge_pose"])
+    return pr
+for i, kw in enumerate(eval(sys.argv[3])):
+    pr = make_ba_problem(**kw)
+    if i == 5: pr = with_duplicates(pr, 80)
+    r = ba.ba_solve(ctx, pr)
+    for k in ("poses", "points", "chi2", "lam", "trials", "edge_chi2"):
+        out[f"{i}_{k}"] = np.asarray(r[k])
+probs = [make_ba_problem(**kw) for kw in eval(sys.argv[3])[:4]] * 3
+rb = ba.BaBatch(ctx, probs, resident=True).solve()
+for i, r in enumerate(rb["results"]):
+    out[f"b{i}_poses"] = r["poses"]; out[f"b{i}_chi2"] = r["chi2"]
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
+    """The pair lists and work items of small windows are built on the device (k_build_lists); SSX_BA_HOST_LISTS=1 makes the
+    host marshalling build them as before.  Both must give the same bits: single solves (duplicate observations, fixed
+    poses and landmarks, 4 .. 16 keyframes, sparse co-visibility) and a resident batch in two groups."""
+    import subprocess, sys as _sys
+    cases = [dict(P=10, L=700, seed=41), dict(P=12, L=500, obs_per_lm=4, seed=42), dict(P=16, L=600, obs_per_lm=5, seed=43, fix_first_pose=True),
+             dict(P=4, L=60, obs_per_lm=4, seed=44), dict(P=7, L=300, obs_per_lm=2, seed=45), dict(P=10, L=500, seed=46, fix_first_pose=True, frac_fixed=0.3),
+             dict(P=10, L=4000, seed=47)]
+    import inspect
+    accepted = inspect.signature(make_ba_problem).parameters
+    cases = [{k: v for k, v in kw.items() if k in accepted} for kw in cases]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("device", "host"):
+        env = dict(os.environ)
+        env.pop("SSX_BA_HOST_LISTS", None)
+        if mode == "host":
+            env["SSX_BA_HOST_LISTS"] = "1"
+        path = str(tmp_path / f"{mode}.npz")
+        r = subprocess.run([_sys.executable, "-c", _LISTS_SCRIPT, root, path, repr(cases)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(path)
+    assert sorted(outs["device"].files) == sorted(outs["host"].files) and len(outs["device"].files) > 40
+    for k in outs["device"].files:
+        assert np.array_equal(outs["device"][k], outs["host"][k]), k
 
 
 def test_bench_size_batch_equals_single_calls(ctx):
