@@ -611,6 +611,7 @@ constexpr int LIST_MAX_BLK = SSX_BA_SMALL_P * (SSX_BA_SMALL_P + 1) / 2;   // 136
 __device__ __forceinline__ void k_build_lists_body(const BaDev& d, const int c)
 {
   __shared__ uint8_t sEdgeOf[CH_L][SSX_BA_SMALL_P];
+  __shared__ int8_t sLead[CH];                                            // free pose of a leader edge, -1 otherwise
   __shared__ int sCnt[2][LIST_MAX_BLK];
   __shared__ int sBp[LIST_MAX_BLK + 1];
   __shared__ int sLen[LIST_MAX_BLK], sK[LIST_MAX_BLK];
@@ -623,16 +624,22 @@ __device__ __forceinline__ void k_build_lists_body(const BaDev& d, const int c)
   const int e0 = cd.x, lm0 = cd.z, nl = cd.w;
   const int nP = d.nP, nBlk = d.nBlk;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  // 1. every unfixed landmark: which free poses see it (leader edges: free pose, not a duplicate), and through which edge
-  uint32_t mask = 0;
-  if (t < nl) {
-    const int4 lr = d.l_rec[lm0 + t];
-    if (!lr.w)
-      for (int j = lr.x; j < lr.x + lr.y; ++j) {
-        const int4 er = d.e_rec[e0 + j];
-        if (er.y >= 0 && !(er.w & 2)) { mask |= 1u << er.y; sEdgeOf[t][er.y] = (uint8_t)j; }
-      }
+  // 1. every unfixed landmark: which free poses see it (leader edges: free pose, not a duplicate), and through which edge.
+  // (the edge records come in with ONE coalesced load per edge thread; a landmark thread walking its edges in global memory
+  // paid a memory round trip per edge)
+  if (t < cd.y) {
+    const int4 er = d.e_rec[e0 + t];
+    sLead[t] = (er.y >= 0 && !(er.w & 2)) ? (int8_t)er.y : (int8_t)-1;
   }
+  int4 lr = make_int4(0, 0, 0, 1);
+  if (t < nl) lr = d.l_rec[lm0 + t];
+  __syncthreads();
+  uint32_t mask = 0;
+  if (t < nl && !lr.w)
+    for (int j = lr.x; j < lr.x + lr.y; ++j) {
+      const int pf = sLead[j];
+      if (pf >= 0) { mask |= 1u << pf; sEdgeOf[t][pf] = (uint8_t)j; }
+    }
   __syncthreads();
   // 2. pairs per block and wave
   if (wave < 2) {
