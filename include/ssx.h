@@ -53,6 +53,11 @@ typedef struct {
   int device;          /* HIP device ordinal */
   void* stream;        /* hipStream_t to run on, or NULL to create a private non-blocking stream */
   int max_width, max_height; /* largest image the ctx will see (scratch sizing); 0 = grow on demand */
+  /* Partition the chip between contexts that run side by side (the front-end's ctx and the backend's): when cu_count > 0
+   * every stream the ctx CREATES (stream == NULL above, its auxiliary and group streams) is restricted to cu_count
+   * compute units starting at cu_first (hipExtStreamCreateWithCUMask; bit i of the mask lands on XCD i mod 8, so any
+   * contiguous range is spread evenly over the eight XCDs).  0 / 0 = the whole chip.  Ignored for a caller's stream. */
+  int cu_first, cu_count;
 } ssx_config;
 
 SSX_API int ssx_version(void);
@@ -144,8 +149,9 @@ typedef struct {
   int32_t collect_stats;    /* 1 = time every phase with HIP events (fills ssx_ba_result.ms_*; a few us per launch) */
   /* windows with more than 16 free keyframes, the reduced pose system: SSX_LARGE_SOLVER_AUTO picks the band solver
    * (sliding-window block Cholesky + nested dissection along the trajectory) when every keyframe shares landmarks only
-   * with keyframes within 6 positions along the (possibly closed) trajectory, else the 64x64-tile sparse Cholesky;
-   * _TILES / _BAND force one (BAND fails with SSX_ERR_UNSUPPORTED on a wider co-visibility). */
+   * with keyframes within 5 positions along the (possibly closed) trajectory (block bandwidth w <= 5) and the window
+   * has at least 2 w + 2 free keyframes, else the 64x64-tile sparse Cholesky; _TILES / _BAND force one (BAND fails
+   * with SSX_ERR_UNSUPPORTED on a wider co-visibility or a shorter window). */
   int32_t large_solver;
 } ssx_ba_options;
 

@@ -35,7 +35,8 @@ class SsxError(RuntimeError):
 
 
 class Config(C.Structure):
-    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("max_width", C.c_int), ("max_height", C.c_int)]
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("max_width", C.c_int), ("max_height", C.c_int),
+                ("cu_first", C.c_int), ("cu_count", C.c_int)]
 
 
 class BaProblem(C.Structure):
@@ -115,9 +116,10 @@ class Context:
     """One GPU + one HIP stream (ssx_ctx).  stream=None creates a private stream; pass
     `torch.cuda.current_stream().cuda_stream` to run on torch's stream (needed for the RCCL hook)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, cu_first: int = 0, cu_count: int = 0):
+        """cu_count > 0: the streams the ctx creates are restricted to CUs [cu_first, cu_first + cu_count) (ssx_config)"""
         self.lib = load()
-        cfg = Config(device, C.c_void_p(stream) if stream else None, 0, 0)
+        cfg = Config(device, C.c_void_p(stream) if stream else None, 0, 0, cu_first, cu_count)
         h = C.c_void_p()
         st = self.lib.ssx_ctx_create(C.byref(cfg), C.byref(h))
         if st != SSX_OK:

@@ -213,7 +213,22 @@ class BaBatch:
         return dict(results=out, n_iters_total=int(sum(o["n_iters"] for o in out)))
 
     def close(self):
+        """destroy the resident batch (before its Context is closed: the library frees device memory of that device)"""
         if self.handle is not None:
             self.ctx.lib.ssx_ba_batch_destroy.restype = None
+            self.ctx.lib.ssx_ba_batch_destroy.argtypes = [C.c_void_p]
             self.ctx.lib.ssx_ba_batch_destroy(self.handle)
             self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                   # noqa: BLE001 -- interpreter shutdown: the library may be gone
+            pass

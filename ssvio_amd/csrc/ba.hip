@@ -40,6 +40,9 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -1284,30 +1287,7 @@ __global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* __restrict__ dv,
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct BaWorkspace {
-  DevBuf arena;      // everything on the device
-  HostBuf stage;     // pinned upload / download staging
-  HostBuf scal;      // pinned scalars read back per trial
-  DevBuf tiles;      // large windows: tile-sparsity lists of the factor
-  HostBuf tiles_h;
-  DevBuf pairs_a, pairs_b, pairs_c;   // large windows: device-built pair lists (inputs + scan | sort buffers | final lists)
-  HostBuf pairs_h;
-};
-
-static void ssx_ba_workspace_free(BaWorkspace* w)
-{
-  if (!w) return;
-  w->arena.release();
-  w->stage.release();
-  w->scal.release();
-  w->tiles.release();
-  w->tiles_h.release();
-  w->pairs_a.release(); w->pairs_b.release(); w->pairs_c.release(); w->pairs_h.release();
-  delete w;
-}
-
 namespace {
-
 struct HostPrep {
   int P, L, E, nP, nLm, nCh, nBlk;
   std::vector<int> pose_free, lm_id, lm_ptr, ch_lm, e_pose, e_lmc, perm, pair_ptr;
@@ -1326,6 +1306,103 @@ struct HostPrep {
   std::vector<int> lm_chunk;                // compact landmark -> chunk (large windows: the device-side pair builder)
   int band_w = -1;          // cyclic block bandwidth of this rank's part of the reduced system (max over its non-zero blocks)
 };
+}  // namespace
+
+// A few persistent host threads for the per-window host work of a batched call (staging copies, result unpacking): created
+// on first use, parked on a condition variable between calls (the former code spawned up to 16 std::threads twice per call).
+class ParPool {
+ public:
+  ~ParPool()
+  {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // fn(w) for w in [0, n) on up to T threads (the caller is one of them); returns when all are done
+  template <class F>
+  void run(int n, int T, F&& fn)
+  {
+    if (T <= 1 || n <= 1) { for (int w = 0; w < n; ++w) fn(w); return; }
+    std::function<void(int)> f = fn;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      while ((int)th_.size() < T - 1) th_.emplace_back([this] { loop(); });
+      job_ = &f; n_ = n; next_ = 0; pending_ = n; ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void work()
+  {
+    for (;;) {
+      int w;
+      const std::function<void(int)>* f;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!job_ || next_ >= n_) return;
+        w = next_++; f = job_;
+      }
+      (*f)(w);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_cv_.notify_all();
+    }
+  }
+  void loop()
+  {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> th_;
+  const std::function<void(int)>* job_ = nullptr;
+  int n_ = 0, next_ = 0, pending_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+};
+
+struct BaWorkspace {
+  DevBuf arena;      // everything on the device
+  HostBuf stage;     // pinned upload / download staging
+  HostBuf scal;      // pinned scalars read back per trial
+  DevBuf tiles;      // large windows: tile-sparsity lists of the factor
+  HostBuf tiles_h;
+  DevBuf pairs_a, pairs_b, pairs_c;   // large windows: device-built pair lists (inputs + scan | sort buffers | final lists)
+  HostBuf pairs_h;
+  // host marshalling scratch, kept between calls (a ctx is single-threaded by contract, so one set per ctx: the former
+  // thread_local copies lived as long as the calling thread -- ~100 MB per thread after a 64-window batch)
+  HostPrep prep1;                     // ssx_ba_solve / ssx_ba_linearize
+  std::vector<HostPrep> preps;        // batched calls: one per window, trimmed back after a large batch
+  ParPool pool;
+};
+
+static void ssx_ba_workspace_free(BaWorkspace* w)
+{
+  if (!w) return;
+  w->arena.release();
+  w->stage.release();
+  w->scal.release();
+  w->tiles.release();
+  w->tiles_h.release();
+  w->pairs_a.release(); w->pairs_b.release(); w->pairs_c.release(); w->pairs_h.release();
+  delete w;
+}
+
+namespace {
+
 
 ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
 {
@@ -2090,10 +2167,10 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
                             double* chi2)
 {
   if (!ctx || !prob) return SSX_ERR_INVALID_ARG;
-  // the index lists are rebuilt per call (the window changes with every keyframe) but their storage is kept per thread:
+  // the index lists are rebuilt per call (the window changes with every keyframe) but their storage is kept with the ctx:
   // ~20 vectors of up to E entries are not re-allocated and re-faulted every solve
-  static thread_local HostPrep h_tls;
-  HostPrep& h = h_tls;
+  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+  HostPrep& h = ctx->ba->prep1;
   ssx_status st = prepare(ctx, prob, h);
   if (st != SSX_OK) return st;
   BaDev d;
@@ -2162,10 +2239,10 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   if (!ctx || !prob || !res) return SSX_ERR_INVALID_ARG;
   ssx_ba_options opt;
   if (opt_in) opt = *opt_in; else ssx_ba_default_options(&opt);
-  // the index lists are rebuilt per call (the window changes with every keyframe) but their storage is kept per thread:
+  // the index lists are rebuilt per call (the window changes with every keyframe) but their storage is kept with the ctx:
   // ~20 vectors of up to E entries are not re-allocated and re-faulted every solve
-  static thread_local HostPrep h_tls;
-  HostPrep& h = h_tls;
+  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+  HostPrep& h = ctx->ba->prep1;
   ssx_status st = prepare(ctx, prob, h);
   if (st != SSX_OK) return st;
   Comm cm;
@@ -2559,6 +2636,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
 
 struct ssx_ba_batch {
   ssx_ctx* ctx = nullptr;
+  int device = 0;                                    // the ctx's device (ssx_ba_batch_destroy must not read it through ctx)
   int n = 0;
   ssx_ba_options opt;
   DevBuf arena_own; HostBuf stage_own, scal_own;     // a resident batch owns its memory; the one-call path borrows the ctx workspace
@@ -2576,15 +2654,6 @@ struct ssx_ba_batch {
 
 namespace {
 
-template <class F>
-void batch_par_for(int n, int T, F&& fn)
-{
-  if (T <= 1) { for (int w = 0; w < n; ++w) fn(w); return; }
-  std::vector<std::thread> th;
-  for (int k = 0; k < T; ++k) th.emplace_back([&, k] { for (int w = k; w < n; w += T) fn(w); });
-  for (auto& x : th) x.join();
-}
-
 // Groups of windows a batch is run in, each on its own stream (batch_run).  Two: measured 2.61 / 2.45 / 2.39 / 3.01 ms for
 // 64 windows in 1 / 2 / 3 / 4 groups in a process with nothing else on the GPU, but 2.61 / 2.45 / 3.24 ms next to a
 // front-end on its own two streams (more streams than hardware queues: the groups then wait for each other).
@@ -2597,22 +2666,21 @@ int batch_groups(int n)
 // marshal + upload n small windows; SSX_ERR_UNSUPPORTED when one of them is a large window (> 16 free keyframes)
 ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const ssx_ba_options& opt, bool with_err, bool own, ssx_ba_batch* B)
 {
-  // (kept per calling thread between calls; a thread_local named inside a lambda would be the WORKER thread's instance:
-  // the workers go through this reference)
-  static thread_local std::vector<HostPrep> preps_tls;
-  if ((int)preps_tls.size() < n) preps_tls.resize(n);
-  std::vector<HostPrep>& preps = preps_tls;
+  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+  BaWorkspace* ws = ctx->ba;
+  // (the marshalling scratch of the windows is kept with the ctx between calls; after a batch larger than PREPS_KEEP
+  // windows it is trimmed back, see the end of this function)
+  if ((int)ws->preps.size() < n) ws->preps.resize(n);
+  std::vector<HostPrep>& preps = ws->preps;
   const int hw = (int)std::thread::hardware_concurrency();
   const int T = std::max(1, std::min({n, 16, hw > 1 ? hw / 2 : 1}));
-  B->ctx = ctx; B->n = n; B->opt = opt; B->threads = T; B->with_err = with_err;
+  B->ctx = ctx; B->device = ctx->device; B->n = n; B->opt = opt; B->threads = T; B->with_err = with_err;
   // ---- 1. host marshalling of every window (edge sort, chunks, index lists), T threads
   std::vector<ssx_status> sts(n, SSX_OK);
-  batch_par_for(n, T, [&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w]); });
+  ws->pool.run(n, T, [&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w]); });
   for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
   for (int w = 0; w < n; ++w) if (preps[w].big) return SSX_ERR_UNSUPPORTED;
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
-  BaWorkspace* ws = ctx->ba;
   B->arena = own ? &B->arena_own : &ws->arena;
   B->stage = own ? &B->stage_own : &ws->stage;
   B->scal = own ? &B->scal_own : &ws->scal;
@@ -2649,7 +2717,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   char* dev_base = B->arena->as<char>();
   char* hst = B->stage->as<char>();
   // ---- 3. fill the pinned mirror (T threads), one upload
-  batch_par_for(n, T, [&](int w) {
+  ws->pool.run(n, T, [&](int w) {
     BigDev bd; BandDev bnd;
     place[w].dry = false;
     place[w].in_dev = dev_base + B->a_head + in_off[w];
@@ -2689,6 +2757,8 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_b<SSX_JAC_NUMERIC_G2O>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_LDS_BYTES);
     attr_set_b = true;
   }
+  constexpr size_t PREPS_KEEP = 16;                                  // windows whose marshalling scratch stays allocated between calls
+  if (ws->preps.size() > PREPS_KEEP) { ws->preps.resize(PREPS_KEEP); ws->preps.shrink_to_fit(); }
   return SSX_OK;
 }
 
@@ -2717,9 +2787,9 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   for (int w = 0; w < n; ++w) wsn[w].done = !(B->devs[w].nCh > 0) || opt.outer_rounds <= 0;
   const size_t lds_schur = schur_lds_bytes();
   const size_t lds_fused = std::max(lds_schur, LIN_LDS_BYTES);
-  int G = B->groups > 0 ? std::min(B->groups, 4) : batch_groups(n);
+  int G = std::min(B->groups > 0 ? std::min(B->groups, 4) : batch_groups(n), std::max(n, 1));   // never an empty group (gridDim.y == 0)
   for (int g = 0; g + 1 < G; ++g) {
-    if (!ctx->grp[g] && hipStreamCreateWithFlags(&ctx->grp[g], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G = g + 1; break; }
+    if (!ctx->grp[g] && ctx->make_stream(&ctx->grp[g], false) != hipSuccess) { (void)hipGetLastError(); G = g + 1; break; }
     if (!ctx->grp_ev[g] && hipEventCreateWithFlags(&ctx->grp_ev[g], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G = g + 1; break; }
   }
   const bool split = G > 1;
@@ -2822,7 +2892,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-  batch_par_for(n, B->threads, [&](int w) {
+  ctx->ba->pool.run(n, B->threads, [&](int w) {
     ssx_ba_result& r = results[w];
     const WinState& st = wsn[w];
     const int P = B->P[w], L = B->L[w], E = B->E[w];
@@ -2928,7 +2998,7 @@ void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups) { if (batch) b
 void ssx_ba_batch_destroy(ssx_ba_batch* batch)
 {
   if (!batch) return;
-  if (batch->ctx) (void)hipSetDevice(batch->ctx->device);
+  (void)hipSetDevice(batch->device);
   batch->arena_own.release(); batch->stage_own.release(); batch->scal_own.release();
   delete batch;
 }

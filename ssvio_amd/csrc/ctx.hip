@@ -25,11 +25,17 @@ ssx_status ssx_ctx_create(const ssx_config* cfg, ssx_ctx** out)
   c->device = dev;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  if (cfg && cfg->cu_count > 0) {
+    const int n_cu = c->num_cus > 0 ? c->num_cus : 256;
+    if (cfg->cu_first < 0 || cfg->cu_first + cfg->cu_count > n_cu || n_cu > 512) { delete c; return SSX_ERR_INVALID_ARG; }
+    c->cu_mask_words = (n_cu + 31) / 32;
+    for (int i = cfg->cu_first; i < cfg->cu_first + cfg->cu_count; ++i) c->cu_mask[i >> 5] |= 1u << (i & 31);
+  }
   if (cfg && cfg->stream) {
     c->stream = static_cast<hipStream_t>(cfg->stream);
     c->own_stream = false;
   } else {
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (c->make_stream(&c->stream, false) != hipSuccess) {
       delete c;
       return SSX_ERR_HIP;
     }
@@ -39,12 +45,7 @@ ssx_status ssx_ctx_create(const ssx_config* cfg, ssx_ctx** out)
   (void)hipEventCreate(&c->ev1);
   {
     // the auxiliary stream carries work that fills the gaps of the main stream's dependent chain: lowest priority
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, least) != hipSuccess) {
-      (void)hipGetLastError();
-      (void)hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
-    }
+    if (c->make_stream(&c->aux, true) != hipSuccess) (void)hipGetLastError();
   }
   (void)hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -121,6 +122,20 @@ struct ssx_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int num_cus = 256;
+  uint32_t cu_mask[16] = {0};                // ssx_config.cu_first / cu_count as a bit mask; cu_mask_words == 0: no mask
+  int cu_mask_words = 0;
+  // every stream the ctx creates: CU-masked when the ctx is, lowest priority on request
+  hipError_t make_stream(hipStream_t* out, bool low_priority)
+  {
+    if (cu_mask_words > 0) return hipExtStreamCreateWithCUMask(out, (uint32_t)cu_mask_words, cu_mask);
+    if (low_priority) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (hipStreamCreateWithPriority(out, hipStreamNonBlocking, least) == hipSuccess) return hipSuccess;
+      (void)hipGetLastError();
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  }
   char err[512] = {0};
   BaWorkspace* ba = nullptr;
   OrbWorkspace* orb = nullptr;
@@ -137,8 +152,11 @@ struct ssx_ctx {
   DevBuf po_arena;                           // pose-only optimisation scratch
   HostBuf po_stage;
 
+  std::mutex err_mu;                         // worker threads of a batched call may report failures concurrently
+
   void set_error(const char* fmt, ...)
   {
+    std::lock_guard<std::mutex> lk(err_mu);
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(err, sizeof(err), fmt, ap);

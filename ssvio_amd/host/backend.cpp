@@ -49,7 +49,9 @@ void Backend::WaitIdle()
 {
   if (!async_) return;
   std::unique_lock<std::mutex> lk(queue_mutex_);
-  idle_cv_.wait(lk, [this] { return (queue_.empty() && !busy_) || worker_error_; });
+  // (first the worker comes to rest -- also after a failure: the caller must never unwind, or touch the map, while the
+  // worker is still inside a later batch; the synchronous mode this mirrors cannot do that either -- then the parked error)
+  idle_cv_.wait(lk, [this] { return queue_.empty() && !busy_; });
   RethrowWorkerError();
 }
 
