@@ -205,6 +205,11 @@ SSX_API int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch);
 /* 1 .. 4 groups for the following solves; 0 = back to the default (per-kernel profiles want 1: one launch per kernel and
    LM slot, nothing else on the chip beside it) */
 SSX_API void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups);
+/* How the linearise / Schur kernels of the following solves cover a window: 1 = one PERSISTENT workgroup per group of ~7
+   chunks (256-edge pieces of the landmark-sorted edge list) that carries the partial reduced system across its chunks and
+   writes it once; 0 = one workgroup per chunk; -1 = automatic (persistent when the batch alone fills the chip twice over).
+   The results are the same bits either way (test_persistent_groups_equal_per_chunk): a throughput knob only. */
+SSX_API void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
 
 /* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */

@@ -187,6 +187,14 @@ class BaBatch:
             self.ctx.lib.ssx_ba_batch_set_groups.argtypes = [C.c_void_p, C.c_int32]
             self.ctx.lib.ssx_ba_batch_set_groups(self.handle, int(groups))
 
+    def set_persistent(self, mode):
+        """1: one persistent workgroup per group of ~7 chunks in the linearise / Schur kernels, 0: one per chunk, -1: the
+        library decides by batch size.  Same bits either way."""
+        if self.handle is not None:
+            self.ctx.lib.ssx_ba_batch_set_persistent.restype = None
+            self.ctx.lib.ssx_ba_batch_set_persistent.argtypes = [C.c_void_p, C.c_int32]
+            self.ctx.lib.ssx_ba_batch_set_persistent(self.handle, int(mode))
+
     def solve(self, want_edges=True, download=True):
         if self.handle is not None and not download:
             tot = C.c_int32(0)

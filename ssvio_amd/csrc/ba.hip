@@ -68,6 +68,8 @@ constexpr int CH_L = 128;          // max landmarks per chunk (per-landmark LDS 
 constexpr int PL = CH_L + 1;       // their padded pitch
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
+constexpr int GRP_CH = 7;          // chunks per group (a function of the WINDOW only, never of the batch: results must not depend on
+                                   // how many windows share a launch).  64 C3 windows x 12 groups = 768 workgroups = 3 per CU
 constexpr int BSEG_PARTS = 4;      // a block's pair list is cut into at most this many parts (k_schur's block phase) ...
 constexpr int BSEG_MIN = 8;        // ... of at least this many pairs
 constexpr int MAX_PAIRS = CH_E * (SSX_BA_SMALL_P + 1) / 2 + 8;       // leader pairs of one chunk (sum k(k+1)/2, k <= 16)
@@ -80,6 +82,10 @@ struct BaDev {
                             // Jacobians, the linearize hook); 0: small windows with analytic Jacobians RECOMPUTE it where needed --
                             // 150 flops per edge instead of one 144-byte write and two reads
   int lin_stride;           // doubles per chunk in lin_slab: nP*27 + 2 (small) or 2 (big)
+  int nGrp;                 // chunk GROUPS of the window: group g = chunks [g nCh / nGrp, (g + 1) nCh / nGrp), about GRP_CH each
+  int persist;              // 1: a workgroup of the linearise / Schur kernels owns a whole GROUP and emits ONE slab for it
+                            // (slab index = group); 0: one workgroup and one slab per chunk.  Same bits either way: the group's
+                            // sum is formed chunk by chunk in chunk order in both (in the kernel, or in the reduction)
   const int* pose_free;     // P: free index or -1
   const uint8_t* lm_fixed;  // nLm (compact landmarks = landmarks that have edges)
   const int* lm_id;         // nLm -> original landmark
@@ -220,6 +226,16 @@ constexpr size_t BA_LDS_BYTES = BA_OFF_PAB + ((2 * MAX_PAIRS + 63) & ~size_t(63)
 constexpr size_t LIN_LDS_BYTES = BA_LDS_BYTES;
 static_assert(2 * (SSX_BA_SMALL_P + 2) <= 64 && 3 * BA_LDS_BYTES <= 160 * 1024, "LDS budget");
 
+// threadIdx.x behind an opaque move: everything a phase derives from it (LDS row addresses, quarter pointers ...) is then
+// recomputed per chunk instead of being hoisted out of a persistent workgroup's chunk loop and kept in ~20 registers
+// for its whole life (the fused kernel sits on the 168-register line of three workgroups per CU)
+__device__ __forceinline__ int tid_opaque()
+{
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 // What a chunk's workgroup fetches before it looks at the LM state: nothing here depends on it, and the loads are in
 // flight while the state words arrive (the kernel is a chain of dependent global loads: window -> state -> chunk ->
 // edge records -> poses / points; every hop taken off the chain is ~1 us per workgroup).
@@ -230,7 +246,7 @@ struct ChunkLists {
 };
 __device__ __forceinline__ void chunk_lists_load(const BaDev& d, int c, char* smem, bool want_pairs, ChunkLists& cl)
 {
-  const int t = threadIdx.x;
+  const int t = tid_opaque();
   uint16_t* sPptr = reinterpret_cast<uint16_t*>(smem + BA_OFF_PPTR);
   uint16_t* sPab = reinterpret_cast<uint16_t*>(smem + BA_OFF_PAB);
   cl.cd = d.ch_desc[c];
@@ -284,19 +300,44 @@ __device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
   return acc;
 }
 
+// slab entries: the first chunk of a group stores its value, every later chunk ADDS to what is there with a
+// fire-and-forget global_atomic_add_f64 (no returned value: no registers held for the old entry, no round trip waited for).
+// The group's running sum lives in the slab itself -- 16 KB per workgroup that stay in the L2 until the kernel ends; no LDS
+// and no registers are spent on it.  An entry is touched by exactly ONE lane per chunk and the chunks of a workgroup are
+// separated by workgroup barriers, so the additions to an entry happen in chunk order: a sequential IEEE sum, the same
+// one the reductions form from per-chunk slabs (`first` is uniform over the workgroup).
+__device__ __forceinline__ void slab_put(double* p, double v, bool first)
+{
+  if (first) *p = v;
+  else (void)unsafeAtomicAdd(p, v);
+}
+__device__ __forceinline__ void group_range(const BaDev& d, int g, int& c0, int& c1)
+{
+  c0 = (int)((long long)g * d.nCh / d.nGrp);
+  c1 = (int)((long long)(g + 1) * d.nCh / d.nGrp);
+}
+// what a workgroup of the linearise / Schur kernels covers: chunks [c0, c1) and the slab it writes
+__device__ __forceinline__ void wg_range(const BaDev& d, int bx, int& c0, int& c1)
+{
+  if (d.persist) group_range(d, bx, c0, c1);
+  else { c0 = bx; c1 = bx + 1; }
+}
+__device__ __forceinline__ int wg_count(const BaDev& d) { return d.persist ? d.nGrp : d.nCh; }
+
 // Wout (18, nullable): this thread's edge block W = Ji^T w Jj stays in registers for the caller; lmout (9, nullable):
 // this thread's landmark sums (Hll 6 + bl 3).  cur must be >= 0 (the device-driven checks are the wrappers').
 // erw_out (nullable): the flag word of this thread's edge record, for the Schur phase of the fused kernel.
 template <int JAC>
 __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur, char* smem, const ChunkLists& cl, double* Wout, double* lmout,
-                                                 int* erw_out)
+                                                 int* erw_out, double* slab, const bool first)
 {
   double (*sL)[CH] = reinterpret_cast<double (*)[CH]>(smem);            // [9]: per-edge landmark contributions (6 Hll + 3 bl), edge order
   double* sV = reinterpret_cast<double*>(smem) + 9 * CH;                // [LIN_VA][PW]: per-edge pose-block terms, POSE-MAJOR order
   double* sRed = reinterpret_cast<double*>(smem);                       // 16 doubles over sL, which is dead by then
   const uint16_t* sPptr = reinterpret_cast<const uint16_t*>(smem + BA_OFF_PPTR);
 
-  const int c = bx, t = threadIdx.x;
+  const int t = tid_opaque();
+  (void)bx;
   const int4 cd = cl.cd;
   const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const double* pose = d.pose[cur];
@@ -388,12 +429,11 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
 
   // pose blocks: owned entries, each the sum of ITS pose's run of the pose-major term rows, in two rounds of 14 and 13
   // entries per pose (large windows build the pose blocks pose-major instead: k_pose_blocks)
-  double* slab = d.lin_slab + (size_t)c * d.lin_stride;
   if (small) {
     const int nP = d.nP;
     for (int i = t; i < nP * LIN_VA; i += CH) {
       const int p = i / LIN_VA, k = i - p * LIN_VA;
-      slab[p * 27 + k] = run_sum(sV + k * PW, sPptr[p], sPptr[p + 1]);
+      slab_put(slab + p * 27 + k, run_sum(sV + k * PW, sPptr[p], sPptr[p + 1]), first);
     }
     __syncthreads();
     if (t < ne) {
@@ -405,7 +445,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     __syncthreads();
     for (int i = t; i < nP * (27 - LIN_VA); i += CH) {
       const int p = i / (27 - LIN_VA), k = i - p * (27 - LIN_VA);
-      slab[p * 27 + LIN_VA + k] = run_sum(sV + k * PW, sPptr[p], sPptr[p + 1]);
+      slab_put(slab + p * 27 + LIN_VA + k, run_sum(sV + k * PW, sPptr[p], sPptr[p + 1]), first);
     }
   }
   PH(3);
@@ -414,8 +454,9 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
   block_sum3_max_256(chi, z0, z1, md, sRed);
   PH(4);
   if (t == 0) {
-    slab[d.lin_stride - 2] = chi;
-    slab[d.lin_stride - 1] = md;
+    slab_put(slab + d.lin_stride - 2, chi, first);
+    if (first) slab[d.lin_stride - 1] = md;
+    else (void)atomicMax(reinterpret_cast<unsigned long long*>(slab + d.lin_stride - 1), (unsigned long long)__double_as_longlong(md));   // md >= 0: the bit patterns order like the values
   }
 }
 
@@ -423,13 +464,23 @@ template <int JAC>
 __device__ __forceinline__ void k_linearize_entry(const BaDev& d, int bx, int cur)
 {
   extern __shared__ __attribute__((aligned(16))) char lin_smem[];
+  int c0, c1;
+  wg_range(d, bx, c0, c1);
   ChunkLists cl;
-  chunk_lists_load(d, bx, lin_smem, false, cl);
+  chunk_lists_load(d, c0, lin_smem, false, cl);
   if (cur < 0) {                                   // device-driven LM: skip when stopped or when the linearisation at the
     if (d.scal[SC_STOP] != 0.0 || d.scal[SC_NEEDLIN] == 0.0) return;   // kept state is still valid (rejected trial)
     cur = (int)d.scal[SC_CUR];
   }
-  k_linearize_body<JAC>(d, bx, cur, lin_smem, cl, nullptr, nullptr, nullptr);
+  double* slab = d.lin_slab + (size_t)bx * d.lin_stride;
+#pragma unroll 1
+  for (int c = c0; c < c1; ++c) {
+    if (c > c0) {
+      __syncthreads();                             // the previous chunk's lists and term rows are still being read
+      chunk_lists_load(d, c, lin_smem, false, cl);
+    }
+    k_linearize_body<JAC>(d, c, cur, lin_smem, cl, nullptr, nullptr, nullptr, slab, c == c0);
+  }
 }
 template <int JAC>
 __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur) { k_linearize_entry<JAC>(d, blockIdx.x, cur); }
@@ -438,35 +489,56 @@ template <int JAC>
 __global__ __launch_bounds__(CH) void k_linearize_b(const BaDev* __restrict__ dv, int cur)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
-  if ((int)blockIdx.x >= (d.nCh)) return;
+  if ((int)blockIdx.x >= wg_count(d)) return;
   k_linearize_entry<JAC>(d, blockIdx.x, cur);
 }
 
-// slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|: 16 chunk-lanes per entry, 16 entries per 256-thread
-// workgroup, combined by a fixed tree (deterministic for a given nCh); workgroup 0 also reduces chi2 / max-diagonal.
+// One entry of a window's slabs summed over the window, the part of lane group j (0 .. 3): the groups g = j, j + 4, ... in
+// that order, a group's value being the sum of its chunks in chunk order -- read from the group's slab (persistent
+// workgroups formed it exactly so) or formed here from the per-chunk slabs.  The caller adds the four parts in part order.
+__device__ __forceinline__ double slab_sum_part(const BaDev& d, const double* col, size_t stride, int j)
+{
+  double p = 0.0;
+  if (d.persist) {
+    int g = j;
+    for (; g + 28 < d.nGrp; g += 32) {
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = col[(size_t)(g + 4 * i) * stride];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p += v[i];
+    }
+    for (; g < d.nGrp; g += 4) p += col[(size_t)g * stride];
+  } else {
+    for (int g = j; g < d.nGrp; g += 4) {
+      int c0, c1;
+      group_range(d, g, c0, c1);
+      double v[GRP_CH + 1];                                     // a group holds GRP_CH chunks at most (nGrp = ceil(nCh / GRP_CH), even split)
+#pragma unroll
+      for (int i = 0; i <= GRP_CH; ++i) v[i] = (c0 + i < c1) ? col[(size_t)(c0 + i) * stride] : 0.0;
+      double a = v[0];
+#pragma unroll
+      for (int i = 1; i <= GRP_CH; ++i) a = (c0 + i < c1) ? a + v[i] : a;
+      p += a;
+    }
+  }
+  return p;
+}
+
+// slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|: 64 entries x 4 lane groups per 256-thread workgroup, combined in a
+// fixed order (deterministic, and the same bits whether the slabs are per chunk or per group); workgroup 0 also reduces
+// chi2 / max-diagonal.
 // (computeLambdaInit, optimization_algorithm_levenberg.cpp:152-166, wants the max over pose AND landmark
 // diagonals; with several ranks the pose diagonals need the all-reduced Hpp, see k_lambda_init.)
 __device__ __forceinline__ void k_reduce_lin_body(const BaDev& d, const int bx)
 {
-  // 64 entries x 4 groups of chunks per workgroup, as k_reduce_schur
   __shared__ double sAcc[CH];
   const int t = threadIdx.x;
   const int n = d.nP * 27;
   const int stride = n + 2;
   const int ent = bx * 64 + (t & 63), grp = t >> 6;
   double acc = 0.0;
-  if (ent < n) {
-    const double* col = d.lin_slab + ent;
-    int c = grp;
-    for (; c + 28 < d.nCh; c += 32) {
-      double v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = col[(size_t)(c + 4 * i) * stride];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc += v[i];
-    }
-    for (; c < d.nCh; c += 4) acc += col[(size_t)c * stride];
-  }
+  if (ent < n) acc = slab_sum_part(d, d.lin_slab + ent, stride, grp);
   sAcc[t] = acc;
   __syncthreads();
   if (ent < n && grp == 0) {
@@ -477,10 +549,23 @@ __device__ __forceinline__ void k_reduce_lin_body(const BaDev& d, const int bx)
   }
   if (bx != 0) return;
   __syncthreads();
+  // chi2: the groups' values (chunk order inside a group) over the threads, then the fixed tree of block_sum_256
   double chi = 0.0, md = 0.0;
-  for (int c = t; c < d.nCh; c += CH) {
-    chi += d.lin_slab[(size_t)c * stride + n];
-    md = fmax(md, d.lin_slab[(size_t)c * stride + n + 1]);
+  for (int g = t; g < d.nGrp; g += CH) {
+    if (d.persist) {
+      chi += d.lin_slab[(size_t)g * stride + n];
+      md = fmax(md, d.lin_slab[(size_t)g * stride + n + 1]);
+    } else {
+      int c0, c1;
+      group_range(d, g, c0, c1);
+      double a = d.lin_slab[(size_t)c0 * stride + n];
+      md = fmax(md, d.lin_slab[(size_t)c0 * stride + n + 1]);
+      for (int c = c0 + 1; c < c1; ++c) {
+        a += d.lin_slab[(size_t)c * stride + n];
+        md = fmax(md, d.lin_slab[(size_t)c * stride + n + 1]);
+      }
+      chi += a;
+    }
   }
   chi = block_sum_256(chi, sAcc);
   md = block_max_256(md, sAcc);
@@ -775,7 +860,7 @@ __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W
 // nullable): this thread's landmark sums (Hll 6 + bl 3).  The stop / state checks are the wrappers'.
 // erw_in (nullable): this thread's edge flag word from the linearisation phase (fused kernel).
 __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int cur, double lambda, char* smem, const ChunkLists& cl, const double* Win,
-                                             const double* lmin, const int* erw_in)
+                                             const double* lmin, const int* erw_in, double* slab, const bool first)
 {
   // With D = Hll + lambda I = L L^T (3x3 Cholesky) and Y_e = W_e L^-T, the Schur term of an edge pair is
   // W_a D^-1 W_b^T = Y_a Y_b^T and W D^-1 bl = Y (L^-1 bl): ONE 6x3 array per edge in LDS instead of W and W D^-1
@@ -789,7 +874,8 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   const uint16_t* sPptr = reinterpret_cast<const uint16_t*>(smem + BA_OFF_PPTR);   // [SSX_BA_SMALL_P + 2]   (chunk_lists_load)
   const uint16_t* sPab = reinterpret_cast<const uint16_t*>(smem + BA_OFF_PAB);     // [MAX_PAIRS] edge a | edge b << 8, grouped by block
 
-  const int c = bx, t = threadIdx.x;
+  const int t = tid_opaque();
+  (void)bx;
   const int4 cd = cl.cd;
   const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
   const int nP = d.nP;
@@ -880,7 +966,6 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   // (Tried and slower: reading only one 3x3 operand per lane and passing the other between the lanes of the quad
   // through DPP -- half the LDS traffic; an explicit software pipeline of index / operands / multiply.)
   PH(7);
-  double* slab = d.schur_slab + (size_t)c * (d.nBlk * 36 + nP * 6);
   const int nS = d.nBlk * 36;
   for (int base = 0; base < n_items; base += CH) {
     const int4 ir = item_rec;
@@ -927,7 +1012,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j] = acc[i][j];
+        for (int j = 0; j < 3; ++j) slab_put(slab + blk * 36 + (3 * qr + i) * 6 + 3 * qc + j, acc[i][j], first);
     }
   }
   PH(8);
@@ -950,7 +1035,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
       for (int s = sPptr[p] + part; s < sPptr[p + 1]; s += 4) acc += sY[a * PW + s];
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
-    if (on && part == 0) slab[nS + idx] = acc;
+    if (on && part == 0) slab_put(slab + nS + idx, acc, first);
   }
   PH(9);
 }
@@ -961,47 +1046,71 @@ extern "C" __attribute__((visibility("default"))) void ssx_debug_phase_clock(lon
 __device__ __forceinline__ void k_schur_entry(const BaDev& d, int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
   extern __shared__ __attribute__((aligned(16))) char schur_smem[];
+  int c0, c1;
+  wg_range(d, bx, c0, c1);
   ChunkLists cl;
-  chunk_lists_load(d, bx, schur_smem, true, cl);
+  chunk_lists_load(d, c0, schur_smem, true, cl);
   if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
   if (cur < 0) cur = (int)d.scal[SC_CUR];
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
-  k_schur_body(d, bx, cur, lambda, schur_smem, cl, nullptr, nullptr, nullptr);
+  double* slab = d.schur_slab + (size_t)bx * (d.nBlk * 36 + d.nP * 6);
+#pragma unroll 1
+  for (int c = c0; c < c1; ++c) {
+    if (c > c0) {
+      __syncthreads();
+      chunk_lists_load(d, c, schur_smem, true, cl);
+    }
+    k_schur_body(d, c, cur, lambda, schur_smem, cl, nullptr, nullptr, nullptr, slab, c == c0);
+  }
 }
 __global__ __launch_bounds__(CH) void k_schur(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_schur_entry(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
 __global__ __launch_bounds__(CH) void k_schur_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
-  if ((int)blockIdx.x >= (d.nCh)) return;
+  if ((int)blockIdx.x >= wg_count(d)) return;
   k_schur_entry(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
 }
 
 // k_lin_schur: one slot of the device-driven LM loop whose damping is already known (every slot but the first of an
 // optimize()): (re)linearise the chunk if the last trial was accepted, then eliminate its landmarks at the current
 // lambda -- ONE kernel, one pass over the chunk's edges: the edge blocks W and the landmark sums go from the
-// linearisation to the Schur phase in registers, the LDS is reused.
+// linearisation to the Schur phase in registers, the LDS is reused.  With d.persist the workgroup walks the chunks of
+// its GROUP one after the other and leaves one pair of slabs: 12 instead of 79 per C3 window (the slabs were 83 of the
+// 181 MB a 64-window launch moved, and what the reductions re-read).
 template <int JAC>
 __device__ __forceinline__ void k_lin_schur_entry(const BaDev& d, int bx)
 {
   extern __shared__ __attribute__((aligned(16))) char fused_smem[];
   const double stop = d.scal[SC_STOP], curd = d.scal[SC_CUR], lambda = d.scal[SC_LAMBDA], needlin = d.scal[SC_NEEDLIN];
+  int c0, c1;
+  wg_range(d, bx, c0, c1);
   ChunkLists cl;
-  chunk_lists_load(d, bx, fused_smem, true, cl);                   // issued beside the state words, not after them
+  chunk_lists_load(d, c0, fused_smem, true, cl);                   // issued beside the state words, not after them
   if (stop != 0.0) return;
   const int cur = (int)curd;
-  if (needlin != 0.0) {
-    double W[18], lm[9];
-    int erw = 0;
+  double* lslab = d.lin_slab + (size_t)bx * d.lin_stride;
+  double* sslab = d.schur_slab + (size_t)bx * (d.nBlk * 36 + d.nP * 6);
+#pragma unroll 1
+  for (int c = c0; c < c1; ++c) {
+    const bool first = c == c0;
+    if (!first) {
+      __syncthreads();                                             // the previous chunk's lists / Y rows are still being read
+      chunk_lists_load(d, c, fused_smem, true, cl);
+    }
+    if (needlin != 0.0) {
+      double W[18], lm[9];
+      int erw = 0;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) W[k] = 0.0;
+      for (int k = 0; k < 18; ++k) W[k] = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) lm[k] = 0.0;
-    k_linearize_body<JAC>(d, bx, cur, fused_smem, cl, W, lm, &erw);
-    __syncthreads();                                               // the linearisation's LDS is dead: the Schur phase takes it over
-    k_schur_body(d, bx, cur, lambda, fused_smem, cl, W, lm, &erw);
-  } else {
-    k_schur_body(d, bx, cur, lambda, fused_smem, cl, nullptr, nullptr, nullptr);
+      for (int k = 0; k < 9; ++k) lm[k] = 0.0;
+      k_linearize_body<JAC>(d, c, cur, fused_smem, cl, W, lm, &erw, lslab, first);
+      __syncthreads();                                             // the linearisation's LDS is dead: the Schur phase takes it over
+      k_schur_body(d, c, cur, lambda, fused_smem, cl, W, lm, &erw, sslab, first);
+    } else {
+      k_schur_body(d, c, cur, lambda, fused_smem, cl, nullptr, nullptr, nullptr, sslab, first);
+    }
   }
 }
 template <int JAC>
@@ -1010,17 +1119,14 @@ template <int JAC>
 __global__ __launch_bounds__(CH, 3) void k_lin_schur_b(const BaDev* __restrict__ dv)
 {
   const BaDev& d = dv[blockIdx.y];
-  if ((int)blockIdx.x >= (d.nCh)) return;
+  if ((int)blockIdx.x >= wg_count(d)) return;
   k_lin_schur_entry<JAC>(d, blockIdx.x);
 }
 
 // slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c).
-// 16 chunk-lanes per entry (16 entries per 256-thread workgroup), fixed tree: deterministic.
+// 64 entries x 4 lane groups per workgroup (slab_sum_part), the four parts added in part order: deterministic.
 __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx)
 {
-  // 64 entries x 4 groups of chunks per workgroup: a wave reads 64 CONSECUTIVE entries of one chunk's slab (512 bytes in one
-  // piece; the former 16 entries x 16 chunk lanes read 32-byte pieces of 16 different slabs), eight loads in flight, the
-  // four group sums added in group order
   __shared__ double sAcc[3][64];
   const int nS = d.nBlk * 36;
   const int stride = nS + d.nP * 6;
@@ -1028,18 +1134,7 @@ __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx
   const int t = threadIdx.x;
   const int ent = bx * 64 + (t & 63), grp = t >> 6;
   double acc = 0.0;
-  if (ent < stride) {
-    const double* col = d.schur_slab + ent;
-    int c = grp;
-    for (; c + 28 < d.nCh; c += 32) {
-      double v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = col[(size_t)(c + 4 * i) * stride];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc += v[i];
-    }
-    for (; c < d.nCh; c += 4) acc += col[(size_t)c * stride];
-  }
+  if (ent < stride) acc = slab_sum_part(d, d.schur_slab + ent, stride, grp);
   if (grp > 0) sAcc[grp - 1][t & 63] = acc;
   __syncthreads();
   if (grp != 0 || ent >= stride) return;
@@ -1237,6 +1332,13 @@ __global__ __launch_bounds__(64) void k_lm_begin_batch(const BaDev* __restrict__
   if (w >= n) return;
   const BaDev& d = dv[w];
   k_lm_begin_body(d, 0, ctrl[w], iters, ctrl[n + w], ctrl[2 * n + w]);
+}
+
+// batch_run switches all windows of a batch between one workgroup per chunk and one per group of chunks
+__global__ __launch_bounds__(CH) void k_set_persist_b(BaDev* dv, int n, int persist)
+{
+  const int w = blockIdx.x * CH + threadIdx.x;
+  if (w < n) dv[w].persist = dv[w].big ? 0 : persist;
 }
 
 // a resident batch is solved again: both state buffers of every window back to the uploaded state
@@ -1840,6 +1942,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
 
   d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
   d.big = big ? 1 : 0; d.lin_stride = lin_stride;
+  d.nGrp = (nCh > 0 && !big) ? (nCh + GRP_CH - 1) / GRP_CH : (big ? nCh : 0);   // (large windows: one chunk per group, never persistent)
+  d.persist = 0;                                 // batch_run switches it on for batches that fill the chip (see there)
   d.store_w = 1;                                 // the caller clears it for small windows with analytic Jacobians
   d.pose_free = (const int*)(at(o_pose_free));
   d.lm_fixed = (const uint8_t*)(at(o_lm_fixed));
@@ -2646,7 +2750,9 @@ struct ssx_ba_batch {
   std::vector<int> P, L, E;
   std::vector<size_t> out_off;
   size_t out_total = 0, a_out = 0, a_gather = 0, a_head = 0, in_total = 0, o_dv = 0, o_ctrl = 0, o_ooff = 0;
-  int max_ch = 1, max_rl = 1, max_rs = 1;
+  int max_ch = 1, max_rl = 1, max_rs = 1, max_grp = 1, total_ch = 0;
+  int persist = -1;                                  // ssx_ba_batch_set_persist: -1 auto, 0 / 1 forced
+  int persist_dev = 0;                               // what the device copies of the window descriptors currently say
   bool any_solve64 = false, any_solve80 = false, any_solve = false, with_err = false, fresh = false;
   int threads = 1;
   int groups = 0;                                    // ssx_ba_batch_set_groups; 0: batch_groups(n)
@@ -2734,6 +2840,8 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   for (int w = 0; w < n; ++w) {
     const BaDev& d = B->devs[w];
     B->max_ch = std::max(B->max_ch, d.nCh);
+    B->max_grp = std::max(B->max_grp, d.nGrp);
+    B->total_ch += d.nCh;
     B->max_rl = std::max(B->max_rl, (d.nP * 27 + 63) / 64);
     B->max_rs = std::max(B->max_rs, (d.nBlk * 36 + d.nP * 6 + 63) / 64);
     if (6 * d.nP <= NB) B->any_solve64 = true; else if (6 * d.nP <= 80) B->any_solve80 = true; else B->any_solve = true;
@@ -2777,6 +2885,15 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   double* d_out = reinterpret_cast<double*>(dev_base + B->a_out);
   double* d_gather = reinterpret_cast<double*>(dev_base + B->a_gather);
   hipStream_t s = ctx->stream;
+  // Persistent workgroups (one per GROUP of ~7 chunks, one slab each) when the batch alone fills the chip -- >= two rounds of
+  // 3 workgroups per CU at one workgroup per chunk; a smaller batch (and every single window) keeps one workgroup per chunk:
+  // more, shorter workgroups are what a latency-bound launch wants.  The results do not depend on the choice (bit for bit).
+  const int want_persist = B->persist >= 0 ? B->persist : (B->total_ch >= 2 * 3 * ctx->num_cus ? 1 : 0);
+  if (want_persist != B->persist_dev) {
+    hipLaunchKernelGGL(k_set_persist_b, dim3((n + CH - 1) / CH), dim3(CH), 0, s, const_cast<BaDev*>(dv), n, want_persist);
+    B->persist_dev = want_persist;
+  }
+  const int wg_x = want_persist ? B->max_grp : B->max_ch;             // workgroups per window of the linearise / Schur kernels
   if (!B->fresh) hipLaunchKernelGGL(k_reset_state_b, dim3(16, n), dim3(CH), 0, s, dv);
   B->fresh = false;
   // per-window host state of Backend::OptimizeActiveMap's outer loop (backend.cpp:175-203)
@@ -2820,17 +2937,17 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
           hipStream_t hs = g ? ctx->grp[g - 1] : s;
           const int w0 = (int)((long long)n * g / G), hn = (int)((long long)n * (g + 1) / G) - w0;
           const BaDev* hv = dv + w0;
-          const dim3 gCh(B->max_ch, hn), gRl(B->max_rl, hn), gRs(B->max_rs, hn), gOne(1, hn);
+          const dim3 gCh(B->max_ch, hn), gWg(wg_x, hn), gRl(B->max_rl, hn), gRs(B->max_rs, hn), gOne(1, hn);
           if (fused) {
-            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_NUMERIC_G2O>, gCh, dim3(CH), lds_fused, hs, hv));
-            else SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_ANALYTIC>, gCh, dim3(CH), lds_fused, hs, hv));
+            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_NUMERIC_G2O>, gWg, dim3(CH), lds_fused, hs, hv));
+            else SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_ANALYTIC>, gWg, dim3(CH), lds_fused, hs, hv));
           } else {
-            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_NUMERIC_G2O>, gCh, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
-            else SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_ANALYTIC>, gCh, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
+            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_NUMERIC_G2O>, gWg, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
+            else SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_ANALYTIC>, gWg, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
           }
           SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_b, gRl, dim3(CH), 0, hs, hv));
           if (first_slot) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init_b, gOne, dim3(64), 0, hs, hv, 1));
-          if (!fused) SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gCh, dim3(CH), lds_schur, hs, hv, -1, 0.0, 2));
+          if (!fused) SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gWg, dim3(CH), lds_schur, hs, hv, -1, 0.0, 2));
           SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, hs, hv));
           if (B->any_solve64) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve80) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
@@ -2994,6 +3111,8 @@ int32_t ssx_ba_batch_size(const ssx_ba_batch* batch) { return batch ? batch->n :
 int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch) { return !batch ? 0 : (batch->groups > 0 ? std::min(batch->groups, 4) : batch_groups(batch->n)); }
 
 void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups) { if (batch) batch->groups = groups > 0 ? groups : 0; }
+
+void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode) { if (batch) batch->persist = mode < 0 ? -1 : (mode ? 1 : 0); }
 
 void ssx_ba_batch_destroy(ssx_ba_batch* batch)
 {
