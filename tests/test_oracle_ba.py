@@ -16,7 +16,7 @@ import pytest
 from ssvio_amd import synth
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz"))
-BA_CASES = ["tiny", "mid", "C3", "gauge"]
+BA_CASES = ["tiny", "mid", "C3", "gauge", "win12", "win16"]
 
 
 def _problem(name):
