@@ -74,6 +74,33 @@ constexpr int BSEG_PARTS = 4;      // a block's pair list is cut into at most th
 constexpr int BSEG_MIN = 8;        // ... of at least this many pairs
 constexpr int MAX_PAIRS = CH_E * (SSX_BA_SMALL_P + 1) / 2 + 8;       // leader pairs of one chunk (sum k(k+1)/2, k <= 16)
 
+// A pointer into device GLOBAL memory as a struct member.  The batched kernels read their window descriptor through a
+// reference into a device array, so its pointer members are values LOADED from memory: the compiler cannot know their
+// address space and emitted flat_load / flat_store / flat_atomic for every access through them (133 + 53 + 24 in
+// k_lin_schur_b) -- and a FLAT access counts on lgkmcnt as well as vmcnt, so every `s_waitcnt lgkmcnt(0)` in front of an LDS
+// read also waited for the global loads / stores / atomics in flight.  On the device the member converts to a pointer INTO
+// address space 1, so indexing it is a global_* access; code that carries such a pointer around keeps the type (gdouble_p).
+template <class T>
+struct GPtr {
+  T* p;
+#if defined(__HIP_DEVICE_COMPILE__)
+  using G = __attribute__((address_space(1))) T*;          // device code sees a pointer into the GLOBAL address space
+#else
+  using G = T*;
+#endif
+  __host__ __device__ __forceinline__ GPtr& operator=(T* q) { p = q; return *this; }
+  __host__ __device__ __forceinline__ operator G() const { return (G)p; }
+  __host__ __device__ __forceinline__ G get() const { return (G)p; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+using gdouble_p = __attribute__((address_space(1))) double*;
+using gcdouble_p = __attribute__((address_space(1))) const double*;
+#else
+using gdouble_p = double*;
+using gcdouble_p = const double*;
+#endif
+
+
 struct BaDev {
   // problem (uploaded once per ssx_ba_solve)
   int P, L, E, nP, nLm, nCh, nBlk, world, rank;
@@ -86,56 +113,56 @@ struct BaDev {
   int persist;              // 1: a workgroup of the linearise / Schur kernels owns a whole GROUP and emits ONE slab for it
                             // (slab index = group); 0: one workgroup and one slab per chunk.  Same bits either way: the group's
                             // sum is formed chunk by chunk in chunk order in both (in the kernel, or in the reduction)
-  const int* pose_free;     // P: free index or -1
-  const uint8_t* lm_fixed;  // nLm (compact landmarks = landmarks that have edges)
-  const int* lm_id;         // nLm -> original landmark
-  const int* lm_ptr;        // nLm+1 -> first sorted edge
-  const int* ch_lm;         // nCh+1 -> first compact landmark
-  const int* e_pose;        // E (sorted)
-  const int* e_lmc;         // E compact landmark index
-  const uint8_t* e_cam;     // E
-  const uint8_t* e_dup;     // E: 1 = same (landmark,pose) as the previous sorted edge
-  const double* e_uv;       // [2][E]
-  const int8_t* blk_pa;     // nBlk upper blocks (pa<=pb) of the reduced system
-  const int8_t* blk_pb;
+  GPtr<const int> pose_free;     // P: free index or -1
+  GPtr<const uint8_t> lm_fixed;  // nLm (compact landmarks = landmarks that have edges)
+  GPtr<const int> lm_id;         // nLm -> original landmark
+  GPtr<const int> lm_ptr;        // nLm+1 -> first sorted edge
+  GPtr<const int> ch_lm;         // nCh+1 -> first compact landmark
+  GPtr<const int> e_pose;        // E (sorted)
+  GPtr<const int> e_lmc;         // E compact landmark index
+  GPtr<const uint8_t> e_cam;     // E
+  GPtr<const uint8_t> e_dup;     // E: 1 = same (landmark,pose) as the previous sorted edge
+  GPtr<const double> e_uv;       // [2][E]
+  GPtr<const int8_t> blk_pa;     // nBlk upper blocks (pa<=pb) of the reduced system
+  GPtr<const int8_t> blk_pb;
   // packed records: ONE 16-byte load per chunk / edge / landmark instead of a chain of dependent index loads
-  const int4* ch_desc;      // nCh: first sorted edge, #edges, first compact landmark, #landmarks
-  const int4* e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bit3 next edge is a dup, bit5 pose fixed, bits 8..15 chunk-local landmark, bits 16..23 position in the chunk's pose-major order (edges grouped by free pose, fixed-pose edges last)
-  const int4* l_rec;        // nLm: chunk-local first edge, #edges, landmark id (caller's), fixed
-  const uint16_t* pptr;     // nCh x (nP+1): segment of each pose inside the chunk's pose-major order
+  GPtr<const int4> ch_desc;      // nCh: first sorted edge, #edges, first compact landmark, #landmarks
+  GPtr<const int4> e_rec;        // E:   pose, free pose index (-1 fixed), landmark id (caller's), flags: bit0 cam, bit1 dup, bit2 landmark fixed, bit3 next edge is a dup, bit5 pose fixed, bits 8..15 chunk-local landmark, bits 16..23 position in the chunk's pose-major order (edges grouped by free pose, fixed-pose edges last)
+  GPtr<const int4> l_rec;        // nLm: chunk-local first edge, #edges, landmark id (caller's), fixed
+  GPtr<const uint16_t> pptr;     // nCh x (nP+1): segment of each pose inside the chunk's pose-major order
   // (the pair lists and the work items are built by the host marshalling OR, the default, by k_build_lists on the device:
   // the arrays are then scratch with a fixed capacity per chunk)
-  uint8_t* pair_a;          // nPairs: chunk-local leader edge a (pose pa)
-  uint8_t* pair_b;          // nPairs: chunk-local leader edge b (pose pb)
-  int* pair_ptr;            // nCh x (nBlk+1): absolute offsets into pair_a/pair_b
-  int4* bseg;               // work items of k_schur's block phase: (block or -1, first pair, end pair [chunk-relative], part | parts << 4)
-  int* bseg_ptr;            // nCh x 2: first item of the chunk in bseg, number of items
+  GPtr<uint8_t> pair_a;          // nPairs: chunk-local leader edge a (pose pa)
+  GPtr<uint8_t> pair_b;          // nPairs: chunk-local leader edge b (pose pb)
+  GPtr<int> pair_ptr;            // nCh x (nBlk+1): absolute offsets into pair_a/pair_b
+  GPtr<int4> bseg;               // work items of k_schur's block phase: (block or -1, first pair, end pair [chunk-relative], part | parts << 4)
+  GPtr<int> bseg_ptr;            // nCh x 2: first item of the chunk in bseg, number of items
   int bseg_cap;             // device-built lists: items reserved per chunk (pairs: MAX_PAIRS per chunk)
   Cam K;
   double ext[14];
   double huber_delta, chi2_th;
   // state
-  double* pose[2];          // [P*7]
-  double* point[2];         // [L*3]
-  const double* pose_init;  // batched windows: the uploaded state, kept pristine so that a resident batch can be solved again
-  const double* point_init;
+  GPtr<double> pose[2];          // [P*7]
+  GPtr<double> point[2];         // [L*3]
+  GPtr<const double> pose_init;  // batched windows: the uploaded state, kept pristine so that a resident batch can be solved again
+  GPtr<const double> point_init;
   // linearisation
-  double* W;                // [18][E]
-  double* err_lin;          // [2][E]
-  double* err_trial;        // [2][E]
-  double* Hll;              // [6][nLm]
-  double* bl;               // [3][nLm]
-  double* lin_slab;         // nCh x (nP*27 + 2)
-  double* Hpp;              // nP x 21   (this rank's part)
-  double* bp;               // nP x 6    (this rank's part)
-  double* iter_comm;        // [Hpp_g nP*21 | bp_g nP*6 | chi2 | maxdiag slots (world)]  all-reduced per iteration
-  double* schur_slab;       // nCh x (nBlk*36 + nP*6)
-  double* trial_comm;       // [S n*n | bs n]   all-reduced per trial (n = 6 nP), S without lambda
-  double* xp;               // n
-  double* trial_slab;       // nCh x 3
-  double* scal_comm;        // [tempChi, scale_l, nout]  all-reduced per trial
-  double* scal;             // SC_N scalars
-  double* lm_stat;          // device-driven LM: [3][SSX_BA_MAX_STATS] chi2 | lambda | trials per iteration
+  GPtr<double> W;                // [18][E]
+  GPtr<double> err_lin;          // [2][E]
+  GPtr<double> err_trial;        // [2][E]
+  GPtr<double> Hll;              // [6][nLm]
+  GPtr<double> bl;               // [3][nLm]
+  GPtr<double> lin_slab;         // nCh x (nP*27 + 2)
+  GPtr<double> Hpp;              // nP x 21   (this rank's part)
+  GPtr<double> bp;               // nP x 6    (this rank's part)
+  GPtr<double> iter_comm;        // [Hpp_g nP*21 | bp_g nP*6 | chi2 | maxdiag slots (world)]  all-reduced per iteration
+  GPtr<double> schur_slab;       // nCh x (nBlk*36 + nP*6)
+  GPtr<double> trial_comm;       // [S n*n | bs n]   all-reduced per trial (n = 6 nP), S without lambda
+  GPtr<double> xp;               // n
+  GPtr<double> trial_slab;       // nCh x 3
+  GPtr<double> scal_comm;        // [tempChi, scale_l, nout]  all-reduced per trial
+  GPtr<double> scal;             // SC_N scalars
+  GPtr<double> lm_stat;          // device-driven LM: [3][SSX_BA_MAX_STATS] chi2 | lambda | trials per iteration
 };
 
 // scal[] slots
