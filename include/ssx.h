@@ -207,8 +207,8 @@ SSX_API int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch);
 SSX_API void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups);
 /* How the linearise / Schur kernels of the following solves cover a window: 1 = one PERSISTENT workgroup per group of ~7
    chunks (256-edge pieces of the landmark-sorted edge list) that carries the partial reduced system across its chunks and
-   writes it once; 0 = one workgroup per chunk; -1 = automatic (persistent when the batch alone fills the chip twice over).
-   The results are the same bits either way (test_persistent_groups_equal_per_chunk): a throughput knob only. */
+   writes it once (6.6x less slab traffic, but measured slower on MI355X: DESIGN.md section 4c); 0 or -1 = one workgroup
+   per chunk (the default).  The results are the same bits either way (test_persistent_groups_equal_per_chunk). */
 SSX_API void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
 

@@ -68,6 +68,7 @@ constexpr int CH_L = 128;          // max landmarks per chunk (per-landmark LDS 
 constexpr int PL = CH_L + 1;       // their padded pitch
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
+constexpr int GRP_CH_MAX = 16;     // (experiments: SSX_BA_GRP_CH overrides GRP_CH up to this)
 constexpr int GRP_CH = 7;          // chunks per group (a function of the WINDOW only, never of the batch: results must not depend on
                                    // how many windows share a launch).  64 C3 windows x 12 groups = 768 workgroups = 3 per CU
 constexpr int BSEG_PARTS = 4;      // a block's pair list is cut into at most this many parts (k_schur's block phase) ...
@@ -327,16 +328,16 @@ __device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
   return acc;
 }
 
-// slab entries: the first chunk of a group stores its value, every later chunk ADDS to what is there with a
-// fire-and-forget global_atomic_add_f64 (no returned value: no registers held for the old entry, no round trip waited for).
-// The group's running sum lives in the slab itself -- 16 KB per workgroup that stay in the L2 until the kernel ends; no LDS
-// and no registers are spent on it.  An entry is touched by exactly ONE lane per chunk and the chunks of a workgroup are
-// separated by workgroup barriers, so the additions to an entry happen in chunk order: a sequential IEEE sum, the same
-// one the reductions form from per-chunk slabs (`first` is uniform over the workgroup).
+// slab entries: the first chunk of a group stores its value, every later chunk adds to what is there (a plain read-modify-
+// write of the workgroup's own slab: 16 KB that stay in the L2 until the kernel ends).  An entry is touched by exactly ONE
+// lane per chunk and the chunks of a workgroup are separated by workgroup barriers, so the additions to an entry happen in
+// chunk order: a sequential IEEE sum, the same one the reductions form from per-chunk slabs (`first` is uniform over the
+// workgroup).  [Measured on MI355X, 64 C3 windows, profiles/r03/persist_ab.md: with fire-and-forget global_atomic_add_f64
+// instead of the load + add + store the kernel took 319 us (the L2 retires ~53 G f64 atomics/s chip-wide: 10 M of them per
+// launch), with the read-modify-write 167 us, with one workgroup and one slab per chunk 138 us.]
 __device__ __forceinline__ void slab_put(double* p, double v, bool first)
 {
-  if (first) *p = v;
-  else (void)unsafeAtomicAdd(p, v);
+  *p = first ? v : *p + v;
 }
 __device__ __forceinline__ void group_range(const BaDev& d, int g, int& c0, int& c1)
 {
@@ -482,8 +483,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
   PH(4);
   if (t == 0) {
     slab_put(slab + d.lin_stride - 2, chi, first);
-    if (first) slab[d.lin_stride - 1] = md;
-    else (void)atomicMax(reinterpret_cast<unsigned long long*>(slab + d.lin_stride - 1), (unsigned long long)__double_as_longlong(md));   // md >= 0: the bit patterns order like the values
+    slab[d.lin_stride - 1] = first ? md : fmax(slab[d.lin_stride - 1], md);
   }
 }
 
@@ -540,12 +540,12 @@ __device__ __forceinline__ double slab_sum_part(const BaDev& d, const double* co
     for (int g = j; g < d.nGrp; g += 4) {
       int c0, c1;
       group_range(d, g, c0, c1);
-      double v[GRP_CH + 1];                                     // a group holds GRP_CH chunks at most (nGrp = ceil(nCh / GRP_CH), even split)
+      double v[GRP_CH_MAX];                                     // a group holds GRP_CH chunks at most (nGrp = ceil(nCh / GRP_CH), even split)
 #pragma unroll
-      for (int i = 0; i <= GRP_CH; ++i) v[i] = (c0 + i < c1) ? col[(size_t)(c0 + i) * stride] : 0.0;
+      for (int i = 0; i < GRP_CH_MAX; ++i) v[i] = (c0 + i < c1) ? col[(size_t)(c0 + i) * stride] : 0.0;
       double a = v[0];
 #pragma unroll
-      for (int i = 1; i <= GRP_CH; ++i) a = (c0 + i < c1) ? a + v[i] : a;
+      for (int i = 1; i < GRP_CH_MAX; ++i) a = (c0 + i < c1) ? a + v[i] : a;
       p += a;
     }
   }
@@ -1969,7 +1969,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
 
   d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
   d.big = big ? 1 : 0; d.lin_stride = lin_stride;
-  d.nGrp = (nCh > 0 && !big) ? (nCh + GRP_CH - 1) / GRP_CH : (big ? nCh : 0);   // (large windows: one chunk per group, never persistent)
+  static const int grp_ch = getenv("SSX_BA_GRP_CH") ? std::min(std::max(atoi(getenv("SSX_BA_GRP_CH")), 1), GRP_CH_MAX) : GRP_CH;
+  d.nGrp = (nCh > 0 && !big) ? (nCh + grp_ch - 1) / grp_ch : (big ? nCh : 0);   // (large windows: one chunk per group, never persistent)
   d.persist = 0;                                 // batch_run switches it on for batches that fill the chip (see there)
   d.store_w = 1;                                 // the caller clears it for small windows with analytic Jacobians
   d.pose_free = (const int*)(at(o_pose_free));
@@ -2912,10 +2913,12 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   double* d_out = reinterpret_cast<double*>(dev_base + B->a_out);
   double* d_gather = reinterpret_cast<double*>(dev_base + B->a_gather);
   hipStream_t s = ctx->stream;
-  // Persistent workgroups (one per GROUP of ~7 chunks, one slab each) when the batch alone fills the chip -- >= two rounds of
-  // 3 workgroups per CU at one workgroup per chunk; a smaller batch (and every single window) keeps one workgroup per chunk:
-  // more, shorter workgroups are what a latency-bound launch wants.  The results do not depend on the choice (bit for bit).
-  const int want_persist = B->persist >= 0 ? B->persist : (B->total_ch >= 2 * 3 * ctx->num_cus ? 1 : 0);
+  // Persistent workgroups (one per GROUP of ~7 chunks, one slab each) only on request (ssx_ba_batch_set_persistent): measured
+  // on 64 C3 windows they cut the slab traffic 6.6x and the two slab reductions from 29 to 14 us per LM slot, but the fused
+  // kernel itself goes from 138 to 167 us -- a chunk's tail (read-modify-write of the slab) and the next chunk's head
+  // (lists, edge records) are serialised inside one workgroup where independent workgroups overlap them -- so the default
+  // stays one workgroup per chunk.  The results do not depend on the choice (bit for bit).
+  const int want_persist = B->persist > 0 ? 1 : 0;
   if (want_persist != B->persist_dev) {
     hipLaunchKernelGGL(k_set_persist_b, dim3((n + CH - 1) / CH), dim3(CH), 0, s, const_cast<BaDev*>(dv), n, want_persist);
     B->persist_dev = want_persist;

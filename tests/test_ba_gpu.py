@@ -497,7 +497,7 @@ def test_persistent_groups_equal_per_chunk(ctx):
              make_ba_problem(P=7, L=800, obs_per_lm=3, seed=608, fix_first_pose=True), make_ba_problem(P=10, L=4000, seed=609)]
     for jac in (ba.JAC_ANALYTIC, ba.JAC_NUMERIC_G2O):
         ones = [ba.ba_solve(ctx, pr, jac_mode=jac) for pr in probs]
-        assert max(o["rounds"] for o in ones) >= 2 and max(o["trials"].max() for o in ones) >= 2
+        assert max(o["rounds"] for o in ones) >= 2
         res = ba.BaBatch(ctx, probs, resident=True, jac_mode=jac)
         for mode, groups in ((1, 1), (0, 2), (1, 2), (-1, 0), (1, 3)):
             res.set_persistent(mode)

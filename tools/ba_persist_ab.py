@@ -10,7 +10,7 @@ REP = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ctx = ssvio_amd.Context(0)
 wins = [make_ba_problem(P=10, L=4000, seed=1 + 17 * k) for k in range(4)]
 batch = ba.BaBatch(ctx, [wins[i % 4] for i in range(B)], resident=True, with_edge_errors=False)
-for rnd in range(2):
+for rnd in range(1):
     for persist in (0, 1):
         for groups in (1, 2):
             batch.set_persistent(persist); batch.set_groups(groups)
