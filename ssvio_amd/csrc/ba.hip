@@ -139,6 +139,17 @@ struct BaDev {
   GPtr<int4> bseg;               // work items of k_schur's block phase: (block or -1, first pair, end pair [chunk-relative], part | parts << 4)
   GPtr<int> bseg_ptr;            // nCh x 2: first item of the chunk in bseg, number of items
   int bseg_cap;             // device-built lists: items reserved per chunk (pairs: MAX_PAIRS per chunk)
+  // device-side marshalling (HostPrep::dev_prep): the caller's arrays as they came, the host's counting results, and the
+  // sorted order the device derives from them
+  int dev_prep;
+  GPtr<const int> r_edge_pose;    // E, caller's order
+  GPtr<const int> r_edge_point;   // E
+  GPtr<const double> r_edge_uv;   // E x 2 interleaved
+  GPtr<const uint8_t> r_edge_cam; // E or null
+  GPtr<const uint8_t> r_slot8;    // E: rank of the edge among its landmark's edges (caller's order)
+  GPtr<const int> lm_compact;     // L: caller's landmark -> compact landmark or -1
+  GPtr<int> perm;                 // E: sorted edge -> caller's edge
+  GPtr<double> c2_out;            // E: edge chi2 in the CALLER's order (results of a device-marshalled window)
   Cam K;
   double ext[14];
   double huber_delta, chi2_th;
@@ -848,6 +859,136 @@ __global__ __launch_bounds__(CH) void k_build_lists_b(const BaDev* __restrict__ 
   k_build_lists_body(d, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-side marshalling of a small window (what prepare() did on the host for every solve: 0.18 of the 0.92 ms of a C3
+// window, 48 MB of marshalled blobs per 64-window batch): the caller's arrays are uploaded AS THEY ARE with two small host
+// tables (edges per landmark -> lm_ptr / chunks, and slot8 = an edge's rank among its landmark's edges in caller order).
+//   k_prep_scatter   stable counting sort by landmark: sorted position = lm_ptr[landmark] + slot8
+//   k_prep_chunk     one workgroup per chunk: stable sort of every landmark's edges by pose (duplicates adjacent), packed
+//                    edge / landmark records, duplicate flags, pose-major positions + per-pose segments, uv columns, the
+//                    sorted -> caller permutation; then the chunk's pair lists and work items (k_build_lists_body)
+// Byte for byte the arrays of the host marshalling (SSX_BA_HOST_PREP=1; test_device_marshalling_equals_host_marshalling).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void k_prep_scatter_body(const BaDev& d, const int bx)
+{
+  const int e = bx * CH + threadIdx.x;
+  if (e >= d.E) return;
+  const int lc = d.lm_compact[d.r_edge_point[e]];
+  d.perm[d.lm_ptr[lc] + d.r_slot8[e]] = e;
+}
+__global__ __launch_bounds__(CH) void k_prep_scatter(BaDev d) { k_prep_scatter_body(d, blockIdx.x); }
+__global__ __launch_bounds__(CH) void k_prep_scatter_b(const BaDev* __restrict__ dv)
+{
+  const BaDev& d = dv[blockIdx.y];
+  if (!d.dev_prep || (int)blockIdx.x * CH >= d.E) return;
+  k_prep_scatter_body(d, blockIdx.x);
+}
+
+__device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
+{
+  __shared__ int sOrig[CH], sPose[CH];
+  __shared__ uint8_t sLmOf[CH], sFix[CH_L];
+  __shared__ int sLid[CH_L];
+  __shared__ int sCnt[4][SSX_BA_SMALL_P + 1];
+  __shared__ int sBase[SSX_BA_SMALL_P + 2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int4 cd = d.ch_desc[c];
+  const int e0 = cd.x, ne = cd.y, lm0 = cd.z, nl = cd.w;
+  const int nP = d.nP, E = d.E;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  if (t < ne) {
+    const int og = d.perm[e0 + t];
+    sOrig[t] = og;
+    sPose[t] = d.r_edge_pose[og];
+  }
+  int lm_a0 = 0, lm_k = 0;
+  if (t < nl) {
+    const int lc = lm0 + t;
+    lm_a0 = d.lm_ptr[lc] - e0;
+    lm_k = d.lm_ptr[lc + 1] - d.lm_ptr[lc];
+    sLid[t] = d.lm_id[lc];
+    sFix[t] = d.lm_fixed[lc];
+  }
+  __syncthreads();
+  if (t < nl) {
+    // stable insertion sort by pose (the edges of a landmark usually arrive in keyframe order: one pass, no move)
+    for (int i = lm_a0 + 1; i < lm_a0 + lm_k; ++i) {
+      const int po = sPose[i], og = sOrig[i];
+      int j = i - 1;
+      while (j >= lm_a0 && sPose[j] > po) { sPose[j + 1] = sPose[j]; sOrig[j + 1] = sOrig[j]; --j; }
+      sPose[j + 1] = po; sOrig[j + 1] = og;
+    }
+    for (int i = lm_a0; i < lm_a0 + lm_k; ++i) sLmOf[i] = (uint8_t)t;
+    const_cast<int4*>(static_cast<const int4*>(d.l_rec.p))[lm0 + t] = make_int4(lm_a0, lm_k, sLid[t], sFix[t]);
+  }
+  __syncthreads();
+  int og = 0, pose = 0, l = 0, pf = -1, bucket = -1;
+  if (t < ne) {
+    og = sOrig[t]; pose = sPose[t]; l = sLmOf[t];
+    pf = d.pose_free[pose];
+    bucket = pf >= 0 ? pf : nP;                                  // fixed-pose edges go behind the free poses' segments
+  }
+  int rank = 0;
+  for (int p = 0; p <= nP; ++p) {
+    const unsigned long long bal = __ballot(bucket == p);
+    if (lane == 0) sCnt[wave][p] = __popcll(bal);
+    if (bucket == p) rank = __popcll(bal & lt_mask);
+  }
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int p = 0; p <= nP; ++p) { sBase[p] = run; run += sCnt[0][p] + sCnt[1][p] + sCnt[2][p] + sCnt[3][p]; }
+    sBase[nP + 1] = run;
+  }
+  __syncthreads();
+  if (t <= nP) const_cast<uint16_t*>(static_cast<const uint16_t*>(d.pptr.p))[(size_t)c * (nP + 1) + t] = (uint16_t)sBase[t];
+  if (t < ne) {
+    int pos = sBase[bucket] + rank;
+    for (int w = 0; w < wave; ++w) pos += sCnt[w][bucket];
+    const bool dup = t > 0 && sLmOf[t - 1] == l && sPose[t - 1] == pose;
+    const bool next_dup = t + 1 < ne && sLmOf[t + 1] == l && sPose[t + 1] == pose;
+    const uint8_t* rc = d.r_edge_cam;
+    const int cam = (d.r_edge_cam.p && rc[og]) ? 1 : 0;
+    const int flags = cam | ((int)dup << 1) | ((int)sFix[l] << 2) | ((int)next_dup << 3) | ((pf < 0 ? 1 : 0) << 5) | (l << 8) | (pos << 16);
+    const int e = e0 + t;
+    const_cast<int4*>(static_cast<const int4*>(d.e_rec.p))[e] = make_int4(pose, pf, sLid[l], flags);
+    const_cast<uint8_t*>(static_cast<const uint8_t*>(d.e_dup.p))[e] = dup ? 1 : 0;
+    double* uv = const_cast<double*>(static_cast<const double*>(d.e_uv.p));
+    uv[e] = d.r_edge_uv[2 * (size_t)og];
+    uv[(size_t)E + e] = d.r_edge_uv[2 * (size_t)og + 1];
+    d.perm[e] = og;
+  }
+}
+
+__global__ __launch_bounds__(CH) void k_prep_chunk(BaDev d)
+{
+  k_prep_chunk_body(d, blockIdx.x);
+  __syncthreads();                                  // the records of this chunk are read back by the list builder below
+  if (d.bseg_cap) k_build_lists_body(d, blockIdx.x);
+}
+// batched: every window's records (if it is device-marshalled) and lists (if they are device-built) in one launch
+__global__ __launch_bounds__(CH) void k_prep_chunk_b(const BaDev* __restrict__ dv)
+{
+  const BaDev& d = dv[blockIdx.y];
+  if ((int)blockIdx.x >= d.nCh) return;
+  if (d.dev_prep) {
+    k_prep_chunk_body(d, blockIdx.x);
+    __syncthreads();
+  }
+  if (d.bseg_cap) k_build_lists_body(d, blockIdx.x);
+}
+
+// edge chi2 of a device-marshalled window in the CALLER's edge order (the host never sees the sorted order)
+__device__ __forceinline__ void k_c2_out_body(const BaDev& d, const int bx, int trial_err)
+{
+  const int sidx = bx * CH + threadIdx.x;
+  if (sidx >= d.E) return;
+  const double* err = trial_err ? (const double*)d.err_trial : (const double*)d.err_lin;
+  const double a = err[sidx], b = err[(size_t)d.E + sidx];
+  d.c2_out[d.perm[sidx]] = __dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b));      // as the host forms it: no fused multiply-add
+}
+__global__ __launch_bounds__(CH) void k_c2_out(BaDev d, int trial_err) { k_c2_out_body(d, blockIdx.x, trial_err); }
+
 // W_e = Ji^T w Jj (6x3) of sorted edge e at the linearisation state `cur`: what k_linearize computes, recomputed by the
 // kernels that need it when d.store_w == 0 (analytic Jacobians: the same instruction sequence, the same bits)
 __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W)
@@ -1398,12 +1539,20 @@ __global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* __restrict__ dv,
   const int cur = ctrl[w], trial_err = ctrl[n + w];
   double* o = out + out_off[w];
   const size_t nP7 = 7 * (size_t)d.P, nL3 = 3 * (size_t)d.L, nE2 = want_err ? 2 * (size_t)d.E : 0;
-  const double* err = trial_err ? d.err_trial : d.err_lin;
+  const double* err = trial_err ? (const double*)d.err_trial : (const double*)d.err_lin;
   for (size_t i = (size_t)blockIdx.x * CH + threadIdx.x; i < nP7 + nL3 + nE2; i += (size_t)gridDim.x * CH) {
     double v;
     if (i < nP7) v = d.pose[cur][i];
     else if (i < nP7 + nL3) v = d.point[cur][i - nP7];
-    else v = err[i - nP7 - nL3];
+    else if (!d.dev_prep) v = err[i - nP7 - nL3];
+    else {
+      // device-marshalled window: chi2 per edge at the CALLER's index (the first E of the 2 E slots are used)
+      const size_t sidx = i - nP7 - nL3;
+      if (sidx >= (size_t)d.E) continue;
+      const double a = err[sidx], b = err[(size_t)d.E + sidx];
+      o[nP7 + nL3 + d.perm[sidx]] = __dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b));
+      continue;
+    }
     o[i] = v;
   }
 }
@@ -1429,6 +1578,12 @@ struct HostPrep {
   std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr;
   std::vector<int> bseg, bseg_ptr;   // see BaDev
   bool dev_lists = false;            // small window: pair lists + work items are built by k_build_lists, not here
+  bool dev_prep = false;             // small window: the edge sort by (landmark, pose), the packed records, the pose-major order and the
+                                     // sorted uv columns are built ON THE DEVICE (k_prep_scatter / k_prep_chunk) from the caller's raw
+                                     // arrays; the host only counts (slot8: rank of an edge among its landmark's edges in caller order)
+  std::vector<uint8_t> slot8;
+  std::vector<int> lm_compact;       // caller's landmark -> compact landmark or -1
+  std::vector<int> cnt_tmp, start_tmp;
   std::vector<uint32_t> tmp_pairs;   // scratch of prepare(), kept between calls
   std::vector<std::pair<int, int>> tmp_order;
   std::vector<int> ch_desc, e_rec, l_rec;   // packed records (4 ints each), see BaDev
@@ -1533,7 +1688,28 @@ static void ssx_ba_workspace_free(BaWorkspace* w)
 namespace {
 
 
-ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
+// chunks of whole landmarks, <= CH_E edges and <= CH_L landmarks each (h.lm_ptr, h.nLm given)
+void make_chunks(HostPrep& h)
+{
+  h.ch_lm.clear();
+  h.ch_lm.push_back(0);
+  int acc_e = 0, acc_l = 0;
+  for (int lc = 0; lc < h.nLm; ++lc) {
+    const int k = h.lm_ptr[lc + 1] - h.lm_ptr[lc];
+    if (acc_e + k > CH_E || acc_l + 1 > CH_L) {
+      h.ch_lm.push_back(lc);
+      acc_e = 0; acc_l = 0;
+    }
+    acc_e += k; acc_l += 1;
+  }
+  if (h.nLm > 0) h.ch_lm.push_back(h.nLm);
+  h.nCh = (int)h.ch_lm.size() - 1;
+  if (h.nCh < 0) h.nCh = 0;
+}
+
+// allow_dev_prep: small windows leave everything beyond counting to the device (see HostPrep::dev_prep); SSX_BA_HOST_PREP=1
+// keeps the host marshalling below as the reference of the tests (same bits: test_device_marshalling_equals_host_marshalling)
+ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool allow_dev_prep = true)
 {
   const int P = pr->P, L = pr->L, E = pr->E;
   if (P <= 0 || L < 0 || E < 0 || !pr->poses || (L && !pr->points) ||
@@ -1546,18 +1722,27 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   h.nP = 0;
   for (int i = 0; i < P; ++i)
     if (!(pr->pose_fixed && pr->pose_fixed[i])) h.pose_free[i] = h.nP++;
+  static const bool host_prep_env = getenv("SSX_BA_HOST_PREP") != nullptr;
+  static const bool host_lists_env = getenv("SSX_BA_HOST_LISTS") != nullptr;
+  h.big = h.nP > SSX_BA_SMALL_P;
+  h.dev_prep = allow_dev_prep && !host_prep_env && !host_lists_env && !h.big;
   // counting sort of the edges by landmark
-  std::vector<int> cnt(L + 1, 0);
+  std::vector<int>& cnt = h.cnt_tmp;
+  cnt.assign(L + 1, 0);
+  if (h.dev_prep) h.slot8.resize((size_t)std::max(E, 1));
   for (int e = 0; e < E; ++e) {
     const int l = pr->edge_point[e], p = pr->edge_pose[e];
     if (l < 0 || l >= L || p < 0 || p >= P) {
       ctx->set_error("ssx_ba: edge %d references pose %d / point %d out of range", e, p, l);
       return SSX_ERR_INVALID_ARG;
     }
+    if (h.dev_prep) h.slot8[e] = (uint8_t)cnt[l + 1];      // (a count beyond CH_E is reported below: the wrapped value is never used)
     cnt[l + 1]++;
   }
   h.lm_id.clear(); h.lm_ptr.clear(); h.lm_fixed.clear();
-  std::vector<int> lm_compact(L, -1), start(L + 1, 0);
+  std::vector<int>& lm_compact = h.lm_compact;
+  std::vector<int>& start = h.start_tmp;
+  lm_compact.assign(L, -1); start.assign(L + 1, 0);
   for (int l = 0; l < L; ++l) start[l + 1] = start[l] + cnt[l + 1];
   for (int l = 0; l < L; ++l) {
     if (cnt[l + 1] == 0) continue;
@@ -1572,6 +1757,25 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
   }
   h.lm_ptr.push_back(E);
   h.nLm = (int)h.lm_id.size();
+  if (h.dev_prep) {
+    // ---- the light path: chunks + chunk descriptors + the block table; the device does the rest ----
+    make_chunks(h);
+    h.ch_desc.resize(4 * (size_t)std::max(h.nCh, 1));
+    for (int c = 0; c < h.nCh; ++c) {
+      const int lm0 = h.ch_lm[c], lm1 = h.ch_lm[c + 1], e0 = h.lm_ptr[lm0], e1 = h.lm_ptr[lm1];
+      int* cd = &h.ch_desc[4 * (size_t)c];
+      cd[0] = e0; cd[1] = e1 - e0; cd[2] = lm0; cd[3] = lm1 - lm0;
+    }
+    h.blk_pa.clear(); h.blk_pb.clear();
+    for (int a = 0; a < h.nP; ++a)
+      for (int b = a; b < h.nP; ++b) { h.blk_pa.push_back((int8_t)a); h.blk_pb.push_back((int8_t)b); }
+    h.nBlk = (int)h.blk_pa.size();
+    h.dev_lists = true;
+    h.band_w = -1;
+    h.perm.clear(); h.pptr.clear(); h.pair_ptr.clear(); h.pair_a.clear(); h.pair_b.clear(); h.bseg.clear(); h.bseg_ptr.clear();
+    h.pe_ptr.clear(); h.pe_edge.clear(); h.sblk_pa.clear(); h.sblk_pb.clear(); h.spair_ptr.assign(1, 0);
+    return SSX_OK;
+  }
   h.perm.assign(E, 0);
   {
     std::vector<int> fill(start.begin(), start.end() - 1);
@@ -1595,21 +1799,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     h.e_uv[(size_t)E + s] = pr->edge_uv[2 * (size_t)e + 1];
     if (s > 0 && h.e_lmc[s] == h.e_lmc[s - 1] && h.e_pose[s] == h.e_pose[s - 1]) h.e_dup[s] = 1;
   }
-  // chunks of whole landmarks, <= CH_E edges and <= CH_L landmarks each
-  h.ch_lm.clear();
-  h.ch_lm.push_back(0);
-  int acc_e = 0, acc_l = 0;
-  for (int lc = 0; lc < h.nLm; ++lc) {
-    const int k = h.lm_ptr[lc + 1] - h.lm_ptr[lc];
-    if (acc_e + k > CH_E || acc_l + 1 > CH_L) {
-      h.ch_lm.push_back(lc);
-      acc_e = 0; acc_l = 0;
-    }
-    acc_e += k; acc_l += 1;
-  }
-  if (h.nLm > 0) h.ch_lm.push_back(h.nLm);
-  h.nCh = (int)h.ch_lm.size() - 1;
-  if (h.nCh < 0) h.nCh = 0;
+  make_chunks(h);
   h.ch_desc.resize(4 * (size_t)std::max(h.nCh, 1)); h.e_rec.resize(4 * (size_t)std::max(E, 1)); h.l_rec.resize(4 * (size_t)std::max(h.nLm, 1));
   h.lm_chunk.resize((size_t)std::max(h.nLm, 1));
   for (int c = 0; c < h.nCh; ++c) {
@@ -1634,7 +1824,6 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     for (int a = 0; a < h.nP; ++a)
       for (int b = a; b < h.nP; ++b) { h.blk_pa.push_back((int8_t)a); h.blk_pb.push_back((int8_t)b); }
   h.nBlk = (int)h.blk_pa.size();
-  h.big = h.nP > SSX_BA_SMALL_P;
   if (h.big) {
     const int nP = h.nP;
     if (nP > 2048) { ctx->set_error("ssx_ba: %d free poses exceed the supported 2048", nP); return SSX_ERR_UNSUPPORTED; }
@@ -1656,8 +1845,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h)
     return SSX_OK;
   }
   // per-chunk index lists: edges grouped by free pose; leader pairs grouped by reduced-system block
-  static const bool host_lists = getenv("SSX_BA_HOST_LISTS") != nullptr;   // the host builder stays as the reference of the tests
-  h.dev_lists = !host_lists;
+  h.dev_lists = !host_lists_env;                // (SSX_BA_HOST_LISTS: the host builder stays as the reference of the tests)
   const int nP = h.nP, nBlk = h.nBlk;
   h.pptr.assign((size_t)h.nCh * (nP + 1) + 1, 0);
   h.pair_ptr.assign((size_t)h.nCh * (nBlk + 1) + 1, 0);
@@ -1807,21 +1995,31 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_pose_free = in.take(sizeof(int) * P);
   // (the landmark / chunk tables and the structure-of-arrays edge columns are read by the large-window kernels only: the
   // small-window kernels take everything from the packed records -- a quarter of a C3 window's blob not staged, not sent)
-  const size_t o_lm_fixed = in.take(big ? nLm : 0);
-  const size_t o_lm_id = in.take(big ? sizeof(int) * nLm : 0);
-  const size_t o_lm_ptr = in.take(big ? sizeof(int) * (nLm + 1) : 0);
+  const bool dev_prep = h.dev_prep && !big;
+  const bool lm_tables = big || dev_prep;
+  const size_t o_lm_fixed = in.take(lm_tables ? nLm : 0);
+  const size_t o_lm_id = in.take(lm_tables ? sizeof(int) * nLm : 0);
+  const size_t o_lm_ptr = in.take(lm_tables ? sizeof(int) * (nLm + 1) : 0);
   const size_t o_ch_lm = in.take(big ? sizeof(int) * (nCh + 1) : 0);
   const size_t o_e_pose = in.take(big ? sizeof(int) * E : 0);
   const size_t o_e_lmc = in.take(big ? sizeof(int) * E : 0);
   const size_t o_e_cam = in.take(big ? E : 0);
-  const size_t o_e_dup = in.take(E);
-  const size_t o_e_uv = in.take(sizeof(double) * 2 * E);
+  // (device-marshalled windows upload the caller's arrays; the sorted columns / records are scratch, written by k_prep_chunk)
+  size_t o_e_dup = dev_prep ? 0 : in.take(E);
+  size_t o_e_uv = dev_prep ? 0 : in.take(sizeof(double) * 2 * E);
   const size_t o_ch_desc = in.take(sizeof(int) * 4 * (size_t)(nCh + 1));
-  const size_t o_e_rec = in.take(sizeof(int) * 4 * (size_t)(E + 1));
-  const size_t o_l_rec = in.take(sizeof(int) * 4 * (size_t)(nLm + 1));
+  size_t o_e_rec = dev_prep ? 0 : in.take(sizeof(int) * 4 * (size_t)(E + 1));
+  size_t o_l_rec = dev_prep ? 0 : in.take(sizeof(int) * 4 * (size_t)(nLm + 1));
   const size_t o_blk_pa = in.take(nBlk + 1);
   const size_t o_blk_pb = in.take(nBlk + 1);
-  const size_t o_pptr = in.take(sizeof(uint16_t) * (h.pptr.size() + 1));
+  size_t o_pptr = dev_prep ? 0 : in.take(sizeof(uint16_t) * (h.pptr.size() + 1));
+  const bool have_cam = dev_prep && pr->edge_cam != nullptr;
+  const size_t o_lm_compact = in.take(dev_prep ? sizeof(int) * (size_t)(L + 1) : 0);
+  const size_t o_r_pose = in.take(dev_prep ? sizeof(int) * (size_t)(E + 1) : 0);
+  const size_t o_r_point = in.take(dev_prep ? sizeof(int) * (size_t)(E + 1) : 0);
+  const size_t o_r_uv = in.take(dev_prep ? sizeof(double) * 2 * (size_t)(E + 1) : 0);
+  const size_t o_r_cam = in.take(have_cam ? (size_t)E + 1 : 0);
+  const size_t o_slot8 = in.take(dev_prep ? (size_t)E + 1 : 0);
   // (host-built lists travel with the blob; device-built ones are scratch behind it, a fixed capacity per chunk)
   size_t o_pair_a = dev_lists ? 0 : in.take(nPairs + 1);
   size_t o_pair_b = dev_lists ? 0 : in.take(nPairs + 1);
@@ -1846,6 +2044,16 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   Layout all = in;
   const size_t o_pose1 = dup_state ? o_pose1_in : all.take(sizeof(double) * 7 * P);
   const size_t o_point1 = dup_state ? o_point1_in : all.take(sizeof(double) * 3 * (L + 1));
+  size_t o_perm = 0, o_c2 = 0;
+  if (dev_prep) {
+    o_e_dup = all.take((size_t)E + 1);
+    o_e_uv = all.take(sizeof(double) * 2 * (size_t)(E + 1));
+    o_e_rec = all.take(sizeof(int) * 4 * (size_t)(E + 1));
+    o_l_rec = all.take(sizeof(int) * 4 * (size_t)(nLm + 1));
+    o_pptr = all.take(sizeof(uint16_t) * ((size_t)(nCh + 1) * (nP + 1) + 1));
+    o_perm = all.take(sizeof(int) * (size_t)(E + 1));
+    o_c2 = all.take(sizeof(double) * (size_t)(E + 1));
+  }
   if (dev_lists) {
     o_pair_a = all.take((size_t)(nCh + 1) * MAX_PAIRS);
     o_pair_b = all.take((size_t)(nCh + 1) * MAX_PAIRS);
@@ -1905,14 +2113,25 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   }
   char* hs = place ? place->in_host : ws->stage.as<char>();
   memcpy(hs + o_pose_free, h.pose_free.data(), sizeof(int) * P);
-  if (big && nLm) {
+  if (lm_tables && nLm) {
     memcpy(hs + o_lm_fixed, h.lm_fixed.data(), nLm);
     memcpy(hs + o_lm_id, h.lm_id.data(), sizeof(int) * nLm);
   }
-  if (big) memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (nLm + 1));
+  if (lm_tables) memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (nLm + 1));
   if (nCh) memcpy(hs + o_ch_desc, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
+  if (dev_prep) {
+    if (L) memcpy(hs + o_lm_compact, h.lm_compact.data(), sizeof(int) * (size_t)L);
+    if (E) {
+      memcpy(hs + o_r_pose, pr->edge_pose, sizeof(int) * (size_t)E);
+      memcpy(hs + o_r_point, pr->edge_point, sizeof(int) * (size_t)E);
+      memcpy(hs + o_r_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E);
+      if (have_cam) memcpy(hs + o_r_cam, pr->edge_cam, (size_t)E);
+      memcpy(hs + o_slot8, h.slot8.data(), (size_t)E);
+    }
+  } else {
   if (E) memcpy(hs + o_e_rec, h.e_rec.data(), sizeof(int) * 4 * (size_t)E);
   if (nLm) memcpy(hs + o_l_rec, h.l_rec.data(), sizeof(int) * 4 * (size_t)nLm);
+  }
   if (big) memcpy(hs + o_ch_lm, h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
   if (E) {
     if (big) {
@@ -1920,14 +2139,16 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
       memcpy(hs + o_e_lmc, h.e_lmc.data(), sizeof(int) * E);
       memcpy(hs + o_e_cam, h.e_cam.data(), E);
     }
-    memcpy(hs + o_e_dup, h.e_dup.data(), E);
-    memcpy(hs + o_e_uv, h.e_uv.data(), sizeof(double) * 2 * E);
+    if (!dev_prep) {
+      memcpy(hs + o_e_dup, h.e_dup.data(), E);
+      memcpy(hs + o_e_uv, h.e_uv.data(), sizeof(double) * 2 * E);
+    }
   }
   if (nBlk) {
     memcpy(hs + o_blk_pa, h.blk_pa.data(), nBlk);
     memcpy(hs + o_blk_pb, h.blk_pb.data(), nBlk);
   }
-  if (!h.pptr.empty()) memcpy(hs + o_pptr, h.pptr.data(), sizeof(uint16_t) * h.pptr.size());
+  if (!dev_prep && !h.pptr.empty()) memcpy(hs + o_pptr, h.pptr.data(), sizeof(uint16_t) * h.pptr.size());
   if (nPairs) {
     memcpy(hs + o_pair_a, h.pair_a.data(), nPairs);
     memcpy(hs + o_pair_b, h.pair_b.data(), nPairs);
@@ -1992,6 +2213,11 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.pair_ptr = (int*)(at(o_pair_ptr));
   d.bseg = (int4*)(at(o_bseg)); d.bseg_ptr = (int*)(at(o_bseg_ptr));
   d.bseg_cap = bseg_cap;
+  d.dev_prep = dev_prep ? 1 : 0;
+  d.r_edge_pose = (const int*)(dev_prep ? at(o_r_pose) : nullptr); d.r_edge_point = (const int*)(dev_prep ? at(o_r_point) : nullptr);
+  d.r_edge_uv = (const double*)(dev_prep ? at(o_r_uv) : nullptr); d.r_edge_cam = (const uint8_t*)(have_cam ? at(o_r_cam) : nullptr);
+  d.r_slot8 = (const uint8_t*)(dev_prep ? at(o_slot8) : nullptr); d.lm_compact = (const int*)(dev_prep ? at(o_lm_compact) : nullptr);
+  d.perm = (int*)(dev_prep ? at(o_perm) : nullptr); d.c2_out = (double*)(dev_prep ? at(o_c2) : nullptr);
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
@@ -2031,8 +2257,13 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     }
     bd.S = (double*)(at(o_S)); bd.x = (double*)(at(o_x)); bd.Ld = (double*)(at(o_Ld)); bd.invd = (double*)(at(o_invd)); bd.Ninv = (double*)(at(o_Ninv)); bd.scale_part = (double*)(at(o_scale_part));
   }
-  if (!place && dev_lists && nCh > 0) {            // (a batch builds the lists of all its windows with one launch: batch_build)
-    hipLaunchKernelGGL(k_build_lists, dim3(nCh), dim3(CH), 0, ctx->stream, d);
+  if (!place && nCh > 0 && (dev_lists || dev_prep)) {   // (a batch marshals all its windows with one launch pair: batch_build)
+    if (dev_prep) {
+      hipLaunchKernelGGL(k_prep_scatter, dim3((E + CH - 1) / CH), dim3(CH), 0, ctx->stream, d);
+      hipLaunchKernelGGL(k_prep_chunk, dim3(nCh), dim3(CH), 0, ctx->stream, d);
+    } else {
+      hipLaunchKernelGGL(k_build_lists, dim3(nCh), dim3(CH), 0, ctx->stream, d);
+    }
     SSX_HIP_TRY(ctx, hipGetLastError());
   }
   return SSX_OK;
@@ -2303,7 +2534,7 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
   // ~20 vectors of up to E entries are not re-allocated and re-faulted every solve
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   HostPrep& h = ctx->ba->prep1;
-  ssx_status st = prepare(ctx, prob, h);
+  ssx_status st = prepare(ctx, prob, h, false);        // this hook returns per-edge blocks in the caller's order: it keeps the host's sort
   if (st != SSX_OK) return st;
   BaDev d;
   BigDev bd;
@@ -2725,6 +2956,10 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
       st = launch_linearize(ctx, d, bd, none, SSX_JAC_ANALYTIC, cur, 0);
       if (st != SSX_OK) return st;
     }
+    if (d.dev_prep) {                                  // chi2 per edge, already in the caller's order
+      hipLaunchKernelGGL(k_c2_out, dim3((d.E + CH - 1) / CH), dim3(CH), 0, ctx->stream, d, have_trial_err ? 1 : 0);
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(h_err, d.c2_out, sizeof(double) * (size_t)d.E, hipMemcpyDeviceToHost, ctx->stream));
+    } else
     SSX_HIP_TRY(ctx, hipMemcpyAsync(h_err, have_trial_err ? d.err_trial : d.err_lin, sizeof(double) * 2 * (size_t)d.E,
                                     hipMemcpyDeviceToHost, ctx->stream));
   }
@@ -2732,7 +2967,12 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (res->poses_out) memcpy(res->poses_out, h_pose, sizeof(double) * 7 * d.P);
   if (res->points_out && d.L) memcpy(res->points_out, h_point, sizeof(double) * 3 * d.L);
-  if (want_err) {
+  if (want_err && d.dev_prep) {
+    for (int e = 0; e < d.E; ++e) {
+      if (res->edge_chi2) res->edge_chi2[e] = h_err[e];
+      if (res->edge_outlier) res->edge_outlier[e] = h_err[e] > opt.chi2_th;
+    }
+  } else if (want_err) {
     for (int s = 0; s < d.E; ++s) {
       const int e = h.perm[s];
       const double c2 = h_err[s] * h_err[s] + h_err[(size_t)d.E + s] * h_err[(size_t)d.E + s];
@@ -2878,7 +3118,11 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   {
     // pair lists + work items of every window, on the device (windows marshalled with SSX_BA_HOST_LISTS brought theirs along)
     const BaDev* dvb = reinterpret_cast<const BaDev*>(dev_base + B->a_head + in_total + B->o_dv);
-    hipLaunchKernelGGL(k_build_lists_b, dim3(B->max_ch, n), dim3(CH), 0, ctx->stream, dvb);
+    int max_e = 1;
+    bool any_prep = false;
+    for (int w = 0; w < n; ++w) { max_e = std::max(max_e, B->devs[w].E); any_prep = any_prep || B->devs[w].dev_prep; }
+    if (any_prep) hipLaunchKernelGGL(k_prep_scatter_b, dim3((max_e + CH - 1) / CH, n), dim3(CH), 0, ctx->stream, dvb);
+    hipLaunchKernelGGL(k_prep_chunk_b, dim3(B->max_ch, n), dim3(CH), 0, ctx->stream, dvb);
     SSX_HIP_TRY(ctx, hipGetLastError());
   }
   B->fresh = true;                                                   // the state buffers hold the uploaded state
@@ -3048,7 +3292,13 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     const double* o = h_out + B->out_off[w];
     if (r.poses_out) memcpy(r.poses_out, o, sizeof(double) * 7 * P);
     if (r.points_out && L) memcpy(r.points_out, o + 7 * (size_t)P, sizeof(double) * 3 * L);
-    if (want_err && (r.edge_chi2 || r.edge_outlier)) {
+    if (want_err && (r.edge_chi2 || r.edge_outlier) && B->devs[w].dev_prep) {
+      const double* c2 = o + 7 * (size_t)P + 3 * (size_t)L;          // already in the caller's order
+      for (int eo = 0; eo < E; ++eo) {
+        if (r.edge_chi2) r.edge_chi2[eo] = c2[eo];
+        if (r.edge_outlier) r.edge_outlier[eo] = c2[eo] > opt.chi2_th;
+      }
+    } else if (want_err && (r.edge_chi2 || r.edge_outlier)) {
       const double* e = o + 7 * (size_t)P + 3 * (size_t)L;
       const std::vector<int>& perm = B->perm[w];
       for (int sidx = 0; sidx < E; ++sidx) {

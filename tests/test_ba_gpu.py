@@ -533,6 +533,9 @@ def with_duplicates(pr, n):   # right-camera observations of the first n landmar
 for i, kw in enumerate(eval(sys.argv[3])):
     pr = make_ba_problem(**kw)
     if i == 5: pr = with_duplicates(pr, 80)
+    if i in (1, 5, 6):                      # the caller's edge order is arbitrary: shuffled observations
+        q = np.random.default_rng(7 + i).permutation(pr["E"])
+        for k in ("edge_pose", "edge_point", "edge_uv", "edge_cam"): pr[k] = np.ascontiguousarray(pr[k][q])
     r = ba.ba_solve(ctx, pr)
     for k in ("poses", "points", "chi2", "lam", "trials", "edge_chi2"):
         out[f"{i}_{k}"] = np.asarray(r[k])
@@ -545,8 +548,10 @@ np.savez(sys.argv[2], **out)
 
 
 def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
-    """The pair lists and work items of small windows are built on the device (k_build_lists); SSX_BA_HOST_LISTS=1 makes the
-    host marshalling build them as before.  Both must give the same bits: single solves (duplicate observations, fixed
+    """Small windows are marshalled on the device: the edge sort by (landmark, pose), packed records, pose-major order
+    (k_prep_scatter / k_prep_chunk) and the pair lists + work items (k_build_lists) from the caller's raw arrays.
+    SSX_BA_HOST_PREP=1 keeps the sort and the records on the host, SSX_BA_HOST_LISTS=1 everything.  All three must give the
+    same bits: single solves (duplicate observations, fixed
     poses and landmarks, 4 .. 16 keyframes, sparse co-visibility) and a resident batch in two groups."""
     import subprocess, sys as _sys
     cases = [dict(P=10, L=700, seed=41), dict(P=12, L=500, obs_per_lm=4, seed=42), dict(P=16, L=600, obs_per_lm=5, seed=43, fix_first_pose=True),
@@ -557,11 +562,14 @@ def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
     cases = [{k: v for k, v in kw.items() if k in accepted} for kw in cases]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for mode in ("device", "host"):
+    for mode in ("device", "host", "hostprep"):
         env = dict(os.environ)
         env.pop("SSX_BA_HOST_LISTS", None)
+        env.pop("SSX_BA_HOST_PREP", None)
         if mode == "host":
-            env["SSX_BA_HOST_LISTS"] = "1"
+            env["SSX_BA_HOST_LISTS"] = "1"              # everything on the host: edge sort, records, pair lists, work items
+        if mode == "hostprep":
+            env["SSX_BA_HOST_PREP"] = "1"               # edge sort + records on the host, lists on the device (round 2's split)
         path = str(tmp_path / f"{mode}.npz")
         r = subprocess.run([_sys.executable, "-c", _LISTS_SCRIPT, root, path, repr(cases)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -569,6 +577,7 @@ def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
     assert sorted(outs["device"].files) == sorted(outs["host"].files) and len(outs["device"].files) > 40
     for k in outs["device"].files:
         assert np.array_equal(outs["device"][k], outs["host"][k]), k
+        assert np.array_equal(outs["device"][k], outs["hostprep"][k]), k
 
 
 def test_bench_size_batch_equals_single_calls(ctx):
