@@ -978,6 +978,15 @@ __global__ __launch_bounds__(CH) void k_prep_chunk_b(const BaDev* __restrict__ d
   if (d.bseg_cap) k_build_lists_body(d, blockIdx.x);
 }
 
+// e0^2 + e1^2 exactly as the host forms it from the two downloaded components: two products, one sum, no contraction into a
+// fused multiply-add (the results of a device-marshalled window must be the bits of a host-marshalled one)
+__device__ __forceinline__ double chi2_of(double a, double b)
+{
+#pragma clang fp contract(off)
+  const double aa = a * a, bb = b * b;
+  return aa + bb;
+}
+
 // edge chi2 of a device-marshalled window in the CALLER's edge order (the host never sees the sorted order)
 __device__ __forceinline__ void k_c2_out_body(const BaDev& d, const int bx, int trial_err)
 {
@@ -985,7 +994,7 @@ __device__ __forceinline__ void k_c2_out_body(const BaDev& d, const int bx, int 
   if (sidx >= d.E) return;
   const double* err = trial_err ? (const double*)d.err_trial : (const double*)d.err_lin;
   const double a = err[sidx], b = err[(size_t)d.E + sidx];
-  d.c2_out[d.perm[sidx]] = __dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b));      // as the host forms it: no fused multiply-add
+  d.c2_out[d.perm[sidx]] = chi2_of(a, b);
 }
 __global__ __launch_bounds__(CH) void k_c2_out(BaDev d, int trial_err) { k_c2_out_body(d, blockIdx.x, trial_err); }
 
@@ -1550,7 +1559,7 @@ __global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* __restrict__ dv,
       const size_t sidx = i - nP7 - nL3;
       if (sidx >= (size_t)d.E) continue;
       const double a = err[sidx], b = err[(size_t)d.E + sidx];
-      o[nP7 + nL3 + d.perm[sidx]] = __dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b));
+      o[nP7 + nL3 + d.perm[sidx]] = chi2_of(a, b);
       continue;
     }
     o[i] = v;
