@@ -212,6 +212,47 @@ SSX_API void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups);
 SSX_API void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
 
+/* ------------------------------------------------------------------------------------------------
+ * A sliding local-BA window that STAYS in HBM.  Backend::OptimizeActiveMap (src/ssvio/backend.cpp:88-169) rebuilds its
+ * graph from the active map at every keyframe, and that map changes by ONE keyframe between two optimisations
+ * (Map::InsertKeyFrame, RemoveOldActiveKeyframe, RemoveOldActiveMapPoints: src/ssvio/map.cpp:27-56, 89-160).  The window
+ * mirrors that: push a keyframe (its pose, the landmarks it introduces, its observations: the only data that crosses PCIe),
+ * pop a keyframe (its observations go, and every landmark nobody observes any more), solve what is resident.  The device
+ * sorts the observations by landmark itself; per solve the host counts observations per landmark (one pass over the
+ * window) and uploads ~3.6 bytes per observation + 13 per landmark of tables.  Keyframes and landmarks are named by the
+ * caller's 64-bit ids (KeyFrame::key_frame_id_, MapPoint::id_).  <= 16 free keyframes (the reference keeps 12:
+ * config/kitti_00.yaml:30).  A window belongs to its ctx and must be destroyed before it.
+ * The result of ssx_ba_window_solve is, bit for bit, that of ssx_ba_solve on the problem ssx_ba_window_export lists.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ssx_ba_window ssx_ba_window;
+SSX_API ssx_status ssx_ba_window_create(ssx_ctx* ctx, const ssx_ba_options* opt, const double* K4, const double* cam_ext14,
+                                        ssx_ba_window** out);
+SSX_API void ssx_ba_window_destroy(ssx_ba_window* win);
+/* new_ids / new_xyz / new_fixed: the n_new landmarks this keyframe brings into the window (ids not yet in it);
+ * obs_lm / obs_uv (n_obs x 2) / obs_cam (nullable = all left): its observations, of those or of landmarks already in
+ * the window (backend.cpp:135-168).  Nothing is changed when the call fails. */
+SSX_API ssx_status ssx_ba_window_push_keyframe(ssx_ba_window* win, int64_t kf_id, const double* pose7, int32_t pose_fixed,
+                                               int32_t n_new, const int64_t* new_ids, const double* new_xyz,
+                                               const uint8_t* new_fixed, int32_t n_obs, const int64_t* obs_lm,
+                                               const double* obs_uv, const uint8_t* obs_cam);
+SSX_API ssx_status ssx_ba_window_pop_keyframe(ssx_ba_window* win, int64_t kf_id);
+/* overwrite the estimate / the fixed flag of a keyframe or landmark of the window (fixed < 0: unchanged; xyz NULL: unchanged) */
+SSX_API ssx_status ssx_ba_window_set_pose(ssx_ba_window* win, int64_t kf_id, const double* pose7, int32_t fixed);
+SSX_API ssx_status ssx_ba_window_set_landmark(ssx_ba_window* win, int64_t lm_id, const double* xyz, int32_t fixed);
+SSX_API ssx_status ssx_ba_window_size(const ssx_ba_window* win, int32_t* n_keyframes, int32_t* n_landmarks,
+                                      int32_t* n_observations);
+/* the window as an ordinary ssx_ba_problem (current estimate): arrays of ssx_ba_window_size() entries, any may be NULL */
+SSX_API ssx_status ssx_ba_window_export(const ssx_ba_window* win, int64_t* kf_ids, double* poses, uint8_t* pose_fixed,
+                                        int64_t* lm_ids, double* points, uint8_t* point_fixed, int32_t* edge_pose,
+                                        int32_t* edge_point, double* edge_uv, uint8_t* edge_cam);
+/* res->poses_out / points_out / edge_chi2 / edge_outlier (nullable) in the order of ssx_ba_window_export; the window's
+ * state becomes the result (the next solve starts from it) */
+SSX_API ssx_status ssx_ba_window_solve(ssx_ba_window* win, ssx_ba_result* res);
+/* n windows of ONE ctx in one call (one launch sequence for all of them, like ssx_ba_solve_batch): the windows of the
+ * concurrent streams of BASELINE configs[4], or of a batch of stereo pairs.  Per window the bits of ssx_ba_window_solve.
+ * The options of the first window apply. */
+SSX_API ssx_status ssx_ba_window_solve_batch(int32_t n, ssx_ba_window* const* wins, ssx_ba_result* results);
+
 /* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */
 SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps);
 

@@ -240,3 +240,131 @@ class BaBatch:
             self.close()
         except Exception:                                   # noqa: BLE001 -- interpreter shutdown: the library may be gone
             pass
+
+
+i64_p = C.POINTER(C.c_int64)
+
+
+class BaWindow:
+    """A sliding local-BA window resident in HBM -- ssx_ba_window (include/ssx.h): push / pop keyframes, solve in place.
+    What Backend::OptimizeActiveMap sees at consecutive keyframes (backend.cpp:88-169, map.cpp:27-56, 89-160)."""
+
+    def __init__(self, ctx: Context, K, cam_ext, outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891, inlier_ratio=0.7,
+                 jac_mode=JAC_ANALYTIC):
+        self.ctx = ctx
+        self.handle = None
+        self.opt = BaOptions()
+        ctx.lib.ssx_ba_default_options(C.byref(self.opt))
+        self.opt.outer_rounds = outer_rounds; self.opt.iters = iters; self.opt.chi2_th = chi2_th
+        self.opt.huber_delta = huber_delta; self.opt.inlier_ratio = inlier_ratio; self.opt.jac_mode = jac_mode
+        self.K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).ravel()[:4])
+        self.cam_ext = np.ascontiguousarray(np.asarray(cam_ext, dtype=np.float64).ravel()[:14])
+        lib = ctx.lib
+        lib.ssx_ba_window_create.argtypes = [C.c_void_p, C.POINTER(BaOptions), dbl_p, dbl_p, C.POINTER(C.c_void_p)]
+        lib.ssx_ba_window_destroy.argtypes = [C.c_void_p]; lib.ssx_ba_window_destroy.restype = None
+        lib.ssx_ba_window_push_keyframe.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32, C.c_int32, i64_p, dbl_p, u8_p, C.c_int32, i64_p, dbl_p, u8_p]
+        lib.ssx_ba_window_pop_keyframe.argtypes = [C.c_void_p, C.c_int64]
+        lib.ssx_ba_window_set_pose.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32]
+        lib.ssx_ba_window_set_landmark.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32]
+        lib.ssx_ba_window_size.argtypes = [C.c_void_p, i32_p, i32_p, i32_p]
+        lib.ssx_ba_window_export.argtypes = [C.c_void_p, i64_p, dbl_p, u8_p, i64_p, dbl_p, u8_p, i32_p, i32_p, dbl_p, u8_p]
+        lib.ssx_ba_window_solve.argtypes = [C.c_void_p, C.POINTER(BaResult)]
+        lib.ssx_ba_window_solve_batch.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(BaResult)]
+        h = C.c_void_p()
+        ctx.check(lib.ssx_ba_window_create(ctx.handle, C.byref(self.opt), ptr(self.K, dbl_p), ptr(self.cam_ext, dbl_p), C.byref(h)))
+        self.handle = h
+
+    def push(self, kf_id, pose, new_ids=(), new_xyz=(), new_fixed=None, obs_lm=(), obs_uv=(), obs_cam=None, pose_fixed=False):
+        pose = np.ascontiguousarray(pose, dtype=np.float64).ravel()
+        new_ids = np.ascontiguousarray(new_ids, dtype=np.int64).ravel()
+        new_xyz = np.ascontiguousarray(new_xyz, dtype=np.float64).reshape(-1, 3)
+        new_fixed = None if new_fixed is None else np.ascontiguousarray(new_fixed, dtype=np.uint8)
+        obs_lm = np.ascontiguousarray(obs_lm, dtype=np.int64).ravel()
+        obs_uv = np.ascontiguousarray(obs_uv, dtype=np.float64).reshape(-1, 2)
+        obs_cam = None if obs_cam is None else np.ascontiguousarray(obs_cam, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.ssx_ba_window_push_keyframe(
+            self.handle, int(kf_id), ptr(pose, dbl_p), 1 if pose_fixed else 0, len(new_ids), ptr(new_ids, i64_p), ptr(new_xyz, dbl_p),
+            ptr(new_fixed, u8_p), len(obs_lm), ptr(obs_lm, i64_p), ptr(obs_uv, dbl_p), ptr(obs_cam, u8_p)))
+
+    def pop(self, kf_id):
+        self.ctx.check(self.ctx.lib.ssx_ba_window_pop_keyframe(self.handle, int(kf_id)))
+
+    def set_pose(self, kf_id, pose, fixed=-1):
+        pose = np.ascontiguousarray(pose, dtype=np.float64).ravel()
+        self.ctx.check(self.ctx.lib.ssx_ba_window_set_pose(self.handle, int(kf_id), ptr(pose, dbl_p), int(fixed)))
+
+    def set_landmark(self, lm_id, xyz=None, fixed=-1):
+        xyz = None if xyz is None else np.ascontiguousarray(xyz, dtype=np.float64).ravel()
+        self.ctx.check(self.ctx.lib.ssx_ba_window_set_landmark(self.handle, int(lm_id), ptr(xyz, dbl_p), int(fixed)))
+
+    def size(self):
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_ba_window_size(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def export(self):
+        """the window as an ordinary problem dict (current estimate) + the ids of its keyframes / landmarks"""
+        P, L, E = self.size()
+        o = dict(P=P, L=L, E=E, kf_ids=np.zeros(P, np.int64), poses=np.zeros((P, 7)), pose_fixed=np.zeros(P, np.uint8),
+                 lm_ids=np.zeros(L, np.int64), points=np.zeros((L, 3)), point_fixed=np.zeros(L, np.uint8),
+                 edge_pose=np.zeros(E, np.int32), edge_point=np.zeros(E, np.int32), edge_uv=np.zeros((E, 2)), edge_cam=np.zeros(E, np.uint8),
+                 K=self.K.copy(), cam_ext=self.cam_ext.copy())
+        self.ctx.check(self.ctx.lib.ssx_ba_window_export(
+            self.handle, ptr(o["kf_ids"], i64_p), ptr(o["poses"], dbl_p), ptr(o["pose_fixed"], u8_p), ptr(o["lm_ids"], i64_p),
+            ptr(o["points"], dbl_p), ptr(o["point_fixed"], u8_p), ptr(o["edge_pose"], i32_p), ptr(o["edge_point"], i32_p),
+            ptr(o["edge_uv"], dbl_p), ptr(o["edge_cam"], u8_p)))
+        return o
+
+    def _result_buffers(self, want_edges):
+        P, L, E = self.size()
+        res = BaResult()
+        bufs = dict(poses=np.zeros((P, 7)), points=np.zeros((L, 3)), chi2=np.zeros(E) if want_edges else None,
+                    outl=np.zeros(E, dtype=np.uint8) if want_edges else None)
+        res.poses_out = ptr(bufs["poses"], dbl_p); res.points_out = ptr(bufs["points"], dbl_p)
+        res.edge_chi2 = ptr(bufs["chi2"], dbl_p); res.edge_outlier = ptr(bufs["outl"], u8_p)
+        return res, bufs
+
+    @staticmethod
+    def _result_dict(res, bufs):
+        k = min(res.n_iters, _lib.SSX_BA_MAX_STATS)
+        return dict(rounds=res.rounds, n_iters=res.n_iters, poses=bufs["poses"], points=bufs["points"], edge_chi2=bufs["chi2"],
+                    edge_outlier=bufs["outl"], chi2=np.array(res.iter_chi2[:k]), lam=np.array(res.iter_lambda[:k]),
+                    trials=np.array(res.iter_trials[:k]), n_inliers=res.n_inliers, n_outliers=res.n_outliers, ms_total=res.ms_total)
+
+    def solve(self, want_edges=True):
+        res, bufs = self._result_buffers(want_edges)
+        self.ctx.check(self.ctx.lib.ssx_ba_window_solve(self.handle, C.byref(res)))
+        return self._result_dict(res, bufs)
+
+    @staticmethod
+    def solve_batch(windows, want_edges=True):
+        """ssx_ba_window_solve_batch: the windows (of one Context) in one call"""
+        n = len(windows)
+        arr = (BaResult * n)()
+        bufs = []
+        for i, w in enumerate(windows):
+            r, b = w._result_buffers(want_edges)
+            arr[i] = r
+            bufs.append(b)
+        hs = (C.c_void_p * n)(*[w.handle for w in windows])
+        ctx = windows[0].ctx
+        ctx.check(ctx.lib.ssx_ba_window_solve_batch(n, hs, arr))
+        return [BaWindow._result_dict(arr[i], bufs[i]) for i in range(n)]
+
+    def close(self):
+        if self.handle is not None:
+            self.ctx.lib.ssx_ba_window_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                   # noqa: BLE001
+            pass

@@ -45,6 +45,7 @@
 #include <mutex>
 #include <numeric>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <cstring>
@@ -142,7 +143,9 @@ struct BaDev {
   // device-side marshalling (HostPrep::dev_prep): the caller's arrays as they came, the host's counting results, and the
   // sorted order the device derives from them
   int dev_prep;
-  GPtr<const int> r_edge_pose;    // E, caller's order
+  int E_raw;                      // entries of the caller's edge arrays (== E except for an ssx_ba_window, whose storage keeps the
+                                  // observations of removed keyframes as dead entries, edge_point < 0, until it is compacted)
+  GPtr<const int> r_edge_pose;    // E_raw, caller's order
   GPtr<const int> r_edge_point;   // E
   GPtr<const double> r_edge_uv;   // E x 2 interleaved
   GPtr<const uint8_t> r_edge_cam; // E or null
@@ -872,15 +875,16 @@ __global__ __launch_bounds__(CH) void k_build_lists_b(const BaDev* __restrict__ 
 __device__ __forceinline__ void k_prep_scatter_body(const BaDev& d, const int bx)
 {
   const int e = bx * CH + threadIdx.x;
-  if (e >= d.E) return;
-  const int lc = d.lm_compact[d.r_edge_point[e]];
-  d.perm[d.lm_ptr[lc] + d.r_slot8[e]] = e;
+  if (e >= d.E_raw) return;
+  const int l = d.r_edge_point[e];
+  if (l < 0) return;                                  // a dead entry of a window's storage
+  d.perm[d.lm_ptr[d.lm_compact[l]] + d.r_slot8[e]] = e;
 }
 __global__ __launch_bounds__(CH) void k_prep_scatter(BaDev d) { k_prep_scatter_body(d, blockIdx.x); }
 __global__ __launch_bounds__(CH) void k_prep_scatter_b(const BaDev* __restrict__ dv)
 {
   const BaDev& d = dv[blockIdx.y];
-  if (!d.dev_prep || (int)blockIdx.x * CH >= d.E) return;
+  if (!d.dev_prep || (int)blockIdx.x * CH >= d.E_raw) return;
   k_prep_scatter_body(d, blockIdx.x);
 }
 
@@ -1577,6 +1581,7 @@ __global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* __restrict__ dv,
 namespace {
 struct HostPrep {
   int P, L, E, nP, nLm, nCh, nBlk;
+  int E_raw = 0;                     // entries of the caller's edge arrays (E of them alive; see BaDev::E_raw)
   std::vector<int> pose_free, lm_id, lm_ptr, ch_lm, e_pose, e_lmc, perm, pair_ptr;
   std::vector<uint8_t> lm_fixed, e_cam, e_dup, pair_a, pair_b;
   std::vector<uint16_t> pptr;
@@ -1716,9 +1721,17 @@ void make_chunks(HostPrep& h)
   if (h.nCh < 0) h.nCh = 0;
 }
 
+// A window whose raw observation arrays and state live in device buffers of their own (ssx_ba_window): upload() then sends
+// only the counting tables, and the solve starts from / leaves its result in the window's state buffers.
+struct WinExt {
+  const int* r_edge_pose = nullptr; const int* r_edge_point = nullptr; const double* r_edge_uv = nullptr; const uint8_t* r_edge_cam = nullptr;
+  double* pose[2] = {nullptr, nullptr}; double* point[2] = {nullptr, nullptr};
+  int cur = 0;                       // in: the buffer that holds the current estimate; out: the one that holds the result
+};
+
 // allow_dev_prep: small windows leave everything beyond counting to the device (see HostPrep::dev_prep); SSX_BA_HOST_PREP=1
 // keeps the host marshalling below as the reference of the tests (same bits: test_device_marshalling_equals_host_marshalling)
-ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool allow_dev_prep = true)
+ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool allow_dev_prep = true, bool dead_ok = false)
 {
   const int P = pr->P, L = pr->L, E = pr->E;
   if (P <= 0 || L < 0 || E < 0 || !pr->poses || (L && !pr->points) ||
@@ -1726,7 +1739,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
     ctx->set_error("ssx_ba: invalid problem (P=%d L=%d E=%d or null arrays)", P, L, E);
     return SSX_ERR_INVALID_ARG;
   }
-  h.P = P; h.L = L; h.E = E;
+  h.P = P; h.L = L; h.E = E; h.E_raw = E;
   h.pose_free.assign(P, -1);
   h.nP = 0;
   for (int i = 0; i < P; ++i)
@@ -1739,8 +1752,10 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   std::vector<int>& cnt = h.cnt_tmp;
   cnt.assign(L + 1, 0);
   if (h.dev_prep) h.slot8.resize((size_t)std::max(E, 1));
+  int n_dead = 0;
   for (int e = 0; e < E; ++e) {
     const int l = pr->edge_point[e], p = pr->edge_pose[e];
+    if (dead_ok && l < 0) { ++n_dead; continue; }           // a window's storage: observation of a removed keyframe
     if (l < 0 || l >= L || p < 0 || p >= P) {
       ctx->set_error("ssx_ba: edge %d references pose %d / point %d out of range", e, p, l);
       return SSX_ERR_INVALID_ARG;
@@ -1748,6 +1763,8 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
     if (h.dev_prep) h.slot8[e] = (uint8_t)cnt[l + 1];      // (a count beyond CH_E is reported below: the wrapped value is never used)
     cnt[l + 1]++;
   }
+  if (n_dead && !h.dev_prep) { ctx->set_error("ssx_ba: dead observations need the device-side marshalling"); return SSX_ERR_UNSUPPORTED; }
+  h.E = E - n_dead;
   h.lm_id.clear(); h.lm_ptr.clear(); h.lm_fixed.clear();
   std::vector<int>& lm_compact = h.lm_compact;
   std::vector<int>& start = h.start_tmp;
@@ -1764,7 +1781,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
     h.lm_ptr.push_back(start[l]);
     h.lm_fixed.push_back(pr->point_fixed ? (pr->point_fixed[l] ? 1 : 0) : 0);
   }
-  h.lm_ptr.push_back(E);
+  h.lm_ptr.push_back(h.E);
   h.nLm = (int)h.lm_id.size();
   if (h.dev_prep) {
     // ---- the light path: chunks + chunk descriptors + the block table; the device does the rest ----
@@ -1986,7 +2003,8 @@ struct UploadPlace {          // where a window of a batch lives (nullptr = a si
 };
 
 ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, double huber_delta, double chi2_th,
-                  int world, int rank, BaDev& d, BigDev& bd, const BandPlan& bp, BandDev& bnd, UploadPlace* place = nullptr)
+                  int world, int rank, BaDev& d, BigDev& bd, const BandPlan& bp, BandDev& bnd, UploadPlace* place = nullptr,
+                  const WinExt* ext = nullptr)
 {
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
@@ -2022,13 +2040,16 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_blk_pa = in.take(nBlk + 1);
   const size_t o_blk_pb = in.take(nBlk + 1);
   size_t o_pptr = dev_prep ? 0 : in.take(sizeof(uint16_t) * (h.pptr.size() + 1));
-  const bool have_cam = dev_prep && pr->edge_cam != nullptr;
+  // (an ssx_ba_window keeps the raw observation arrays and the state in device buffers of its own: `ext`)
+  const int E_raw = h.E_raw;
+  const bool raw_in = dev_prep && !ext;
+  const bool have_cam = dev_prep && (ext ? ext->r_edge_cam != nullptr : pr->edge_cam != nullptr);
   const size_t o_lm_compact = in.take(dev_prep ? sizeof(int) * (size_t)(L + 1) : 0);
-  const size_t o_r_pose = in.take(dev_prep ? sizeof(int) * (size_t)(E + 1) : 0);
-  const size_t o_r_point = in.take(dev_prep ? sizeof(int) * (size_t)(E + 1) : 0);
-  const size_t o_r_uv = in.take(dev_prep ? sizeof(double) * 2 * (size_t)(E + 1) : 0);
-  const size_t o_r_cam = in.take(have_cam ? (size_t)E + 1 : 0);
-  const size_t o_slot8 = in.take(dev_prep ? (size_t)E + 1 : 0);
+  const size_t o_r_pose = in.take(raw_in ? sizeof(int) * (size_t)(E + 1) : 0);
+  const size_t o_r_point = in.take(raw_in ? sizeof(int) * (size_t)(E + 1) : 0);
+  const size_t o_r_uv = in.take(raw_in ? sizeof(double) * 2 * (size_t)(E + 1) : 0);
+  const size_t o_r_cam = in.take(have_cam && raw_in ? (size_t)E + 1 : 0);
+  const size_t o_slot8 = in.take(dev_prep ? (size_t)E_raw + 1 : 0);
   // (host-built lists travel with the blob; device-built ones are scratch behind it, a fixed capacity per chunk)
   size_t o_pair_a = dev_lists ? 0 : in.take(nPairs + 1);
   size_t o_pair_b = dev_lists ? 0 : in.take(nPairs + 1);
@@ -2043,16 +2064,17 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const bool band = big && bp.w > 0;
   const size_t o_seg_p0 = in.take(sizeof(int) * (bp.seg_p0.size() + 1));
   const size_t o_seg_m = in.take(sizeof(int) * (bp.seg_m.size() + 1));
-  const size_t o_pose0 = in.take(sizeof(double) * 7 * P);
-  const size_t o_point0 = in.take(sizeof(double) * 3 * (L + 1));
-  const size_t o_pose1_in = dup_state ? in.take(sizeof(double) * 7 * P) : 0;
-  const size_t o_point1_in = dup_state ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
-  const size_t o_pose_init = dup_state ? in.take(sizeof(double) * 7 * P) : 0;
-  const size_t o_point_init = dup_state ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
+  if (ext && !dev_prep) { ctx->set_error("ssx_ba: a window needs the device-side marshalling (<= %d free keyframes, no SSX_BA_HOST_PREP)", SSX_BA_SMALL_P); return SSX_ERR_UNSUPPORTED; }
+  const size_t o_pose0 = in.take(ext ? 0 : sizeof(double) * 7 * P);
+  const size_t o_point0 = in.take(ext ? 0 : sizeof(double) * 3 * (L + 1));
+  const size_t o_pose1_in = (dup_state && !ext) ? in.take(sizeof(double) * 7 * P) : 0;
+  const size_t o_point1_in = (dup_state && !ext) ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
+  const size_t o_pose_init = (dup_state && !ext) ? in.take(sizeof(double) * 7 * P) : 0;
+  const size_t o_point_init = (dup_state && !ext) ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
   const size_t in_bytes = in.off;
   Layout all = in;
-  const size_t o_pose1 = dup_state ? o_pose1_in : all.take(sizeof(double) * 7 * P);
-  const size_t o_point1 = dup_state ? o_point1_in : all.take(sizeof(double) * 3 * (L + 1));
+  const size_t o_pose1 = (dup_state || ext) ? o_pose1_in : all.take(sizeof(double) * 7 * P);
+  const size_t o_point1 = (dup_state || ext) ? o_point1_in : all.take(sizeof(double) * 3 * (L + 1));
   size_t o_perm = 0, o_c2 = 0;
   if (dev_prep) {
     o_e_dup = all.take((size_t)E + 1);
@@ -2061,7 +2083,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     o_l_rec = all.take(sizeof(int) * 4 * (size_t)(nLm + 1));
     o_pptr = all.take(sizeof(uint16_t) * ((size_t)(nCh + 1) * (nP + 1) + 1));
     o_perm = all.take(sizeof(int) * (size_t)(E + 1));
-    o_c2 = all.take(sizeof(double) * (size_t)(E + 1));
+    o_c2 = all.take(sizeof(double) * (size_t)(E_raw + 1));
   }
   if (dev_lists) {
     o_pair_a = all.take((size_t)(nCh + 1) * MAX_PAIRS);
@@ -2117,7 +2139,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (!place) {
     SSX_HIP_TRY(ctx, ws->arena.reserve(all.off));
-    SSX_HIP_TRY(ctx, ws->stage.reserve(std::max(in_bytes, sizeof(double) * (7 * (size_t)P + 3 * (size_t)L + 2 * (size_t)E))));
+    SSX_HIP_TRY(ctx, ws->stage.reserve(std::max(in_bytes, sizeof(double) * (7 * (size_t)P + 3 * (size_t)L + 2 * (size_t)E + (size_t)h.E_raw))));
     SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * (SC_N + 3 * SSX_BA_MAX_STATS)));
   }
   char* hs = place ? place->in_host : ws->stage.as<char>();
@@ -2130,13 +2152,13 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   if (nCh) memcpy(hs + o_ch_desc, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
   if (dev_prep) {
     if (L) memcpy(hs + o_lm_compact, h.lm_compact.data(), sizeof(int) * (size_t)L);
-    if (E) {
+    if (E && raw_in) {
       memcpy(hs + o_r_pose, pr->edge_pose, sizeof(int) * (size_t)E);
       memcpy(hs + o_r_point, pr->edge_point, sizeof(int) * (size_t)E);
       memcpy(hs + o_r_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E);
       if (have_cam) memcpy(hs + o_r_cam, pr->edge_cam, (size_t)E);
-      memcpy(hs + o_slot8, h.slot8.data(), (size_t)E);
     }
+    if (E_raw) memcpy(hs + o_slot8, h.slot8.data(), (size_t)E_raw);
   } else {
   if (E) memcpy(hs + o_e_rec, h.e_rec.data(), sizeof(int) * 4 * (size_t)E);
   if (nLm) memcpy(hs + o_l_rec, h.l_rec.data(), sizeof(int) * 4 * (size_t)nLm);
@@ -2178,8 +2200,10 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     memcpy(hs + o_seg_p0, bp.seg_p0.data(), sizeof(int) * bp.seg_p0.size());
     memcpy(hs + o_seg_m, bp.seg_m.data(), sizeof(int) * bp.seg_m.size());
   }
-  memcpy(hs + o_pose0, pr->poses, sizeof(double) * 7 * P);
-  if (L) memcpy(hs + o_point0, pr->points, sizeof(double) * 3 * L);
+  if (!ext) {
+    memcpy(hs + o_pose0, pr->poses, sizeof(double) * 7 * P);
+    if (L) memcpy(hs + o_point0, pr->points, sizeof(double) * 3 * L);
+  }
   // device addresses: the uploaded blob and the scratch behind it (one arena; a batch keeps all blobs together so that
   // ONE copy uploads every window)
   char* base_in = place ? place->in_dev : ws->arena.as<char>();
@@ -2188,10 +2212,12 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   if (!place) {
     SSX_HIP_TRY(ctx, hipMemcpyAsync(base_in, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     // the second state buffer starts as a copy (landmarks without edges are never rewritten)
+    if (!ext) {
     SSX_HIP_TRY(ctx, hipMemcpyAsync(at(o_pose1), at(o_pose0), sizeof(double) * 7 * P, hipMemcpyDeviceToDevice, ctx->stream));
     if (L)
       SSX_HIP_TRY(ctx, hipMemcpyAsync(at(o_point1), at(o_point0), sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, ctx->stream));
-  } else {
+    }
+  } else if (!ext) {
     memcpy(hs + o_pose1, pr->poses, sizeof(double) * 7 * P);
     memcpy(hs + o_pose_init, pr->poses, sizeof(double) * 7 * P);
     if (L) { memcpy(hs + o_point1, pr->points, sizeof(double) * 3 * L); memcpy(hs + o_point_init, pr->points, sizeof(double) * 3 * L); }
@@ -2223,17 +2249,26 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.bseg = (int4*)(at(o_bseg)); d.bseg_ptr = (int*)(at(o_bseg_ptr));
   d.bseg_cap = bseg_cap;
   d.dev_prep = dev_prep ? 1 : 0;
+  d.E_raw = E_raw;
+  if (ext) {
+    d.r_edge_pose = ext->r_edge_pose; d.r_edge_point = ext->r_edge_point; d.r_edge_uv = ext->r_edge_uv; d.r_edge_cam = ext->r_edge_cam;
+  } else {
   d.r_edge_pose = (const int*)(dev_prep ? at(o_r_pose) : nullptr); d.r_edge_point = (const int*)(dev_prep ? at(o_r_point) : nullptr);
   d.r_edge_uv = (const double*)(dev_prep ? at(o_r_uv) : nullptr); d.r_edge_cam = (const uint8_t*)(have_cam ? at(o_r_cam) : nullptr);
+  }
   d.r_slot8 = (const uint8_t*)(dev_prep ? at(o_slot8) : nullptr); d.lm_compact = (const int*)(dev_prep ? at(o_lm_compact) : nullptr);
   d.perm = (int*)(dev_prep ? at(o_perm) : nullptr); d.c2_out = (double*)(dev_prep ? at(o_c2) : nullptr);
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
-  d.pose_init = dup_state ? (const double*)(at(o_pose_init)) : nullptr;
-  d.point_init = dup_state ? (const double*)(at(o_point_init)) : nullptr;
+  d.pose_init = (dup_state && !ext) ? (const double*)(at(o_pose_init)) : nullptr;
+  d.point_init = (dup_state && !ext) ? (const double*)(at(o_point_init)) : nullptr;
+  if (ext) {
+    d.pose[0] = ext->pose[0]; d.pose[1] = ext->pose[1]; d.point[0] = ext->point[0]; d.point[1] = ext->point[1];
+  } else {
   d.pose[0] = (double*)(at(o_pose0)); d.pose[1] = (double*)(at(o_pose1));
   d.point[0] = (double*)(at(o_point0)); d.point[1] = (double*)(at(o_point1));
+  }
   d.W = (double*)(at(o_W));
   d.err_lin = (double*)(at(o_err_lin));
   d.err_trial = (double*)(at(o_err_trial));
@@ -2268,7 +2303,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   }
   if (!place && nCh > 0 && (dev_lists || dev_prep)) {   // (a batch marshals all its windows with one launch pair: batch_build)
     if (dev_prep) {
-      hipLaunchKernelGGL(k_prep_scatter, dim3((E + CH - 1) / CH), dim3(CH), 0, ctx->stream, d);
+      hipLaunchKernelGGL(k_prep_scatter, dim3((E_raw + CH - 1) / CH), dim3(CH), 0, ctx->stream, d);
       hipLaunchKernelGGL(k_prep_chunk, dim3(nCh), dim3(CH), 0, ctx->stream, d);
     } else {
       hipLaunchKernelGGL(k_build_lists, dim3(nCh), dim3(CH), 0, ctx->stream, d);
@@ -2605,8 +2640,10 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
   return SSX_OK;
 }
 
-ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_options* opt_in,
-                        ssx_ba_result* res)
+}  // extern "C"
+
+// ssx_ba_solve, and the solve of one ssx_ba_window (`ext`: raw arrays and state resident in the window's buffers)
+static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_options* opt_in, ssx_ba_result* res, WinExt* ext)
 {
   if (!ctx || !prob || !res) return SSX_ERR_INVALID_ARG;
   ssx_ba_options opt;
@@ -2615,8 +2652,12 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   // ~20 vectors of up to E entries are not re-allocated and re-faulted every solve
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   HostPrep& h = ctx->ba->prep1;
-  ssx_status st = prepare(ctx, prob, h);
+  ssx_status st = prepare(ctx, prob, h, true, ext != nullptr);
   if (st != SSX_OK) return st;
+  if (ext && !h.dev_prep) {
+    ctx->set_error("ssx_ba_window: %d free keyframes (a window holds at most %d) or the device-side marshalling is switched off", h.nP, SSX_BA_SMALL_P);
+    return SSX_ERR_UNSUPPORTED;
+  }
   Comm cm;
   // world_size 1 with a hook is allowed (the hook is then an identity): it exercises the collective plumbing
   if (opt.comm) {                                   // RCCL inside the library (comm.hip): ncclAllReduce on the ctx stream
@@ -2674,7 +2715,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     return SSX_ERR_UNSUPPORTED;
   }
   BandDev bnd;
-  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd);
+  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd, nullptr, ext);
   if (st != SSX_OK) return st;
   d.store_w = (d.big || opt.jac_mode == SSX_JAC_NUMERIC_G2O) ? 1 : 0;
   bd.spair_ab = pairs_dev;
@@ -2766,7 +2807,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   const int nSchurEntries = d.nBlk * 36 + d.nP * 6;
 
   res->rounds = 0; res->n_iters = 0; res->n_inliers = 0; res->n_outliers = 0;
-  int cur = 0;                 // index of the accepted state buffer
+  int cur = ext ? ext->cur : 0; // index of the accepted state buffer
   bool have_trial_err = false; // err_trial holds the errors of the last trial evaluated
   int round = 0;
   // with several ranks every rank must take part in every collective, even with an empty shard
@@ -2967,7 +3008,7 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
     }
     if (d.dev_prep) {                                  // chi2 per edge, already in the caller's order
       hipLaunchKernelGGL(k_c2_out, dim3((d.E + CH - 1) / CH), dim3(CH), 0, ctx->stream, d, have_trial_err ? 1 : 0);
-      SSX_HIP_TRY(ctx, hipMemcpyAsync(h_err, d.c2_out, sizeof(double) * (size_t)d.E, hipMemcpyDeviceToHost, ctx->stream));
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(h_err, d.c2_out, sizeof(double) * (size_t)d.E_raw, hipMemcpyDeviceToHost, ctx->stream));
     } else
     SSX_HIP_TRY(ctx, hipMemcpyAsync(h_err, have_trial_err ? d.err_trial : d.err_lin, sizeof(double) * 2 * (size_t)d.E,
                                     hipMemcpyDeviceToHost, ctx->stream));
@@ -2976,8 +3017,10 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (res->poses_out) memcpy(res->poses_out, h_pose, sizeof(double) * 7 * d.P);
   if (res->points_out && d.L) memcpy(res->points_out, h_point, sizeof(double) * 3 * d.L);
+  if (ext) ext->cur = cur;
   if (want_err && d.dev_prep) {
-    for (int e = 0; e < d.E; ++e) {
+    for (int e = 0; e < d.E_raw; ++e) {
+      if (ext && prob->edge_point[e] < 0) continue;                  // a dead entry of the window's storage: never evaluated
       if (res->edge_chi2) res->edge_chi2[e] = h_err[e];
       if (res->edge_outlier) res->edge_outlier[e] = h_err[e] > opt.chi2_th;
     }
@@ -3008,12 +3051,16 @@ ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_o
   return SSX_OK;
 }
 
+extern "C" ssx_status ssx_ba_solve(ssx_ctx* ctx, const ssx_ba_problem* prob, const ssx_ba_options* opt_in, ssx_ba_result* res)
+{
+  return ba_solve_impl(ctx, prob, opt_in, res, nullptr);
+}
+
 // ---- batches of small windows ----------------------------------------------------------------------------------------------
 // Many small windows together (one window per stereo pair of a batch, per stream of BASELINE configs[4], ...): every
 // kernel of the small-window path runs ONCE for all windows (blockIdx.y = window), the device-driven LM loop of each
 // window advances independently, one upload and one download carry all windows.  Same arithmetic as n calls of
 // ssx_ba_solve -- identical bits per window.
-}  // extern "C"
 
 struct ssx_ba_batch {
   ssx_ctx* ctx = nullptr;
@@ -3024,7 +3071,9 @@ struct ssx_ba_batch {
   DevBuf* arena = nullptr; HostBuf* stage = nullptr; HostBuf* scal = nullptr;
   std::vector<BaDev> devs;
   std::vector<std::vector<int>> perm;                // sorted edge -> caller's edge, per window
-  std::vector<int> P, L, E;
+  std::vector<int> P, L, E, E_raw;
+  std::vector<WinExt*> exts;                         // windows of ssx_ba_window objects (one-shot batches only), else empty
+  const ssx_ba_problem* probs = nullptr;             // (valid during a one-shot call: the dead entries of a window's storage)
   std::vector<size_t> out_off;
   size_t out_total = 0, a_out = 0, a_gather = 0, a_head = 0, in_total = 0, o_dv = 0, o_ctrl = 0, o_ooff = 0;
   int max_ch = 1, max_rl = 1, max_rs = 1, max_grp = 1, total_ch = 0;
@@ -3047,7 +3096,8 @@ int batch_groups(int n)
 }
 
 // marshal + upload n small windows; SSX_ERR_UNSUPPORTED when one of them is a large window (> 16 free keyframes)
-ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const ssx_ba_options& opt, bool with_err, bool own, ssx_ba_batch* B)
+ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const ssx_ba_options& opt, bool with_err, bool own, ssx_ba_batch* B,
+                       WinExt* const* exts = nullptr)
 {
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
@@ -3060,9 +3110,11 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   B->ctx = ctx; B->device = ctx->device; B->n = n; B->opt = opt; B->threads = T; B->with_err = with_err;
   // ---- 1. host marshalling of every window (edge sort, chunks, index lists), T threads
   std::vector<ssx_status> sts(n, SSX_OK);
-  ws->pool.run(n, T, [&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w]); });
+  ws->pool.run(n, T, [&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w], true, exts != nullptr); });
   for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
-  for (int w = 0; w < n; ++w) if (preps[w].big) return SSX_ERR_UNSUPPORTED;
+  for (int w = 0; w < n; ++w) if (preps[w].big || (exts && !preps[w].dev_prep)) return SSX_ERR_UNSUPPORTED;
+  B->probs = probs;
+  if (exts) B->exts.assign(exts, exts + n); else B->exts.clear();
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
   B->arena = own ? &B->arena_own : &ws->arena;
   B->stage = own ? &B->stage_own : &ws->stage;
@@ -3073,17 +3125,17 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   BandPlan no_band;
   size_t in_total = 0, rest_total = 0, out_total = 0;
   std::vector<size_t> in_off(n), rest_off(n);
-  B->out_off.assign(n, 0); B->P.resize(n); B->L.resize(n); B->E.resize(n); B->perm.resize(n);
+  B->out_off.assign(n, 0); B->P.resize(n); B->L.resize(n); B->E.resize(n); B->E_raw.resize(n); B->perm.resize(n);
   for (int w = 0; w < n; ++w) {
     BigDev bd; BandDev bnd;
     place[w].dry = true;
-    ssx_status st = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w]);
+    ssx_status st = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w], exts ? exts[w] : nullptr);
     if (st != SSX_OK) return st;
     in_off[w] = in_total; in_total += place[w].in_bytes;
     rest_off[w] = rest_total; rest_total += place[w].rest_bytes;
     B->out_off[w] = out_total;
-    B->P[w] = preps[w].P; B->L[w] = preps[w].L; B->E[w] = preps[w].E;
-    out_total += 7 * (size_t)preps[w].P + 3 * (size_t)preps[w].L + (with_err ? 2 * (size_t)preps[w].E : 0);
+    B->P[w] = preps[w].P; B->L[w] = preps[w].L; B->E[w] = preps[w].E; B->E_raw[w] = preps[w].E_raw;
+    out_total += 7 * (size_t)preps[w].P + 3 * (size_t)preps[w].L + (with_err ? std::max(2 * (size_t)preps[w].E, (size_t)preps[w].E_raw) : 0);
   }
   Layout tail;
   B->o_dv = tail.take(sizeof(BaDev) * n); B->o_ctrl = tail.take(sizeof(int) * 3 * n); B->o_ooff = tail.take(sizeof(size_t) * n);
@@ -3106,7 +3158,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     place[w].in_dev = dev_base + B->a_head + in_off[w];
     place[w].rest_dev = dev_base + a_rest + rest_off[w];
     place[w].in_host = hst + in_off[w];
-    sts[w] = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w]);
+    sts[w] = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w], exts ? exts[w] : nullptr);
     B->devs[w].store_w = opt.jac_mode == SSX_JAC_NUMERIC_G2O ? 1 : 0;
     if (with_err) B->perm[w] = preps[w].perm;
   });
@@ -3129,7 +3181,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     const BaDev* dvb = reinterpret_cast<const BaDev*>(dev_base + B->a_head + in_total + B->o_dv);
     int max_e = 1;
     bool any_prep = false;
-    for (int w = 0; w < n; ++w) { max_e = std::max(max_e, B->devs[w].E); any_prep = any_prep || B->devs[w].dev_prep; }
+    for (int w = 0; w < n; ++w) { max_e = std::max(max_e, B->devs[w].E_raw); any_prep = any_prep || B->devs[w].dev_prep; }
     if (any_prep) hipLaunchKernelGGL(k_prep_scatter_b, dim3((max_e + CH - 1) / CH, n), dim3(CH), 0, ctx->stream, dvb);
     hipLaunchKernelGGL(k_prep_chunk_b, dim3(B->max_ch, n), dim3(CH), 0, ctx->stream, dvb);
     SSX_HIP_TRY(ctx, hipGetLastError());
@@ -3185,6 +3237,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   double* hscal = B->scal->as<double>();                             // n x SC_N, then n x 3 x MAX_STATS, then the ctrl words
   int* h_ctrl = reinterpret_cast<int*>(hscal + (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS));
   for (int w = 0; w < n; ++w) wsn[w].done = !(B->devs[w].nCh > 0) || opt.outer_rounds <= 0;
+  if (!B->exts.empty()) for (int w = 0; w < n; ++w) wsn[w].cur = B->exts[w]->cur;   // windows: the buffer that holds their estimate
   const size_t lds_schur = schur_lds_bytes();
   const size_t lds_fused = std::max(lds_schur, LIN_LDS_BYTES);
   int G = std::min(B->groups > 0 ? std::min(B->groups, 4) : batch_groups(n), std::max(n, 1));   // never an empty group (gridDim.y == 0)
@@ -3270,6 +3323,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     }
   }
   if (lm_iterations_total) { int t = 0; for (int w = 0; w < n; ++w) t += wsn[w].n_iters; *lm_iterations_total = t; }
+  if (!B->exts.empty()) for (int w = 0; w < n; ++w) B->exts[w]->cur = wsn[w].cur;   // ... and the one that holds the result
   if (!results) {                                                    // nothing to download: the caller only wants the work done
     SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
     SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -3303,7 +3357,9 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     if (r.points_out && L) memcpy(r.points_out, o + 7 * (size_t)P, sizeof(double) * 3 * L);
     if (want_err && (r.edge_chi2 || r.edge_outlier) && B->devs[w].dev_prep) {
       const double* c2 = o + 7 * (size_t)P + 3 * (size_t)L;          // already in the caller's order
-      for (int eo = 0; eo < E; ++eo) {
+      const int* ept = (!B->exts.empty() && B->probs) ? B->probs[w].edge_point : nullptr;
+      for (int eo = 0; eo < B->E_raw[w]; ++eo) {
+        if (ept && ept[eo] < 0) continue;                            // a dead entry of a window's storage
         if (r.edge_chi2) r.edge_chi2[eo] = c2[eo];
         if (r.edge_outlier) r.edge_outlier[eo] = c2[eo] > opt.chi2_th;
       }
@@ -3413,4 +3469,5 @@ void ssx_ba_batch_destroy(ssx_ba_batch* batch)
 
 }  // extern "C"
 
+#include "ba_window.inc"
 #include "pg.inc"

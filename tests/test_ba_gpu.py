@@ -642,3 +642,93 @@ def test_batched_windows_equal_single_calls(ctx):
     mo = ba.BaBatch(ctx, mixed, outer_rounds=1, iters=4).solve()
     for pr, b in zip(mixed, mo["results"]):
         assert np.array_equal(b["poses"], ba.ba_solve(ctx, pr, outer_rounds=1, iters=4)["poses"])
+
+
+def _window_feed(pr):
+    """per keyframe of a synthetic problem: (pose, ids / xyz / fixed of the landmarks first seen there, its observations)"""
+    first = np.full(pr["L"], 10 ** 9, dtype=np.int64)
+    np.minimum.at(first, pr["edge_point"], pr["edge_pose"])
+    feed = []
+    for k in range(pr["P"]):
+        new = np.nonzero(first == k)[0]
+        e = np.nonzero(pr["edge_pose"] == k)[0]
+        feed.append(dict(pose=pr["poses"][k], new_ids=1000 + new, new_xyz=pr["points"][new], new_fixed=pr["point_fixed"][new],
+                         obs_lm=1000 + pr["edge_point"][e], obs_uv=pr["edge_uv"][e], obs_cam=pr["edge_cam"][e]))
+    return feed
+
+
+def _assert_same(a, b, what):
+    for k in ("poses", "points", "chi2", "lam", "trials", "edge_chi2", "edge_outlier"):
+        assert np.array_equal(a[k], b[k]), (what, k)
+    assert a["rounds"] == b["rounds"] and a["n_iters"] == b["n_iters"], what
+
+
+def test_resident_window_equals_fresh_solves(ctx):
+    """ssx_ba_window: keyframes are pushed (pose + the landmarks they introduce + their observations), popped (their
+    observations and the landmarks nobody sees any more go with them) and the window is optimised where it lies; after
+    every change the solve returns, bit for bit, what ssx_ba_solve returns for the problem ssx_ba_window_export lists --
+    a sliding 10-keyframe window over a 16-keyframe trajectory (keyframe and landmark slots reused, dead observation
+    blocks, the storage rewritten), a fixed landmark set, an overwritten pose, numeric Jacobians, and three windows solved in
+    one call."""
+    pr = make_ba_problem(P=16, L=2400, obs_per_lm=5, seed=71, pose_t_noise=0.05)
+    feed = _window_feed(pr)
+    for jac in (ba.JAC_ANALYTIC, ba.JAC_NUMERIC_G2O):
+        win = ba.BaWindow(ctx, pr["K"], pr["cam_ext"], jac_mode=jac)
+        for k in range(10):
+            win.push(100 + k, **feed[k])
+        assert win.size()[0] == 10
+        steps = 0
+        for k in range(10, 17):
+            ex = win.export()
+            fresh = ba.ba_solve(ctx, ex, jac_mode=jac)
+            got = win.solve()
+            _assert_same(got, fresh, ("step", k, jac))
+            assert got["chi2"][-1] <= got["chi2"][0]
+            assert np.array_equal(win.export()["poses"], got["poses"])          # the state is the result
+            steps += 1
+            if k == 16:
+                break
+            win.pop(100 + k - 10)                                            # Map::RemoveOldActiveKeyframe
+            win.push(100 + k, **feed[k])
+            if k == 12:
+                win.set_landmark(int(win.export()["lm_ids"][5]), fixed=1)
+                win.set_pose(100 + k, feed[k]["pose"] + np.array([0, 0, 0, 0, 0.01, 0, 0.02]))
+        assert steps == 7 and win.size()[0] == 10
+        win.close()
+    # several windows of one context in one call
+    prs = [make_ba_problem(P=12, L=900, obs_per_lm=4, seed=81), make_ba_problem(P=10, L=2000, seed=82), make_ba_problem(P=6, L=300, obs_per_lm=3, seed=83)]
+    wins = []
+    for q in prs:
+        w = ba.BaWindow(ctx, q["K"], q["cam_ext"])
+        for k, f in enumerate(_window_feed(q)):
+            w.push(k, **f)
+        w.pop(0)
+        wins.append(w)
+    fresh = [ba.ba_solve(ctx, w.export()) for w in wins]
+    got = ba.BaWindow.solve_batch(wins)
+    for a, b in zip(got, fresh):
+        _assert_same(a, b, "batch")
+    again = [ba.ba_solve(ctx, w.export()) for w in wins]                     # and from the state the batch left
+    got2 = ba.BaWindow.solve_batch(wins)
+    for a, b in zip(got2, again):
+        _assert_same(a, b, "batch, second solve")
+    for w in wins:
+        w.close()
+
+
+def test_window_misuse(ctx):
+    pr = make_ba_problem(P=4, L=60, obs_per_lm=4, seed=2)
+    feed = _window_feed(pr)
+    from ssvio_amd._lib import SsxError
+    win = ba.BaWindow(ctx, pr["K"], pr["cam_ext"])
+    win.push(1, **feed[0])
+    with pytest.raises(SsxError):
+        win.push(1, **feed[1])                                               # the keyframe is already there
+    with pytest.raises(SsxError):
+        win.push(2, feed[1]["pose"], obs_lm=[999999], obs_uv=[[1.0, 2.0]])   # an observation of an unknown landmark
+    with pytest.raises(SsxError):
+        win.pop(77)
+    assert win.size() == (1, len(feed[0]["new_ids"]), len(feed[0]["obs_lm"]))   # nothing was changed by the failures
+    win.pop(1)
+    assert win.size() == (0, 0, 0)
+    win.close()
