@@ -188,6 +188,84 @@ def main():
     except Exception as exc:                                           # noqa: BLE001 -- an extra figure, never fatal
         print(f"[bench] pipelined host-buffer region skipped: {exc}", file=sys.stderr)
 
+    # ---------------- timed region 1d: resident sliding windows (ssx_ba_window), one keyframe replaced per step ----------------
+    # What a live backend hands over at every keyframe (backend.cpp:88-169, map.cpp:52-56, 89-160): the window it optimised
+    # last time minus its oldest keyframe plus the new one.  B window objects stay in HBM; per step every window pops one
+    # keyframe and pushes one (its pose, ~400 new landmarks, ~2000 observations: ~75 KB over PCIe), then all B windows are
+    # optimised in ONE call (ssx_ba_window_solve_batch) and their poses / landmarks come back.  10 keyframes x ~5600 landmarks
+    # (partially observed ones included) x 20 000 observations per window: configs[2]'s edge count on a moving window.
+    churn = None
+    try:
+        import ctypes as C
+        from ssvio_amd._lib import BaResult, dbl_p, u8_p, ptr
+        CH_STEPS = max(3, args.steps // 4)
+        n_kf_total = 10 + CH_STEPS + 3
+        traj = [make_ba_problem(P=n_kf_total, L=400 * (n_kf_total - 4), seed=900 + k + 1000 * rank) for k in range(N_WIN)]
+        i64_p = C.POINTER(C.c_int64)
+
+        def feed_of(pr):
+            first = np.full(pr["L"], 10 ** 9, dtype=np.int64)
+            np.minimum.at(first, pr["edge_point"], pr["edge_pose"])
+            out = []
+            for k in range(pr["P"]):
+                new = np.nonzero(first == k)[0]
+                e = np.nonzero(pr["edge_pose"] == k)[0]
+                a = dict(pose=np.ascontiguousarray(pr["poses"][k]), new_ids=np.ascontiguousarray(new.astype(np.int64)),
+                         new_xyz=np.ascontiguousarray(pr["points"][new]), new_fixed=np.ascontiguousarray(pr["point_fixed"][new]),
+                         obs_lm=np.ascontiguousarray(pr["edge_point"][e].astype(np.int64)), obs_uv=np.ascontiguousarray(pr["edge_uv"][e]))
+                # the ctypes argument tuple, built once: the timed loop only makes the library call
+                a["args"] = (ptr(a["pose"], dbl_p), 0, len(new), ptr(a["new_ids"], i64_p), ptr(a["new_xyz"], dbl_p), ptr(a["new_fixed"], u8_p),
+                             len(e), ptr(a["obs_lm"], i64_p), ptr(a["obs_uv"], dbl_p), None)
+                out.append(a)
+            return out
+        feeds = [feed_of(t) for t in traj]
+        wins_r = [ba.BaWindow(ctx_ba, traj[i % N_WIN]["K"], traj[i % N_WIN]["cam_ext"]) for i in range(B)]
+        lib = ctx_ba.lib
+        for i, w in enumerate(wins_r):
+            for k in range(10):
+                ctx_ba.check(lib.ssx_ba_window_push_keyframe(w.handle, k, *feeds[i % N_WIN][k]["args"]))
+        hs_arr = (C.c_void_p * B)(*[w.handle for w in wins_r])
+        res_arr = (BaResult * B)()
+        keep_out = []
+        for i, w in enumerate(wins_r):                                  # result buffers sized for the largest window state
+            po = np.zeros((16, 7)); pt = np.zeros((400 * 16, 3))
+            keep_out.append((po, pt))
+            res_arr[i].poses_out = ptr(po, dbl_p); res_arr[i].points_out = ptr(pt, dbl_p)
+        pool = cf.ThreadPoolExecutor(max_workers=16)
+
+        def churn_one(i, k):
+            w = wins_r[i]
+            lib.ssx_ba_window_pop_keyframe(w.handle, k - 10)
+            return lib.ssx_ba_window_push_keyframe(w.handle, k, *feeds[i % N_WIN][k]["args"])
+
+        def churn_step(k):
+            orb.stereo_batch_enqueue(ctx)
+            for st_ in pool.map(lambda i: churn_one(i, k), range(B)):      # ctypes releases the GIL: the pushes run in parallel
+                ctx_ba.check(st_)
+            ctx_ba.check(lib.ssx_ba_window_solve_batch(B, hs_arr, res_arr))
+            return sum(res_arr[i].n_iters for i in range(B))
+
+        ctx_ba.check(lib.ssx_ba_window_solve_batch(B, hs_arr, res_arr))
+        churn_step(10); churn_step(11)
+        barrier()
+        t0 = time.perf_counter()
+        it_ch = 0
+        for k in range(12, 12 + CH_STEPS):
+            it_ch += churn_step(k)
+        barrier()
+        ch_elapsed = max_over_ranks(time.perf_counter() - t0)
+        nkf, nlm, nob = wins_r[0].size()
+        churn = {"value": round(world * B * CH_STEPS / ch_elapsed, 2), "unit": "stereo frames/s", "ms_per_step": round(ch_elapsed / CH_STEPS * 1e3, 4),
+                 "window": {"keyframes": nkf, "landmarks": nlm, "observations": nob}, "lm_iterations_per_window": round(it_ch / (CH_STEPS * B), 2),
+                 "what": "front-end batch + B resident sliding windows (ssx_ba_window): per step every window pops its oldest keyframe and "
+                         "pushes a new one (pose, ~400 landmarks, ~2000 observations over PCIe; 16 host threads), then ssx_ba_window_solve_batch "
+                         "optimises all of them where they lie and returns poses + landmarks"}
+        for w in wins_r:
+            w.close()
+        pool.shutdown()
+    except Exception as exc:                                           # noqa: BLE001 -- an extra figure, never fatal
+        print(f"[bench] resident-window region skipped: {exc!r}", file=sys.stderr)
+
     # ---------------- timed region 2: the front-end alone (round 1's `value`) ----------------
     barrier()
     t0 = time.perf_counter()
@@ -522,7 +600,8 @@ def main():
             "host_buffers_inclusive": {"value": round(host_value, 2), "unit": "stereo frames/s",
                                        "what": "the same step with the B windows handed over as host arrays every step (ssx_ba_solve_batch: host "
                                                "marshalling on 16 threads + one PCIe upload + one download of poses / points); images still resident",
-                                       "two_batches_in_flight": None if pipe_value is None else round(pipe_value, 2)},
+                                       "two_batches_in_flight": None if pipe_value is None else round(pipe_value, 2),
+                                       "resident_windows_one_keyframe_replaced_per_step": churn},
             "roofline": roofline,
             "frontend": {"metric": "stereo frames/s (ORB extract + row-band match + triangulate), no BA", "value": round(fe_value, 2),
                          "ms_per_step": round(fe_elapsed / args.steps * 1e3, 4),

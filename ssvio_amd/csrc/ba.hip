@@ -1685,6 +1685,8 @@ struct BaWorkspace {
   HostPrep prep1;                     // ssx_ba_solve / ssx_ba_linearize
   std::vector<HostPrep> preps;        // batched calls: one per window, trimmed back after a large batch
   ParPool pool;
+  DevBuf win_stage_d;                 // ssx_ba_window: pending uploads of the windows of a call, one block (ba_window.inc)
+  HostBuf win_stage_h;
 };
 
 static void ssx_ba_workspace_free(BaWorkspace* w)
@@ -1696,6 +1698,7 @@ static void ssx_ba_workspace_free(BaWorkspace* w)
   w->tiles.release();
   w->tiles_h.release();
   w->pairs_a.release(); w->pairs_b.release(); w->pairs_c.release(); w->pairs_h.release();
+  w->win_stage_d.release(); w->win_stage_h.release();
   delete w;
 }
 
