@@ -263,6 +263,8 @@ class BaWindow:
         lib.ssx_ba_window_create.argtypes = [C.c_void_p, C.POINTER(BaOptions), dbl_p, dbl_p, C.POINTER(C.c_void_p)]
         lib.ssx_ba_window_destroy.argtypes = [C.c_void_p]; lib.ssx_ba_window_destroy.restype = None
         lib.ssx_ba_window_push_keyframe.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32, C.c_int32, i64_p, dbl_p, u8_p, C.c_int32, i64_p, dbl_p, u8_p]
+        lib.ssx_ba_window_push_keyframe_slots.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32, C.c_int32, i64_p, dbl_p, u8_p, i32_p, C.c_int32, i32_p,
+                                                          dbl_p, u8_p]
         lib.ssx_ba_window_pop_keyframe.argtypes = [C.c_void_p, C.c_int64]
         lib.ssx_ba_window_set_pose.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32]
         lib.ssx_ba_window_set_landmark.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32]
@@ -285,6 +287,22 @@ class BaWindow:
         self.ctx.check(self.ctx.lib.ssx_ba_window_push_keyframe(
             self.handle, int(kf_id), ptr(pose, dbl_p), 1 if pose_fixed else 0, len(new_ids), ptr(new_ids, i64_p), ptr(new_xyz, dbl_p),
             ptr(new_fixed, u8_p), len(obs_lm), ptr(obs_lm, i64_p), ptr(obs_uv, dbl_p), ptr(obs_cam, u8_p)))
+
+    def push_slots(self, kf_id, pose, new_ids=(), new_xyz=(), new_fixed=None, obs_slot=(), obs_uv=(), obs_cam=None, pose_fixed=False):
+        """ssx_ba_window_push_keyframe_slots: observations name their landmark by window slot (>= 0) or as -1 - i = the i-th new
+        landmark of this call; returns the slots given to the new landmarks"""
+        pose = np.ascontiguousarray(pose, dtype=np.float64).ravel()
+        new_ids = np.ascontiguousarray(new_ids, dtype=np.int64).ravel()
+        new_xyz = np.ascontiguousarray(new_xyz, dtype=np.float64).reshape(-1, 3)
+        new_fixed = None if new_fixed is None else np.ascontiguousarray(new_fixed, dtype=np.uint8)
+        obs_slot = np.ascontiguousarray(obs_slot, dtype=np.int32).ravel()
+        obs_uv = np.ascontiguousarray(obs_uv, dtype=np.float64).reshape(-1, 2)
+        obs_cam = None if obs_cam is None else np.ascontiguousarray(obs_cam, dtype=np.uint8)
+        slots = np.zeros(len(new_ids), dtype=np.int32)
+        self.ctx.check(self.ctx.lib.ssx_ba_window_push_keyframe_slots(
+            self.handle, int(kf_id), ptr(pose, dbl_p), 1 if pose_fixed else 0, len(new_ids), ptr(new_ids, i64_p), ptr(new_xyz, dbl_p),
+            ptr(new_fixed, u8_p), ptr(slots, i32_p), len(obs_slot), ptr(obs_slot, i32_p), ptr(obs_uv, dbl_p), ptr(obs_cam, u8_p)))
+        return slots
 
     def pop(self, kf_id):
         self.ctx.check(self.ctx.lib.ssx_ba_window_pop_keyframe(self.handle, int(kf_id)))

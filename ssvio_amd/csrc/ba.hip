@@ -3201,8 +3201,15 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_b<SSX_JAC_NUMERIC_G2O>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_LDS_BYTES);
     attr_set_b = true;
   }
-  constexpr size_t PREPS_KEEP = 16;                                  // windows whose marshalling scratch stays allocated between calls
-  if (ws->preps.size() > PREPS_KEEP) { ws->preps.resize(PREPS_KEEP); ws->preps.shrink_to_fit(); }
+  // the marshalling scratch stays allocated between calls up to 64 MB (device-marshalled windows keep ~6 bytes per observation:
+  // 64 C3 windows = 8 MB; host-marshalled ones ~100 bytes: the cache is trimmed back to 16 windows after such a batch)
+  size_t prep_bytes = 0;
+  for (const HostPrep& hp : ws->preps)
+    prep_bytes += hp.slot8.capacity() + sizeof(int) * (hp.cnt_tmp.capacity() + hp.start_tmp.capacity() + hp.lm_compact.capacity() + hp.e_rec.capacity() +
+                                                       hp.perm.capacity() + hp.e_pose.capacity() + hp.e_lmc.capacity() + hp.bseg.capacity()) +
+                  sizeof(double) * hp.e_uv.capacity() + hp.pair_a.capacity() + hp.pair_b.capacity();
+  constexpr size_t PREPS_KEEP = 16;
+  if (ws->preps.size() > PREPS_KEEP && prep_bytes > (size_t(64) << 20)) { ws->preps.resize(PREPS_KEEP); ws->preps.shrink_to_fit(); }
   return SSX_OK;
 }
 

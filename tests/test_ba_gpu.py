@@ -695,6 +695,24 @@ def test_resident_window_equals_fresh_solves(ctx):
                 win.set_pose(100 + k, feed[k]["pose"] + np.array([0, 0, 0, 0, 0.01, 0, 0.02]))
         assert steps == 7 and win.size()[0] == 10
         win.close()
+    # the slot form of push (the caller keeps the window's landmark slots): same window, same bits
+    a = ba.BaWindow(ctx, pr["K"], pr["cam_ext"]); b = ba.BaWindow(ctx, pr["K"], pr["cam_ext"])
+    slot_of = {}
+    for k in range(13):
+        if k >= 10:
+            a.pop(100 + k - 10); b.pop(100 + k - 10)
+        f = feed[k]
+        a.push(100 + k, **f)
+        new_index = {int(i): j for j, i in enumerate(f["new_ids"])}
+        obs_slot = np.array([slot_of[int(i)] if int(i) not in new_index else -1 - new_index[int(i)] for i in f["obs_lm"]], dtype=np.int32)
+        slots = b.push_slots(100 + k, f["pose"], new_ids=f["new_ids"], new_xyz=f["new_xyz"], new_fixed=f["new_fixed"], obs_slot=obs_slot,
+                             obs_uv=f["obs_uv"], obs_cam=f["obs_cam"])
+        slot_of.update({int(i): int(s_) for i, s_ in zip(f["new_ids"], slots)})
+    ea, eb = a.export(), b.export()
+    for key in ea:
+        assert np.array_equal(ea[key], eb[key]), key
+    _assert_same(a.solve(), b.solve(), "slots")
+    a.close(); b.close()
     # several windows of one context in one call
     prs = [make_ba_problem(P=12, L=900, obs_per_lm=4, seed=81), make_ba_problem(P=10, L=2000, seed=82), make_ba_problem(P=6, L=300, obs_per_lm=3, seed=83)]
     wins = []
