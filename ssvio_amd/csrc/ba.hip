@@ -2766,7 +2766,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
       const size_t band_doubles = (size_t)bnd.nP * (bnd.w + 1) * 36;
       SSX_HIP_TRY(ctx, hipMemsetAsync(bnd.Sb, 0, sizeof(double) * band_doubles, s));
       if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_prep, dim3(nCh), dim3(CH), lds_prep, s, d, bd, lambda, dev_lambda));
-      SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_blocks_band, dim3((bd.nBlkS + 3) / 4), dim3(CH), 0, s, d, bd, bnd));
+      SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_blocks_band, dim3((bd.nBlkS + 3) / 4), dim3(CH), 0, s, d, bd, bnd, dev_lambda == 2 ? 1 : 0));
       SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_bs_band, dim3(d.nP), dim3(CH), 0, s, d, bd, bnd));
       ssx_status st2 = allreduce(ctx, cm, bnd.Sb, band_doubles + (size_t)bd.n);
       if (st2 != SSX_OK) return st2;
@@ -2776,7 +2776,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
         SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_assemble, dim3(std::min(64, (total + BAND_T - 1) / BAND_T)), dim3(BAND_T), 0, s, d, bnd, lambda, dev_lambda));
       }
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_top, dim3(1), dim3(BAND_TOP_T), lds_top, s, d, bnd, bd, lambda, dev_lambda));
-      if (bnd.K > 1) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_back, dim3(bnd.K), dim3(BAND_T), lds_back, s, d, bnd, bd));
+      if (bnd.K > 1) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_back, dim3(bnd.K), dim3(BAND_T), lds_back, s, d, bnd, bd, dev_lambda == 2 ? 1 : 0));
       const int nparts = std::min(32, (d.P + CH - 1) / CH);
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_pose_update_big, dim3(nparts), dim3(CH), 0, s, d, bd, cur_, lambda, dev_lambda));
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_scale_finish, dim3(1), dim3(64), 0, s, d, bd, nparts));
@@ -2823,8 +2823,10 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
     // the host waits for the trial's scalars: the GPU works through the ~25 us of the host round trip instead of
     // idling.  A rejected trial pays one extra linearisation at the kept state (identical values: deterministic).
     bool spec_done = false;
-    if (!d.big) {
-      // ---- small windows: the whole optimize(iters) is enqueued; lm_step() on the device decides after every trial ----
+    static const bool host_lm_env = getenv("SSX_BA_HOST_LM") != nullptr;   // large windows: the former host-driven LM loop (A/B, tests)
+    if (!d.big || !host_lm_env) {
+      // ---- the whole optimize(iters) is enqueued; lm_step() on the device decides after every trial (large windows too:
+      // their former loop paid one stream synchronisation per LM trial, 0.4 of 1.26 ms per iteration at C4) ----
       // One slot = (re)linearise if needed + one trial.  A rejected trial consumes a slot without finishing its
       // iteration, so after the first `iters` slots the host looks at the control block once and tops up.
       hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(1), 0, ctx->stream, d, cur, opt.iters, res->n_iters, active ? 0 : 1);
@@ -2835,7 +2837,19 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
         for (int sidx = 0; sidx < slots; ++sidx) {
           // the first slot of an optimize() needs lambda_0 between the linearisation and the Schur complement; every
           // later slot (and every slot with a collective between the two) knows its damping: one fused kernel
-          const bool fused = !first_slot && !cm.fn && nCh > 0 && n > 0;
+          const bool fused = !d.big && !first_slot && !cm.fn && nCh > 0 && n > 0;
+          if (d.big) {
+            // (k_linearize skips itself while the kept linearisation is valid; the pose blocks too unless a collective follows:
+            // their all-reduced copy must be rebuilt from this rank's part before it is summed again)
+            const int pb_cur = cm.fn ? -1 : -2;
+            if (nCh > 0) {
+              if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
+              else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
+            }
+            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_pose_blocks<SSX_JAC_NUMERIC_G2O>, dim3(d.nP), dim3(CH), 0, ctx->stream, d, bd, pb_cur));
+            else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_pose_blocks<SSX_JAC_ANALYTIC>, dim3(d.nP), dim3(CH), 0, ctx->stream, d, bd, pb_cur));
+            SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_big, dim3(1), dim3(CH), 0, ctx->stream, d));
+          } else
           if (fused) {
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), lds_fused, ctx->stream, d));
             else SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), lds_fused, ctx->stream, d));
@@ -2843,11 +2857,15 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
             else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
           }
-          SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 63) / 64)), dim3(CH), 0, ctx->stream, d));
+          if (!d.big) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 63) / 64)), dim3(CH), 0, ctx->stream, d));
           st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
           if (st != SSX_OK) return st;
           if (first_slot || cm.fn) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_slot ? 1 : 0));
           first_slot = false;
+          if (d.big) {
+            st = big_trial(0.0, 2, -1);
+            if (st != SSX_OK) return st;
+          } else {
           if (n > 0) {
             if (nCh > 0 && !fused) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, -1, 0.0, 2));
             SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 63) / 64), dim3(CH), 0, ctx->stream, d));
@@ -2857,6 +2875,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
           if (n <= NB) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
           else if (n <= 80) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
           else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
+          }
           if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
           SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, cm.fn ? 0 : 1));
           if (cm.fn) {
