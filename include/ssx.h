@@ -175,7 +175,8 @@ typedef struct {
   float ms_schur;           /* landmark elimination                     [timeSchurComplement]                               */
   float ms_linear_solution; /* reduced-system factorisation + solves    [timeLinearSolution]                                */
   float ms_update;          /* back-substitution, state update, trial residuals  [timeUpdate + the next computeActiveErrors] */
-  float ms_reduce;          /* cross-chunk reductions and collectives   [no g2o counterpart: single-threaded]               */
+  float ms_reduce;          /* cross-chunk reductions                   [no g2o counterpart: single-threaded]               */
+  float ms_comm;            /* the all-reduces of a landmark-sharded solve (enqueue to completion on the ctx stream)         */
 } ssx_ba_result;
 
 SSX_API void ssx_ba_default_options(ssx_ba_options* opt);

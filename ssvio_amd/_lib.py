@@ -63,7 +63,7 @@ class BaResult(C.Structure):
                 ("iter_trials", C.c_int32 * SSX_BA_MAX_STATS),
                 ("n_inliers", C.c_int32), ("n_outliers", C.c_int32),
                 ("ms_total", C.c_float), ("ms_setup", C.c_float), ("ms_linearize", C.c_float), ("ms_schur", C.c_float),
-                ("ms_linear_solution", C.c_float), ("ms_update", C.c_float), ("ms_reduce", C.c_float)]
+                ("ms_linear_solution", C.c_float), ("ms_update", C.c_float), ("ms_reduce", C.c_float), ("ms_comm", C.c_float)]
 
 
 class KeyPoint(C.Structure):

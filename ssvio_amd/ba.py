@@ -73,7 +73,7 @@ def ba_solve(ctx: Context, pr, outer_rounds=5, iters=10, chi2_th=5.891, huber_de
                 trials=np.array(res.iter_trials[:k]), n_inliers=res.n_inliers, n_outliers=res.n_outliers,
                 ms_total=res.ms_total,
                 phase_ms=(dict(linearize=res.ms_linearize, schur=res.ms_schur, linear_solution=res.ms_linear_solution,
-                               update=res.ms_update, reduce=res.ms_reduce) if collect_stats else None))
+                               update=res.ms_update, reduce=res.ms_reduce, comm=res.ms_comm) if collect_stats else None))
 
 
 def ba_linearize(ctx: Context, pr, huber_delta=5.891, jac_mode=JAC_ANALYTIC):

@@ -2103,7 +2103,11 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_lin_slab = all.take(sizeof(double) * (size_t)(nCh + 1) * lin_stride);
   const size_t o_Hpp = all.take(sizeof(double) * (nP + 1) * UPPER6);
   const size_t o_bp = all.take(sizeof(double) * (nP + 1) * 6);
-  const size_t o_iter = all.take(sizeof(double) * ((size_t)nP * 27 + 1 + world + 1));
+  const size_t iter_count = (size_t)nP * 27 + 1 + world;
+  // (band solver: iter_comm sits right behind [band | rhs] so that ONE all-reduce per trial carries the reduced system AND the
+  // linearisation's pose blocks / chi2 -- see big_trial)
+  const bool band_pre = big && bp.w > 0;
+  size_t o_iter = band_pre ? 0 : all.take(sizeof(double) * (iter_count + 1));
   const size_t o_schur = all.take(big ? 256 : sizeof(double) * (size_t)(nCh + 1) * (nBlk * 36 + nP * 6));
   const size_t o_trial_comm = all.take(big ? 256 : sizeof(double) * ((size_t)n * n + n + 1));
   const size_t o_BDa = all.take(big ? sizeof(double) * 18 * (size_t)(E + 1) : 256);
@@ -2117,7 +2121,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const int NU = 12 * bw + 1;
   const size_t sb_count = band ? (size_t)nP * (bw + 1) * 36 + (size_t)n : 0;
   const size_t sr_count = (band && bK > 1) ? (size_t)bnPr * (bwr + 1) * 36 + 6 * (size_t)bnPr : 0;
-  const size_t o_Sb = all.take(sizeof(double) * (sb_count + 1));
+  const size_t o_Sb = all.take(sizeof(double) * (sb_count + 1 + (band ? iter_count + 1 : 0)));
+  if (band) o_iter = o_Sb + sizeof(double) * sb_count;
   const size_t o_U = all.take(band ? sizeof(double) * (size_t)bK * NU * NU : 256);
   const size_t o_Ls0 = all.take((band && bK > 1) ? sizeof(double) * (size_t)nP * LS0 : 256);
   const size_t o_Sr = all.take(sizeof(double) * (sr_count + 1));
@@ -2435,7 +2440,9 @@ struct Comm {
 ssx_status allreduce(ssx_ctx* ctx, const Comm& cm, double* buf, size_t count)
 {
   if (!cm.fn) return SSX_OK;
-  if (cm.fn(cm.user, buf, count, ctx->stream) != 0) {
+  int rc = 0;
+  SSX_PROF(ctx, KID_BA_COMM, rc = cm.fn(cm.user, buf, count, ctx->stream));
+  if (rc != 0) {
     ctx->set_error("ssx_ba: the all-reduce hook reported a failure");
     return SSX_ERR_COMM;
   }
@@ -2682,7 +2689,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
     ~StatsGuard() { if (mine) { c->prof.on = false; c->prof.recs.clear(); c->prof.used = 0; } }
   } stats_guard{ctx, opt.collect_stats != 0 && !ctx->prof.on};
   if (stats_guard.mine) { ctx->prof.on = true; ctx->prof.used = 0; ctx->prof.recs.clear(); }
-  res->ms_linearize = res->ms_schur = res->ms_linear_solution = res->ms_update = res->ms_reduce = 0.f;
+  res->ms_linearize = res->ms_schur = res->ms_linear_solution = res->ms_update = res->ms_reduce = res->ms_comm = 0.f;
   BaDev d;
   BigDev bd;
   // large windows: trajectory-shaped co-visibility (cyclic block band) -> the sliding-window / nested-dissection solver
@@ -2759,7 +2766,9 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
     if (lds_back > set_back) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_back), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back); set_back = lds_back; }
   }
   // large windows: Schur blocks -> dense S (+ rhs row) -> all-reduce -> blocked Cholesky (MFMA) -> back-substitution
-  auto big_trial = [&](double lambda, int dev_lambda, int cur_) -> ssx_status {
+  // fuse_iter: the trial's all-reduce also carries iter_comm (pose blocks, chi2, max-diagonal slots of the linearisation), which
+  // then needs no collective of its own: two all-reduces per LM trial instead of three
+  auto big_trial = [&](double lambda, int dev_lambda, int cur_, bool fuse_iter = false) -> ssx_status {
     hipStream_t s = ctx->stream;
     if (bnd.on) {
       // Schur blocks straight into the band layout -> (all-reduce) -> segments || -> separator system -> segments ||
@@ -2768,8 +2777,9 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
       if (nCh > 0) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_prep, dim3(nCh), dim3(CH), lds_prep, s, d, bd, lambda, dev_lambda));
       SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_blocks_band, dim3((bd.nBlkS + 3) / 4), dim3(CH), 0, s, d, bd, bnd, dev_lambda == 2 ? 1 : 0));
       SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_bs_band, dim3(d.nP), dim3(CH), 0, s, d, bd, bnd));
-      ssx_status st2 = allreduce(ctx, cm, bnd.Sb, band_doubles + (size_t)bd.n);
+      ssx_status st2 = allreduce(ctx, cm, bnd.Sb, band_doubles + (size_t)bd.n + (fuse_iter ? (size_t)d.nP * 27 + 1 + d.world : 0));
       if (st2 != SSX_OK) return st2;
+      if (fuse_iter) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, s, d, 0));   // the global chi2 of the linearisation
       if (bnd.K > 1) {
         SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_seg, dim3(bnd.K), dim3(BAND_T), lds_seg, s, d, bnd, lambda, dev_lambda));
         const int total = bnd.nPr * (bnd.wr + 1) * 36 + 6 * bnd.nPr;
@@ -2858,12 +2868,17 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
             else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
           }
           if (!d.big) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 63) / 64)), dim3(CH), 0, ctx->stream, d));
-          st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
-          if (st != SSX_OK) return st;
-          if (first_slot || cm.fn) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_slot ? 1 : 0));
+          // (band solver, later slots: lambda is known, so the linearisation's sums travel with the trial's reduced system)
+          static const bool no_fuse_env = getenv("SSX_BA_NO_FUSED_ALLREDUCE") != nullptr;
+          const bool fuse_iter = d.big && bnd.on && cm.fn && !first_slot && !no_fuse_env;
+          if (!fuse_iter) {
+            st = allreduce(ctx, cm, d.iter_comm, (size_t)d.nP * 27 + 1 + d.world);
+            if (st != SSX_OK) return st;
+            if (first_slot || cm.fn) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, ctx->stream, d, first_slot ? 1 : 0));
+          }
           first_slot = false;
           if (d.big) {
-            st = big_trial(0.0, 2, -1);
+            st = big_trial(0.0, 2, -1, fuse_iter);
             if (st != SSX_OK) return st;
           } else {
           if (n > 0) {
@@ -3067,6 +3082,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
         case KID_BA_SCHUR: res->ms_schur += t; break;
         case KID_BA_SOLVE: res->ms_linear_solution += t; break;
         case KID_BA_BACKSUB: res->ms_update += t; break;
+        case KID_BA_COMM: res->ms_comm += t; break;
         default: res->ms_reduce += t; break;
       }
     }
@@ -3380,7 +3396,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     const WinState& st = wsn[w];
     const int P = B->P[w], L = B->L[w], E = B->E[w];
     r.rounds = st.rounds; r.n_iters = st.n_iters; r.n_inliers = st.n_in; r.n_outliers = st.n_outl;
-    r.ms_linearize = r.ms_schur = r.ms_linear_solution = r.ms_update = r.ms_reduce = 0.f;
+    r.ms_linearize = r.ms_schur = r.ms_linear_solution = r.ms_update = r.ms_reduce = r.ms_comm = 0.f;
     const double* o = h_out + B->out_off[w];
     if (r.poses_out) memcpy(r.poses_out, o, sizeof(double) * 7 * P);
     if (r.points_out && L) memcpy(r.points_out, o + 7 * (size_t)P, sizeof(double) * 3 * L);

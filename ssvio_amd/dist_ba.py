@@ -107,3 +107,12 @@ def init_native_comm(ctx, rank: int, world: int, group=None):
 def destroy_native_comm(ctx, comm):
     ctx.lib.ssx_comm_destroy.restype = None
     ctx.lib.ssx_comm_destroy(comm)
+
+
+def native_comm_info(ctx, comm):
+    """-> (rank, world_size) as the communicator inside libssx.so reports them (ssx_comm_info)"""
+    import ctypes as C
+    r, w = C.c_int32(-1), C.c_int32(-1)
+    ctx.lib.ssx_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    ctx.check(ctx.lib.ssx_comm_info(comm, C.byref(r), C.byref(w)))
+    return r.value, w.value
