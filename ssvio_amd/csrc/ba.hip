@@ -1341,67 +1341,6 @@ __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx
   }
 }
 
-// k_reduce_iter = k_reduce_lin + k_reduce_schur in ONE launch (single GPU: with several ranks an all-reduce of the pose blocks
-// sits between the two).  A workgroup cannot read the pose blocks another workgroup of the same launch is still summing, so a
-// thread that needs one (the 36 entries of a diagonal block of S, the 6 of a pose's rhs) sums that entry of the
-// linearisation's slabs itself -- the same four parts in the same order as k_reduce_lin_body: the same bits.
-__device__ __forceinline__ void k_reduce_iter_body(const BaDev& d, const int bx)
-{
-  __shared__ double sAcc[3][64], sH[3][64];
-  const int nS = d.nBlk * 36;
-  const int stride = nS + d.nP * 6;
-  const int n = 6 * d.nP;
-  const int lstride = d.nP * 27 + 2;
-  const int t = threadIdx.x;
-  const int ent = bx * 64 + (t & 63), grp = t >> 6;
-  double acc = 0.0, h = 0.0;
-  int blk = 0, r = 0, cc = 0, pa = 0, pb = 0;
-  if (ent < stride) {
-    acc = slab_sum_part(d, d.schur_slab + ent, stride, grp);
-    int le = -1;                                                   // the entry of the linearisation this entry needs
-    if (ent < nS) {
-      blk = ent / 36; const int rc = ent - blk * 36;
-      r = rc / 6; cc = rc - r * 6;
-      pa = d.blk_pa[blk]; pb = d.blk_pb[blk];
-      if (pa == pb) {
-        const int rr = r < cc ? r : cc, c2 = r < cc ? cc : r;
-        le = pa * 27 + rr * 6 - (rr * (rr - 1)) / 2 + (c2 - rr);   // (rr, c2) in the 21-entry upper layout
-      }
-    } else {
-      const int j = ent - nS;
-      le = (j / 6) * 27 + UPPER6 + (j % 6);
-    }
-    if (le >= 0) h = slab_sum_part(d, d.lin_slab + le, lstride, grp);
-  }
-  if (grp > 0) { sAcc[grp - 1][t & 63] = acc; sH[grp - 1][t & 63] = h; }
-  __syncthreads();
-  if (grp == 0 && ent < stride) {
-    acc = ((acc + sAcc[0][t]) + sAcc[1][t]) + sAcc[2][t];
-    h = ((h + sH[0][t]) + sH[1][t]) + sH[2][t];
-    double* S = d.trial_comm;
-    double* bs = d.trial_comm + (size_t)n * n;
-    if (ent < nS) {
-      const double v = h - acc;
-      S[(size_t)(6 * pa + r) * n + 6 * pb + cc] = v;
-      if (pa != pb) S[(size_t)(6 * pb + cc) * n + 6 * pa + r] = v;
-    } else {
-      bs[ent - nS] = h - acc;
-    }
-  }
-  // the pose blocks, chi2 and the max-diagonal for everybody else (k_lambda_init, the reduced solve's scale, lm_step)
-  if (bx < (d.nP * 27 + 63) / 64 || bx == 0) {
-    __syncthreads();
-    k_reduce_lin_body(d, bx);
-  }
-}
-__global__ __launch_bounds__(CH) void k_reduce_iter(BaDev d) { k_reduce_iter_body(d, blockIdx.x); }
-__global__ __launch_bounds__(CH) void k_reduce_iter_b(const BaDev* __restrict__ dv)
-{
-  const BaDev& d = dv[blockIdx.y];
-  if ((int)blockIdx.x >= std::max((d.nBlk * 36 + d.nP * 6 + 63) / 64, std::max(1, (d.nP * 27 + 63) / 64))) return;
-  k_reduce_iter_body(d, blockIdx.x);
-}
-
 __global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d) { k_reduce_schur_body(d, blockIdx.x); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
 __global__ __launch_bounds__(CH) void k_reduce_schur_b(const BaDev* __restrict__ dv)
@@ -2928,9 +2867,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
             else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
           }
-          // (single GPU, lambda known: the two slab reductions are one launch, k_reduce_iter, further down)
-          const bool merged_reduce = fused && !cm.fn && n > 0;
-          if (!d.big && !merged_reduce) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 63) / 64)), dim3(CH), 0, ctx->stream, d));
+          if (!d.big) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 63) / 64)), dim3(CH), 0, ctx->stream, d));
           // (band solver, later slots: lambda is known, so the linearisation's sums travel with the trial's reduced system)
           static const bool no_fuse_env = getenv("SSX_BA_NO_FUSED_ALLREDUCE") != nullptr;
           const bool fuse_iter = d.big && bnd.on && cm.fn && !first_slot && !no_fuse_env;
@@ -2946,8 +2883,6 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
           } else {
           if (n > 0) {
             if (nCh > 0 && !fused) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, -1, 0.0, 2));
-            if (merged_reduce) SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_iter, dim3(std::max((nSchurEntries + 63) / 64, std::max(1, (d.nP * 27 + 63) / 64))), dim3(CH), 0, ctx->stream, d));
-            else
             SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 63) / 64), dim3(CH), 0, ctx->stream, d));
             st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
             if (st != SSX_OK) return st;
@@ -3391,12 +3326,10 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_NUMERIC_G2O>, gWg, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
             else SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_ANALYTIC>, gWg, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
           }
-          if (!fused) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_b, gRl, dim3(CH), 0, hs, hv));
+          SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_b, gRl, dim3(CH), 0, hs, hv));
           if (first_slot) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init_b, gOne, dim3(64), 0, hs, hv, 1));
           if (!fused) SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gWg, dim3(CH), lds_schur, hs, hv, -1, 0.0, 2));
-          // (fused slots: the slab reductions of the linearisation and of the Schur complement are ONE launch)
-          if (fused) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_iter_b, dim3(std::max(B->max_rs, B->max_rl), hn), dim3(CH), 0, hs, hv));
-          else SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, hs, hv));
+          SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, hs, hv));
           if (B->any_solve64) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve80) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
