@@ -261,6 +261,10 @@ SSX_API ssx_status ssx_ba_window_solve(ssx_ba_window* win, ssx_ba_result* res);
  * The options of the first window apply. */
 SSX_API ssx_status ssx_ba_window_solve_batch(int32_t n, ssx_ba_window* const* wins, ssx_ba_result* results);
 
+/* tools hook, needs no GPU: dynamic LDS bytes a BA kernel is launched with (-1: depends on the problem); the compiler's
+ * resource report and rocprofv3's dispatch rows only know static __shared__ arrays (tools/kernel_resources.py) */
+SSX_API int64_t ssx_debug_kernel_dynamic_lds(const char* kernel);
+
 /* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */
 SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps);
 

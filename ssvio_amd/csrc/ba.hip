@@ -3434,6 +3434,19 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
 
 extern "C" {
 
+// tools hook (no GPU needed): dynamic LDS bytes a kernel of this file is launched with (the compiler's resource report only
+// knows static __shared__ arrays, and rocprofv3's dispatch rows show 0 for these); -1 = depends on the problem / unknown
+int64_t ssx_debug_kernel_dynamic_lds(const char* kernel)
+{
+  if (!kernel) return -1;
+  const std::string k(kernel);
+  auto starts = [&](const char* p) { return k.rfind(p, 0) == 0; };
+  if (starts("k_lin_schur") || starts("k_linearize") || k == "k_schur" || k == "k_schur_b") return (int64_t)BA_LDS_BYTES;
+  if (k == "k_schur_prep") return (int64_t)(sizeof(double) * (18 + 9 + 3) * PW + 64);
+  if (starts("k_band_")) return -1;
+  return 0;
+}
+
 // tools hook (no GPU needed): seconds of host marshalling (edge sort, chunks, index lists) of one problem
 double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps)
 {

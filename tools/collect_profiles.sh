@@ -30,6 +30,7 @@ unset SSX_BA_GROUPS
 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
 # the raw per-dispatch tables are hundreds of MB (gpurun merges <= 64 MiB back): summarise HERE, keep the summaries
+mkdir -p "$OUT/summary"; cp "profiles/${3:-r03}/kernel_resources.csv" "$OUT/summary/" 2>/dev/null
 python tools/summarize_profiles.py "$TAG" "$OUT/summary" "${2:-bench}" > "$OUT/summary.log" 2>&1
 cp profiles/pmc_counters.json "$OUT/summary/" 2>/dev/null
 for d in stats fetch write sq1 sq2; do

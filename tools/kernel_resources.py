@@ -34,11 +34,17 @@ for src in b.sources():
             key, val = [x.strip() for x in t.split(":", 1)]
             cur[key] = val
 cols = ["file", "kernel", "VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "LDS Size [bytes/block]", "Occupancy [waves/SIMD]"]
+# dynamic LDS (extern __shared__, set at launch): the library knows what it launches its BA kernels with
+import ctypes
+lib = ctypes.CDLL(b.build())
+lib.ssx_debug_kernel_dynamic_lds.restype = ctypes.c_int64
+lib.ssx_debug_kernel_dynamic_lds.argtypes = [ctypes.c_char_p]
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with open(out, "w") as f:
-    f.write("file,kernel,vgprs,agprs,sgprs,scratch_bytes_per_lane,static_lds_bytes_per_block,waves_per_simd_by_registers\n")
+    f.write("file,kernel,vgprs,agprs,sgprs,scratch_bytes_per_lane,static_lds_bytes_per_block,waves_per_simd_by_registers,dynamic_lds_bytes_per_block\n")
     for r in rows:
         if not r["kernel"].startswith("k_"):
             continue
-        f.write(",".join('"%s"' % r.get(c, "") if c == "kernel" else str(r.get(c, "")) for c in cols) + "\n")
+        dyn = lib.ssx_debug_kernel_dynamic_lds(r["kernel"].split("<")[0].encode()) if r["file"] == "ba.hip" else 0
+        f.write(",".join('"%s"' % r.get(c, "") if c == "kernel" else str(r.get(c, "")) for c in cols) + f",{dyn}\n")
 print(out, len(rows), "kernels")

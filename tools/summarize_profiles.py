@@ -84,6 +84,16 @@ def pmc_all(sub):
     return {k: {c: tot[k][c] / cnt[k][c] for c in tot[k]} for k in tot}, meta
 
 
+# registers / scratch / LDS per kernel as the COMPILER reports them (tools/kernel_resources.py; the dispatch rows of rocprofv3
+# show half the VGPRs of a wave64 kernel and no dynamic LDS): <round-dir>/kernel_resources.csv, else profiles/kernel_resources.csv
+cres = {}
+for cand in (os.path.join(rdir, "kernel_resources.csv"), os.path.join("profiles", "kernel_resources.csv")):
+    if os.path.exists(cand):
+        for r in csv.DictReader(open(cand)):
+            dyn = int(r.get("dynamic_lds_bytes_per_block") or 0)
+            cres[r["kernel"]] = dict(vgpr=int(r["vgprs"] or 0), agpr=int(r["agprs"] or 0), sgpr=int(r["sgprs"] or 0), scratch=int(r["scratch_bytes_per_lane"] or 0),
+                                     lds=int(r["static_lds_bytes_per_block"] or 0) + max(dyn, 0), lds_known=dyn >= 0)
+        break
 sq = {}
 meta = {}
 for sub in ("sq1", "sq2"):
@@ -101,8 +111,8 @@ if sq:
     with open(os.path.join(rdir, name + "_occupancy_valu.md"), "w") as o:
         o.write(f"# Occupancy and VALU issue per kernel, `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` ({pairs} pairs/step), MI355X\n\n"
                 "Two `rocprofv3 --pmc SQ_* --kernel-trace` passes (tools/collect_profiles.sh), values averaged per launch; `avg us` from the\n"
-                "separate `--kernel-trace --stats` pass.  Resources are the dispatch packet's (VGPR/AGPR allocation granule 8, LDS bytes per\n"
-                "workgroup).  `waves/SIMD limit` = min(8, floor(512 / (VGPR+AGPR)), LDS: floor(160 KB / LDS per WG) x waves per WG / 4).\n"
+                "separate `--kernel-trace --stats` pass.  Registers, scratch and LDS (static + the dynamic bytes the library launches with) are the\n"
+                "COMPILER's (kernel_resources.csv; the dispatch rows are only used for kernels it does not list; VGPR/AGPR allocation granule 8).  `waves/SIMD limit` = min(8, floor(512 / (VGPR+AGPR)), LDS: floor(160 KB / LDS per WG) x waves per WG / 4).\n"
                 "`achieved waves/SIMD` = SQ_WAVE_CYCLES x 4 (the counter ticks in quad-cycles) / (avg duration x 2.4 GHz x 1024 SIMDs): the\n"
                 "time-averaged number of resident waves per SIMD while the kernel runs (GRBM_GUI_ACTIVE spans the profiler's dispatch envelope,\n"
                 "~0.4 ms even for a 5 us kernel, and is not used; LDS_Block_Size of the dispatch row misses static __shared__ arrays: the LDS\n"
@@ -113,9 +123,11 @@ if sq:
                 "| kernel | WG | VGPR | AGPR | SGPR | LDS B/WG | scratch | waves/SIMD limit | achieved waves/SIMD | avg us | SQ_INSTS_VALU | VALU issue | VALU busy | SQ_INSTS_LDS | LDS stall | bank-conflict cycles / LDS active | SQ_INSTS_SALU | SQ_INSTS_VMEM |\n"
                 "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for k in sorted(sq, key=lambda k: -sq[k].get("SQ_INSTS_VALU", 0) * 1.0):
-            m, v = meta.get(k, {}), sq[k]
+            m, v = dict(meta.get(k, {})), sq[k]
             if not m:
                 continue
+            if k in cres:                                  # the compiler's numbers win
+                m.update({kk: vv for kk, vv in cres[k].items() if kk != "lds_known"})
             regs = max(((m["vgpr"] + m["agpr"] + 7) // 8) * 8, 8)
             wpw = max(m["wg"] // 64, 1)
             lim_v = min(8, 512 // regs)
@@ -133,7 +145,7 @@ if sq:
                     f"{v.get('SQ_INSTS_VALU', 0):.0f} | {issue:.3f} | {busy:.3f} | {v.get('SQ_INSTS_LDS', 0):.0f} | {stall:.3f} | {bank:.3f} | "
                     f"{v.get('SQ_INSTS_SALU', 0):.0f} | {v.get('SQ_INSTS_VMEM', 0):.0f} |\n")
     print(open(os.path.join(rdir, name + "_occupancy_valu.md")).read())
-json.dump({"source": f"profiles/r02/{name}_pmc_hbm.md + profiles/r02/{name}_occupancy_valu.md", "pairs_per_step": pairs,
+json.dump({"source": f"{rdir}/{name}_pmc_hbm.md + {rdir}/{name}_occupancy_valu.md", "pairs_per_step": pairs,
            "ba_groups": 1, "per_launch": per_launch},
           open(os.path.join("profiles", "pmc_counters.json"), "w"), indent=1)
 json.dump(bj, open(os.path.join(rdir, name + ".json"), "w"), indent=1)
