@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs (and BA windows) per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=16, help="stereo pairs + windows timed on the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="only the headline region + the per-kernel pass (what tools/collect_profiles.sh "
+                    "profiles: every launch of a kernel then has the same shape, so rocprofv3's per-kernel averages mean something)")
     args = ap.parse_args()
 
     import torch
@@ -144,15 +146,17 @@ def main():
     value = frames / elapsed
 
     # ---------------- timed region 1b: the same with the windows handed over as HOST buffers every step ----------------
-    composite_step_host()
-    barrier()
-    t0 = time.perf_counter()
-    HOST_STEPS = max(2, args.steps // 4)
-    for _ in range(HOST_STEPS):
+    host_value = float("nan")
+    if not args.lean:
         composite_step_host()
-    barrier()
-    host_elapsed = max_over_ranks(time.perf_counter() - t0)
-    host_value = world * B * HOST_STEPS / host_elapsed
+        barrier()
+        t0 = time.perf_counter()
+        HOST_STEPS = max(2, args.steps // 4)
+        for _ in range(HOST_STEPS):
+            composite_step_host()
+        barrier()
+        host_elapsed = max_over_ranks(time.perf_counter() - t0)
+        host_value = world * B * HOST_STEPS / host_elapsed
 
     # ---------------- timed region 1c: host buffers, TWO batches in flight (what a server fed by several streams does) ----------------
     # two host threads, each with its own context, marshal + upload + solve + download their batch while the other's is
@@ -160,6 +164,8 @@ def main():
     import threading
     pipe_value = None
     try:
+        if args.lean:
+            raise RuntimeError("--lean")
         ctx_p = [ssvio_amd.Context(dev_index) for _ in range(2)]
         bh = [ba.BaBatch(c, step_windows) for c in ctx_p]
         for b_ in bh:
@@ -186,7 +192,8 @@ def main():
         for c in ctx_p:
             c.close()
     except Exception as exc:                                           # noqa: BLE001 -- an extra figure, never fatal
-        print(f"[bench] pipelined host-buffer region skipped: {exc}", file=sys.stderr)
+        if not args.lean:
+            print(f"[bench] pipelined host-buffer region skipped: {exc}", file=sys.stderr)
 
     # ---------------- timed region 1d: resident sliding windows (ssx_ba_window), one keyframe replaced per step ----------------
     # What a live backend hands over at every keyframe (backend.cpp:88-169, map.cpp:52-56, 89-160): the window it optimised
@@ -196,6 +203,8 @@ def main():
     # (partially observed ones included) x 20 000 observations per window: configs[2]'s edge count on a moving window.
     churn = None
     try:
+        if args.lean:
+            raise RuntimeError("--lean")
         import ctypes as C
         from ssvio_amd._lib import BaResult, dbl_p, u8_p, ptr
         CH_STEPS = max(3, args.steps // 4)
@@ -338,7 +347,8 @@ def main():
             c_.close()
 
     except Exception as exc:                                           # noqa: BLE001 -- an extra figure, never fatal
-        print(f"[bench] resident-window region skipped: {exc!r}", file=sys.stderr)
+        if not args.lean:
+            print(f"[bench] resident-window region skipped: {exc!r}", file=sys.stderr)
 
     # ---------------- timed region 2: the front-end alone (round 1's `value`) ----------------
     barrier()
@@ -373,7 +383,7 @@ def main():
     # ---------------- single-pair latency: ssx_stereo_frame, HOST images in, host results out ----------------
     # (a live front-end is single-stream: the dependent-launch chain of ONE pair, PCIe both ways; never `value`)
     lat = None
-    if rank == 0:
+    if rank == 0 and not args.lean:
         import ctypes as C
         from ssvio_amd._lib import ptr, u8_p, dbl_p
         ctx_lat = ssvio_amd.Context(dev_index)
@@ -617,6 +627,9 @@ def main():
                 "phase_ms_per_iteration": split}
 
     C4_LM_PER_GPU = 10000
+    if args.lean:
+        def time_c4(n_landmarks, reps):                               # noqa: F811 -- not part of the profiled run
+            return {"skipped": "--lean", "ms_per_lm_iteration": None}
     c4 = {"workload": "C4 shape: 500 KF on a loop, 6 observations per landmark, pose 0 fixed, analytic Jacobians, f64",
           "weak": time_c4(C4_LM_PER_GPU * world, 2),
           "sharding": (f"landmarks l mod {world} + RCCL all-reduce of the banded reduced system" if world > 1 else "none"),
@@ -638,7 +651,7 @@ def main():
 
     # ---------------- CPU baseline (rank 0, N == 1 only): the same composite on one host core ----------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.lean:
         from oracle import pyoracle as po
         po.build()
         ns = max(1, min(args.cpu_sample, B))
@@ -693,7 +706,7 @@ def main():
                        "avg_matches_per_pair": round(float(counts[:, 2].mean()), 1),
                        "avg_triangulated_per_pair": round(float(counts[:, 3].mean()), 1),
                        "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2)},
-            "host_buffers_inclusive": {"value": round(host_value, 2), "unit": "stereo frames/s",
+            "host_buffers_inclusive": {"value": None if host_value != host_value else round(host_value, 2), "unit": "stereo frames/s",
                                        "what": "the same step with the B windows handed over as host arrays every step (ssx_ba_solve_batch: host "
                                                "marshalling on 16 threads + one PCIe upload + one download of poses / points); images still resident",
                                        "two_batches_in_flight": None if pipe_value is None else round(pipe_value, 2),

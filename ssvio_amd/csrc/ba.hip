@@ -152,6 +152,7 @@ struct BaDev {
   GPtr<const uint8_t> r_slot8;    // E: rank of the edge among its landmark's edges (caller's order)
   GPtr<const int> lm_compact;     // L: caller's landmark -> compact landmark or -1
   GPtr<int> perm;                 // E: sorted edge -> caller's edge
+  GPtr<int> lm_chunk;             // nLm: compact landmark -> chunk (large windows, device-marshalled: the pair builder reads it)
   GPtr<double> c2_out;            // E: edge chi2 in the CALLER's order (results of a device-marshalled window)
   Cam K;
   double ext[14];
@@ -933,6 +934,8 @@ __device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
     bucket = pf >= 0 ? pf : nP;                                  // fixed-pose edges go behind the free poses' segments
   }
   int rank = 0;
+  const bool small = !d.big;                                     // (large windows have no pose-major order inside a chunk)
+  if (small) {
   for (int p = 0; p <= nP; ++p) {
     const unsigned long long bal = __ballot(bucket == p);
     if (lane == 0) sCnt[wave][p] = __popcll(bal);
@@ -946,9 +949,15 @@ __device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
   }
   __syncthreads();
   if (t <= nP) const_cast<uint16_t*>(static_cast<const uint16_t*>(d.pptr.p))[(size_t)c * (nP + 1) + t] = (uint16_t)sBase[t];
+  } else if (t < nl) {
+    d.lm_chunk[lm0 + t] = c;
+  }
   if (t < ne) {
-    int pos = sBase[bucket] + rank;
-    for (int w = 0; w < wave; ++w) pos += sCnt[w][bucket];
+    int pos = 0;
+    if (small) {
+      pos = sBase[bucket] + rank;
+      for (int w = 0; w < wave; ++w) pos += sCnt[w][bucket];
+    }
     const bool dup = t > 0 && sLmOf[t - 1] == l && sPose[t - 1] == pose;
     const bool next_dup = t + 1 < ne && sLmOf[t + 1] == l && sPose[t + 1] == pose;
     const uint8_t* rc = d.r_edge_cam;
@@ -961,7 +970,22 @@ __device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
     uv[e] = d.r_edge_uv[2 * (size_t)og];
     uv[(size_t)E + e] = d.r_edge_uv[2 * (size_t)og + 1];
     d.perm[e] = og;
+    if (!small) {                                                  // the structure-of-arrays columns the large-window kernels read
+      const_cast<int*>(static_cast<const int*>(d.e_pose.p))[e] = pose;
+      const_cast<int*>(static_cast<const int*>(d.e_lmc.p))[e] = lm0 + l;
+      const_cast<uint8_t*>(static_cast<const uint8_t*>(d.e_cam.p))[e] = (uint8_t)cam;
+    }
   }
+}
+
+// large windows: keys / values of the stable sort that groups the sorted edges by free pose (BigDev::pe_edge)
+__global__ __launch_bounds__(CH) void k_pe_keys(BaDev d, unsigned int* keys, unsigned int* vals)
+{
+  const int sidx = blockIdx.x * CH + threadIdx.x;
+  if (sidx >= d.E) return;
+  const int pf = d.e_rec[sidx].y;
+  keys[sidx] = pf >= 0 ? (unsigned int)pf : (unsigned int)d.nP;      // fixed poses' edges sort behind every free pose's
+  vals[sidx] = (unsigned int)sidx;
 }
 
 __global__ __launch_bounds__(CH) void k_prep_chunk(BaDev d)
