@@ -352,7 +352,8 @@ __device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
 // launch), with the read-modify-write 167 us, with one workgroup and one slab per chunk 138 us.]
 __device__ __forceinline__ void slab_put(double* p, double v, bool first)
 {
-  *p = first ? v : *p + v;
+  if (first) *p = v;                                  // (a branch, not a select: the select form loads the old entry speculatively
+  else *p += v;                                       // even when every chunk is a group's first -- one workgroup per chunk)
 }
 __device__ __forceinline__ void group_range(const BaDev& d, int g, int& c0, int& c1)
 {
@@ -498,7 +499,8 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
   PH(4);
   if (t == 0) {
     slab_put(slab + d.lin_stride - 2, chi, first);
-    slab[d.lin_stride - 1] = first ? md : fmax(slab[d.lin_stride - 1], md);
+    if (first) slab[d.lin_stride - 1] = md;
+    else slab[d.lin_stride - 1] = fmax(slab[d.lin_stride - 1], md);
   }
 }
 
@@ -1709,6 +1711,8 @@ struct BaWorkspace {
   HostPrep prep1;                     // ssx_ba_solve / ssx_ba_linearize
   std::vector<HostPrep> preps;        // batched calls: one per window, trimmed back after a large batch
   ParPool pool;
+  DevBuf recs;                        // large windows, device-marshalled: raw inputs + the records / columns built from them
+  HostBuf recs_h;
   DevBuf win_stage_d;                 // ssx_ba_window: pending uploads of the windows of a call, one block (ba_window.inc)
   HostBuf win_stage_h;
 };
@@ -1723,6 +1727,7 @@ static void ssx_ba_workspace_free(BaWorkspace* w)
   w->tiles_h.release();
   w->pairs_a.release(); w->pairs_b.release(); w->pairs_c.release(); w->pairs_h.release();
   w->win_stage_d.release(); w->win_stage_h.release();
+  w->recs.release(); w->recs_h.release();
   delete w;
 }
 
@@ -1774,12 +1779,14 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   static const bool host_prep_env = getenv("SSX_BA_HOST_PREP") != nullptr;
   static const bool host_lists_env = getenv("SSX_BA_HOST_LISTS") != nullptr;
   h.big = h.nP > SSX_BA_SMALL_P;
-  h.dev_prep = allow_dev_prep && !host_prep_env && !host_lists_env && !h.big;
+  h.dev_prep = allow_dev_prep && !host_prep_env && !host_lists_env;
   // counting sort of the edges by landmark
   std::vector<int>& cnt = h.cnt_tmp;
   cnt.assign(L + 1, 0);
   if (h.dev_prep) h.slot8.resize((size_t)std::max(E, 1));
   int n_dead = 0;
+  const bool big_dev = h.big && h.dev_prep;               // large window, device-marshalled: the host also counts edges per free pose
+  if (big_dev) h.pe_ptr.assign((size_t)h.nP + 1, 0);
   for (int e = 0; e < E; ++e) {
     const int l = pr->edge_point[e], p = pr->edge_pose[e];
     if (dead_ok && l < 0) { ++n_dead; continue; }           // a window's storage: observation of a removed keyframe
@@ -1789,6 +1796,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
     }
     if (h.dev_prep) h.slot8[e] = (uint8_t)cnt[l + 1];      // (a count beyond CH_E is reported below: the wrapped value is never used)
     cnt[l + 1]++;
+    if (big_dev) { const int pf = h.pose_free[p]; if (pf >= 0) h.pe_ptr[pf + 1]++; }
   }
   if (n_dead && !h.dev_prep) { ctx->set_error("ssx_ba: dead observations need the device-side marshalling"); return SSX_ERR_UNSUPPORTED; }
   h.E = E - n_dead;
@@ -1820,13 +1828,21 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
       cd[0] = e0; cd[1] = e1 - e0; cd[2] = lm0; cd[3] = lm1 - lm0;
     }
     h.blk_pa.clear(); h.blk_pb.clear();
+    h.band_w = -1;
+    h.perm.clear(); h.pptr.clear(); h.pair_ptr.clear(); h.pair_a.clear(); h.pair_b.clear(); h.bseg.clear(); h.bseg_ptr.clear();
+    h.pe_edge.clear(); h.sblk_pa.clear(); h.sblk_pb.clear(); h.spair_ptr.assign(1, 0);
+    if (h.big) {
+      if (h.nP > 2048) { ctx->set_error("ssx_ba: %d free poses exceed the supported 2048", h.nP); return SSX_ERR_UNSUPPORTED; }
+      for (int p = 0; p < h.nP; ++p) h.pe_ptr[p + 1] += h.pe_ptr[p];   // counts -> offsets; the edge list itself is the device's (big_records)
+      h.nBlk = 0;
+      h.dev_lists = false;
+      return SSX_OK;
+    }
+    h.pe_ptr.clear();
     for (int a = 0; a < h.nP; ++a)
       for (int b = a; b < h.nP; ++b) { h.blk_pa.push_back((int8_t)a); h.blk_pb.push_back((int8_t)b); }
     h.nBlk = (int)h.blk_pa.size();
     h.dev_lists = true;
-    h.band_w = -1;
-    h.perm.clear(); h.pptr.clear(); h.pair_ptr.clear(); h.pair_a.clear(); h.pair_b.clear(); h.bseg.clear(); h.bseg_ptr.clear();
-    h.pe_ptr.clear(); h.pe_edge.clear(); h.sblk_pa.clear(); h.sblk_pb.clear(); h.spair_ptr.assign(1, 0);
     return SSX_OK;
   }
   h.perm.assign(E, 0);
@@ -2031,8 +2047,9 @@ struct UploadPlace {          // where a window of a batch lives (nullptr = a si
 
 ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, double huber_delta, double chi2_th,
                   int world, int rank, BaDev& d, BigDev& bd, const BandPlan& bp, BandDev& bnd, UploadPlace* place = nullptr,
-                  const WinExt* ext = nullptr)
+                  const WinExt* ext = nullptr, const BaDev* recs = nullptr, const int* pe_ptr_dev = nullptr, const int* pe_edge_dev = nullptr)
 {
+  const bool rz = recs != nullptr;               // large window whose records / columns / raw arrays already live on the device (big_records)
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
   const bool dup_state = place != nullptr;       // batched windows: the second state buffer is part of the uploaded blob
@@ -2046,27 +2063,27 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const int n_pad = big ? ((n + NB - 1) / NB) * NB : 0;
   const size_t nBlkS = h.sblk_pa.size();
   Layout in;   // input blob (mirrored in pinned staging)
-  const size_t o_pose_free = in.take(sizeof(int) * P);
+  const size_t o_pose_free = in.take(rz ? 0 : sizeof(int) * P);
   // (the landmark / chunk tables and the structure-of-arrays edge columns are read by the large-window kernels only: the
   // small-window kernels take everything from the packed records -- a quarter of a C3 window's blob not staged, not sent)
   const bool dev_prep = h.dev_prep && !big;
   const bool lm_tables = big || dev_prep;
-  const size_t o_lm_fixed = in.take(lm_tables ? nLm : 0);
-  const size_t o_lm_id = in.take(lm_tables ? sizeof(int) * nLm : 0);
-  const size_t o_lm_ptr = in.take(lm_tables ? sizeof(int) * (nLm + 1) : 0);
-  const size_t o_ch_lm = in.take(big ? sizeof(int) * (nCh + 1) : 0);
-  const size_t o_e_pose = in.take(big ? sizeof(int) * E : 0);
-  const size_t o_e_lmc = in.take(big ? sizeof(int) * E : 0);
-  const size_t o_e_cam = in.take(big ? E : 0);
+  const size_t o_lm_fixed = in.take(lm_tables && !rz ? nLm : 0);
+  const size_t o_lm_id = in.take(lm_tables && !rz ? sizeof(int) * nLm : 0);
+  const size_t o_lm_ptr = in.take(lm_tables && !rz ? sizeof(int) * (nLm + 1) : 0);
+  const size_t o_ch_lm = in.take(big && !rz ? sizeof(int) * (nCh + 1) : 0);
+  const size_t o_e_pose = in.take(big && !rz ? sizeof(int) * E : 0);
+  const size_t o_e_lmc = in.take(big && !rz ? sizeof(int) * E : 0);
+  const size_t o_e_cam = in.take(big && !rz ? E : 0);
   // (device-marshalled windows upload the caller's arrays; the sorted columns / records are scratch, written by k_prep_chunk)
-  size_t o_e_dup = dev_prep ? 0 : in.take(E);
-  size_t o_e_uv = dev_prep ? 0 : in.take(sizeof(double) * 2 * E);
-  const size_t o_ch_desc = in.take(sizeof(int) * 4 * (size_t)(nCh + 1));
-  size_t o_e_rec = dev_prep ? 0 : in.take(sizeof(int) * 4 * (size_t)(E + 1));
-  size_t o_l_rec = dev_prep ? 0 : in.take(sizeof(int) * 4 * (size_t)(nLm + 1));
+  size_t o_e_dup = (dev_prep || rz) ? 0 : in.take(E);
+  size_t o_e_uv = (dev_prep || rz) ? 0 : in.take(sizeof(double) * 2 * E);
+  const size_t o_ch_desc = in.take(rz ? 0 : sizeof(int) * 4 * (size_t)(nCh + 1));
+  size_t o_e_rec = (dev_prep || rz) ? 0 : in.take(sizeof(int) * 4 * (size_t)(E + 1));
+  size_t o_l_rec = (dev_prep || rz) ? 0 : in.take(sizeof(int) * 4 * (size_t)(nLm + 1));
   const size_t o_blk_pa = in.take(nBlk + 1);
   const size_t o_blk_pb = in.take(nBlk + 1);
-  size_t o_pptr = dev_prep ? 0 : in.take(sizeof(uint16_t) * (h.pptr.size() + 1));
+  size_t o_pptr = (dev_prep || rz) ? 0 : in.take(sizeof(uint16_t) * (h.pptr.size() + 1));
   // (an ssx_ba_window keeps the raw observation arrays and the state in device buffers of its own: `ext`)
   const int E_raw = h.E_raw;
   const bool raw_in = dev_prep && !ext;
@@ -2083,8 +2100,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   size_t o_pair_ptr = dev_lists ? 0 : in.take(sizeof(int) * (h.pair_ptr.size() + 1));
   size_t o_bseg = dev_lists ? 0 : in.take(sizeof(int) * (h.bseg.size() + 4));
   size_t o_bseg_ptr = dev_lists ? 0 : in.take(sizeof(int) * (h.bseg_ptr.size() + 1));
-  const size_t o_pe_ptr = in.take(sizeof(int) * (h.pe_ptr.size() + 1));
-  const size_t o_pe_edge = in.take(sizeof(int) * (h.pe_edge.size() + 1));
+  const size_t o_pe_ptr = in.take(rz ? 0 : sizeof(int) * (h.pe_ptr.size() + 1));
+  const size_t o_pe_edge = in.take(rz ? 0 : sizeof(int) * (h.pe_edge.size() + 1));
   const size_t o_sblk_pa = in.take(sizeof(int) * (nBlkS + 1));
   const size_t o_sblk_pb = in.take(sizeof(int) * (nBlkS + 1));
   const size_t o_spair_ptr = in.take(sizeof(int) * (h.spair_ptr.size() + 1));
@@ -2175,13 +2192,13 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     SSX_HIP_TRY(ctx, ws->scal.reserve(sizeof(double) * (SC_N + 3 * SSX_BA_MAX_STATS)));
   }
   char* hs = place ? place->in_host : ws->stage.as<char>();
-  memcpy(hs + o_pose_free, h.pose_free.data(), sizeof(int) * P);
-  if (lm_tables && nLm) {
+  if (!rz) memcpy(hs + o_pose_free, h.pose_free.data(), sizeof(int) * P);
+  if (lm_tables && nLm && !rz) {
     memcpy(hs + o_lm_fixed, h.lm_fixed.data(), nLm);
     memcpy(hs + o_lm_id, h.lm_id.data(), sizeof(int) * nLm);
   }
-  if (lm_tables) memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (nLm + 1));
-  if (nCh) memcpy(hs + o_ch_desc, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
+  if (lm_tables && !rz) memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (nLm + 1));
+  if (nCh && !rz) memcpy(hs + o_ch_desc, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
   if (dev_prep) {
     if (L) memcpy(hs + o_lm_compact, h.lm_compact.data(), sizeof(int) * (size_t)L);
     if (E && raw_in) {
@@ -2191,12 +2208,12 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
       if (have_cam) memcpy(hs + o_r_cam, pr->edge_cam, (size_t)E);
     }
     if (E_raw) memcpy(hs + o_slot8, h.slot8.data(), (size_t)E_raw);
-  } else {
+  } else if (!rz) {
   if (E) memcpy(hs + o_e_rec, h.e_rec.data(), sizeof(int) * 4 * (size_t)E);
   if (nLm) memcpy(hs + o_l_rec, h.l_rec.data(), sizeof(int) * 4 * (size_t)nLm);
   }
-  if (big) memcpy(hs + o_ch_lm, h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
-  if (E) {
+  if (big && !rz) memcpy(hs + o_ch_lm, h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
+  if (E && !rz) {
     if (big) {
       memcpy(hs + o_e_pose, h.e_pose.data(), sizeof(int) * E);
       memcpy(hs + o_e_lmc, h.e_lmc.data(), sizeof(int) * E);
@@ -2221,9 +2238,11 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     if (!h.bseg.empty()) memcpy(hs + o_bseg, h.bseg.data(), sizeof(int) * h.bseg.size());
     if (!h.bseg_ptr.empty()) memcpy(hs + o_bseg_ptr, h.bseg_ptr.data(), sizeof(int) * h.bseg_ptr.size());
   }
-  if (big) {
+  if (big && !rz) {
     memcpy(hs + o_pe_ptr, h.pe_ptr.data(), sizeof(int) * h.pe_ptr.size());
     memcpy(hs + o_pe_edge, h.pe_edge.data(), sizeof(int) * h.pe_edge.size());
+  }
+  if (big) {
     memcpy(hs + o_sblk_pa, h.sblk_pa.data(), sizeof(int) * nBlkS);
     memcpy(hs + o_sblk_pb, h.sblk_pb.data(), sizeof(int) * nBlkS);
     memcpy(hs + o_spair_ptr, h.spair_ptr.data(), sizeof(int) * h.spair_ptr.size());
@@ -2315,11 +2334,19 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.scal_comm = (double*)(at(o_scal_comm));
   d.scal = (double*)(at(o_scal));
   d.lm_stat = (double*)(at(o_lmstat));
+  if (rz) {                                      // the records, columns and raw arrays of big_records
+    d.dev_prep = 1; d.E_raw = recs->E_raw;
+    d.pose_free = recs->pose_free; d.lm_fixed = recs->lm_fixed; d.lm_id = recs->lm_id; d.lm_ptr = recs->lm_ptr; d.ch_lm = recs->ch_lm;
+    d.e_pose = recs->e_pose; d.e_lmc = recs->e_lmc; d.e_cam = recs->e_cam; d.e_dup = recs->e_dup; d.e_uv = recs->e_uv;
+    d.ch_desc = recs->ch_desc; d.e_rec = recs->e_rec; d.l_rec = recs->l_rec; d.perm = recs->perm; d.c2_out = recs->c2_out; d.lm_chunk = recs->lm_chunk;
+    d.r_edge_pose = recs->r_edge_pose; d.r_edge_point = recs->r_edge_point; d.r_edge_uv = recs->r_edge_uv; d.r_edge_cam = recs->r_edge_cam;
+    d.r_slot8 = recs->r_slot8; d.lm_compact = recs->lm_compact;
+  }
   bd = BigDev{};
   bnd = BandDev{};
   if (big) {
     bd.n = n; bd.n_pad = n_pad; bd.ld = n_pad; bd.T = n_pad / NB; bd.nBlkS = (int)nBlkS;
-    bd.pe_ptr = (const int*)(at(o_pe_ptr)); bd.pe_edge = (const int*)(at(o_pe_edge));
+    bd.pe_ptr = rz ? pe_ptr_dev : (const int*)(at(o_pe_ptr)); bd.pe_edge = rz ? pe_edge_dev : (const int*)(at(o_pe_edge));
     bd.sblk_pa = (const int*)(at(o_sblk_pa)); bd.sblk_pb = (const int*)(at(o_sblk_pb));
     bd.spair_ptr = (const int*)(at(o_spair_ptr)); bd.spair_ab = nullptr;   // the pair lists live in the workspace of build_pairs
     bd.BDa = (double*)(at(o_BDa)); bd.Wma = (double*)(at(o_Wma)); bd.Cv = (double*)(at(o_Cv));
@@ -2348,7 +2375,89 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
 // Large windows: the non-zero blocks of the reduced system and their pair lists, on the device (kernels in ba_big.inc).
 // Fills h.sblk_pa / h.sblk_pb / h.spair_ptr (sorted by (pa, pb); every diagonal block present, possibly with an empty
 // list) and h.band_w; the lists themselves stay in the workspace: *ab_dev.
-ssx_status build_pairs(ssx_ctx* ctx, HostPrep& h, const unsigned long long** ab_dev)
+// Large windows, device-side marshalling (HostPrep::dev_prep): the caller's arrays and the host's counting tables go up once
+// (25 bytes per observation instead of ~62 of marshalled records and columns, and none of the ~3 ms of host work a
+// 480 000-observation window cost), k_prep_scatter / k_prep_chunk build the (landmark, pose) order, the packed records and the
+// structure-of-arrays columns, and a stable radix sort by free pose gives the pose-major edge list.  Everything lives in
+// ws->recs for the duration of the solve; `r` receives the pointers (the pair builder and upload() take them from there).
+ssx_status big_records(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, BaDev& r, const int** pe_ptr_dev, const int** pe_edge_dev)
+{
+  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+  BaWorkspace* ws = ctx->ba;
+  hipStream_t s = ctx->stream;
+  const int P = h.P, L = h.L, E = h.E, nP = h.nP, nLm = h.nLm, nCh = h.nCh;
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int key_bits = 1;
+  while ((1u << key_bits) < (unsigned)(nP + 1)) ++key_bits;
+  size_t sort_tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned int*)nullptr, (size_t)std::max(E, 1), 0, key_bits, s);
+  const bool have_cam = pr->edge_cam != nullptr;
+  Layout in;
+  const size_t o_pose_free = in.take(sizeof(int) * P), o_lm_compact = in.take(sizeof(int) * (size_t)(L + 1));
+  const size_t o_lm_ptr = in.take(sizeof(int) * (size_t)(nLm + 1)), o_lm_id = in.take(sizeof(int) * (size_t)(nLm + 1)), o_lm_fixed = in.take((size_t)nLm + 1);
+  const size_t o_ch_lm = in.take(sizeof(int) * (size_t)(nCh + 1)), o_ch_desc = in.take(sizeof(int) * 4 * (size_t)(nCh + 1)), o_pe_ptr = in.take(sizeof(int) * (size_t)(nP + 1));
+  const size_t o_r_pose = in.take(sizeof(int) * (size_t)(E + 1)), o_r_point = in.take(sizeof(int) * (size_t)(E + 1)), o_r_uv = in.take(sizeof(double) * 2 * (size_t)(E + 1));
+  const size_t o_r_cam = in.take(have_cam ? (size_t)E + 1 : 0), o_slot8 = in.take((size_t)E + 1);
+  const size_t in_bytes = in.off;
+  Layout all = in;
+  const size_t o_perm = all.take(sizeof(int) * (size_t)(E + 1)), o_e_rec = all.take(sizeof(int) * 4 * (size_t)(E + 1)), o_l_rec = all.take(sizeof(int) * 4 * (size_t)(nLm + 1));
+  const size_t o_e_dup = all.take((size_t)E + 1), o_e_uv = all.take(sizeof(double) * 2 * (size_t)(E + 1));
+  const size_t o_e_pose = all.take(sizeof(int) * (size_t)(E + 1)), o_e_lmc = all.take(sizeof(int) * (size_t)(E + 1)), o_e_cam = all.take((size_t)E + 1);
+  const size_t o_lm_chunk = all.take(sizeof(int) * (size_t)(nLm + 1)), o_pe_edge = all.take(sizeof(int) * (size_t)(E + 1)), o_c2 = all.take(sizeof(double) * (size_t)(E + 1));
+  const size_t o_k0 = all.take(sizeof(int) * (size_t)(E + 1)), o_k1 = all.take(sizeof(int) * (size_t)(E + 1)), o_v0 = all.take(sizeof(int) * (size_t)(E + 1));
+  const size_t o_tmp = all.take(sort_tmp + 256);
+  SSX_HIP_TRY(ctx, ws->recs.reserve(all.off));
+  SSX_HIP_TRY(ctx, ws->recs_h.reserve(in_bytes));
+  char* hs = ws->recs_h.as<char>();
+  char* dv = ws->recs.as<char>();
+  memcpy(hs + o_pose_free, h.pose_free.data(), sizeof(int) * P);
+  if (L) memcpy(hs + o_lm_compact, h.lm_compact.data(), sizeof(int) * (size_t)L);
+  memcpy(hs + o_lm_ptr, h.lm_ptr.data(), sizeof(int) * (size_t)(nLm + 1));
+  if (nLm) { memcpy(hs + o_lm_id, h.lm_id.data(), sizeof(int) * (size_t)nLm); memcpy(hs + o_lm_fixed, h.lm_fixed.data(), (size_t)nLm); }
+  memcpy(hs + o_ch_lm, h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
+  if (nCh) memcpy(hs + o_ch_desc, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
+  memcpy(hs + o_pe_ptr, h.pe_ptr.data(), sizeof(int) * (size_t)(nP + 1));
+  // the big columns on the worker pool (12 MB at 480 000 observations)
+  struct Cp { size_t off; const void* src; size_t n; };
+  std::vector<Cp> cps;
+  auto add = [&](size_t off, const void* src, size_t n) {
+    for (size_t a = 0; a < n; a += (size_t)1 << 20) cps.push_back({off + a, (const char*)src + a, std::min(n - a, (size_t)1 << 20)});
+  };
+  if (E) {
+    add(o_r_pose, pr->edge_pose, sizeof(int) * (size_t)E); add(o_r_point, pr->edge_point, sizeof(int) * (size_t)E);
+    add(o_r_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E); add(o_slot8, h.slot8.data(), (size_t)E);
+    if (have_cam) add(o_r_cam, pr->edge_cam, (size_t)E);
+  }
+  ws->pool.run((int)cps.size(), std::min<int>(8, (int)cps.size()), [&](int q) { memcpy(hs + cps[q].off, cps[q].src, cps[q].n); });
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(dv, hs, in_bytes, hipMemcpyHostToDevice, s));
+  r = BaDev{};
+  r.P = P; r.L = L; r.E = E; r.E_raw = h.E_raw; r.nP = nP; r.nLm = nLm; r.nCh = nCh; r.nBlk = 0; r.big = 1; r.dev_prep = 1; r.bseg_cap = 0;
+  r.pose_free = (const int*)(dv + o_pose_free); r.lm_compact = (const int*)(dv + o_lm_compact); r.lm_ptr = (const int*)(dv + o_lm_ptr);
+  r.lm_id = (const int*)(dv + o_lm_id); r.lm_fixed = (const uint8_t*)(dv + o_lm_fixed); r.ch_lm = (const int*)(dv + o_ch_lm);
+  r.ch_desc = (const int4*)(dv + o_ch_desc);
+  r.r_edge_pose = (const int*)(dv + o_r_pose); r.r_edge_point = (const int*)(dv + o_r_point); r.r_edge_uv = (const double*)(dv + o_r_uv);
+  r.r_edge_cam = (const uint8_t*)(have_cam ? dv + o_r_cam : nullptr); r.r_slot8 = (const uint8_t*)(dv + o_slot8);
+  r.perm = (int*)(dv + o_perm); r.e_rec = (const int4*)(dv + o_e_rec); r.l_rec = (const int4*)(dv + o_l_rec); r.e_dup = (const uint8_t*)(dv + o_e_dup);
+  r.e_uv = (const double*)(dv + o_e_uv); r.e_pose = (const int*)(dv + o_e_pose); r.e_lmc = (const int*)(dv + o_e_lmc); r.e_cam = (const uint8_t*)(dv + o_e_cam);
+  r.lm_chunk = (int*)(dv + o_lm_chunk); r.c2_out = (double*)(dv + o_c2);
+  r.pptr = (const uint16_t*)nullptr;
+  *pe_ptr_dev = (const int*)(dv + o_pe_ptr);
+  *pe_edge_dev = (const int*)(dv + o_pe_edge);
+  if (E > 0 && nCh > 0) {
+    hipLaunchKernelGGL(k_prep_scatter, dim3((h.E_raw + CH - 1) / CH), dim3(CH), 0, s, r);
+    hipLaunchKernelGGL(k_prep_chunk, dim3(nCh), dim3(CH), 0, s, r);
+    hipLaunchKernelGGL(k_pe_keys, dim3((E + CH - 1) / CH), dim3(CH), 0, s, r, (unsigned int*)(dv + o_k0), (unsigned int*)(dv + o_v0));
+    if (rocprim::radix_sort_pairs(dv + o_tmp, sort_tmp, (unsigned int*)(dv + o_k0), (unsigned int*)(dv + o_k1), (unsigned int*)(dv + o_v0),
+                                  (unsigned int*)(dv + o_pe_edge), (size_t)E, 0, key_bits, s) != hipSuccess) {
+      ctx->set_error("ssx_ba: rocprim::radix_sort_pairs failed (pose-major edge list)"); return SSX_ERR_HIP;
+    }
+    SSX_HIP_TRY(ctx, hipGetLastError());
+  }
+  return SSX_OK;
+}
+
+// recs (nullable): the records already on the device (big_records)
+ssx_status build_pairs(ssx_ctx* ctx, HostPrep& h, const unsigned long long** ab_dev, const BaDev* recs = nullptr)
 {
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   BaWorkspace* ws = ctx->ba;
@@ -2375,15 +2484,19 @@ ssx_status build_pairs(ssx_ctx* ctx, HostPrep& h, const unsigned long long** ab_
   SSX_HIP_TRY(ctx, ws->pairs_h.reserve(std::max(a_in_bytes, sizeof(int) * 2 * ((size_t)nP * (nP + 1) / 2 + 8))));
   char* da = ws->pairs_a.as<char>();
   char* hh = ws->pairs_h.as<char>();
-  memcpy(hh + a_erec, h.e_rec.data(), sizeof(int) * 4 * (size_t)E);
-  memcpy(hh + a_lrec, h.l_rec.data(), sizeof(int) * 4 * (size_t)nLm);
-  memcpy(hh + a_cd, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
-  memcpy(hh + a_lmc, h.lm_chunk.data(), sizeof(int) * (size_t)nLm);
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(da, hh, a_in_bytes, hipMemcpyHostToDevice, s));
+  if (!recs) {
+    memcpy(hh + a_erec, h.e_rec.data(), sizeof(int) * 4 * (size_t)E);
+    memcpy(hh + a_lrec, h.l_rec.data(), sizeof(int) * 4 * (size_t)nLm);
+    memcpy(hh + a_cd, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
+    memcpy(hh + a_lmc, h.lm_chunk.data(), sizeof(int) * (size_t)nLm);
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(da, hh, a_in_bytes, hipMemcpyHostToDevice, s));
+  }
   SSX_HIP_TRY(ctx, hipMemsetAsync(da + a_cnt, 0, sizeof(int) * ((size_t)nLm + 1), s));
   SSX_HIP_TRY(ctx, hipMemsetAsync(da + a_scal, 0, 64, s));
-  const int4* d_erec = (const int4*)(da + a_erec); const int4* d_lrec = (const int4*)(da + a_lrec); const int4* d_cd = (const int4*)(da + a_cd);
-  const int* d_lmc = (const int*)(da + a_lmc);
+  const int4* d_erec = recs ? (const int4*)recs->e_rec.p : (const int4*)(da + a_erec);
+  const int4* d_lrec = recs ? (const int4*)recs->l_rec.p : (const int4*)(da + a_lrec);
+  const int4* d_cd = recs ? (const int4*)recs->ch_desc.p : (const int4*)(da + a_cd);
+  const int* d_lmc = recs ? (const int*)recs->lm_chunk.p : (const int*)(da + a_lmc);
   int* d_cnt = (int*)(da + a_cnt); int* d_off = (int*)(da + a_off); int* d_scal = (int*)(da + a_scal);
   hipLaunchKernelGGL(k_pairs_count, dim3((nLm + CH - 1) / CH), dim3(CH), 0, s, d_erec, d_lrec, d_cd, d_lmc, nLm, nP, d_cnt, d_scal);
   if (rocprim::exclusive_scan(da + a_tmp, scan_tmp, d_cnt, d_off, 0, (size_t)nLm + 1, rocprim::plus<int>(), s) != hipSuccess) {
@@ -2688,7 +2801,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   HostPrep& h = ctx->ba->prep1;
   ssx_status st = prepare(ctx, prob, h, true, ext != nullptr);
   if (st != SSX_OK) return st;
-  if (ext && !h.dev_prep) {
+  if (ext && (!h.dev_prep || h.big)) {
     ctx->set_error("ssx_ba_window: %d free keyframes (a window holds at most %d) or the device-side marshalling is switched off", h.nP, SSX_BA_SMALL_P);
     return SSX_ERR_UNSUPPORTED;
   }
@@ -2720,8 +2833,15 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   // of ba_band.inc; anything else -> the 64x64-tile sparse Cholesky of ba_big.inc.  With several ranks the decision
   // must be common: the ranks exchange which bandwidth class their shard falls in (one tiny all-reduce).
   const unsigned long long* pairs_dev = nullptr;
+  BaDev recs;
+  const int* pe_ptr_dev = nullptr; const int* pe_edge_dev = nullptr;
+  const bool big_dev = h.big && h.dev_prep;
+  if (big_dev) {
+    st = big_records(ctx, prob, h, recs, &pe_ptr_dev, &pe_edge_dev);
+    if (st != SSX_OK) return st;
+  }
   if (h.big) {
-    st = build_pairs(ctx, h, &pairs_dev);
+    st = build_pairs(ctx, h, &pairs_dev, big_dev ? &recs : nullptr);
     if (st != SSX_OK) return st;
   }
   BandPlan bp;
@@ -2749,7 +2869,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
     return SSX_ERR_UNSUPPORTED;
   }
   BandDev bnd;
-  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd, nullptr, ext);
+  st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd, nullptr, ext, big_dev ? &recs : nullptr, pe_ptr_dev, pe_edge_dev);
   if (st != SSX_OK) return st;
   d.store_w = (d.big || opt.jac_mode == SSX_JAC_NUMERIC_G2O) ? 1 : 0;
   bd.spair_ab = pairs_dev;

@@ -537,13 +537,13 @@ def with_duplicates(pr, n):   # right-camera observations of the first n landmar
 for i, kw in enumerate(eval(sys.argv[3])):
     pr = make_ba_problem(**kw)
     if i == 5: pr = with_duplicates(pr, 80)
-    if i in (1, 5, 6):                      # the caller's edge order is arbitrary: shuffled observations
+    if i in (1, 5, 6, 7, 8):                # the caller's edge order is arbitrary: shuffled observations
         q = np.random.default_rng(7 + i).permutation(pr["E"])
         for k in ("edge_pose", "edge_point", "edge_uv", "edge_cam"): pr[k] = np.ascontiguousarray(pr[k][q])
     r = ba.ba_solve(ctx, pr)
     for k in ("poses", "points", "chi2", "lam", "trials", "edge_chi2"):
         out[f"{i}_{k}"] = np.asarray(r[k])
-probs = [make_ba_problem(**kw) for kw in eval(sys.argv[3])[:4]] * 3
+probs = [make_ba_problem(**kw) for kw in eval(sys.argv[3])[:4]] * 3     # (small windows only: a batch)
 rb = ba.BaBatch(ctx, probs, resident=True).solve()
 for i, r in enumerate(rb["results"]):
     out[f"b{i}_poses"] = r["poses"]; out[f"b{i}_chi2"] = r["chi2"]
@@ -560,7 +560,10 @@ def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
     import subprocess, sys as _sys
     cases = [dict(P=10, L=700, seed=41), dict(P=12, L=500, obs_per_lm=4, seed=42), dict(P=16, L=600, obs_per_lm=5, seed=43, fix_first_pose=True),
              dict(P=4, L=60, obs_per_lm=4, seed=44), dict(P=7, L=300, obs_per_lm=2, seed=45), dict(P=10, L=500, seed=46, fix_first_pose=True, frac_fixed=0.3),
-             dict(P=10, L=4000, seed=47)]
+             dict(P=10, L=4000, seed=47),
+             # windows beyond 16 keyframes (the large path: records + pose-major edge list built by big_records on the device)
+             dict(P=40, L=1500, obs_per_lm=5, seed=48, fix_first_pose=True, loop=True),
+             dict(P=48, L=1200, obs_per_lm=4, seed=49, fix_first_pose=True, shuffle_poses=True)]
     import inspect
     accepted = inspect.signature(make_ba_problem).parameters
     cases = [{k: v for k, v in kw.items() if k in accepted} for kw in cases]
