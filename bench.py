@@ -208,7 +208,7 @@ def main():
         import ctypes as C
         from ssvio_amd._lib import BaResult, dbl_p, u8_p, ptr
         CH_STEPS = max(3, args.steps // 4)
-        n_kf_total = 12 + 2 * CH_STEPS + 1
+        n_kf_total = 10 + CH_STEPS + 3
         traj = [make_ba_problem(P=n_kf_total, L=400 * (n_kf_total - 4), seed=900 + k + 1000 * rank) for k in range(N_WIN)]
         i64_p = C.POINTER(C.c_int64)
 
@@ -270,6 +270,7 @@ def main():
                 res_arr[j].poses_out = ptr(po, dbl_p); res_arr[j].points_out = ptr(pt, dbl_p)
             groups.append((idx, hs_arr, res_arr))
         it_count = [0] * G_W
+        t_solve = [0.0] * G_W
         err_box = []
 
         def group_steps(g, k0, k1):
@@ -279,7 +280,9 @@ def main():
                     for i in idx:
                         lib.ssx_ba_window_pop_keyframe(wins_r[i].handle, k - 10)
                         ctx_w[g].check(lib.ssx_ba_window_push_keyframe_slots(wins_r[i].handle, k, *feeds[i % N_WIN][k]["args_slots"]))
+                    tq = time.perf_counter()
                     ctx_w[g].check(lib.ssx_ba_window_solve_batch(len(idx), hs_arr, res_arr))
+                    t_solve[g] += time.perf_counter() - tq
                     it_count[g] += sum(res_arr[j].n_iters for j in range(len(idx)))
             except Exception as exc_:                                  # noqa: BLE001
                 err_box.append(exc_)
@@ -302,6 +305,7 @@ def main():
             c_.synchronize()
         barrier()
         it_count = [0] * G_W
+        t_solve = [0.0] * G_W
         t0 = time.perf_counter()
         run_steps(12, 12 + CH_STEPS)
         for c_ in ctx_w:
@@ -311,36 +315,14 @@ def main():
         it_ch = sum(it_count)
         nkf, nlm, nob = wins_r[0].size()
         churn = {"value": round(world * B * CH_STEPS / ch_elapsed, 2), "unit": "stereo frames/s", "ms_per_step": round(ch_elapsed / CH_STEPS * 1e3, 4),
-                 "host_threads": G_W, "window": {"keyframes": nkf, "landmarks": nlm, "observations": nob},
+                 "host_threads": G_W, "ms_per_step_inside_solve_calls": round(max(t_solve) / CH_STEPS * 1e3, 4), "window": {"keyframes": nkf, "landmarks": nlm, "observations": nob},
                  "lm_iterations_per_window": round(it_ch / (CH_STEPS * B), 2),
                  "what": "front-end batch + B resident sliding windows (ssx_ba_window) in G groups, one host thread + context per group: per step "
                          "every window pops its oldest keyframe and pushes a new one by landmark slots (pose, ~400 landmarks, ~2000 observations: "
                          "the only data that crosses PCIe on the way in), then ssx_ba_window_solve_batch optimises the group's windows where they lie and returns "
-                         "poses + landmarks; rank 0's own clock"}
-        # the library's share alone: the same loop on one thread, the clock running only inside ssx_ba_window_solve_batch (upload of
-        # the pushed data + counting tables, device-side marshalling, the solve, download) with a front-end batch enqueued just
-        # before it; the map edits (pop / push: ~70 us of host time per window on this box, memory-latency bound) are not timed
-        if G_W >= 1:
-            t_in = 0.0
-            n_in = 0
-            for k in range(12 + CH_STEPS, min(12 + 2 * CH_STEPS, n_kf_total)):
-                for g in range(G_W):
-                    idx, hs_arr, res_arr = groups[g]
-                    for i in idx:
-                        lib.ssx_ba_window_pop_keyframe(wins_r[i].handle, k - 10)
-                        ctx_w[g].check(lib.ssx_ba_window_push_keyframe_slots(wins_r[i].handle, k, *feeds[i % N_WIN][k]["args_slots"]))
-                torch.cuda.synchronize(dev)
-                tq = time.perf_counter()
-                orb.stereo_batch_enqueue(ctx)
-                for g in range(G_W):
-                    ctx_w[g].check(lib.ssx_ba_window_solve_batch(len(groups[g][0]), groups[g][1], groups[g][2]))
-                ctx.synchronize()
-                t_in += time.perf_counter() - tq
-                n_in += 1
-            if n_in:
-                churn["solve_calls_only"] = {"value": round(world * B * n_in / t_in, 2), "unit": "stereo frames/s", "ms_per_step": round(t_in / n_in * 1e3, 4),
-                                             "what": "the same windows, one host thread, clock only around [front-end enqueue + "
-                                                     "ssx_ba_window_solve_batch of every group + front-end completion]; pop / push untimed"}
+                         "poses + landmarks; rank 0's own clock.  ms_per_step_inside_solve_calls = the busiest thread's time inside "
+                         "ssx_ba_window_solve_batch (pending uploads, counting tables, device-side marshalling, solve, download); the rest of a "
+                         "step is the host's pop / push (~70 us per window on this box, memory-latency bound) and Python"}
         for w in wins_r:
             w.close()
         for c_ in ctx_w:

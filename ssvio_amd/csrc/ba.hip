@@ -1548,6 +1548,19 @@ __global__ __launch_bounds__(CH) void k_set_persist_b(BaDev* dv, int n, int pers
   if (w < n) dv[w].persist = dv[w].big ? 0 : persist;
 }
 
+// after the upload of a batch: the second state buffer (and a resident batch's pristine copy) from the uploaded one
+__global__ __launch_bounds__(CH) void k_dup_state_b(const BaDev* __restrict__ dv)
+{
+  const BaDev& d = dv[blockIdx.y];
+  const size_t nP7 = 7 * (size_t)d.P, nL3 = 3 * (size_t)d.L;
+  double* pi = const_cast<double*>(static_cast<const double*>(d.pose_init.p));
+  double* qi = const_cast<double*>(static_cast<const double*>(d.point_init.p));
+  for (size_t i = (size_t)blockIdx.x * CH + threadIdx.x; i < nP7 + nL3; i += (size_t)gridDim.x * CH) {
+    if (i < nP7) { const double v = d.pose[0][i]; d.pose[1][i] = v; if (pi) pi[i] = v; }
+    else { const double v = d.point[0][i - nP7]; d.point[1][i - nP7] = v; if (qi) qi[i - nP7] = v; }
+  }
+}
+
 // a resident batch is solved again: both state buffers of every window back to the uploaded state
 __global__ __launch_bounds__(CH) void k_reset_state_b(const BaDev* __restrict__ dv)
 {
@@ -2043,6 +2056,7 @@ struct UploadPlace {          // where a window of a batch lives (nullptr = a si
   char* in_dev = nullptr;      // uploaded blob on the device
   char* rest_dev = nullptr;    // scratch on the device
   char* in_host = nullptr;     // pinned mirror of the blob
+  bool keep_init = false;      // a RESIDENT batch keeps a pristine copy of the uploaded state (it is solved again from it)
 };
 
 ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, double huber_delta, double chi2_th,
@@ -2111,14 +2125,15 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   if (ext && !dev_prep) { ctx->set_error("ssx_ba: a window needs the device-side marshalling (<= %d free keyframes, no SSX_BA_HOST_PREP)", SSX_BA_SMALL_P); return SSX_ERR_UNSUPPORTED; }
   const size_t o_pose0 = in.take(ext ? 0 : sizeof(double) * 7 * P);
   const size_t o_point0 = in.take(ext ? 0 : sizeof(double) * 3 * (L + 1));
-  const size_t o_pose1_in = (dup_state && !ext) ? in.take(sizeof(double) * 7 * P) : 0;
-  const size_t o_point1_in = (dup_state && !ext) ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
-  const size_t o_pose_init = (dup_state && !ext) ? in.take(sizeof(double) * 7 * P) : 0;
-  const size_t o_point_init = (dup_state && !ext) ? in.take(sizeof(double) * 3 * (L + 1)) : 0;
+  // (the state crosses PCIe ONCE: the second buffer and, for a resident batch, the pristine copy are made on the device,
+  // k_dup_state_b -- the blob of a C3 window carried three copies of its 96 KB of landmarks)
   const size_t in_bytes = in.off;
   Layout all = in;
-  const size_t o_pose1 = (dup_state || ext) ? o_pose1_in : all.take(sizeof(double) * 7 * P);
-  const size_t o_point1 = (dup_state || ext) ? o_point1_in : all.take(sizeof(double) * 3 * (L + 1));
+  const size_t o_pose1 = ext ? 0 : all.take(sizeof(double) * 7 * P);
+  const size_t o_point1 = ext ? 0 : all.take(sizeof(double) * 3 * (L + 1));
+  const bool keep_init = dup_state && !ext && place->keep_init;
+  const size_t o_pose_init = keep_init ? all.take(sizeof(double) * 7 * P) : 0;
+  const size_t o_point_init = keep_init ? all.take(sizeof(double) * 3 * (L + 1)) : 0;
   size_t o_perm = 0, o_c2 = 0;
   if (dev_prep) {
     o_e_dup = all.take((size_t)E + 1);
@@ -2268,10 +2283,6 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     if (L)
       SSX_HIP_TRY(ctx, hipMemcpyAsync(at(o_point1), at(o_point0), sizeof(double) * 3 * L, hipMemcpyDeviceToDevice, ctx->stream));
     }
-  } else if (!ext) {
-    memcpy(hs + o_pose1, pr->poses, sizeof(double) * 7 * P);
-    memcpy(hs + o_pose_init, pr->poses, sizeof(double) * 7 * P);
-    if (L) { memcpy(hs + o_point1, pr->points, sizeof(double) * 3 * L); memcpy(hs + o_point_init, pr->points, sizeof(double) * 3 * L); }
   }
 
   d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
@@ -2312,8 +2323,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
-  d.pose_init = (dup_state && !ext) ? (const double*)(at(o_pose_init)) : nullptr;
-  d.point_init = (dup_state && !ext) ? (const double*)(at(o_point_init)) : nullptr;
+  d.pose_init = keep_init ? (const double*)(at(o_pose_init)) : nullptr;
+  d.point_init = keep_init ? (const double*)(at(o_point_init)) : nullptr;
   if (ext) {
     d.pose[0] = ext->pose[0]; d.pose[1] = ext->pose[1]; d.point[0] = ext->point[0]; d.point[1] = ext->point[1];
   } else {
@@ -3311,6 +3322,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   for (int w = 0; w < n; ++w) {
     BigDev bd; BandDev bnd;
     place[w].dry = true;
+    place[w].keep_init = own;
     ssx_status st = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w], exts ? exts[w] : nullptr);
     if (st != SSX_OK) return st;
     in_off[w] = in_total; in_total += place[w].in_bytes;
@@ -3361,6 +3373,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   {
     // pair lists + work items of every window, on the device (windows marshalled with SSX_BA_HOST_LISTS brought theirs along)
     const BaDev* dvb = reinterpret_cast<const BaDev*>(dev_base + B->a_head + in_total + B->o_dv);
+    if (!exts) hipLaunchKernelGGL(k_dup_state_b, dim3(16, n), dim3(CH), 0, ctx->stream, dvb);   // (windows keep both buffers themselves)
     int max_e = 1;
     bool any_prep = false;
     for (int w = 0; w < n; ++w) { max_e = std::max(max_e, B->devs[w].E_raw); any_prep = any_prep || B->devs[w].dev_prep; }
