@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssx.so")
+# (SSX_LIB points the loader at another build of the same library: same-box A/B runs of tools/, never used by tests or bench)
+LIB_PATH = os.environ.get("SSX_LIB") or os.path.join(_HERE, "libssx.so")
 
 SSX_OK = 0
 SSX_ERR_INVALID_ARG = -1
