@@ -415,6 +415,44 @@ __device__ __forceinline__ uint32_t udot2(uint32_t pair, uint32_t w, uint32_t ac
   return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, w), acc, false);
 }
 
+constexpr int GT_RUN = 4;                       // consecutive tiles of one tile row per workgroup: the next tile's loads fly during this tile's passes
+constexpr int GT_NLD = ((GT_H + 6) * (GT_PITCH / 4) + 255) / 256;   // dwords of an input tile per thread (6)
+
+// the dwords thread t holds of input tile (x0, y0): aligned loads inside the image, reflect-101 gathers at its borders
+__device__ __forceinline__ void gauss_load_tile(const uint8_t* __restrict__ src, int rows, int cols, int pitch, int x0, int y0, int t, uint32_t (&v)[GT_NLD])
+{
+  constexpr int NDW = GT_PITCH / 4;   // 34 dwords per tile row
+  const bool interior = y0 >= 3 && y0 + GT_H + 3 <= rows && x0 >= 4 && x0 + GT_W + 4 <= cols;   // block-uniform
+  if (interior) {
+    const uint8_t* base = src + (size_t)(y0 - 3) * pitch + (x0 - 4);
+#pragma unroll
+    for (int k = 0; k < GT_NLD; ++k) {
+      const int i = t + 256 * k;
+      const int r = i / NDW, dwi = i - r * NDW;
+      v[k] = i < (GT_H + 6) * NDW ? *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * dwi) : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < GT_NLD; ++k) {
+      const int i = t + 256 * k;
+      const int r = i / NDW, dwi = i - r * NDW;
+      uint32_t w = 0u;
+      if (i < (GT_H + 6) * NDW) {
+        const int gy = reflect101(y0 + r - 3, rows);
+        const int gx = x0 - 4 + 4 * dwi;
+        if (gx >= 0 && gx + 3 < cols) {
+          w = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
+        } else {
+          const uint8_t* row = src + (size_t)gy * pitch;
+          w = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
+              ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
+        }
+      }
+      v[k] = w;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
 {
   __shared__ __attribute__((aligned(16))) uint8_t sIn[(GT_H + 6) * GT_PITCH];
@@ -423,37 +461,28 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
   const int img = blockIdx.y, t = threadIdx.x;
   int level = 0;
   while (level + 1 < o.nlevels && (int)blockIdx.x >= o.gauss_tile0[level + 1]) ++level;
-  const int tile = blockIdx.x - o.gauss_tile0[level];
+  const int grp = blockIdx.x - o.gauss_tile0[level];             // a run of GT_RUN tiles of one tile row
   const int rows = o.lvl_rows[level], cols = o.lvl_cols[level], pitch = o.lvl_pitch[level];
   const int tiles_x = (cols + GT_W - 1) / GT_W;
-  const int ty_ = tile / tiles_x, tx_ = tile - ty_ * tiles_x;
-  const int x0 = tx_ * GT_W, y0 = ty_ * GT_H;
+  const int groups_x = (tiles_x + GT_RUN - 1) / GT_RUN;
+  const int ty_ = grp / groups_x, tx0 = (grp - ty_ * groups_x) * GT_RUN;
+  const int tx1 = min(tx0 + GT_RUN, tiles_x);
+  const int y0 = ty_ * GT_H;
   const uint8_t* src = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[level];
   uint8_t* dst = o.blur + (size_t)img * o.pyr_bytes + o.lvl_off[level];
   constexpr int NDW = GT_PITCH / 4;   // 34 dwords per tile row
-  const bool interior = y0 >= 3 && y0 + GT_H + 3 <= rows && x0 >= 4 && x0 + GT_W + 4 <= cols;   // block-uniform
-  if (interior) {
-    const uint8_t* base = src + (size_t)(y0 - 3) * pitch + (x0 - 4);
-    for (int i = t; i < (GT_H + 6) * NDW; i += 256) {
-      const int r = i / NDW, dwi = i - r * NDW;
-      reinterpret_cast<uint32_t*>(sIn)[i] = *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * dwi);
-    }
-  } else {
-    for (int i = t; i < (GT_H + 6) * NDW; i += 256) {
-      const int r = i / NDW, dwi = i - r * NDW;
-      const int gy = reflect101(y0 + r - 3, rows);
-      const int gx = x0 - 4 + 4 * dwi;
-      uint32_t v;
-      if (gx >= 0 && gx + 3 < cols) {
-        v = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
-      } else {
-        const uint8_t* row = src + (size_t)gy * pitch;
-        v = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
-            ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
-      }
-      reinterpret_cast<uint32_t*>(sIn)[i] = v;
-    }
+  uint32_t ld[GT_NLD];
+  gauss_load_tile(src, rows, cols, pitch, tx0 * GT_W, y0, t, ld);
+#pragma unroll 1
+  for (int tx_ = tx0; tx_ < tx1; ++tx_) {
+  const int x0 = tx_ * GT_W;
+  if (tx_ > tx0) __syncthreads();                                  // the previous tile's column pass has read sRowP, its row pass sIn
+#pragma unroll
+  for (int k = 0; k < GT_NLD; ++k) {
+    const int i = t + 256 * k;
+    if (i < (GT_H + 6) * NDW) reinterpret_cast<uint32_t*>(sIn)[i] = ld[k];
   }
+  if (tx_ + 1 < tx1) gauss_load_tile(src, rows, cols, pitch, x0 + GT_W, y0, t, ld);   // in flight during the two passes below
   __syncthreads();
   // row pass: tile column x sits at byte x + 4 of a tile row, so the taps of pixels 4g .. 4g+3 are bytes
   // 4g+1 .. 4g+10 = bytes 1 .. 10 of the dwords g, g+1, g+2
@@ -514,6 +543,7 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
       if (y < rows && x < pitch) *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x) = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
     }
   }
+  }   // tiles of the run
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -986,7 +1016,7 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
     d.fast_lds_per_wave = 2 * d.fast_tile_bytes + ((2 * npx + 15) & ~15);
     for (int l = 0; l < nlevels; ++l) {
       d.gauss_tile0[l] = t0;
-      t0 += ((d.lvl_cols[l] + GT_W - 1) / GT_W) * ((d.lvl_rows[l] + GT_H - 1) / GT_H);
+      t0 += ((((d.lvl_cols[l] + GT_W - 1) / GT_W) + GT_RUN - 1) / GT_RUN) * ((d.lvl_rows[l] + GT_H - 1) / GT_H);   // runs of GT_RUN tiles
     }
     for (int l = nlevels; l <= MAX_LEVELS; ++l) d.gauss_tile0[l] = t0;
   }

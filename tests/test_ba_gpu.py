@@ -737,6 +737,30 @@ def test_resident_window_equals_fresh_solves(ctx):
         w.close()
 
 
+def test_window_storage_is_rewritten_when_mostly_dead(ctx):
+    """A window that slides for a long time: the observation blocks of popped keyframes stay as dead entries until more than
+    half of the storage (and more than 1024 entries) is dead, then the storage is rewritten and re-sent.  Before and after the
+    rewrite the solve equals a fresh ssx_ba_solve of the exported problem; slots of keyframes and landmarks are reused
+    throughout."""
+    pr = make_ba_problem(P=30, L=9000, obs_per_lm=5, seed=91, pose_t_noise=0.03)
+    feed = _window_feed(pr)
+    win = ba.BaWindow(ctx, pr["K"], pr["cam_ext"], iters=4)
+    for k in range(8):
+        win.push(k, **feed[k])
+    sizes = []
+    for k in range(8, 30):
+        win.pop(k - 8)
+        win.push(k, **feed[k])
+        ex = win.export()
+        assert ex["P"] == 8 and ex["E"] == len(ex["edge_pose"]) and ex["edge_point"].max() < ex["L"]
+        if k % 3 == 0 or k >= 27:
+            _assert_same(win.solve(), ba.ba_solve(ctx, ex, iters=4), ("slide", k))
+        sizes.append(win.size())
+    # every keyframe carries ~1700 observations: 22 pops leave > 30 000 dead entries behind unless the storage was rewritten
+    assert sizes[-1][0] == 8 and sizes[-1][2] < 16000
+    win.close()
+
+
 def test_window_misuse(ctx):
     pr = make_ba_problem(P=4, L=60, obs_per_lm=4, seed=2)
     feed = _window_feed(pr)
