@@ -58,7 +58,7 @@ def level_pixels(rows, cols, scale=1.2, nlevels=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs (and BA windows) per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=16, help="stereo pairs + windows timed on the CPU baseline")
@@ -116,7 +116,7 @@ def main():
     imgs = torch.from_numpy(host).to(dev)
     torch.cuda.synchronize(dev)
     counts = orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)   # plans, runs once, syncs
-    N_WIN = 4                                                          # distinct C3 graphs, used round-robin
+    N_WIN = 16 if not args.lean else 4                                 # distinct C3 graphs, used round-robin
     wins = [make_ba_problem(P=10, L=4000, seed=1 + 17 * k + 1000 * rank) for k in range(N_WIN)]
     step_windows = [wins[i % N_WIN] for i in range(B)]
     # the windows are resident in HBM like the images (ssx_ba_batch_create: marshalled + uploaded before the clock starts);

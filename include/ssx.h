@@ -261,6 +261,10 @@ SSX_API ssx_status ssx_ba_window_solve(ssx_ba_window* win, ssx_ba_result* res);
  * The options of the first window apply. */
 SSX_API ssx_status ssx_ba_window_solve_batch(int32_t n, ssx_ba_window* const* wins, ssx_ba_result* results);
 
+/* test hook, needs no GPU: `steps` random pushes / pops on a window without a device, its contents checked against a plain model
+ * after every step; 0 = all steps agree, else the first step that does not */
+SSX_API int32_t ssx_ba_window_selftest(uint32_t seed, int32_t steps);
+
 /* tools hook, needs no GPU: dynamic LDS bytes a BA kernel is launched with (-1: depends on the problem); the compiler's
  * resource report and rocprofv3's dispatch rows only know static __shared__ arrays (tools/kernel_resources.py) */
 SSX_API int64_t ssx_debug_kernel_dynamic_lds(const char* kernel);

@@ -737,6 +737,39 @@ def test_resident_window_equals_fresh_solves(ctx):
         w.close()
 
 
+def test_resident_window_matches_reference_golden(ctx):
+    """The reference's own window (12 keyframes, config/kitti_00.yaml:30) built by PUSHING its keyframes into an ssx_ba_window
+    and solved in place, against the vectors of the compiled reference (tests/golden/ref_golden.npz): rounds, LM iterations,
+    trial counts, chi2 trajectory, final poses, per-edge residuals -- the incremental path against g2o, no oracle in between."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz"))
+    for name in ("win12", "C3"):
+        pr = _golden_problem(G, name)
+        for jac in (ba.JAC_NUMERIC_G2O, ba.JAC_ANALYTIC):
+            win = ba.BaWindow(ctx, pr["K"], pr["cam_ext"], jac_mode=jac)
+            for k, f in enumerate(_window_feed(pr)):
+                win.push(k, **f)
+            ex = win.export()
+            g = win.solve()
+            win.close()
+            assert g["rounds"] == int(G[f"ba_{name}_rounds"]) and g["n_iters"] == len(G[f"ba_{name}_chi2"])
+            np.testing.assert_array_equal(g["trials"], G[f"ba_{name}_trials"])
+            np.testing.assert_allclose(g["chi2"], G[f"ba_{name}_chi2"], rtol=2e-5)
+            assert np.abs(g["poses"] - G[f"ba_{name}_poses"]).max() < 5e-6          # keyframes were pushed in pose order: slot = pose index
+            # the window lists observations keyframe by keyframe, the golden vectors landmark by landmark: match them up
+            key_w = ex["edge_pose"].astype(np.int64) * 10 ** 7 + (ex["lm_ids"][ex["edge_point"]] - 1000)
+            key_g = pr["edge_pose"].astype(np.int64) * 10 ** 7 + pr["edge_point"]
+            order = np.argsort(key_w)[np.argsort(np.argsort(key_g))]
+            assert np.array_equal(key_w[order], key_g)
+            ec = g["edge_chi2"][order][G[f"ba_{name}_edge_sel"]]
+            d = np.abs(np.sqrt(ec) - np.sqrt(G[f"ba_{name}_edge_chi2"]))
+            frac, p99 = float((d <= RESID_TOL).mean()), float(np.percentile(d, 99))
+            print(f"[window {name} jac={jac}] |r_gpu - r_ref| px: median {np.median(d):.2e} p99 {p99:.2e} max {d.max():.2e} <=1e-4: {100 * frac:.2f} %")
+            assert frac >= 0.99 and p99 <= 1.5e-4
+            if jac == ba.JAC_ANALYTIC:
+                assert d.max() < RESID_TOL
+
+
 def test_window_storage_is_rewritten_when_mostly_dead(ctx):
     """A window that slides for a long time: the observation blocks of popped keyframes stay as dead entries until more than
     half of the storage (and more than 1024 entries) is dead, then the storage is rewritten and re-sent.  Before and after the

@@ -16,3 +16,8 @@ for kw in (dict(P=10,L=4000,obs_per_lm=5,seed=3), dict(P=12,L=1500,obs_per_lm=4,
     st=ba._problem_struct(pr, keep)
     print(kw, "prepare: %.3f ms" % (1e3*lib.ssx_ba_debug_prepare_seconds(C.byref(st), 3)))
 print("done")
+# round 3: the host side of ssx_ba_window (slots, id map, dead blocks, storage rewrite) against its model
+lib.ssx_ba_window_selftest.restype = C.c_int32; lib.ssx_ba_window_selftest.argtypes = [C.c_uint32, C.c_int32]
+for seed in (0, 5, 9):
+    print("window selftest seed", seed, "->", lib.ssx_ba_window_selftest(seed, 500))
+print("done (window)")
