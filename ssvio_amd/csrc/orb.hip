@@ -57,18 +57,24 @@ struct ResizeQuad {          // 32 bytes
 };
 
 constexpr int RS_ROWS = 4;   // destination rows per thread: their 8 source-row loads are issued together
+constexpr int RS_LOOP = 4;   // such groups per wave, one after the other
 template <bool WIDE8>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base,
                                                 size_t img_stride_bytes, int spitch, int drows, int dcols, int dpitch,
                                                 const ResizeQuad* __restrict__ xtab, const uint2* __restrict__ ytab)
 {
   const int q = blockIdx.x * 64 + threadIdx.x;      // quad of destination columns
-  // a wave = RS_ROWS consecutive destination rows of one quad column range: row tables and bases are scalar
-  const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_ROWS;
-  if (dy0 >= drows || 4 * q >= dcols) return;
+  if (4 * q >= dcols) return;
   const uint8_t* src = src_base + (size_t)blockIdx.z * img_stride_bytes;
   uint8_t* dst = dst_base + (size_t)blockIdx.z * img_stride_bytes;
   const uint4 ta = reinterpret_cast<const uint4*>(xtab)[2 * q], tw = reinterpret_cast<const uint4*>(xtab)[2 * q + 1];
+  // RS_LOOP groups of RS_ROWS rows per wave: a quarter of the workgroups (the big levels launched 12 800 of them for 82 us:
+  // their rate, not their work, set the time) and one column-table fetch for 16 rows instead of 4
+#pragma unroll 1
+  for (int it = 0; it < RS_LOOP; ++it) {
+  // a wave = RS_ROWS consecutive destination rows of one quad column range: row tables and bases are scalar
+  const int dy0 = ((blockIdx.y * RS_LOOP + it) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_ROWS;
+  if (dy0 >= drows) break;
   // the kernel is bound by dependent memory round trips (table -> source rows), not by bandwidth or VALU: issue
   // all source-row loads of the RS_ROWS rows before the first use
   uint32_t p00[RS_ROWS], p01[RS_ROWS], p10[RS_ROWS], p11[RS_ROWS];
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src_
     }
     if (dy0 + r < drows) *reinterpret_cast<uint32_t*>(dst + (size_t)(dy0 + r) * dpitch + 4 * q) = out;
   }
+  }   // row groups
 }
 
 // copy a pitched host-layout image into level 0 of the pyramid (pitch change): 8 destination bytes per thread
@@ -1126,7 +1133,7 @@ static void launch_pyramid(ssx_ctx* ctx, const OrbDev& d, hipStream_t s, int ima
 {
   for (int l = 1; l < d.nlevels; ++l) {
     if (d.lvl_cols[l] <= 0 || d.lvl_rows[l] <= 0) break;     // a tiny image runs out of pixels before it runs out of levels: nothing there
-    const dim3 grid((d.lvl_cols[l] + 255) / 256, (d.lvl_rows[l] + 4 * RS_ROWS - 1) / (4 * RS_ROWS), images);
+    const dim3 grid((d.lvl_cols[l] + 255) / 256, (d.lvl_rows[l] + 4 * RS_ROWS * RS_LOOP - 1) / (4 * RS_ROWS * RS_LOOP), images);
     auto kern = d.rs_wide8[l] ? k_resize<true> : k_resize<false>;
     for (int m = 0; m < (d.has_mask ? 2 : 1); ++m) {
       uint8_t* pyr = m ? d.maskpyr : d.pyr;
