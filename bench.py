@@ -210,7 +210,8 @@ def main():
         from ssvio_amd._lib import BaResult, dbl_p, u8_p, ptr
         CH_STEPS = max(3, args.steps // 4)
         n_kf_total = 10 + CH_STEPS + 3
-        traj = [make_ba_problem(P=n_kf_total, L=400 * (n_kf_total - 4), seed=900 + k + 1000 * rank) for k in range(N_WIN)]
+        N_TRAJ = 4                                                       # distinct trajectories (the generator is a Python loop over observations)
+        traj = [make_ba_problem(P=n_kf_total, L=400 * (n_kf_total - 4), seed=900 + k + 1000 * rank) for k in range(N_TRAJ)]
         i64_p = C.POINTER(C.c_int64)
 
         def feed_of(pr):
@@ -254,11 +255,11 @@ def main():
         G_W = max(1, min(int(os.environ.get("SSX_BENCH_WINDOW_THREADS", "2")), B))
         ctx_w = [ssvio_amd.Context(dev_index) for _ in range(G_W)]
         grp_of = [i * G_W // B for i in range(B)]
-        wins_r = [ba.BaWindow(ctx_w[grp_of[i]], traj[i % N_WIN]["K"], traj[i % N_WIN]["cam_ext"]) for i in range(B)]
+        wins_r = [ba.BaWindow(ctx_w[grp_of[i]], traj[i % N_TRAJ]["K"], traj[i % N_TRAJ]["cam_ext"]) for i in range(B)]
         lib = ctx_ba.lib
         for i, w in enumerate(wins_r):
             for k in range(10):
-                w.ctx.check(lib.ssx_ba_window_push_keyframe_slots(w.handle, k, *feeds[i % N_WIN][k]["args_slots"]))
+                w.ctx.check(lib.ssx_ba_window_push_keyframe_slots(w.handle, k, *feeds[i % N_TRAJ][k]["args_slots"]))
         groups = []
         keep_out = []
         for g in range(G_W):
@@ -280,7 +281,7 @@ def main():
                 for k in range(k0, k1):
                     for i in idx:
                         lib.ssx_ba_window_pop_keyframe(wins_r[i].handle, k - 10)
-                        ctx_w[g].check(lib.ssx_ba_window_push_keyframe_slots(wins_r[i].handle, k, *feeds[i % N_WIN][k]["args_slots"]))
+                        ctx_w[g].check(lib.ssx_ba_window_push_keyframe_slots(wins_r[i].handle, k, *feeds[i % N_TRAJ][k]["args_slots"]))
                     tq = time.perf_counter()
                     ctx_w[g].check(lib.ssx_ba_window_solve_batch(len(idx), hs_arr, res_arr))
                     t_solve[g] += time.perf_counter() - tq
