@@ -118,7 +118,9 @@ def main():
     torch.cuda.synchronize(dev)
     counts = orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)   # plans, runs once, syncs
     N_WIN = 16 if not args.lean else 4                                 # distinct C3 graphs, used round-robin
-    wins = [make_ba_problem(P=10, L=4000, seed=1 + 17 * k + 1000 * rank) for k in range(N_WIN)]
+    # (uv_f32: the measurements are float values, as the reference's keypoints are -- cv::KeyPoint::pt; it only matters to the
+    # host-buffer regions, where the library then sends 8 instead of 16 bytes of coordinates per observation)
+    wins = [make_ba_problem(P=10, L=4000, seed=1 + 17 * k + 1000 * rank, uv_f32=True) for k in range(N_WIN)]
     step_windows = [wins[i % N_WIN] for i in range(B)]
     # the windows are resident in HBM like the images (ssx_ba_batch_create: marshalled + uploaded before the clock starts);
     # a second, non-resident batch object measures the same work with host marshalling + PCIe inside the region
@@ -131,7 +133,7 @@ def main():
 
     def composite_step_host():
         orb.stereo_batch_enqueue(ctx)
-        return batch_host.solve(want_edges=False)                      # marshal + upload + solve + download poses / points
+        return batch_host.solve(want_edges=False, summaries=False)                      # marshal + upload + solve + download poses / points
 
     # ---------------- timed region 1 (the headline): front-end + one local BA per pair ----------------
     for _ in range(args.warmup):
@@ -170,12 +172,12 @@ def main():
         ctx_p = [ssvio_amd.Context(dev_index) for _ in range(2)]
         bh = [ba.BaBatch(c, step_windows) for c in ctx_p]
         for b_ in bh:
-            b_.solve(want_edges=False)
+            b_.solve(want_edges=False, summaries=False)
         PSTEPS = max(2, args.steps // 4)
 
         def pipe_worker(k):
             for _ in range(PSTEPS):
-                bh[k].solve(want_edges=False)
+                bh[k].solve(want_edges=False, summaries=False)
 
         # (no collective in here: an exception on one rank must not leave the others waiting; rank 0's own clock, times the ranks)
         torch.cuda.synchronize(dev)

@@ -272,6 +272,12 @@ SSX_API int64_t ssx_debug_kernel_dynamic_lds(const char* kernel);
 /* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */
 SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps);
 
+/* tools / tests hook, needs no GPU: how ssx_ba_solve / ssx_ba_solve_batch would send this problem's observation arrays
+ * across PCIe (lossless narrowing): bit 0 = keyframe indices as bytes, bit 1 = landmark indices as 16-bit words, bit 2 =
+ * pixel coordinates as floats (every edge_uv value is a float's value, as the reference's cv::KeyPoint::pt measurements
+ * are); 0 = as handed over (large windows, SSX_BA_WIDE_UPLOAD / SSX_BA_HOST_PREP set); -1 = invalid problem */
+SSX_API int32_t ssx_ba_debug_upload_format(const ssx_ba_problem* prob);
+
 /* One linearisation of the problem at its current state (no update): the blocks the kernels build,
  * for kernel-level parity tests and profiling.  Any output may be NULL.
  *   Hpp P x 36 (row-major 6x6), bp P x 6, Hll L x 9, bl L x 3, Hpl E x 18 (6x3 row-major, per edge),

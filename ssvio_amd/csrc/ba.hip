@@ -150,6 +150,8 @@ struct BaDev {
   GPtr<const double> r_edge_uv;   // E x 2 interleaved
   GPtr<const uint8_t> r_edge_cam; // E or null
   GPtr<const uint8_t> r_slot8;    // E: rank of the edge among its landmark's edges (caller's order)
+  int raw_fmt;                    // how the raw arrays crossed PCIe (lossless): bit 0 = r_edge_pose holds bytes, bit 1 = r_edge_point holds
+                                  // 16-bit words, bit 2 = r_edge_uv holds floats (every coordinate was a float's value: keypoints are)
   GPtr<const int> lm_compact;     // L: caller's landmark -> compact landmark or -1
   GPtr<int> perm;                 // E: sorted edge -> caller's edge
   GPtr<int> lm_chunk;             // nLm: compact landmark -> chunk (large windows, device-marshalled: the pair builder reads it)
@@ -875,11 +877,24 @@ __global__ __launch_bounds__(CH) void k_build_lists_b(const BaDev* __restrict__ 
 //                    sorted -> caller permutation; then the chunk's pair lists and work items (k_build_lists_body)
 // Byte for byte the arrays of the host marshalling (SSX_BA_HOST_PREP=1; test_device_marshalling_equals_host_marshalling).
 // ------------------------------------------------------------------------------------------------
+#define SSX_AS1(T) const __attribute__((address_space(1))) T*
+__device__ __forceinline__ int raw_pose(const BaDev& d, int e)
+{
+  return (d.raw_fmt & 1) ? (int)((SSX_AS1(uint8_t))d.r_edge_pose.get())[e] : d.r_edge_pose[e];
+}
+__device__ __forceinline__ int raw_point(const BaDev& d, int e)
+{
+  return (d.raw_fmt & 2) ? (int)((SSX_AS1(uint16_t))d.r_edge_point.get())[e] : d.r_edge_point[e];
+}
+__device__ __forceinline__ double raw_uv(const BaDev& d, size_t i)
+{
+  return (d.raw_fmt & 4) ? (double)((SSX_AS1(float))d.r_edge_uv.get())[i] : d.r_edge_uv[i];
+}
 __device__ __forceinline__ void k_prep_scatter_body(const BaDev& d, const int bx)
 {
   const int e = bx * CH + threadIdx.x;
   if (e >= d.E_raw) return;
-  const int l = d.r_edge_point[e];
+  const int l = raw_point(d, e);
   if (l < 0) return;                                  // a dead entry of a window's storage
   d.perm[d.lm_ptr[d.lm_compact[l]] + d.r_slot8[e]] = e;
 }
@@ -906,7 +921,7 @@ __device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
   if (t < ne) {
     const int og = d.perm[e0 + t];
     sOrig[t] = og;
-    sPose[t] = d.r_edge_pose[og];
+    sPose[t] = raw_pose(d, og);
   }
   int lm_a0 = 0, lm_k = 0;
   if (t < nl) {
@@ -969,8 +984,8 @@ __device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
     const_cast<int4*>(static_cast<const int4*>(d.e_rec.p))[e] = make_int4(pose, pf, sLid[l], flags);
     const_cast<uint8_t*>(static_cast<const uint8_t*>(d.e_dup.p))[e] = dup ? 1 : 0;
     double* uv = const_cast<double*>(static_cast<const double*>(d.e_uv.p));
-    uv[e] = d.r_edge_uv[2 * (size_t)og];
-    uv[(size_t)E + e] = d.r_edge_uv[2 * (size_t)og + 1];
+    uv[e] = raw_uv(d, 2 * (size_t)og);
+    uv[(size_t)E + e] = raw_uv(d, 2 * (size_t)og + 1);
     d.perm[e] = og;
     if (!small) {                                                  // the structure-of-arrays columns the large-window kernels read
       const_cast<int*>(static_cast<const int*>(d.e_pose.p))[e] = pose;
@@ -1621,6 +1636,7 @@ namespace {
 struct HostPrep {
   int P, L, E, nP, nLm, nCh, nBlk;
   int E_raw = 0;                     // entries of the caller's edge arrays (E of them alive; see BaDev::E_raw)
+  int raw_fmt = 0;                   // BaDev::raw_fmt of the blob this window is uploaded in
   std::vector<int> pose_free, lm_id, lm_ptr, ch_lm, e_pose, e_lmc, perm, pair_ptr;
   std::vector<uint8_t> lm_fixed, e_cam, e_dup, pair_a, pair_b;
   std::vector<uint16_t> pptr;
@@ -1813,6 +1829,19 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   }
   if (n_dead && !h.dev_prep) { ctx->set_error("ssx_ba: dead observations need the device-side marshalling"); return SSX_ERR_UNSUPPORTED; }
   h.E = E - n_dead;
+  // Lossless narrowing of the raw arrays on their way across PCIe (26 -> 13 bytes per observation): pose indices as bytes,
+  // landmark indices as 16-bit words, and the pixel coordinates as floats when every one of them IS a float's value -- the
+  // reference's measurements are cv::KeyPoint::pt (Point2f) widened to double (frontend.cpp:232-236, backend.cpp:126-160).
+  h.raw_fmt = 0;
+  static const bool wide_env = getenv("SSX_BA_WIDE_UPLOAD") != nullptr;
+  if (h.dev_prep && !h.big && !dead_ok && !wide_env) {
+    if (P <= 256) h.raw_fmt |= 1;
+    if (L <= 65536) h.raw_fmt |= 2;
+    bool exact = true;
+    const double* uvp = pr->edge_uv;
+    for (size_t i = 0; i < 2 * (size_t)E; ++i) exact &= (double)(float)uvp[i] == uvp[i];
+    if (exact) h.raw_fmt |= 4;
+  }
   h.lm_id.clear(); h.lm_ptr.clear(); h.lm_fixed.clear();
   std::vector<int>& lm_compact = h.lm_compact;
   std::vector<int>& start = h.start_tmp;
@@ -2103,9 +2132,10 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const bool raw_in = dev_prep && !ext;
   const bool have_cam = dev_prep && (ext ? ext->r_edge_cam != nullptr : pr->edge_cam != nullptr);
   const size_t o_lm_compact = in.take(dev_prep ? sizeof(int) * (size_t)(L + 1) : 0);
-  const size_t o_r_pose = in.take(raw_in ? sizeof(int) * (size_t)(E + 1) : 0);
-  const size_t o_r_point = in.take(raw_in ? sizeof(int) * (size_t)(E + 1) : 0);
-  const size_t o_r_uv = in.take(raw_in ? sizeof(double) * 2 * (size_t)(E + 1) : 0);
+  const int raw_fmt = raw_in && !rz ? h.raw_fmt : 0;
+  const size_t o_r_pose = in.take(raw_in ? ((raw_fmt & 1) ? 1 : sizeof(int)) * (size_t)(E + 1) : 0);
+  const size_t o_r_point = in.take(raw_in ? ((raw_fmt & 2) ? sizeof(uint16_t) : sizeof(int)) * (size_t)(E + 1) : 0);
+  const size_t o_r_uv = in.take(raw_in ? ((raw_fmt & 4) ? sizeof(float) : sizeof(double)) * 2 * (size_t)(E + 1) : 0);
   const size_t o_r_cam = in.take(have_cam && raw_in ? (size_t)E + 1 : 0);
   const size_t o_slot8 = in.take(dev_prep ? (size_t)E_raw + 1 : 0);
   // (host-built lists travel with the blob; device-built ones are scratch behind it, a fixed capacity per chunk)
@@ -2217,9 +2247,12 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   if (dev_prep) {
     if (L) memcpy(hs + o_lm_compact, h.lm_compact.data(), sizeof(int) * (size_t)L);
     if (E && raw_in) {
-      memcpy(hs + o_r_pose, pr->edge_pose, sizeof(int) * (size_t)E);
-      memcpy(hs + o_r_point, pr->edge_point, sizeof(int) * (size_t)E);
-      memcpy(hs + o_r_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E);
+      if (raw_fmt & 1) { uint8_t* o = (uint8_t*)(hs + o_r_pose); for (int e = 0; e < E; ++e) o[e] = (uint8_t)pr->edge_pose[e]; }
+      else memcpy(hs + o_r_pose, pr->edge_pose, sizeof(int) * (size_t)E);
+      if (raw_fmt & 2) { uint16_t* o = (uint16_t*)(hs + o_r_point); for (int e = 0; e < E; ++e) o[e] = (uint16_t)pr->edge_point[e]; }
+      else memcpy(hs + o_r_point, pr->edge_point, sizeof(int) * (size_t)E);
+      if (raw_fmt & 4) { float* o = (float*)(hs + o_r_uv); for (size_t i = 0; i < 2 * (size_t)E; ++i) o[i] = (float)pr->edge_uv[i]; }
+      else memcpy(hs + o_r_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E);
       if (have_cam) memcpy(hs + o_r_cam, pr->edge_cam, (size_t)E);
     }
     if (E_raw) memcpy(hs + o_slot8, h.slot8.data(), (size_t)E_raw);
@@ -2312,6 +2345,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.bseg_cap = bseg_cap;
   d.dev_prep = dev_prep ? 1 : 0;
   d.E_raw = E_raw;
+  d.raw_fmt = raw_fmt;
   if (ext) {
     d.r_edge_pose = ext->r_edge_pose; d.r_edge_point = ext->r_edge_point; d.r_edge_uv = ext->r_edge_uv; d.r_edge_cam = ext->r_edge_cam;
   } else {
@@ -3301,11 +3335,16 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   const int hw = (int)std::thread::hardware_concurrency();
   const int T = std::max(1, std::min({n, 16, hw > 1 ? hw / 2 : 1}));
   B->ctx = ctx; B->device = ctx->device; B->n = n; B->opt = opt; B->threads = T; B->with_err = with_err;
+  static const bool timing = getenv("SSX_BATCH_TIMING") != nullptr;   // phase times of the call on stderr (tools/batch_time.py)
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+  const auto t_begin = now();
   // ---- 1. host marshalling of every window (edge sort, chunks, index lists), T threads
   std::vector<ssx_status> sts(n, SSX_OK);
   ws->pool.run(n, T, [&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w], true, exts != nullptr); });
   for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
   for (int w = 0; w < n; ++w) if (preps[w].big || (exts && !preps[w].dev_prep)) return SSX_ERR_UNSUPPORTED;
+  const double t_prepare = ms_since(t_begin);
   B->probs = probs;
   if (exts) B->exts.assign(exts, exts + n); else B->exts.clear();
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -3345,8 +3384,14 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   SSX_HIP_TRY(ctx, B->scal->reserve(sizeof(double) * (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS) + sizeof(int) * 3 * n + 64));
   char* dev_base = B->arena->as<char>();
   char* hst = B->stage->as<char>();
-  // ---- 3. fill the pinned mirror (T threads), one upload
-  ws->pool.run(n, T, [&](int w) {
+  // ---- 3. fill the pinned mirror (T threads) and upload it, in Q pieces: the copy engine moves one piece while the threads fill
+  // the next (128 C3 windows: 0.7 ms of filling, 1.65 ms on PCIe for 86 MB)
+  static const int pieces_env = getenv("SSX_BA_UPLOAD_PIECES") ? std::min(std::max(atoi(getenv("SSX_BA_UPLOAD_PIECES")), 1), 16) : 4;
+  const int Q = n >= 32 && !exts ? pieces_env : 1;                   // (resident windows send a few KB each: one piece)
+  for (int q = 0; q < Q; ++q) {
+  const int q0 = (int)((long long)n * q / Q), q1 = (int)((long long)n * (q + 1) / Q);
+  ws->pool.run(q1 - q0, T, [&](int wi) {
+    const int w = q0 + wi;
     BigDev bd; BandDev bnd;
     place[w].dry = false;
     place[w].in_dev = dev_base + B->a_head + in_off[w];
@@ -3356,7 +3401,13 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     B->devs[w].store_w = opt.jac_mode == SSX_JAC_NUMERIC_G2O ? 1 : 0;
     if (with_err) B->perm[w] = preps[w].perm;
   });
-  for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
+  for (int w = q0; w < q1; ++w) if (sts[w] != SSX_OK) { (void)hipStreamSynchronize(ctx->stream); return sts[w]; }
+  if (q + 1 < Q) {
+    const size_t b0 = in_off[q0], b1 = in_off[q1];
+    if (b1 > b0) SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + B->a_head + b0, hst + b0, b1 - b0, hipMemcpyHostToDevice, ctx->stream));
+  }
+  }
+  const size_t up0 = Q > 1 ? in_off[(int)((long long)n * (Q - 1) / Q)] : 0;   // the last piece goes with the tail
   memcpy(hst + in_total + B->o_dv, B->devs.data(), sizeof(BaDev) * n);
   memset(hst + in_total + B->o_ctrl, 0, sizeof(int) * 3 * n);
   memcpy(hst + in_total + B->o_ooff, B->out_off.data(), sizeof(size_t) * n);
@@ -3369,7 +3420,10 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     B->max_rs = std::max(B->max_rs, (d.nBlk * 36 + d.nP * 6 + 63) / 64);
     if (6 * d.nP <= NB) B->any_solve64 = true; else if (6 * d.nP <= 80) B->any_solve80 = true; else B->any_solve = true;
   }
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + B->a_head, hst, head_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const double t_fill = ms_since(t_begin);
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(dev_base + B->a_head + up0, hst + up0, head_bytes - up0, hipMemcpyHostToDevice, ctx->stream));
+  double t_up = 0.0;
+  if (timing) { (void)hipStreamSynchronize(ctx->stream); t_up = ms_since(t_begin); }
   {
     // pair lists + work items of every window, on the device (windows marshalled with SSX_BA_HOST_LISTS brought theirs along)
     const BaDev* dvb = reinterpret_cast<const BaDev*>(dev_base + B->a_head + in_total + B->o_dv);
@@ -3380,6 +3434,11 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     if (any_prep) hipLaunchKernelGGL(k_prep_scatter_b, dim3((max_e + CH - 1) / CH, n), dim3(CH), 0, ctx->stream, dvb);
     hipLaunchKernelGGL(k_prep_chunk_b, dim3(B->max_ch, n), dim3(CH), 0, ctx->stream, dvb);
     SSX_HIP_TRY(ctx, hipGetLastError());
+  }
+  if (timing) {
+    (void)hipStreamSynchronize(ctx->stream);
+    fprintf(stderr, "[batch_build n=%d] prepare %.3f | sizes + fill (+ upload of 3 pieces of 4) %.3f | %.1f MB on the device %.3f later | device marshalling %.3f ms\n", n, t_prepare,
+            t_fill - t_prepare, head_bytes / 1e6, t_up - t_fill, ms_since(t_begin) - t_up);
   }
   B->fresh = true;                                                   // the state buffers hold the uploaded state
   const size_t lds_schur = schur_lds_bytes();
@@ -3548,6 +3607,8 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  static const bool timing = getenv("SSX_BATCH_TIMING") != nullptr;
+  const auto t_unpack = std::chrono::steady_clock::now();
   ctx->ba->pool.run(n, B->threads, [&](int w) {
     ssx_ba_result& r = results[w];
     const WinState& st = wsn[w];
@@ -3584,6 +3645,9 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     r.ms_total = ms;
     r.ms_setup = 0.f;
   });
+  if (timing)
+    fprintf(stderr, "[batch_run n=%d] solve + download of %.1f MB %.3f (GPU clock) | unpack %.3f ms\n", n, sizeof(double) * B->out_total / 1e6, ms,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_unpack).count());
   return SSX_OK;
 }
 
@@ -3614,6 +3678,15 @@ double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps)
   for (int i = 0; i < reps; ++i)
     if (prepare(&dummy, prob, h) != SSX_OK) return -1.0;
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+}
+
+int32_t ssx_ba_debug_upload_format(const ssx_ba_problem* prob)
+{
+  if (!prob) return -1;
+  ssx_ctx dummy;
+  static thread_local HostPrep h;
+  if (prepare(&dummy, prob, h) != SSX_OK) return -1;
+  return h.raw_fmt;
 }
 
 ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt_in, ssx_ba_result* results)

@@ -56,7 +56,7 @@ def stereo_cam_ext(baseline=KITTI_BASELINE):
 
 def make_ba_problem(P=10, L=4000, obs_per_lm=5, seed=1, frac_fixed=0.15, frac_gross=0.03,
                     pix_sigma=0.5, gross_sigma=30.0, pose_t_noise=0.02, pose_r_noise=0.002,
-                    point_noise=0.0, loop=False, fix_first_pose=False, K=KITTI_K, wrap=False, shuffle_poses=False):
+                    point_noise=0.0, loop=False, fix_first_pose=False, K=KITTI_K, wrap=False, shuffle_poses=False, uv_f32=False):
     """Synthetic BA graph of SURVEY.md section 8-D.
 
     C3 (local BA): P=10, L=4000, obs_per_lm=5 -> E=20000, 15 % fixed landmarks, no pose fixed
@@ -66,6 +66,9 @@ def make_ba_problem(P=10, L=4000, obs_per_lm=5, seed=1, frac_fixed=0.15, frac_gr
     wrap=True (with loop=True): landmarks near the end of the loop are also seen by the first keyframes -- a closed
     loop, the co-visibility band wraps around.  shuffle_poses=True renumbers the keyframes at random (same graph, no
     band structure left in the pose order).
+
+    uv_f32=True: the measurements are float values widened to double, as the reference's are (cv::KeyPoint::pt is a
+    Point2f; backend.cpp:126-160 hands them to g2o as Vector2d) -- the library then sends them across PCIe as floats.
 
     Returns a dict of flat arrays in the layout of ssx_ba_problem (include/ssx.h).
     """
@@ -117,6 +120,8 @@ def make_ba_problem(P=10, L=4000, obs_per_lm=5, seed=1, frac_fixed=0.15, frac_gr
     edge_uv += rng.normal(0, pix_sigma, edge_uv.shape)
     gross = rng.random(E) < frac_gross
     edge_uv[gross] += rng.normal(0, gross_sigma, (int(gross.sum()), 2))
+    if uv_f32:
+        edge_uv = edge_uv.astype(np.float32).astype(np.float64)
 
     poses = gt.copy()
     for i in range(P):

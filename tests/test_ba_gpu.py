@@ -4,6 +4,7 @@ Tolerances: the north_star asks for reprojection residuals within 1e-4 px of the
 path and the oracle run the same algorithm (analytic or numeric Jacobians) in f64 with different
 summation orders, so the bars here are much tighter than that where the arithmetic allows.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -664,6 +665,45 @@ def _assert_same(a, b, what):
     for k in ("poses", "points", "chi2", "lam", "trials", "edge_chi2", "edge_outlier"):
         assert np.array_equal(a[k], b[k]), (what, k)
     assert a["rounds"] == b["rounds"] and a["n_iters"] == b["n_iters"], what
+
+
+def _upload_format(ctx, pr):
+    keep = []
+    st = ba._problem_struct(pr, keep)
+    ctx.lib.ssx_ba_debug_upload_format.restype = C.c_int32
+    ctx.lib.ssx_ba_debug_upload_format.argtypes = [C.POINTER(type(st))]
+    return int(ctx.lib.ssx_ba_debug_upload_format(C.byref(st)))
+
+
+def test_compact_upload_is_lossless(ctx):
+    """Observation arrays whose pixel coordinates are float values (as the reference's cv::KeyPoint measurements are) cross
+    PCIe as bytes / 16-bit words / floats (13 instead of 26 bytes per observation).  The window object keeps WIDE device
+    arrays (int / double) of the same observations: a fresh solve of what it exports (compact upload) and its own solve
+    (wide arrays) must agree bit for bit -- alone, in a batch next to a window whose coordinates are not floats, and with
+    right-camera observations."""
+    pr = make_ba_problem(P=10, L=1500, obs_per_lm=5, seed=91, pose_t_noise=0.05, uv_f32=True)
+    pr["edge_cam"] = (np.arange(len(pr["edge_pose"])) % 3 == 0).astype(np.uint8)
+    pw = make_ba_problem(P=10, L=1500, obs_per_lm=5, seed=92, pose_t_noise=0.05)
+    assert _upload_format(ctx, pr) == 7 and _upload_format(ctx, pw) == 3
+    win = ba.BaWindow(ctx, pr["K"], pr["cam_ext"])
+    for k, f in enumerate(_window_feed(pr)):
+        win.push(k, **f)
+    ex = win.export()
+    assert _upload_format(ctx, ex) == 7
+    fresh = ba.ba_solve(ctx, ex)
+    both = ba.BaBatch(ctx, [ex, pw]).solve()["results"]
+    alone = ba.ba_solve(ctx, pw)
+    got = win.solve()
+    _assert_same(got, fresh, "compact vs wide")
+    for k in ("poses", "points", "edge_chi2", "edge_outlier"):
+        assert np.array_equal(both[0][k], fresh[k]), k
+        assert np.array_equal(both[1][k], alone[k]), k
+    win.close()
+    # one coordinate that is not a float's value: the window goes up wide, and nothing else changes
+    pr2 = dict(pr); pr2["edge_uv"] = pr["edge_uv"].copy(); pr2["edge_uv"][17, 1] += 1e-9
+    assert _upload_format(ctx, pr2) == 3
+    r2 = ba.ba_solve(ctx, pr2)
+    assert r2["n_iters"] == ba.ba_solve(ctx, pr)["n_iters"] and np.isfinite(r2["chi2"][-1])
 
 
 def test_resident_window_equals_fresh_solves(ctx):
