@@ -425,11 +425,26 @@ __device__ __forceinline__ uint32_t udot2(uint32_t pair, uint32_t w, uint32_t ac
 constexpr int GT_RUN = 4;                       // consecutive tiles of one tile row per workgroup: the next tile's loads fly during this tile's passes
 constexpr int GT_NLD = ((GT_H + 6) * (GT_PITCH / 4) + 255) / 256;   // dwords of an input tile per thread (6)
 
-// the dwords thread t holds of input tile (x0, y0): aligned loads inside the image, reflect-101 gathers at its borders
-__device__ __forceinline__ void gauss_load_tile(const uint8_t* __restrict__ src, int rows, int cols, int pitch, int x0, int y0, int t, uint32_t (&v)[GT_NLD])
+// the dwords thread t holds of input tile (x0, y0).  Tiles inside the image: aligned loads.  Tiles at its border (a third of
+// level 0's tiles, all of the small levels'): the same aligned loads from the reflected row at a clamped column, and the
+// dwords that straddle the left / right edge of the image -- at most three per tile row -- are assembled from reflected bytes by
+// the first 3 x 38 threads (`fix` = the four bytes, `fix_at` = the dword's index in the tile or -1) and replace the clamped ones when the tile is
+// written to LDS.  (Each thread used to branch into the byte gather for each of its six dwords: every wave holds an edge dword,
+// so every wave took six dependent round trips per border tile.  Alone on the chip: 0.345 -> 0.326 ms per 256 images; 0.28 without
+// the fix-up threads, 0.21 with every tile read like an interior one -- 45 % of the tiles touch the border.)  One reflection is exact for the rows / columns that reach a stored
+// pixel of the image (at most 3 outside it); the ones further out only feed outputs that are never stored or land in the row
+// padding, and are clamped.
+__device__ __forceinline__ bool gauss_fixed_dword(int cols, int x0, int dwi)
+{
+  const int gx = x0 - 4 + 4 * dwi, gxa = cols & ~3;
+  return gx < 0 || gx == gxa || gx == gxa + 4;
+}
+__device__ __forceinline__ void gauss_load_tile(const uint8_t* __restrict__ src, int rows, int cols, int pitch, int x0, int y0, int t, uint32_t (&v)[GT_NLD],
+                                                uint32_t (&fix)[4], int& fix_at)
 {
   constexpr int NDW = GT_PITCH / 4;   // 34 dwords per tile row
   const bool interior = y0 >= 3 && y0 + GT_H + 3 <= rows && x0 >= 4 && x0 + GT_W + 4 <= cols;   // block-uniform
+  fix[0] = fix[1] = fix[2] = fix[3] = 0u; fix_at = -1;
   if (interior) {
     const uint8_t* base = src + (size_t)(y0 - 3) * pitch + (x0 - 4);
 #pragma unroll
@@ -438,8 +453,36 @@ __device__ __forceinline__ void gauss_load_tile(const uint8_t* __restrict__ src,
       const int r = i / NDW, dwi = i - r * NDW;
       v[k] = i < (GT_H + 6) * NDW ? *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * dwi) : 0u;
     }
-  } else {
+  } else if (rows >= 8 && cols >= 8) {
+    auto refl_row = [&](int y) { y = y < 0 ? -y : y; y = y >= rows ? 2 * rows - 2 - y : y; return min(max(y, 0), rows - 1); };
+    const int gx_max = (cols - 4) & ~3;
 #pragma unroll
+    for (int k = 0; k < GT_NLD; ++k) {
+      const int i = t + 256 * k;
+      const int r = i / NDW, dwi = i - r * NDW;
+      const int gx = min(max(x0 - 4 + 4 * dwi, 0), gx_max);
+      v[k] = i < (GT_H + 6) * NDW ? *reinterpret_cast<const uint32_t*>(src + (size_t)refl_row(y0 + r - 3) * pitch + gx) : 0u;
+    }
+    if (t < 3 * (GT_H + 6)) {
+      const int r = t / 3, which = t - 3 * r;
+      const int gx = which == 0 ? -4 : (cols & ~3) + 4 * (which - 1);
+      const int dwi = (gx - (x0 - 4)) >> 2;
+      if (gx >= x0 - 4 && dwi < NDW && (which > 0 || x0 == 0)) {
+        const uint8_t* row = src + (size_t)refl_row(y0 + r - 3) * pitch;
+        // (the four bytes stay in four registers until the tile is written to LDS: combining them here would wait for the loads)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          int x = gx + b;
+          x = x < 0 ? -x : x;
+          x = x >= cols ? 2 * cols - 2 - x : x;
+          fix[b] = row[min(max(x, 0), cols - 1)];
+        }
+        fix_at = r * NDW + dwi;
+      }
+    }
+  } else {
+    // (images of a few pixels: the general reflection)
+#pragma unroll 1
     for (int k = 0; k < GT_NLD; ++k) {
       const int i = t + 256 * k;
       const int r = i / NDW, dwi = i - r * NDW;
@@ -447,13 +490,9 @@ __device__ __forceinline__ void gauss_load_tile(const uint8_t* __restrict__ src,
       if (i < (GT_H + 6) * NDW) {
         const int gy = reflect101(y0 + r - 3, rows);
         const int gx = x0 - 4 + 4 * dwi;
-        if (gx >= 0 && gx + 3 < cols) {
-          w = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
-        } else {
-          const uint8_t* row = src + (size_t)gy * pitch;
-          w = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
-              ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
-        }
+        const uint8_t* row = src + (size_t)gy * pitch;
+        w = (uint32_t)row[reflect101(gx, cols)] | ((uint32_t)row[reflect101(gx + 1, cols)] << 8) |
+            ((uint32_t)row[reflect101(gx + 2, cols)] << 16) | ((uint32_t)row[reflect101(gx + 3, cols)] << 24);
       }
       v[k] = w;
     }
@@ -479,17 +518,36 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
   uint8_t* dst = o.blur + (size_t)img * o.pyr_bytes + o.lvl_off[level];
   constexpr int NDW = GT_PITCH / 4;   // 34 dwords per tile row
   uint32_t ld[GT_NLD];
-  gauss_load_tile(src, rows, cols, pitch, tx0 * GT_W, y0, t, ld);
+  uint32_t fix[4]; int fix_at;
+  gauss_load_tile(src, rows, cols, pitch, tx0 * GT_W, y0, t, ld, fix, fix_at);
+  // The results of a tile stay in registers and are stored one tile LATE, behind the next tile's loads: loads and stores share
+  // one counter on this target (vmcnt) and complete out of order with respect to each other, so the wait for a tile's input is
+  // s_waitcnt vmcnt(0) -- with the stores issued right after the column pass it also waited for their completion, every tile.
+  uint32_t outv[4];
+  const int og = t & 31, orq = t >> 5;                                // (the column pass's pixel quad and row quad)
+  auto store_tile = [&](int x0s) {
+    const int x = x0s + 4 * og;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + 4 * orq + j;
+      // the pitch is a multiple of the tile width: the dword store stays inside the row's padding
+      if (y < rows && x < pitch) *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x) = outv[j];
+    }
+  };
 #pragma unroll 1
   for (int tx_ = tx0; tx_ < tx1; ++tx_) {
   const int x0 = tx_ * GT_W;
+  const bool border_fix = rows >= 8 && cols >= 8 && !(y0 >= 3 && y0 + GT_H + 3 <= rows && x0 >= 4 && x0 + GT_W + 4 <= cols);
   if (tx_ > tx0) __syncthreads();                                  // the previous tile's column pass has read sRowP, its row pass sIn
 #pragma unroll
   for (int k = 0; k < GT_NLD; ++k) {
     const int i = t + 256 * k;
-    if (i < (GT_H + 6) * NDW) reinterpret_cast<uint32_t*>(sIn)[i] = ld[k];
+    // (a dword that straddles the image's edge comes from the fix-up threads; fix_at >= 0 only in border tiles of images >= 8 x 8)
+    if (i < (GT_H + 6) * NDW && !(border_fix && gauss_fixed_dword(cols, x0, i % NDW))) reinterpret_cast<uint32_t*>(sIn)[i] = ld[k];
   }
-  if (tx_ + 1 < tx1) gauss_load_tile(src, rows, cols, pitch, x0 + GT_W, y0, t, ld);   // in flight during the two passes below
+  if (fix_at >= 0) reinterpret_cast<uint32_t*>(sIn)[fix_at] = fix[0] | (fix[1] << 8) | (fix[2] << 16) | (fix[3] << 24);
+  if (tx_ + 1 < tx1) gauss_load_tile(src, rows, cols, pitch, x0 + GT_W, y0, t, ld, fix, fix_at);   // in flight during the two passes below
+  if (tx_ > tx0) store_tile(x0 - GT_W);
   __syncthreads();
   // row pass: tile column x sits at byte x + 4 of a tile row, so the taps of pixels 4g .. 4g+3 are bytes
   // 4g+1 .. 4g+10 = bytes 1 .. 10 of the dwords g, g+1, g+2
@@ -526,10 +584,8 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
     // weights of the vertical pairs: an even output row starts on a pair, an odd one in the middle of a pair
     constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
     constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
-    const int x = x0 + 4 * g;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int y = y0 + 4 * rq + j;
       const int k0 = j >> 1;
       const bool odd = j & 1;
       const uint32_t w0 = odd ? O0 : E0, w1 = odd ? O1 : E1, w2 = odd ? O2 : E2, w3 = odd ? O3 : E3;
@@ -546,11 +602,11 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
         // and then assumes the upper 16 bits of its result are zero, which they are not on gfx950
         a[c] = min(acc >> 16, 255u);
       }
-      // the pitch is a multiple of the tile width: the dword store stays inside the row's padding
-      if (y < rows && x < pitch) *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x) = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
+      outv[j] = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
     }
   }
   }   // tiles of the run
+  store_tile((tx1 - 1) * GT_W);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1183,7 +1239,8 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   // (level-0 candidates) and before the descriptors (blur).
   // (One or two images: the chain is latency bound either way and the event hand-offs cost more than the overlap
   // returns -- 0.319 against 0.312 ms for a single stereo pair -- so a single frame stays on one stream.)
-  const bool fork = !d.detect_only && ctx->aux != nullptr && d.I > 2;
+  static const bool no_fork_env = getenv("SSX_ORB_NO_FORK") != nullptr;   // (tools: every kernel alone on one stream, for per-kernel times)
+  const bool fork = !d.detect_only && ctx->aux != nullptr && d.I > 2 && !no_fork_env;
   if (fork) {
     SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
     SSX_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
