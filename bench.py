@@ -211,7 +211,8 @@ def main():
         import ctypes as C
         from ssvio_amd._lib import BaResult, dbl_p, u8_p, ptr
         CH_STEPS = max(3, args.steps // 4)
-        n_kf_total = 10 + CH_STEPS + 3
+        CH_WARM = 12                                                     # untimed steps: one full turnover of the windows (their storage has been rewritten once, every buffer has its final size)
+        n_kf_total = 10 + CH_WARM + CH_STEPS + 1
         N_TRAJ = 4                                                       # distinct trajectories (the generator is a Python loop over observations)
         traj = [make_ba_problem(P=n_kf_total, L=400 * (n_kf_total - 4), seed=900 + k + 1000 * rank) for k in range(N_TRAJ)]
         i64_p = C.POINTER(C.c_int64)
@@ -275,43 +276,79 @@ def main():
             groups.append((idx, hs_arr, res_arr))
         it_count = [0] * G_W
         t_solve = [0.0] * G_W
+        t_edit = [0.0] * G_W
         err_box = []
+        # the edits of a step, one ssx_ba_window_update per (window, step), built once (a C caller fills them from its map);
+        # every window gets its own output array for the slots of its new landmarks
+        from ssvio_amd._lib import BaWindowUpdate
+        lib.ssx_ba_window_update_batch.restype = C.c_int32
+        lib.ssx_ba_window_update_batch.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(BaWindowUpdate), C.POINTER(C.c_int32)]
+        upd = {}
+        for g in range(G_W):
+            idx = groups[g][0]
+            for k in range(10, 10 + CH_WARM + CH_STEPS):
+                arr = (BaWindowUpdate * len(idx))()
+                for j, i in enumerate(idx):
+                    a = feeds[i % N_TRAJ][k]
+                    so = np.zeros(len(a["new_ids"]), dtype=np.int32)
+                    keep_out.append(so)
+                    u = arr[j]
+                    u.pop = 1; u.pop_kf_id = k - 10; u.push = 1; u.kf_id = k
+                    u.pose7 = ptr(a["pose"], dbl_p); u.pose_fixed = 0; u.n_new = len(a["new_ids"]); u.new_ids = ptr(a["new_ids"], i64_p)
+                    u.new_xyz = ptr(a["new_xyz"], dbl_p); u.new_fixed = ptr(a["new_fixed"], u8_p); u.new_slots_out = ptr(so, i32p)
+                    u.n_obs = len(a["obs_slot"]); u.obs_slot = ptr(a["obs_slot"], i32p); u.obs_uv = ptr(a["obs_uv"], dbl_p)
+                upd[(g, k)] = arr
 
         def group_steps(g, k0, k1):
             idx, hs_arr, res_arr = groups[g]
             try:
                 for k in range(k0, k1):
-                    for i in idx:
-                        lib.ssx_ba_window_pop_keyframe(wins_r[i].handle, k - 10)
-                        ctx_w[g].check(lib.ssx_ba_window_push_keyframe_slots(wins_r[i].handle, k, *feeds[i % N_TRAJ][k]["args_slots"]))
+                    tq = time.perf_counter()
+                    ctx_w[g].check(lib.ssx_ba_window_update_batch(len(idx), hs_arr, upd[(g, k)], None))
+                    t_edit[g] += time.perf_counter() - tq
                     tq = time.perf_counter()
                     ctx_w[g].check(lib.ssx_ba_window_solve_batch(len(idx), hs_arr, res_arr))
                     t_solve[g] += time.perf_counter() - tq
+                    if os.environ.get("SSX_WIN_TIMING"):
+                        print(f"[bench] group {g} step {k}: solve call {1e3 * (time.perf_counter() - tq):.3f} ms (Python's clock)", file=sys.stderr)
                     it_count[g] += sum(res_arr[j].n_iters for j in range(len(idx)))
+                    step_bar.wait()
             except Exception as exc_:                                  # noqa: BLE001
                 err_box.append(exc_)
+                step_bar.abort()
+
+        # (the group threads live through warm-up and timed steps: a new thread's first HIP call costs ~10 ms of runtime set-up)
+        import concurrent.futures as cf
+        pool_w = cf.ThreadPoolExecutor(max_workers=G_W)
+
+        # one front-end batch per step, enqueued when the step starts (as in region 1: it runs beside the step's window solves);
+        # enqueueing all of them up front puts 100 ms of front-end kernels ahead of the solves' streams
+        step_bar = threading.Barrier(G_W + 1)
 
         def run_steps(k0, k1):
-            th_ = [threading.Thread(target=group_steps, args=(g, k0, k1)) for g in range(G_W)]
-            for t_ in th_:
-                t_.start()
-            for _ in range(k1 - k0):
-                orb.stereo_batch_enqueue(ctx)
-            for t_ in th_:
-                t_.join()
+            fut = [pool_w.submit(group_steps, g, k0, k1) for g in range(G_W)]
+            try:
+                for _ in range(k1 - k0):
+                    orb.stereo_batch_enqueue(ctx)
+                    step_bar.wait()
+            except threading.BrokenBarrierError:
+                pass
+            for f_ in fut:
+                f_.result()
             if err_box:
                 raise err_box[0]
 
         for g in range(G_W):
             ctx_w[g].check(lib.ssx_ba_window_solve_batch(len(groups[g][0]), groups[g][1], groups[g][2]))
-        run_steps(10, 12)
+        run_steps(10, 10 + CH_WARM)
         for c_ in ctx_w:
             c_.synchronize()
         barrier()
         it_count = [0] * G_W
         t_solve = [0.0] * G_W
+        t_edit = [0.0] * G_W
         t0 = time.perf_counter()
-        run_steps(12, 12 + CH_STEPS)
+        run_steps(10 + CH_WARM, 10 + CH_WARM + CH_STEPS)
         for c_ in ctx_w:
             c_.synchronize()
         torch.cuda.synchronize(dev)
@@ -319,14 +356,17 @@ def main():
         it_ch = sum(it_count)
         nkf, nlm, nob = wins_r[0].size()
         churn = {"value": round(world * B * CH_STEPS / ch_elapsed, 2), "unit": "stereo frames/s", "ms_per_step": round(ch_elapsed / CH_STEPS * 1e3, 4),
-                 "host_threads": G_W, "ms_per_step_inside_solve_calls": round(max(t_solve) / CH_STEPS * 1e3, 4), "window": {"keyframes": nkf, "landmarks": nlm, "observations": nob},
+                 "host_threads": G_W, "ms_per_step_inside_solve_calls": round(max(t_solve) / CH_STEPS * 1e3, 4),
+                 "ms_per_step_inside_update_calls": round(max(t_edit) / CH_STEPS * 1e3, 4), "window": {"keyframes": nkf, "landmarks": nlm, "observations": nob},
                  "lm_iterations_per_window": round(it_ch / (CH_STEPS * B), 2),
                  "what": "front-end batch + B resident sliding windows (ssx_ba_window) in G groups, one host thread + context per group: per step "
                          "every window pops its oldest keyframe and pushes a new one by landmark slots (pose, ~400 landmarks, ~2000 observations: "
-                         "the only data that crosses PCIe on the way in), then ssx_ba_window_solve_batch optimises the group's windows where they lie and returns "
-                         "poses + landmarks; rank 0's own clock.  ms_per_step_inside_solve_calls = the busiest thread's time inside "
-                         "ssx_ba_window_solve_batch (pending uploads, counting tables, device-side marshalling, solve, download); the rest of a "
-                         "step is the host's pop / push (~70 us per window on this box, memory-latency bound) and Python"}
+                         "the only data that crosses PCIe on the way in) -- one ssx_ba_window_update_batch call per group, the windows spread over "
+                         "the library's host threads -- then ssx_ba_window_solve_batch optimises the group's windows where they lie and returns "
+                         "poses + landmarks; rank 0's own clock.  ms_per_step_inside_solve_calls / _update_calls = the busiest thread's time inside "
+                         "ssx_ba_window_solve_batch (pending uploads, counting tables, device-side marshalling, solve, download) / inside "
+                         "ssx_ba_window_update_batch"}
+        pool_w.shutdown()
         for w in wins_r:
             w.close()
         for c_ in ctx_w:

@@ -244,6 +244,29 @@ SSX_API ssx_status ssx_ba_window_push_keyframe_slots(ssx_ba_window* win, int64_t
                                                      const uint8_t* new_fixed, int32_t* new_slots_out, int32_t n_obs,
                                                      const int32_t* obs_slot, const double* obs_uv, const uint8_t* obs_cam);
 SSX_API ssx_status ssx_ba_window_pop_keyframe(ssx_ba_window* win, int64_t kf_id);
+/* One keyframe replaced in each of n windows of ONE ctx, in one call, the windows spread over the ctx's host threads (the
+ * windows of concurrent streams all change at every keyframe; the edits are independent host work, ~25-70 us per window).
+ * Per window: pop != 0 -> ssx_ba_window_pop_keyframe(pop_kf_id); then push != 0 -> ssx_ba_window_push_keyframe (obs_lm) or
+ * _push_keyframe_slots (obs_lm NULL, obs_slot) with the remaining fields.  status_out (nullable) receives every window's own
+ * status; the call returns the first one that is not SSX_OK (a failing window is left as its own failing call leaves it, the
+ * others are updated).  The windows must be distinct. */
+typedef struct ssx_ba_window_update {
+  int32_t pop, push;
+  int64_t pop_kf_id, kf_id;
+  const double* pose7;
+  int32_t pose_fixed, n_new;
+  const int64_t* new_ids;
+  const double* new_xyz;
+  const uint8_t* new_fixed;
+  int32_t* new_slots_out;       /* slots form only */
+  int32_t n_obs, reserved;
+  const int64_t* obs_lm;        /* observations by landmark id, or NULL and ... */
+  const int32_t* obs_slot;      /* ... by slot (see ssx_ba_window_push_keyframe_slots) */
+  const double* obs_uv;
+  const uint8_t* obs_cam;
+} ssx_ba_window_update;
+SSX_API ssx_status ssx_ba_window_update_batch(int32_t n, ssx_ba_window* const* wins, const ssx_ba_window_update* updates,
+                                              ssx_status* status_out);
 /* overwrite the estimate / the fixed flag of a keyframe or landmark of the window (fixed < 0: unchanged; xyz NULL: unchanged) */
 SSX_API ssx_status ssx_ba_window_set_pose(ssx_ba_window* win, int64_t kf_id, const double* pose7, int32_t fixed);
 SSX_API ssx_status ssx_ba_window_set_landmark(ssx_ba_window* win, int64_t lm_id, const double* xyz, int32_t fixed);

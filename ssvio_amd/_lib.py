@@ -67,6 +67,14 @@ class BaResult(C.Structure):
                 ("ms_linear_solution", C.c_float), ("ms_update", C.c_float), ("ms_reduce", C.c_float), ("ms_comm", C.c_float)]
 
 
+class BaWindowUpdate(C.Structure):
+    """ssx_ba_window_update (include/ssx.h): one keyframe replaced in one window of an ssx_ba_window_update_batch call"""
+    _fields_ = [("pop", C.c_int32), ("push", C.c_int32), ("pop_kf_id", C.c_int64), ("kf_id", C.c_int64), ("pose7", dbl_p),
+                ("pose_fixed", C.c_int32), ("n_new", C.c_int32), ("new_ids", C.POINTER(C.c_int64)), ("new_xyz", dbl_p), ("new_fixed", u8_p),
+                ("new_slots_out", C.POINTER(C.c_int32)), ("n_obs", C.c_int32), ("reserved", C.c_int32), ("obs_lm", C.POINTER(C.c_int64)),
+                ("obs_slot", C.POINTER(C.c_int32)), ("obs_uv", dbl_p), ("obs_cam", u8_p)]
+
+
 class KeyPoint(C.Structure):
     """cv::KeyPoint layout (28 bytes): pt.x pt.y size angle response octave class_id."""
     _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),

@@ -375,6 +375,50 @@ class BaWindow:
         ctx.check(ctx.lib.ssx_ba_window_solve_batch(n, hs, arr))
         return [BaWindow._result_dict(arr[i], bufs[i]) for i in range(n)]
 
+    @staticmethod
+    def update_batch(windows, updates):
+        """ssx_ba_window_update_batch: one keyframe replaced in each window (of one Context) in one call, on the library's host
+        threads.  updates[i] = dict(pop=kf id or None, push=kf id or None, pose, new_ids, new_xyz, new_fixed, obs_lm | obs_slot,
+        obs_uv, obs_cam, pose_fixed); returns the slots of the new landmarks per window (slot form) or None."""
+        n = len(windows)
+        arr = (_lib.BaWindowUpdate * n)()
+        keep, slots = [], []
+        i64p = C.POINTER(C.c_int64)
+        for i, u in enumerate(updates):
+            a = arr[i]
+            a.pop = 0 if u.get("pop") is None else 1
+            a.pop_kf_id = 0 if u.get("pop") is None else int(u["pop"])
+            a.push = 0 if u.get("push") is None else 1
+            slots.append(None)
+            if not a.push:
+                continue
+            a.kf_id = int(u["push"])
+            pose = np.ascontiguousarray(u["pose"], dtype=np.float64).ravel()
+            new_ids = np.ascontiguousarray(u.get("new_ids", ()), dtype=np.int64).ravel()
+            new_xyz = np.ascontiguousarray(u.get("new_xyz", ()), dtype=np.float64).reshape(-1, 3)
+            new_fixed = None if u.get("new_fixed") is None else np.ascontiguousarray(u["new_fixed"], dtype=np.uint8)
+            obs_uv = np.ascontiguousarray(u.get("obs_uv", ()), dtype=np.float64).reshape(-1, 2)
+            obs_cam = None if u.get("obs_cam") is None else np.ascontiguousarray(u["obs_cam"], dtype=np.uint8)
+            a.pose7 = ptr(pose, dbl_p); a.pose_fixed = 1 if u.get("pose_fixed") else 0
+            a.n_new = len(new_ids); a.new_ids = ptr(new_ids, i64p); a.new_xyz = ptr(new_xyz, dbl_p); a.new_fixed = ptr(new_fixed, u8_p)
+            a.n_obs = len(obs_uv); a.obs_uv = ptr(obs_uv, dbl_p); a.obs_cam = ptr(obs_cam, u8_p)
+            if u.get("obs_slot") is not None:
+                obs_slot = np.ascontiguousarray(u["obs_slot"], dtype=np.int32).ravel()
+                so = np.zeros(len(new_ids), dtype=np.int32)
+                a.obs_slot = ptr(obs_slot, i32_p); a.new_slots_out = ptr(so, i32_p)
+                keep.append(obs_slot); slots[i] = so
+            else:
+                obs_lm = np.ascontiguousarray(u.get("obs_lm", ()), dtype=np.int64).ravel()
+                a.obs_lm = ptr(obs_lm, i64p)
+                keep.append(obs_lm)
+            keep.extend([pose, new_ids, new_xyz, new_fixed, obs_uv, obs_cam])
+        hs = (C.c_void_p * n)(*[w.handle for w in windows])
+        ctx = windows[0].ctx
+        ctx.lib.ssx_ba_window_update_batch.restype = C.c_int32
+        ctx.lib.ssx_ba_window_update_batch.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(_lib.BaWindowUpdate), C.POINTER(C.c_int32)]
+        ctx.check(ctx.lib.ssx_ba_window_update_batch(n, hs, arr, None))
+        return slots
+
     def close(self):
         if self.handle is not None:
             self.ctx.lib.ssx_ba_window_destroy(self.handle)

@@ -3335,7 +3335,8 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   const int hw = (int)std::thread::hardware_concurrency();
   const int T = std::max(1, std::min({n, 16, hw > 1 ? hw / 2 : 1}));
   B->ctx = ctx; B->device = ctx->device; B->n = n; B->opt = opt; B->threads = T; B->with_err = with_err;
-  static const bool timing = getenv("SSX_BATCH_TIMING") != nullptr;   // phase times of the call on stderr (tools/batch_time.py)
+  static const int timing_mode = getenv("SSX_BATCH_TIMING") ? std::max(atoi(getenv("SSX_BATCH_TIMING")), 1) : 0;   // phase times on stderr
+  const bool timing = timing_mode == 1;                              // 1: with synchronisations (tools/batch_time.py), 2: host clocks only
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
   const auto t_begin = now();
@@ -3379,8 +3380,11 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   B->a_out = arena.take(sizeof(double) * (out_total + 1));
   B->a_gather = arena.take(sizeof(double) * (size_t)n * (3 * SSX_BA_MAX_STATS));
   B->in_total = in_total; B->out_total = out_total;
-  SSX_HIP_TRY(ctx, B->arena->reserve(arena.off));
-  SSX_HIP_TRY(ctx, B->stage->reserve(std::max(head_bytes, sizeof(double) * (out_total + 1))));
+  // (resident windows: their storage grows with every keyframe until it is rewritten at twice the live size, and a grown arena
+  // is a hipFree -- a device-wide synchronisation, 5-20 ms in the middle of a step -- so a reallocation asks for 2.5x the need)
+  const double grow = exts ? 2.5 : 1.25;
+  SSX_HIP_TRY(ctx, B->arena->reserve(arena.off, grow));
+  SSX_HIP_TRY(ctx, B->stage->reserve(std::max(head_bytes, sizeof(double) * (out_total + 1)), grow));
   SSX_HIP_TRY(ctx, B->scal->reserve(sizeof(double) * (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS) + sizeof(int) * 3 * n + 64));
   char* dev_base = B->arena->as<char>();
   char* hst = B->stage->as<char>();
@@ -3435,6 +3439,9 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     hipLaunchKernelGGL(k_prep_chunk_b, dim3(B->max_ch, n), dim3(CH), 0, ctx->stream, dvb);
     SSX_HIP_TRY(ctx, hipGetLastError());
   }
+  if (timing_mode == 2)
+    fprintf(stderr, "[batch_build n=%d, no syncs] prepare %.3f | sizes + fill %.3f | enqueue of upload + marshalling kernels %.3f ms\n", n, t_prepare,
+            t_fill - t_prepare, ms_since(t_begin) - t_fill);
   if (timing) {
     (void)hipStreamSynchronize(ctx->stream);
     fprintf(stderr, "[batch_build n=%d] prepare %.3f | sizes + fill (+ upload of 3 pieces of 4) %.3f | %.1f MB on the device %.3f later | device marshalling %.3f ms\n", n, t_prepare,

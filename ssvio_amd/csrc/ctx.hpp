@@ -52,12 +52,13 @@
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
-  hipError_t reserve(size_t bytes)
+  // (grow = what a reallocation asks for, in units of the request: a hipFree synchronises the whole device)
+  hipError_t reserve(size_t bytes, double grow = 1.25)
   {
     if (bytes <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = (size_t)((double)bytes * grow) + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;
@@ -70,12 +71,12 @@ struct DevBuf {
 struct HostBuf {
   void* p = nullptr;
   size_t cap = 0;
-  hipError_t reserve(size_t bytes)
+  hipError_t reserve(size_t bytes, double grow = 1.25)
   {
     if (bytes <= cap) return hipSuccess;
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = (size_t)((double)bytes * grow) + 256;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
     return e;

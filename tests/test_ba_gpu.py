@@ -706,6 +706,57 @@ def test_compact_upload_is_lossless(ctx):
     assert r2["n_iters"] == ba.ba_solve(ctx, pr)["n_iters"] and np.isfinite(r2["chi2"][-1])
 
 
+def test_window_update_batch_equals_single_edits(ctx):
+    """ssx_ba_window_update_batch (one keyframe replaced in each of n windows, on the library's host threads) leaves every window
+    exactly as its own pop + push calls do -- by landmark id and by landmark slot -- and reports a failing window without
+    touching the others."""
+    from ssvio_amd._lib import SsxError
+    prs = [make_ba_problem(P=14, L=1800, obs_per_lm=5, seed=300 + q, pose_t_noise=0.05) for q in range(3)]
+    feeds = [_window_feed(p) for p in prs]
+    n = 6
+    ref = [ba.BaWindow(ctx, prs[i % 3]["K"], prs[i % 3]["cam_ext"]) for i in range(n)]
+    got = [ba.BaWindow(ctx, prs[i % 3]["K"], prs[i % 3]["cam_ext"]) for i in range(n)]
+    slot_of = [dict() for _ in range(n)]
+    for k in range(14):
+        ups = []
+        for i in range(n):
+            f = feeds[i % 3][k]
+            if k >= 10:
+                ref[i].pop(100 + k - 10)
+            ref[i].push(100 + k, **f)
+            u = dict(pop=100 + k - 10 if k >= 10 else None, push=100 + k, pose=f["pose"], new_ids=f["new_ids"], new_xyz=f["new_xyz"],
+                     new_fixed=f["new_fixed"], obs_uv=f["obs_uv"], obs_cam=f["obs_cam"])
+            if i % 2 == 0:
+                u["obs_lm"] = f["obs_lm"]
+            else:
+                new_index = {int(x): j for j, x in enumerate(f["new_ids"])}
+                u["obs_slot"] = np.array([slot_of[i][int(x)] if int(x) not in new_index else -1 - new_index[int(x)] for x in f["obs_lm"]], dtype=np.int32)
+            ups.append(u)
+        slots = ba.BaWindow.update_batch(got, ups)
+        for i in range(n):
+            if i % 2 == 1:
+                slot_of[i].update({int(x): int(s_) for x, s_ in zip(feeds[i % 3][k]["new_ids"], slots[i])})
+    for i in range(n):
+        ea, eb = ref[i].export(), got[i].export()
+        for key in ea:
+            assert np.array_equal(ea[key], eb[key]), (i, key)
+    ra = ba.BaWindow.solve_batch(ref); rb = ba.BaWindow.solve_batch(got)
+    for i in range(n):
+        _assert_same(ra[i], rb[i], ("window", i))
+    # a failing window (its keyframe is already there) is reported, the other one is updated; a window listed twice is refused
+    f = feeds[0][13]
+    bad = dict(pop=None, push=100 + 13, pose=f["pose"], new_ids=[], new_xyz=np.zeros((0, 3)), obs_lm=[], obs_uv=np.zeros((0, 2)))
+    ok = dict(pop=100 + 4, push=None)
+    with pytest.raises(SsxError):
+        ba.BaWindow.update_batch([got[0], got[1]], [bad, ok])
+    assert got[1].size()[0] == 9 and got[0].size()[0] == 10
+    with pytest.raises(SsxError):
+        ba.BaWindow.update_batch([got[2], got[2]], [dict(pop=100 + 4, push=None), dict(pop=100 + 5, push=None)])
+    assert got[2].size()[0] == 10
+    for w in ref + got:
+        w.close()
+
+
 def test_resident_window_equals_fresh_solves(ctx):
     """ssx_ba_window: keyframes are pushed (pose + the landmarks they introduce + their observations), popped (their
     observations and the landmarks nobody sees any more go with them) and the window is optimised where it lies; after
