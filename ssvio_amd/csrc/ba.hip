@@ -150,6 +150,7 @@ struct BaDev {
   GPtr<const double> r_edge_uv;   // E x 2 interleaved
   GPtr<const uint8_t> r_edge_cam; // E or null
   GPtr<const uint8_t> r_slot8;    // E: rank of the edge among its landmark's edges (caller's order)
+  int no_err;                     // 1: nobody will ask for per-edge errors (err_lin / err_trial are not written: 32 bytes per edge and LM slot)
   int raw_fmt;                    // how the raw arrays crossed PCIe (lossless): bit 0 = r_edge_pose holds bytes, bit 1 = r_edge_point holds
                                   // 16-bit words, bit 2 = r_edge_uv holds floats (every coordinate was a float's value: keypoints are)
   GPtr<const int> lm_compact;     // L: caller's landmark -> compact landmark or -1
@@ -416,8 +417,10 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     else ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
     double w;
     ssx::huber(er[0] * er[0] + er[1] * er[1], d.huber_delta, rho0, w);
-    d.err_lin[e] = er[0];
-    d.err_lin[d.E + e] = er[1];
+    if (!d.no_err) {
+      d.err_lin[e] = er[0];
+      d.err_lin[d.E + e] = er[1];
+    }
     // an edge whose vertices are both fixed is not active in g2o (sparse_optimizer.cpp:237): no chi2 term
     if (pf < 0 && !lfree) rho0 = 0.0;
     wq = w; r0 = -er[0] * w; r1 = -er[1] * w;
@@ -1478,8 +1481,10 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
     const double X[3] = {sPt[0][l], sPt[1][l], sPt[2][l]};
     double er[2], p1[3], pc[3], w;
     ssx::edge_error(T, X, d.ext + 7 * (er4.w & 1), d.K, d.e_uv[e], d.e_uv[d.E + e], er, p1, pc);
-    d.err_trial[e] = er[0];
-    d.err_trial[d.E + e] = er[1];
+    if (!d.no_err) {
+      d.err_trial[e] = er[0];
+      d.err_trial[d.E + e] = er[1];
+    }
     const double c2 = er[0] * er[0] + er[1] * er[1];
     ssx::huber(c2, d.huber_delta, rho0, w);
     if (er4.y < 0 && (er4.w & 4)) rho0 = 0.0;                        // inactive edge (all vertices fixed)
@@ -2346,6 +2351,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.dev_prep = dev_prep ? 1 : 0;
   d.E_raw = E_raw;
   d.raw_fmt = raw_fmt;
+  d.no_err = 0;                                  // (the solve entry points set it when no per-edge errors were asked for)
   if (ext) {
     d.r_edge_pose = ext->r_edge_pose; d.r_edge_point = ext->r_edge_point; d.r_edge_uv = ext->r_edge_uv; d.r_edge_cam = ext->r_edge_cam;
   } else {
@@ -2917,6 +2923,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd, nullptr, ext, big_dev ? &recs : nullptr, pe_ptr_dev, pe_edge_dev);
   if (st != SSX_OK) return st;
   d.store_w = (d.big || opt.jac_mode == SSX_JAC_NUMERIC_G2O) ? 1 : 0;
+  d.no_err = (!d.big && !(res->edge_chi2 || res->edge_outlier)) ? 1 : 0;
   bd.spair_ab = pairs_dev;
   BaWorkspace* ws = ctx->ba;
   double* hscal = ws->scal.as<double>();
@@ -3403,6 +3410,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
     place[w].in_host = hst + in_off[w];
     sts[w] = upload(ctx, &probs[w], preps[w], opt.huber_delta, opt.chi2_th, 1, 0, B->devs[w], bd, no_band, bnd, &place[w], exts ? exts[w] : nullptr);
     B->devs[w].store_w = opt.jac_mode == SSX_JAC_NUMERIC_G2O ? 1 : 0;
+    B->devs[w].no_err = with_err ? 0 : 1;
     if (with_err) B->perm[w] = preps[w].perm;
   });
   for (int w = q0; w < q1; ++w) if (sts[w] != SSX_OK) { (void)hipStreamSynchronize(ctx->stream); return sts[w]; }
