@@ -57,11 +57,11 @@ struct ResizeQuad {          // 32 bytes
 };
 
 constexpr int RS_ROWS = 4;   // destination rows per thread: their 8 source-row loads are issued together
-constexpr int RS_LOOP = 4;   // such groups per wave, one after the other
+constexpr int RS_LOOP = 4;   // such groups per wave, one after the other, in a batch (a frame or two: 1 -- the chain of seven levels is latency bound)
 template <bool WIDE8>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src_base, uint8_t* __restrict__ dst_base,
                                                 size_t img_stride_bytes, int spitch, int drows, int dcols, int dpitch,
-                                                const ResizeQuad* __restrict__ xtab, const uint2* __restrict__ ytab)
+                                                const ResizeQuad* __restrict__ xtab, const uint2* __restrict__ ytab, int loops)
 {
   const int q = blockIdx.x * 64 + threadIdx.x;      // quad of destination columns
   if (4 * q >= dcols) return;
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src_
   // RS_LOOP groups of RS_ROWS rows per wave: a quarter of the workgroups (the big levels launched 12 800 of them for 82 us:
   // their rate, not their work, set the time) and one column-table fetch for 16 rows instead of 4
 #pragma unroll 1
-  for (int it = 0; it < RS_LOOP; ++it) {
+  for (int it = 0; it < loops; ++it) {
   // a wave = RS_ROWS consecutive destination rows of one quad column range: row tables and bases are scalar
-  const int dy0 = ((blockIdx.y * RS_LOOP + it) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_ROWS;
+  const int dy0 = ((blockIdx.y * loops + it) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * RS_ROWS;
   if (dy0 >= drows) break;
   // the kernel is bound by dependent memory round trips (table -> source rows), not by bandwidth or VALU: issue
   // all source-row loads of the RS_ROWS rows before the first use
@@ -422,7 +422,7 @@ __device__ __forceinline__ uint32_t udot2(uint32_t pair, uint32_t w, uint32_t ac
   return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, w), acc, false);
 }
 
-constexpr int GT_RUN = 4;                       // consecutive tiles of one tile row per workgroup: the next tile's loads fly during this tile's passes
+constexpr int GT_RUN = 4;                       // consecutive tiles of one tile row per workgroup of a batch (OrbDev::gauss_run): the next tile's loads fly during this tile's passes
 constexpr int GT_NLD = ((GT_H + 6) * (GT_PITCH / 4) + 255) / 256;   // dwords of an input tile per thread (6)
 
 // the dwords thread t holds of input tile (x0, y0).  Tiles inside the image: aligned loads.  Tiles at its border (a third of
@@ -510,9 +510,10 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
   const int grp = blockIdx.x - o.gauss_tile0[level];             // a run of GT_RUN tiles of one tile row
   const int rows = o.lvl_rows[level], cols = o.lvl_cols[level], pitch = o.lvl_pitch[level];
   const int tiles_x = (cols + GT_W - 1) / GT_W;
-  const int groups_x = (tiles_x + GT_RUN - 1) / GT_RUN;
-  const int ty_ = grp / groups_x, tx0 = (grp - ty_ * groups_x) * GT_RUN;
-  const int tx1 = min(tx0 + GT_RUN, tiles_x);
+  const int run = o.gauss_run;
+  const int groups_x = (tiles_x + run - 1) / run;
+  const int ty_ = grp / groups_x, tx0 = (grp - ty_ * groups_x) * run;
+  const int tx1 = min(tx0 + run, tiles_x);
   const int y0 = ty_ * GT_H;
   const uint8_t* src = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[level];
   uint8_t* dst = o.blur + (size_t)img * o.pyr_bytes + o.lvl_off[level];
@@ -1077,9 +1078,10 @@ ssx_status plan(ssx_ctx* ctx, int rows, int cols, int I, const ssx_orb_params& p
     }
     d.fast_tile_bytes = (tile + 15) & ~15;
     d.fast_lds_per_wave = 2 * d.fast_tile_bytes + ((2 * npx + 15) & ~15);
+    d.gauss_run = I > 8 ? GT_RUN : 1;
     for (int l = 0; l < nlevels; ++l) {
       d.gauss_tile0[l] = t0;
-      t0 += ((((d.lvl_cols[l] + GT_W - 1) / GT_W) + GT_RUN - 1) / GT_RUN) * ((d.lvl_rows[l] + GT_H - 1) / GT_H);   // runs of GT_RUN tiles
+      t0 += ((((d.lvl_cols[l] + GT_W - 1) / GT_W) + d.gauss_run - 1) / d.gauss_run) * ((d.lvl_rows[l] + GT_H - 1) / GT_H);   // runs of tiles
     }
     for (int l = nlevels; l <= MAX_LEVELS; ++l) d.gauss_tile0[l] = t0;
   }
@@ -1189,12 +1191,13 @@ static void launch_pyramid(ssx_ctx* ctx, const OrbDev& d, hipStream_t s, int ima
 {
   for (int l = 1; l < d.nlevels; ++l) {
     if (d.lvl_cols[l] <= 0 || d.lvl_rows[l] <= 0) break;     // a tiny image runs out of pixels before it runs out of levels: nothing there
-    const dim3 grid((d.lvl_cols[l] + 255) / 256, (d.lvl_rows[l] + 4 * RS_ROWS * RS_LOOP - 1) / (4 * RS_ROWS * RS_LOOP), images);
+    const int loops = images > 8 ? RS_LOOP : 1;
+    const dim3 grid((d.lvl_cols[l] + 255) / 256, (d.lvl_rows[l] + 4 * RS_ROWS * loops - 1) / (4 * RS_ROWS * loops), images);
     auto kern = d.rs_wide8[l] ? k_resize<true> : k_resize<false>;
     for (int m = 0; m < (d.has_mask ? 2 : 1); ++m) {
       uint8_t* pyr = m ? d.maskpyr : d.pyr;
       SSX_PROF(ctx, KID_ORB_RESIZE, hipLaunchKernelGGL(kern, grid, dim3(64, 4), 0, s, pyr + d.lvl_off[l - 1], pyr + d.lvl_off[l], d.pyr_bytes,
-                         d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l], d.rs_xtab + d.rs_xoff[l], d.rs_ytab + d.rs_yoff[l]));
+                         d.lvl_pitch[l - 1], d.lvl_rows[l], d.lvl_cols[l], d.lvl_pitch[l], d.rs_xtab + d.rs_xoff[l], d.rs_ytab + d.rs_yoff[l], loops));
     }
   }
 }

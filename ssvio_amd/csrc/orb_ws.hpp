@@ -48,7 +48,9 @@ struct OrbDev {
   int out_cap;                   // keypoints per image in the output arrays
   int fast_tile_bytes;           // LDS bytes of one ROI tile (max over cells, pitch rounded to 4)
   int fast_lds_per_wave;         // image tile + score tile + compaction list
-  int gauss_tile0[MAX_LEVELS + 1]; // first blur tile of each level (one launch covers all levels)
+  int gauss_tile0[MAX_LEVELS + 1]; // first blur tile RUN of each level (one launch covers all levels)
+  int gauss_run;                 // tiles per workgroup of k_gauss7: 4 for a batch (the next tile's loads fly during a tile's passes), 1 for a
+                                 // frame or two (the chip is empty: every tile its own workgroup is the shorter chain)
   int rs_xoff[MAX_LEVELS], rs_yoff[MAX_LEVELS];   // first row of level l in the cv::resize tables below
   int rs_wide8[MAX_LEVELS];      // every quad of the level reads <= 8 consecutive source bytes
   // buffers
