@@ -72,5 +72,6 @@ for k in range(10, 10 + STEPS):
     if k >= 12: tc += t1 - t0; ts += t2 - t1
 n = STEPS - 2
 print(f"pop {tpop / STEPS / B * 1e6:.1f} us, push {tpush / STEPS / B * 1e6:.1f} us per window ({'slots' if USE_SLOTS else 'ids'})")
+print(f"GPU clock of the last solve_batch (kernels + download, after the uploads): {res[0].ms_total:.3f} ms")
 print(f"B={B}: churn (pop + push, {'serial' if os.environ.get('SERIAL') else '16 threads'}) {tc / n * 1e3:.3f} ms, solve_batch {ts / n * 1e3:.3f} ms per step; window {wins[0].size()}")
 os.environ["SSX_WIN_TIMING"] = "1"
