@@ -15,6 +15,10 @@ for kw in (dict(P=10,L=4000,obs_per_lm=5,seed=3), dict(P=12,L=1500,obs_per_lm=4,
     pr=make_ba_problem(**kw)
     st=ba._problem_struct(pr, keep)
     print(kw, "prepare: %.3f ms" % (1e3*lib.ssx_ba_debug_prepare_seconds(C.byref(st), 3)))
+lib.ssx_ba_debug_upload_format.restype = C.c_int32
+for kw in (dict(P=10, L=900, seed=4, uv_f32=True), dict(P=10, L=900, seed=4)):
+    pr = make_ba_problem(**kw); st = ba._problem_struct(pr, keep)
+    print(kw, "upload format", lib.ssx_ba_debug_upload_format(C.byref(st)))
 print("done")
 # round 3: the host side of ssx_ba_window (slots, id map, dead blocks, storage rewrite) against its model
 lib.ssx_ba_window_selftest.restype = C.c_int32; lib.ssx_ba_window_selftest.argtypes = [C.c_uint32, C.c_int32]
