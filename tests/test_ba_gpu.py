@@ -642,6 +642,17 @@ def test_batched_windows_equal_single_calls(ctx):
     # without per-edge outputs, and a batch that contains a large window (falls back to one call per window)
     again = ba.BaBatch(ctx, probs[:3]).solve(want_edges=False)
     assert all(np.array_equal(a["poses"], ba.ba_solve(ctx, p)["poses"]) for a, p in zip(again["results"], probs[:3]))
+    # (nobody asks for per-edge results: the kernels do not write the per-edge error arrays -- nothing else may change)
+    for p in probs[:2]:
+        w, wo = ba.ba_solve(ctx, p), ba.ba_solve(ctx, p, want_edges=False)
+        for k in ("poses", "points", "chi2", "lam", "trials"):
+            assert np.array_equal(w[k], wo[k]), k
+        assert (w["n_inliers"], w["n_outliers"], w["rounds"]) == (wo["n_inliers"], wo["n_outliers"], wo["rounds"])
+    lean = ba.BaBatch(ctx, probs[:3], resident=True, with_edge_errors=False)
+    lr = lean.solve()
+    assert all(np.array_equal(a["poses"], ba.ba_solve(ctx, p)["poses"]) and a["n_outliers"] == ba.ba_solve(ctx, p)["n_outliers"]
+               for a, p in zip(lr["results"], probs[:3]))
+    lean.close()
     mixed = [probs[0], make_ba_problem(P=30, L=1200, obs_per_lm=5, seed=28, fix_first_pose=True)]
     mo = ba.BaBatch(ctx, mixed, outer_rounds=1, iters=4).solve()
     for pr, b in zip(mixed, mo["results"]):
