@@ -285,7 +285,8 @@ SSX_API ssx_status ssx_ba_window_solve(ssx_ba_window* win, ssx_ba_result* res);
 SSX_API ssx_status ssx_ba_window_solve_batch(int32_t n, ssx_ba_window* const* wins, ssx_ba_result* results);
 
 /* test hook, needs no GPU: `steps` random pushes / pops on a window without a device, its contents checked against a plain model
- * after every step; 0 = all steps agree, else the first step that does not */
+ * after every step, and two twin windows that receive the same edits through ssx_ba_window_update_batch (two windows per call: the
+ * threaded path) against the window itself; 0 = all steps agree, else the first step that does not */
 SSX_API int32_t ssx_ba_window_selftest(uint32_t seed, int32_t steps);
 
 /* tools hook, needs no GPU: dynamic LDS bytes a BA kernel is launched with (-1: depends on the problem); the compiler's
