@@ -22,13 +22,15 @@
 #ifndef SSX_H
 #define SSX_H
 #include <stddef.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SSX_VERSION 100 /* 0.1.0 */
+#define SSX_VERSION 110 /* 0.1.10: ssx_config grew by cu_first / cu_count, ssx_ba_result by ms_comm, ssx_ba_window_update by the
+                           * removal fields -- see ssx_abi_check */
 #if defined(__GNUC__)
 #define SSX_API __attribute__((visibility("default")))
 #else
@@ -61,6 +63,16 @@ typedef struct {
 } ssx_config;
 
 SSX_API int ssx_version(void);
+/* The structs of this header carry no size field: a caller built against another version of it would hand the library a
+ * shorter ssx_config (cu_count read from garbage) or receive ms_comm past the end of its ssx_ba_result.  Call this once after
+ * loading the library with SSX_VERSION and the sizeof of the structs AS THE CALLER WAS COMPILED:
+ *   ssx_abi_check(SSX_VERSION, sizeof(ssx_config), sizeof(ssx_ba_problem), sizeof(ssx_ba_options), sizeof(ssx_ba_result),
+ *                 sizeof(ssx_ba_window_update))
+ * SSX_OK when they are the library's, SSX_ERR_UNSUPPORTED otherwise (include/ssx_shim.hpp and ssvio_amd/_lib.py do it when they
+ * load the library).  Every struct must be zero-initialised before its fields are set: later versions append fields whose
+ * zero value means "as before". */
+SSX_API ssx_status ssx_abi_check(int header_version, size_t sizeof_config, size_t sizeof_ba_problem, size_t sizeof_ba_options,
+                                 size_t sizeof_ba_result, size_t sizeof_window_update);
 SSX_API int ssx_device_count(void);
 SSX_API ssx_status ssx_ctx_create(const ssx_config* cfg, ssx_ctx** out);
 SSX_API void ssx_ctx_destroy(ssx_ctx* ctx);
@@ -223,7 +235,14 @@ SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
  * window) and uploads ~3.6 bytes per observation + 13 per landmark of tables.  Keyframes and landmarks are named by the
  * caller's 64-bit ids (KeyFrame::key_frame_id_, MapPoint::id_).  <= 16 free keyframes (the reference keeps 12:
  * config/kitti_00.yaml:30).  A window belongs to its ctx and must be destroyed before it.
- * The result of ssx_ba_window_solve is, bit for bit, that of ssx_ba_solve on the problem ssx_ba_window_export lists.
+ * ORDER: a solve gives its vertices the order of the caller's ids -- keyframes ascending by id, landmarks ascending by id, as
+ * g2o orders its vertices and as a caller that re-marshals its map per keyframe does -- so its bits depend on what the window
+ * holds, never on the storage slots it reused.  ssx_ba_window_export lists the window in that order, and the result of
+ * ssx_ba_window_solve is, bit for bit, that of ssx_ba_solve on the exported problem.
+ * BETWEEN TWO OPTIMISATIONS the reference changes its map by more than one keyframe in / one out (backend.cpp:205-244,
+ * map.cpp:142-194): outlier observations are unlinked (ssx_ba_window_remove_flagged / _remove_observations), condemned map
+ * points are deleted (ssx_ba_window_remove_landmarks), and a map point is FIXED while the keyframe of its first remaining
+ * observation is outside the window (backend.cpp:125-130: ssx_ba_window_set_fix_rule).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct ssx_ba_window ssx_ba_window;
 SSX_API ssx_status ssx_ba_window_create(ssx_ctx* ctx, const ssx_ba_options* opt, const double* K4, const double* cam_ext14,
@@ -244,9 +263,33 @@ SSX_API ssx_status ssx_ba_window_push_keyframe_slots(ssx_ba_window* win, int64_t
                                                      const uint8_t* new_fixed, int32_t* new_slots_out, int32_t n_obs,
                                                      const int32_t* obs_slot, const double* obs_uv, const uint8_t* obs_cam);
 SSX_API ssx_status ssx_ba_window_pop_keyframe(ssx_ba_window* win, int64_t kf_id);
+/* backend.cpp:205-227 (`if (ef.first->chi2() > chi2_th)`: mappoint->RemoveActiveObservation + RemoveObservation): unlink
+ * observations; a landmark left without any leaves the window (Map::RemoveOldActiveMapPoints, and map.cpp:175-194 when the
+ * reference deletes it altogether).
+ *   _remove_flagged       flags[i] != 0 removes the i-th observation in the order of ssx_ba_window_export: the
+ *                         ssx_ba_result.edge_outlier of the solve that just ran can be handed back as it is; n_obs must be the
+ *                         window's observation count
+ *   _remove_observations  the observations keyframe kf_id holds of the landmarks lm_ids[i] (camera cams[i] != 0 = right;
+ *                         cams NULL = either); pairs the window does not hold are skipped, an unknown kf_id is an error
+ * *n_removed (nullable) receives the number of observations removed. */
+SSX_API ssx_status ssx_ba_window_remove_flagged(ssx_ba_window* win, int32_t n_obs, const uint8_t* flags, int32_t* n_removed);
+SSX_API ssx_status ssx_ba_window_remove_observations(ssx_ba_window* win, int64_t kf_id, int32_t n, const int64_t* lm_ids,
+                                                     const uint8_t* cams, int32_t* n_removed);
+/* Map::RemoveAllOutlierMapPoints (map.cpp:175-194; the map points FrontEnd::EstimateCurrentPose, frontend.cpp:283-288, or the
+ * backend condemned): the landmarks leave with all their observations.  Ids the window does not hold are skipped;
+ * *n_removed (nullable) = landmarks removed. */
+SSX_API ssx_status ssx_ba_window_remove_landmarks(ssx_ba_window* win, int32_t n, const int64_t* lm_ids, int32_t* n_removed);
+/* rule 0 (default): a landmark is fixed when the caller says so (new_fixed, ssx_ba_window_set_landmark).
+ * rule 1: backend.cpp:125-130 as well -- `mp->GetObservations().front()`'s keyframe is not active: a landmark is fixed while the
+ * earliest-pushed keyframe among its remaining observations (MapPoint::observations_ keeps those of keyframes that left the
+ * window, and loses those removed as outliers) is no longer in the window; ssx_ba_window_pop_keyframe and the removals keep
+ * that up to date.  A landmark that comes BACK into a window it had left is pushed with new_fixed = what the caller's map says. */
+SSX_API ssx_status ssx_ba_window_set_fix_rule(ssx_ba_window* win, int32_t rule);
 /* One keyframe replaced in each of n windows of ONE ctx, in one call, the windows spread over the ctx's host threads (the
  * windows of concurrent streams all change at every keyframe; the edits are independent host work, ~25-70 us per window).
- * Per window: pop != 0 -> ssx_ba_window_pop_keyframe(pop_kf_id); then push != 0 -> ssx_ba_window_push_keyframe (obs_lm) or
+ * Per window, in this order: n_remove_flags > 0 -> ssx_ba_window_remove_flagged (what the LAST optimisation decided: its flags
+ * refer to the window as that solve saw it); n_remove_lm > 0 -> ssx_ba_window_remove_landmarks; pop != 0 ->
+ * ssx_ba_window_pop_keyframe(pop_kf_id); push != 0 -> ssx_ba_window_push_keyframe (obs_lm) or
  * _push_keyframe_slots (obs_lm NULL, obs_slot) with the remaining fields.  status_out (nullable) receives every window's own
  * status; the call returns the first one that is not SSX_OK (a failing window is left as its own failing call leaves it, the
  * others are updated).  The windows must be distinct. */
@@ -264,6 +307,9 @@ typedef struct ssx_ba_window_update {
   const int32_t* obs_slot;      /* ... by slot (see ssx_ba_window_push_keyframe_slots) */
   const double* obs_uv;
   const uint8_t* obs_cam;
+  int32_t n_remove_flags, n_remove_lm;
+  const uint8_t* remove_flags;  /* n_remove_flags = the window's observation count before this update */
+  const int64_t* remove_lm_ids;
 } ssx_ba_window_update;
 SSX_API ssx_status ssx_ba_window_update_batch(int32_t n, ssx_ba_window* const* wins, const ssx_ba_window_update* updates,
                                               ssx_status* status_out);
@@ -272,7 +318,9 @@ SSX_API ssx_status ssx_ba_window_set_pose(ssx_ba_window* win, int64_t kf_id, con
 SSX_API ssx_status ssx_ba_window_set_landmark(ssx_ba_window* win, int64_t lm_id, const double* xyz, int32_t fixed);
 SSX_API ssx_status ssx_ba_window_size(const ssx_ba_window* win, int32_t* n_keyframes, int32_t* n_landmarks,
                                       int32_t* n_observations);
-/* the window as an ordinary ssx_ba_problem (current estimate): arrays of ssx_ba_window_size() entries, any may be NULL */
+/* the window as an ordinary ssx_ba_problem (current estimate): arrays of ssx_ba_window_size() entries, any may be NULL.
+ * Keyframes ascending by id, landmarks ascending by id, observations in the order they were pushed; point_fixed = the flags
+ * the next solve uses (fix rule included). */
 SSX_API ssx_status ssx_ba_window_export(const ssx_ba_window* win, int64_t* kf_ids, double* poses, uint8_t* pose_fixed,
                                         int64_t* lm_ids, double* points, uint8_t* point_fixed, int32_t* edge_pose,
                                         int32_t* edge_point, double* edge_uv, uint8_t* edge_cam);
@@ -284,8 +332,8 @@ SSX_API ssx_status ssx_ba_window_solve(ssx_ba_window* win, ssx_ba_result* res);
  * The options of the first window apply. */
 SSX_API ssx_status ssx_ba_window_solve_batch(int32_t n, ssx_ba_window* const* wins, ssx_ba_result* results);
 
-/* test hook, needs no GPU: `steps` random pushes / pops on a window without a device, its contents checked against a plain model
- * after every step, and two twin windows that receive the same edits through ssx_ba_window_update_batch (two windows per call: the
+/* test hook, needs no GPU: `steps` random pushes / pops / removals of observations and landmarks on a window without a device (fix
+ * rule 1), its contents, order and fixed flags checked against a plain model after every step, and two twin windows that receive the same edits through ssx_ba_window_update_batch (two windows per call: the
  * threaded path) against the window itself; 0 = all steps agree, else the first step that does not */
 SSX_API int32_t ssx_ba_window_selftest(uint32_t seed, int32_t steps);
 

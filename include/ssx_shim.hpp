@@ -25,7 +25,11 @@ class Context {
  public:
   explicit Context(int device = 0, void* hip_stream = nullptr)
   {
-    ssx_config cfg{device, hip_stream, 0, 0};
+    if (ssx_abi_check(SSX_VERSION, sizeof(ssx_config), sizeof(ssx_ba_problem), sizeof(ssx_ba_options), sizeof(ssx_ba_result),
+                      sizeof(ssx_ba_window_update)) != SSX_OK)
+      throw std::runtime_error("libssx.so was built from another version of include/ssx.h than this caller");
+    ssx_config cfg{};
+    cfg.device = device; cfg.stream = hip_stream;
     const ssx_status st = ssx_ctx_create(&cfg, &ctx_);
     if (st != SSX_OK) throw std::runtime_error("ssx_ctx_create failed (no gfx950 device? there is no CPU fallback)");
   }

@@ -22,6 +22,7 @@ SSX_ERR_CAPACITY = -4
 SSX_ERR_UNSUPPORTED = -5
 SSX_ERR_COMM = -6
 SSX_BA_MAX_STATS = 128
+SSX_VERSION = 110        # include/ssx.h
 
 dbl_p = C.POINTER(C.c_double)
 u8_p = C.POINTER(C.c_uint8)
@@ -72,7 +73,8 @@ class BaWindowUpdate(C.Structure):
     _fields_ = [("pop", C.c_int32), ("push", C.c_int32), ("pop_kf_id", C.c_int64), ("kf_id", C.c_int64), ("pose7", dbl_p),
                 ("pose_fixed", C.c_int32), ("n_new", C.c_int32), ("new_ids", C.POINTER(C.c_int64)), ("new_xyz", dbl_p), ("new_fixed", u8_p),
                 ("new_slots_out", C.POINTER(C.c_int32)), ("n_obs", C.c_int32), ("reserved", C.c_int32), ("obs_lm", C.POINTER(C.c_int64)),
-                ("obs_slot", C.POINTER(C.c_int32)), ("obs_uv", dbl_p), ("obs_cam", u8_p)]
+                ("obs_slot", C.POINTER(C.c_int32)), ("obs_uv", dbl_p), ("obs_cam", u8_p),
+                ("n_remove_flags", C.c_int32), ("n_remove_lm", C.c_int32), ("remove_flags", u8_p), ("remove_lm_ids", C.POINTER(C.c_int64))]
 
 
 class KeyPoint(C.Structure):
@@ -111,6 +113,12 @@ def load() -> C.CDLL:
         lib.ssx_ctx_stream.restype = C.c_void_p
         lib.ssx_ctx_stream.argtypes = [C.c_void_p]
         lib.ssx_ctx_synchronize.argtypes = [C.c_void_p]
+        # the ctypes mirrors of the header's structs must be the library's (ssx_abi_check, include/ssx.h)
+        lib.ssx_abi_check.argtypes = [C.c_int] + [C.c_size_t] * 5
+        if lib.ssx_abi_check(SSX_VERSION, C.sizeof(Config), C.sizeof(BaProblem), C.sizeof(BaOptions), C.sizeof(BaResult),
+                             C.sizeof(BaWindowUpdate)) != SSX_OK:
+            raise SsxError(SSX_ERR_UNSUPPORTED, f"{LIB_PATH} does not match the struct layouts of ssvio_amd/_lib.py (version "
+                                                f"{lib.ssx_version()} vs {SSX_VERSION}): rebuild with `python -m ssvio_amd.build`")
         _lib = lib
     return _lib
 

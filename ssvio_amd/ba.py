@@ -256,7 +256,9 @@ class BaWindow:
     What Backend::OptimizeActiveMap sees at consecutive keyframes (backend.cpp:88-169, map.cpp:27-56, 89-160)."""
 
     def __init__(self, ctx: Context, K, cam_ext, outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891, inlier_ratio=0.7,
-                 jac_mode=JAC_ANALYTIC):
+                 jac_mode=JAC_ANALYTIC, fix_rule=0):
+        """fix_rule=1: the window keeps backend.cpp:125-130 itself (a landmark is fixed while the keyframe of its first remaining
+        observation is outside the window)"""
         self.ctx = ctx
         self.handle = None
         self.opt = BaOptions()
@@ -272,6 +274,10 @@ class BaWindow:
         lib.ssx_ba_window_push_keyframe_slots.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32, C.c_int32, i64_p, dbl_p, u8_p, i32_p, C.c_int32, i32_p,
                                                           dbl_p, u8_p]
         lib.ssx_ba_window_pop_keyframe.argtypes = [C.c_void_p, C.c_int64]
+        lib.ssx_ba_window_remove_flagged.argtypes = [C.c_void_p, C.c_int32, u8_p, i32_p]
+        lib.ssx_ba_window_remove_observations.argtypes = [C.c_void_p, C.c_int64, C.c_int32, i64_p, u8_p, i32_p]
+        lib.ssx_ba_window_remove_landmarks.argtypes = [C.c_void_p, C.c_int32, i64_p, i32_p]
+        lib.ssx_ba_window_set_fix_rule.argtypes = [C.c_void_p, C.c_int32]
         lib.ssx_ba_window_set_pose.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32]
         lib.ssx_ba_window_set_landmark.argtypes = [C.c_void_p, C.c_int64, dbl_p, C.c_int32]
         lib.ssx_ba_window_size.argtypes = [C.c_void_p, i32_p, i32_p, i32_p]
@@ -281,6 +287,28 @@ class BaWindow:
         h = C.c_void_p()
         ctx.check(lib.ssx_ba_window_create(ctx.handle, C.byref(self.opt), ptr(self.K, dbl_p), ptr(self.cam_ext, dbl_p), C.byref(h)))
         self.handle = h
+        if fix_rule:
+            ctx.check(lib.ssx_ba_window_set_fix_rule(h, int(fix_rule)))
+
+    def remove_flagged(self, flags):
+        """ssx_ba_window_remove_flagged: flags in export order (the edge_outlier of the solve that just ran); -> observations removed"""
+        flags = np.ascontiguousarray(flags, dtype=np.uint8).ravel()
+        n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_ba_window_remove_flagged(self.handle, len(flags), ptr(flags, u8_p), C.byref(n)))
+        return n.value
+
+    def remove_observations(self, kf_id, lm_ids, cams=None):
+        lm_ids = np.ascontiguousarray(lm_ids, dtype=np.int64).ravel()
+        cams = None if cams is None else np.ascontiguousarray(cams, dtype=np.uint8)
+        n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_ba_window_remove_observations(self.handle, int(kf_id), len(lm_ids), ptr(lm_ids, i64_p), ptr(cams, u8_p), C.byref(n)))
+        return n.value
+
+    def remove_landmarks(self, lm_ids):
+        lm_ids = np.ascontiguousarray(lm_ids, dtype=np.int64).ravel()
+        n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_ba_window_remove_landmarks(self.handle, len(lm_ids), ptr(lm_ids, i64_p), C.byref(n)))
+        return n.value
 
     def push(self, kf_id, pose, new_ids=(), new_xyz=(), new_fixed=None, obs_lm=(), obs_uv=(), obs_cam=None, pose_fixed=False):
         pose = np.ascontiguousarray(pose, dtype=np.float64).ravel()
@@ -378,8 +406,9 @@ class BaWindow:
     @staticmethod
     def update_batch(windows, updates):
         """ssx_ba_window_update_batch: one keyframe replaced in each window (of one Context) in one call, on the library's host
-        threads.  updates[i] = dict(pop=kf id or None, push=kf id or None, pose, new_ids, new_xyz, new_fixed, obs_lm | obs_slot,
-        obs_uv, obs_cam, pose_fixed); returns the slots of the new landmarks per window (slot form) or None."""
+        threads.  updates[i] = dict(remove_flags=per-observation flags or None, remove_lm=landmark ids or None, pop=kf id or None,
+        push=kf id or None, pose, new_ids, new_xyz, new_fixed, obs_lm | obs_slot, obs_uv, obs_cam, pose_fixed), applied in that
+        order; returns the slots of the new landmarks per window (slot form) or None."""
         n = len(windows)
         arr = (_lib.BaWindowUpdate * n)()
         keep, slots = [], []
@@ -390,6 +419,14 @@ class BaWindow:
             a.pop_kf_id = 0 if u.get("pop") is None else int(u["pop"])
             a.push = 0 if u.get("push") is None else 1
             slots.append(None)
+            if u.get("remove_flags") is not None:
+                rf = np.ascontiguousarray(u["remove_flags"], dtype=np.uint8).ravel()
+                a.n_remove_flags = len(rf); a.remove_flags = ptr(rf, u8_p)
+                keep.append(rf)
+            if u.get("remove_lm") is not None:
+                rl = np.ascontiguousarray(u["remove_lm"], dtype=np.int64).ravel()
+                a.n_remove_lm = len(rl); a.remove_lm_ids = ptr(rl, i64p)
+                keep.append(rl)
             if not a.push:
                 continue
             a.kf_id = int(u["push"])

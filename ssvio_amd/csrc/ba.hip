@@ -40,6 +40,7 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <map>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -154,6 +155,8 @@ struct BaDev {
   int raw_fmt;                    // how the raw arrays crossed PCIe (lossless): bit 0 = r_edge_pose holds bytes, bit 1 = r_edge_point holds
                                   // 16-bit words, bit 2 = r_edge_uv holds floats (every coordinate was a float's value: keypoints are)
   GPtr<const int> lm_compact;     // L: caller's landmark -> compact landmark or -1
+  GPtr<const int> pose_rank;      // P or null: a landmark's edges are ordered by this key instead of the pose index (an ssx_ba_window
+                                  // orders its keyframes by the caller's ids, not by the slots they happen to live in)
   GPtr<int> perm;                 // E: sorted edge -> caller's edge
   GPtr<int> lm_chunk;             // nLm: compact landmark -> chunk (large windows, device-marshalled: the pair builder reads it)
   GPtr<double> c2_out;            // E: edge chi2 in the CALLER's order (results of a device-marshalled window)
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(CH) void k_prep_scatter_b(const BaDev* __restrict__
 
 __device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
 {
-  __shared__ int sOrig[CH], sPose[CH];
+  __shared__ int sOrig[CH], sPose[CH], sKey[CH];
   __shared__ uint8_t sLmOf[CH], sFix[CH_L];
   __shared__ int sLid[CH_L];
   __shared__ int sCnt[4][SSX_BA_SMALL_P + 1];
@@ -924,7 +927,9 @@ __device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
   if (t < ne) {
     const int og = d.perm[e0 + t];
     sOrig[t] = og;
-    sPose[t] = raw_pose(d, og);
+    const int po = raw_pose(d, og);
+    sPose[t] = po;
+    sKey[t] = d.pose_rank.p ? d.pose_rank[po] : po;
   }
   int lm_a0 = 0, lm_k = 0;
   if (t < nl) {
@@ -938,10 +943,10 @@ __device__ __forceinline__ void k_prep_chunk_body(const BaDev& d, const int c)
   if (t < nl) {
     // stable insertion sort by pose (the edges of a landmark usually arrive in keyframe order: one pass, no move)
     for (int i = lm_a0 + 1; i < lm_a0 + lm_k; ++i) {
-      const int po = sPose[i], og = sOrig[i];
+      const int po = sPose[i], og = sOrig[i], ky = sKey[i];
       int j = i - 1;
-      while (j >= lm_a0 && sPose[j] > po) { sPose[j + 1] = sPose[j]; sOrig[j + 1] = sOrig[j]; --j; }
-      sPose[j + 1] = po; sOrig[j + 1] = og;
+      while (j >= lm_a0 && sKey[j] > ky) { sPose[j + 1] = sPose[j]; sOrig[j + 1] = sOrig[j]; sKey[j + 1] = sKey[j]; --j; }
+      sPose[j + 1] = po; sOrig[j + 1] = og; sKey[j + 1] = ky;
     }
     for (int i = lm_a0; i < lm_a0 + lm_k; ++i) sLmOf[i] = (uint8_t)t;
     const_cast<int4*>(static_cast<const int4*>(d.l_rec.p))[lm0 + t] = make_int4(lm_a0, lm_k, sLid[t], sFix[t]);
@@ -1657,6 +1662,7 @@ struct HostPrep {
                                      // arrays; the host only counts (slot8: rank of an edge among its landmark's edges in caller order)
   std::vector<uint8_t> slot8;
   std::vector<int> lm_compact;       // caller's landmark -> compact landmark or -1
+  std::vector<int> pose_rank;        // empty, or BaDev::pose_rank (a window's keyframes in the order of their ids)
   std::vector<int> cnt_tmp, start_tmp;
   std::vector<uint32_t> tmp_pairs;   // scratch of prepare(), kept between calls
   std::vector<std::pair<int, int>> tmp_order;
@@ -1793,12 +1799,18 @@ struct WinExt {
   const int* r_edge_pose = nullptr; const int* r_edge_point = nullptr; const double* r_edge_uv = nullptr; const uint8_t* r_edge_cam = nullptr;
   double* pose[2] = {nullptr, nullptr}; double* point[2] = {nullptr, nullptr};
   int cur = 0;                       // in: the buffer that holds the current estimate; out: the one that holds the result
+  // the order the solve gives its vertices: the window's live keyframe / landmark SLOTS sorted by the caller's ids (what g2o does
+  // with its vertex ids, sparse_optimizer.cpp:305-330) -- free-pose indices, the order of a landmark's edges, the landmark order of
+  // the chunks all follow it, so the bits of a solve do not depend on which slots the window happened to reuse
+  const int* pose_order = nullptr; int n_pose_order = 0;
+  const int* lm_order = nullptr; int n_lm_order = 0;
 };
 
 // allow_dev_prep: small windows leave everything beyond counting to the device (see HostPrep::dev_prep); SSX_BA_HOST_PREP=1
 // keeps the host marshalling below as the reference of the tests (same bits: test_device_marshalling_equals_host_marshalling)
-ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool allow_dev_prep = true, bool dead_ok = false)
+ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool allow_dev_prep = true, const WinExt* ext = nullptr)
 {
+  const bool dead_ok = ext != nullptr;
   const int P = pr->P, L = pr->L, E = pr->E;
   if (P <= 0 || L < 0 || E < 0 || !pr->poses || (L && !pr->points) ||
       (E && (!pr->edge_pose || !pr->edge_point || !pr->edge_uv))) {
@@ -1808,6 +1820,15 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   h.P = P; h.L = L; h.E = E; h.E_raw = E;
   h.pose_free.assign(P, -1);
   h.nP = 0;
+  h.pose_rank.clear();
+  if (ext && ext->pose_order) {
+    h.pose_rank.assign(P, P);                             // (dead slots: behind every live keyframe; nothing refers to them)
+    for (int i = 0; i < ext->n_pose_order; ++i) {
+      const int sl = ext->pose_order[i];
+      h.pose_rank[sl] = i;
+      if (!(pr->pose_fixed && pr->pose_fixed[sl])) h.pose_free[sl] = h.nP++;
+    }
+  } else
   for (int i = 0; i < P; ++i)
     if (!(pr->pose_fixed && pr->pose_fixed[i])) h.pose_free[i] = h.nP++;
   static const bool host_prep_env = getenv("SSX_BA_HOST_PREP") != nullptr;
@@ -1851,8 +1872,12 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   std::vector<int>& lm_compact = h.lm_compact;
   std::vector<int>& start = h.start_tmp;
   lm_compact.assign(L, -1); start.assign(L + 1, 0);
-  for (int l = 0; l < L; ++l) start[l + 1] = start[l] + cnt[l + 1];
-  for (int l = 0; l < L; ++l) {
+  const bool lm_ordered = ext && ext->lm_order;           // a window: compact landmarks in the order of the caller's ids
+  if (!lm_ordered) for (int l = 0; l < L; ++l) start[l + 1] = start[l] + cnt[l + 1];
+  const int n_visit = lm_ordered ? ext->n_lm_order : L;
+  int run = 0;
+  for (int i = 0; i < n_visit; ++i) {
+    const int l = lm_ordered ? ext->lm_order[i] : i;
     if (cnt[l + 1] == 0) continue;
     if (cnt[l + 1] > CH_E) {
       ctx->set_error("ssx_ba: landmark %d has %d observations (> %d per landmark unsupported)", l, cnt[l + 1], CH_E);
@@ -1860,9 +1885,11 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
     }
     lm_compact[l] = (int)h.lm_id.size();
     h.lm_id.push_back(l);
-    h.lm_ptr.push_back(start[l]);
+    h.lm_ptr.push_back(lm_ordered ? run : start[l]);
+    run += cnt[l + 1];
     h.lm_fixed.push_back(pr->point_fixed ? (pr->point_fixed[l] ? 1 : 0) : 0);
   }
+  if (lm_ordered && run != E - n_dead) { ctx->set_error("ssx_ba_window: an observation refers to a landmark that is not in the window's order list"); return SSX_ERR_INVALID_ARG; }
   h.lm_ptr.push_back(h.E);
   h.nLm = (int)h.lm_id.size();
   if (h.dev_prep) {
@@ -2137,6 +2164,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const bool raw_in = dev_prep && !ext;
   const bool have_cam = dev_prep && (ext ? ext->r_edge_cam != nullptr : pr->edge_cam != nullptr);
   const size_t o_lm_compact = in.take(dev_prep ? sizeof(int) * (size_t)(L + 1) : 0);
+  const bool have_rank = dev_prep && !h.pose_rank.empty();
+  const size_t o_pose_rank = in.take(have_rank ? sizeof(int) * (size_t)P : 0);
   const int raw_fmt = raw_in && !rz ? h.raw_fmt : 0;
   const size_t o_r_pose = in.take(raw_in ? ((raw_fmt & 1) ? 1 : sizeof(int)) * (size_t)(E + 1) : 0);
   const size_t o_r_point = in.take(raw_in ? ((raw_fmt & 2) ? sizeof(uint16_t) : sizeof(int)) * (size_t)(E + 1) : 0);
@@ -2251,6 +2280,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   if (nCh && !rz) memcpy(hs + o_ch_desc, h.ch_desc.data(), sizeof(int) * 4 * (size_t)nCh);
   if (dev_prep) {
     if (L) memcpy(hs + o_lm_compact, h.lm_compact.data(), sizeof(int) * (size_t)L);
+    if (have_rank) memcpy(hs + o_pose_rank, h.pose_rank.data(), sizeof(int) * (size_t)P);
     if (E && raw_in) {
       if (raw_fmt & 1) { uint8_t* o = (uint8_t*)(hs + o_r_pose); for (int e = 0; e < E; ++e) o[e] = (uint8_t)pr->edge_pose[e]; }
       else memcpy(hs + o_r_pose, pr->edge_pose, sizeof(int) * (size_t)E);
@@ -2360,6 +2390,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   }
   d.r_slot8 = (const uint8_t*)(dev_prep ? at(o_slot8) : nullptr); d.lm_compact = (const int*)(dev_prep ? at(o_lm_compact) : nullptr);
   d.perm = (int*)(dev_prep ? at(o_perm) : nullptr); d.c2_out = (double*)(dev_prep ? at(o_c2) : nullptr);
+  d.pose_rank = (const int*)(have_rank ? at(o_pose_rank) : nullptr);
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
@@ -2391,7 +2422,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     d.e_pose = recs->e_pose; d.e_lmc = recs->e_lmc; d.e_cam = recs->e_cam; d.e_dup = recs->e_dup; d.e_uv = recs->e_uv;
     d.ch_desc = recs->ch_desc; d.e_rec = recs->e_rec; d.l_rec = recs->l_rec; d.perm = recs->perm; d.c2_out = recs->c2_out; d.lm_chunk = recs->lm_chunk;
     d.r_edge_pose = recs->r_edge_pose; d.r_edge_point = recs->r_edge_point; d.r_edge_uv = recs->r_edge_uv; d.r_edge_cam = recs->r_edge_cam;
-    d.r_slot8 = recs->r_slot8; d.lm_compact = recs->lm_compact;
+    d.r_slot8 = recs->r_slot8; d.lm_compact = recs->lm_compact; d.pose_rank = nullptr;
   }
   bd = BigDev{};
   bnd = BandDev{};
@@ -2483,6 +2514,7 @@ ssx_status big_records(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h
   SSX_HIP_TRY(ctx, hipMemcpyAsync(dv, hs, in_bytes, hipMemcpyHostToDevice, s));
   r = BaDev{};
   r.P = P; r.L = L; r.E = E; r.E_raw = h.E_raw; r.nP = nP; r.nLm = nLm; r.nCh = nCh; r.nBlk = 0; r.big = 1; r.dev_prep = 1; r.bseg_cap = 0;
+  r.pose_rank = nullptr;
   r.pose_free = (const int*)(dv + o_pose_free); r.lm_compact = (const int*)(dv + o_lm_compact); r.lm_ptr = (const int*)(dv + o_lm_ptr);
   r.lm_id = (const int*)(dv + o_lm_id); r.lm_fixed = (const uint8_t*)(dv + o_lm_fixed); r.ch_lm = (const int*)(dv + o_ch_lm);
   r.ch_desc = (const int4*)(dv + o_ch_desc);
@@ -2850,7 +2882,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   // ~20 vectors of up to E entries are not re-allocated and re-faulted every solve
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   HostPrep& h = ctx->ba->prep1;
-  ssx_status st = prepare(ctx, prob, h, true, ext != nullptr);
+  ssx_status st = prepare(ctx, prob, h, true, ext);
   if (st != SSX_OK) return st;
   if (ext && (!h.dev_prep || h.big)) {
     ctx->set_error("ssx_ba_window: %d free keyframes (a window holds at most %d) or the device-side marshalling is switched off", h.nP, SSX_BA_SMALL_P);
@@ -3349,7 +3381,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   const auto t_begin = now();
   // ---- 1. host marshalling of every window (edge sort, chunks, index lists), T threads
   std::vector<ssx_status> sts(n, SSX_OK);
-  ws->pool.run(n, T, [&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w], true, exts != nullptr); });
+  ws->pool.run(n, T, [&](int w) { sts[w] = prepare(ctx, &probs[w], preps[w], true, exts ? exts[w] : nullptr); });
   for (int w = 0; w < n; ++w) if (sts[w] != SSX_OK) return sts[w];
   for (int w = 0; w < n; ++w) if (preps[w].big || (exts && !preps[w].dev_prep)) return SSX_ERR_UNSUPPORTED;
   const double t_prepare = ms_since(t_begin);

@@ -5,6 +5,14 @@ extern "C" {
 
 int ssx_version(void) { return SSX_VERSION; }
 
+ssx_status ssx_abi_check(int header_version, size_t sizeof_config, size_t sizeof_ba_problem, size_t sizeof_ba_options, size_t sizeof_ba_result,
+                         size_t sizeof_window_update)
+{
+  return (header_version == SSX_VERSION && sizeof_config == sizeof(ssx_config) && sizeof_ba_problem == sizeof(ssx_ba_problem) &&
+          sizeof_ba_options == sizeof(ssx_ba_options) && sizeof_ba_result == sizeof(ssx_ba_result) &&
+          sizeof_window_update == sizeof(ssx_ba_window_update)) ? SSX_OK : SSX_ERR_UNSUPPORTED;
+}
+
 int ssx_device_count(void)
 {
   int n = 0;

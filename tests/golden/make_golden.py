@@ -96,6 +96,43 @@ def make_bow_golden():
     print("ref_bow.npz:", os.path.getsize(os.path.join(OUT, "ref_bow.npz")), "bytes,", len(g), "arrays")
 
 
+WINDOW_SCENARIO = dict(n_kf=14, n_active=5, new_per_kf=140, track_len=7, seed=0)
+
+
+def make_window_golden():
+    """ref_window.npz: the reference's backend over a DRIVE -- fourteen keyframes through a five-keyframe active map, every
+    window optimised by the REAL g2o classes (po.ba_solve "ref"), every result written back the way backend.cpp:205-244 does
+    (outlier observations unlinked, condemned map points deleted, the first-observer rule of backend.cpp:125-130 deciding which
+    map points are fixed): the map bookkeeping is ssvio_amd.mapmodel.ActiveMap, the arithmetic is the reference's.  The GPU test
+    replays the same drive on an ssx_ba_window and must take the same decisions at every keyframe."""
+    from ssvio_amd.mapmodel import ActiveMap, make_window_scenario
+    frames = make_window_scenario(**WINDOW_SCENARIO)
+    m = ActiveMap(WINDOW_SCENARIO["n_active"])
+    g = {"cfg": np.array([WINDOW_SCENARIO[k] for k in ("n_kf", "n_active", "new_per_kf", "track_len", "seed")])}
+    g["input_sum"] = np.array([sum(f["pose"].sum() for f in frames), sum(float(np.sum([uv for _, uv in f["obs"]])) for f in frames),
+                               sum(float(np.sum(list(f["new_points"].values()))) for f in frames)])
+    margin = np.inf
+    for r, fr in enumerate(frames):
+        for l in fr["condemn"]:
+            m.condemn(l)
+        m.insert_keyframe(fr["kf_id"], fr["pose"], fr["obs"], fr["new_points"], fr["victim"])
+        pr, kf_ids, lm_ids, e_feat = m.problem()
+        res = po.ba_solve(pr, "ref")
+        margin = min(margin, float(np.abs(res["edge_chi2"] - 5.891).min()))
+        g[f"w{r}_sizes"] = np.array([pr["P"], pr["L"], pr["E"], int(pr["point_fixed"].sum())])
+        g[f"w{r}_kf_ids"] = np.array(kf_ids); g[f"w{r}_lm_ids"] = np.array(lm_ids, dtype=np.int32)
+        g[f"w{r}_fixed"] = np.packbits(pr["point_fixed"])
+        g[f"w{r}_poses"] = res["poses"]; g[f"w{r}_points"] = res["points"][::11]
+        g[f"w{r}_outlier"] = np.packbits(res["edge_outlier"]); g[f"w{r}_edge_chi2"] = res["edge_chi2"][::5]
+        g[f"w{r}_chi2"] = res["chi2"]; g[f"w{r}_trials"] = res["trials"]; g[f"w{r}_rounds"] = np.array(res["rounds"])
+        m.apply(kf_ids, lm_ids, e_feat, res["poses"], res["points"], res["edge_outlier"])
+    g["stats"] = np.array([m.stats[k] for k in ("reentered", "fixed_by_rule", "condemned", "outlier_edges")])
+    g["margin"] = np.array(margin)                 # smallest |chi2 - 5.891| over all edges of all rounds: how safe the decisions are
+    assert margin > 5e-3 and m.stats["reentered"] > 0, (margin, m.stats)
+    np.savez_compressed(os.path.join(OUT, "ref_window.npz"), **g)
+    print("ref_window.npz:", os.path.getsize(os.path.join(OUT, "ref_window.npz")), "bytes,", len(g), "arrays; decision margin", margin, m.stats)
+
+
 def main():
     assert po.have_ref(), "needs /root/reference (or a prebuilt oracle/_ref/libssvio_ref.so)"
     rng = np.random.default_rng(1234)
@@ -174,6 +211,7 @@ def main():
     print("ref_golden.npz:", os.path.getsize(os.path.join(OUT, "ref_golden.npz")), "bytes,", len(g), "arrays")
     make_pose_graph_golden()
     make_bow_golden()
+    make_window_golden()
 
     # ---- self pins of the ORB restatement ----
     s = {}

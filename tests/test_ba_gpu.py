@@ -912,3 +912,100 @@ def test_window_misuse(ctx):
     win.pop(1)
     assert win.size() == (0, 0, 0)
     win.close()
+
+
+# ---- the window driven like the reference's backend drives its map (backend.cpp:205-244, map.cpp:89-194) -----------------------
+
+def _drive(ctx, frames, n_active, jac, golden=None, record=None):
+    """Replays a drive (ssvio_amd.mapmodel.make_window_scenario) the way ssvio's backend would: per keyframe the map changes
+    (insert, drop a keyframe, drop unobserved map points, delete condemned ones), the window receives those edits, and is
+    solved; the SAME graph re-marshalled from the map (keyframes / map points ascending by id, backend.cpp:88-169) goes through
+    a fresh ssx_ba_solve.  Window and fresh solve must agree BIT FOR BIT at every keyframe -- contents, fixed flags, result --
+    and the result is written back like backend.cpp:205-244 does (outliers unlinked, ...), which produces the next edits."""
+    from ssvio_amd.mapmodel import ActiveMap, apply_edits
+    m = ActiveMap(n_active)
+    win = ba.BaWindow(ctx, m.K, m.cam_ext, jac_mode=jac, fix_rule=1)
+    worst = dict(pose=0.0, resid=0.0, frac=1.0)
+    for r, fr in enumerate(frames):
+        for l in fr["condemn"]:
+            m.condemn(l)
+        m.insert_keyframe(fr["kf_id"], fr["pose"], fr["obs"], fr["new_points"], fr["victim"])
+        apply_edits(win, m.take_edits())
+        pr, kf_ids, lm_ids, e_feat = m.problem()
+        ex = win.export()
+        # 1. the window holds exactly the graph the reference would build from its map
+        assert list(ex["kf_ids"]) == kf_ids and list(ex["lm_ids"]) == lm_ids, r
+        np.testing.assert_array_equal(ex["point_fixed"], pr["point_fixed"])          # backend.cpp:125-130, kept by the window itself
+        np.testing.assert_array_equal(ex["poses"], pr["poses"]); np.testing.assert_array_equal(ex["points"], pr["points"])
+        key_w = ex["edge_pose"].astype(np.int64) * 10 ** 7 + ex["edge_point"]
+        key_m = pr["edge_pose"].astype(np.int64) * 10 ** 7 + pr["edge_point"]
+        assert len(np.unique(key_w)) == len(key_w) and np.array_equal(np.sort(key_w), np.sort(key_m)), r
+        to_w = np.argsort(key_w)[np.argsort(np.argsort(key_m))]                      # map edge -> window edge
+        np.testing.assert_array_equal(ex["edge_uv"][to_w], pr["edge_uv"])
+        # 2. same bits as the re-marshalled map
+        fresh = ba.ba_solve(ctx, pr, jac_mode=jac)
+        got = win.solve()
+        np.testing.assert_array_equal(got["poses"], fresh["poses"]); np.testing.assert_array_equal(got["points"], fresh["points"])
+        np.testing.assert_array_equal(got["edge_chi2"][to_w], fresh["edge_chi2"])
+        np.testing.assert_array_equal(got["trials"], fresh["trials"]); np.testing.assert_array_equal(got["chi2"], fresh["chi2"])
+        # 3. the reference's own run of the same drive (g2o through oracle/_ref, tests/golden/ref_window.npz)
+        if golden is not None:
+            G = golden
+            assert list(G[f"w{r}_kf_ids"]) == kf_ids and list(G[f"w{r}_lm_ids"]) == lm_ids, f"keyframe {r}: the map took another path than the reference's"
+            np.testing.assert_array_equal(np.unpackbits(G[f"w{r}_fixed"])[:pr["L"]], pr["point_fixed"])
+            np.testing.assert_array_equal(np.unpackbits(G[f"w{r}_outlier"])[:pr["E"]], fresh["edge_outlier"])   # same edges culled
+            assert fresh["rounds"] == int(G[f"w{r}_rounds"])
+            np.testing.assert_array_equal(fresh["trials"], G[f"w{r}_trials"])
+            np.testing.assert_allclose(fresh["chi2"], G[f"w{r}_chi2"], rtol=5e-5)
+            d = np.abs(np.sqrt(fresh["edge_chi2"][::5]) - np.sqrt(G[f"w{r}_edge_chi2"]))
+            worst["resid"] = max(worst["resid"], float(d.max())); worst["frac"] = min(worst["frac"], float((d <= RESID_TOL).mean()))
+            worst["pose"] = max(worst["pose"], float(np.abs(fresh["poses"] - G[f"w{r}_poses"]).max()))
+        m.apply(kf_ids, lm_ids, e_feat, fresh["poses"], fresh["points"], fresh["edge_outlier"])
+        # (the same decisions, handed back the short way: the flags of the solve as they are -- on a twin of the window)
+        if r == len(frames) // 2:
+            twin_flags = got["edge_outlier"].copy()
+            n_before = win.size()[2]
+            assert win.remove_flagged(np.zeros(n_before, np.uint8)) == 0 and win.size()[2] == n_before
+            edits = m.take_edits()
+            assert [k for k, _ in edits] in (["remove_obs"], [])
+            assert win.remove_flagged(twin_flags) == int(twin_flags.sum())
+        else:
+            apply_edits(win, m.take_edits())
+    win.close()
+    if record is not None:
+        record(worst)
+    return m.stats, worst
+
+
+def test_window_driven_like_the_backend_equals_the_remarshalled_map(ctx):
+    """ssx_ba_window_remove_* / pop with the first-observer rule / landmarks that come back: a 14-keyframe drive through a
+    5-keyframe window, non-oldest keyframes dropped now and then, 4 % gross outliers, map points condemned by the frontend"""
+    from ssvio_amd.mapmodel import make_window_scenario
+    for seed, n_active in ((1, 5), (2, 4), (5, 7)):
+        frames = make_window_scenario(n_kf=14, n_active=n_active, seed=seed)
+        stats, _ = _drive(ctx, frames, n_active, ba.JAC_ANALYTIC)
+        assert stats["outlier_edges"] > 100 and stats["condemned"] > 5 and stats["fixed_by_rule"] > 500, stats
+
+
+@pytest.mark.parametrize("jac", [ba.JAC_NUMERIC_G2O, ba.JAC_ANALYTIC])
+def test_window_drive_matches_the_reference_backend_golden(ctx, jac, record_property):
+    """The drive of tests/golden/ref_window.npz: there the REAL g2o optimised every window and backend.cpp:205-244's edits were
+    applied to the map; here the resident window does, through the C ABI.  At every one of the 14 keyframes: the same map
+    (keyframes, map points, fixed flags), the same outlier edges culled, the same LM trial counts, residuals within 1e-4 px of
+    the reference's (bars below: analytic Jacobians all of them; g2o's numeric Jacobians >= 99 % of them)."""
+    from ssvio_amd.mapmodel import make_window_scenario
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_window.npz"))
+    n_kf, n_active, new_per_kf, track_len, seed = (int(x) for x in G["cfg"])
+    frames = make_window_scenario(n_kf=n_kf, n_active=n_active, new_per_kf=new_per_kf, track_len=track_len, seed=seed)
+    s = np.array([sum(f["pose"].sum() for f in frames), sum(float(np.sum([uv for _, uv in f["obs"]])) for f in frames),
+                  sum(float(np.sum(list(f["new_points"].values()))) for f in frames)])
+    np.testing.assert_allclose(s, G["input_sum"], rtol=1e-12)                         # the generator has not drifted
+    stats, worst = _drive(ctx, frames, n_active, jac, golden=G)
+    print(f"[drive jac={jac}] worst over 14 windows: |pose - ref| {worst['pose']:.2e}, |r - r_ref| max {worst['resid']:.2e} px, within 1e-4 px: {100 * worst['frac']:.2f} %")
+    for k, v in worst.items():
+        record_property(f"worst_{k}", v)
+    assert [stats[k] for k in ("reentered", "fixed_by_rule", "condemned", "outlier_edges")] == list(G["stats"])
+    assert stats["reentered"] > 0
+    assert worst["frac"] >= 0.99 and worst["pose"] < 2e-5
+    if jac == ba.JAC_ANALYTIC:
+        assert worst["resid"] < RESID_TOL
