@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <cstring>
+#include <stdexcept>
+#include <string>
+#include <tuple>
 
 namespace ssx::host {
 
@@ -13,6 +16,17 @@ Backend::Backend(const Setting& cfg, Compute& compute, std::shared_ptr<Map> map,
   // Backend.Jacobian.Numeric: 1 reproduces that, the default is the analytic Jacobian (same optimum, fewer flops)
   jac_mode_ = cfg.Get<int>("Backend.Jacobian.Numeric") != 0 ? SSX_JAC_NUMERIC_G2O : SSX_JAC_ANALYTIC;
   async_ = cfg.Get<int>("Backend.Async") != 0;
+  if (!cfg.Has("Backend.Window") || cfg.Get<int>("Backend.Window") != 0) {
+    ssx_ba_options opt;
+    ssx_ba_default_options(&opt);                                      // 5 rounds x optimize(10), chi2 / Huber 5.891, inlier ratio 0.7
+    opt.jac_mode = jac_mode_;
+    const double K4[4] = {camera_left_.fx, camera_left_.fy, camera_left_.cx, camera_left_.cy};
+    double ext[14];
+    std::memcpy(ext, camera_left_.pose.data(), 7 * sizeof(double));
+    std::memcpy(ext + 7, camera_right_.pose.data(), 7 * sizeof(double));
+    window_ = compute_.MakeBaWindow(K4, ext, opt);                     // null: this Compute has no resident window
+  }
+  window_check_ = cfg.Get<int>("Backend.Window.Check") != 0;
   if (async_) worker_ = std::thread([this] { Worker(); });
 }
 
@@ -33,7 +47,7 @@ Backend::~Backend()
 void Backend::InsertKeyFrame(const KeyFramePtr& kf, bool optimization)
 {
   if (!async_) {
-    map_->InsertKeyFrame(kf);
+    InsertIntoMap(kf);
     if (optimization) OptimizeActiveMap();
     return;
   }
@@ -81,13 +95,21 @@ void Backend::Worker()
     std::exception_ptr err;
     try {
       Window w;
+      WindowResult wr;
       bool optimize = false;
       {
         std::lock_guard<std::mutex> map_lock(map_->update_mutex);
-        for (auto& item : batch) { map_->InsertKeyFrame(item.first); optimize = item.second; }
-        if (optimize) Marshal(w);
+        for (auto& item : batch) { InsertIntoMap(item.first); optimize = item.second; }
+        if (optimize && window_) WindowDropCondemned();
+        if (optimize && !window_) Marshal(w);
       }
-      if (optimize && !w.empty()) {
+      if (optimize && window_) {
+        WindowSolve(wr);                                             // the window is this thread's alone: no lock
+        if (wr.solved) {
+          std::lock_guard<std::mutex> map_lock(map_->update_mutex);
+          WindowApply(wr);
+        }
+      } else if (optimize && !w.empty()) {
         Solve(w);                                                    // throws on a HIP / argument error of the BA call
         std::lock_guard<std::mutex> map_lock(map_->update_mutex);
         Apply(w);
@@ -109,6 +131,13 @@ void Backend::Worker()
 // Keyframes and map points are marshalled in ascending id order -- the order g2o gives its vertices.
 void Backend::OptimizeActiveMap()
 {
+  if (window_) {
+    WindowDropCondemned();
+    WindowResult r;
+    WindowSolve(r);
+    if (r.solved) WindowApply(r);
+    return;
+  }
   Window w;
   Marshal(w);
   if (w.empty()) return;
@@ -201,6 +230,154 @@ void Backend::Apply(Window& w)
   for (size_t j = 0; j < w.mps.size(); ++j) std::memcpy(w.mps[j]->position, &w.points_out[3 * j], 3 * sizeof(double));
   map_->RemoveAllOutlierMapPoints();
   map_->RemoveOldActiveMapPoints();
+}
+
+// ---- the resident window ---------------------------------------------------------------------------------------------
+
+void Backend::InsertIntoMap(const KeyFramePtr& kf)
+{
+  map_->InsertKeyFrame(kf);
+  if (window_) WindowMirrorInsert(kf);
+}
+
+// Map::InsertKeyFrame on the window: the keyframe with the observations Marshal would turn into edges (live, not condemned map
+// points), the map points the window does not hold yet -- new ones, or ones that come BACK after all their observers had left
+// or been unlinked: those enter with the flag of backend.cpp:125-130 as the map gives it --, then the keyframe the map dropped.
+void Backend::WindowMirrorInsert(const KeyFramePtr& kf)
+{
+  const auto& active_kfs = map_->GetActiveKeyFrames();
+  const auto& active_mps = map_->GetActiveMapPoints();
+  for (auto it = in_window_.begin(); it != in_window_.end();) it = active_mps.count(*it) ? std::next(it) : in_window_.erase(it);
+  std::vector<int64_t> new_ids, obs_lm;
+  std::vector<double> new_xyz, obs_uv;
+  std::vector<uint8_t> new_fixed, obs_cam;
+  auto& feats = window_feats_[kf->key_frame_id];
+  for (auto& feat : kf->features_left) {
+    MapPointPtr mp = map_->Lock(feat);
+    if (!mp || mp->is_outlier || feat->is_outlier) continue;
+    if (!in_window_.count(mp->id)) {
+      in_window_.insert(mp->id);
+      new_ids.push_back((int64_t)mp->id);
+      new_xyz.insert(new_xyz.end(), mp->position, mp->position + 3);
+      const bool fixed = mp->observations.empty() || active_kfs.find((unsigned long)mp->observations.front()->keyframe) == active_kfs.end();
+      new_fixed.push_back(fixed ? 1 : 0);
+    }
+    obs_lm.push_back((int64_t)mp->id);
+    obs_uv.push_back(feat->x); obs_uv.push_back(feat->y);
+    obs_cam.push_back(feat->is_on_left_frame ? 0 : 1);
+    feats[mp->id] = feat;
+  }
+  window_->Push((int64_t)kf->key_frame_id, kf->pose.data(), (int)new_ids.size(), new_ids.data(), new_xyz.data(), new_fixed.data(), (int)obs_lm.size(),
+                obs_lm.data(), obs_uv.data(), obs_cam.data());
+  const long victim = map_->last_removed_keyframe();
+  if (victim >= 0) {
+    window_->Pop((int64_t)victim);
+    window_feats_.erase((unsigned long)victim);
+    for (auto it = in_window_.begin(); it != in_window_.end();) it = active_mps.count(*it) ? std::next(it) : in_window_.erase(it);
+  }
+  if (window_check_) WindowCheckAgainstMap();
+}
+
+// backend.cpp:116 `if (mp->is_outlier_) continue`: map points the front-end condemned since the last optimisation leave the graph
+void Backend::WindowDropCondemned()
+{
+  std::vector<int64_t> ids;
+  for (unsigned long id : map_->outlier_map_points())
+    if (in_window_.erase(id)) ids.push_back((int64_t)id);
+  if (!ids.empty()) window_->RemoveLandmarks((int)ids.size(), ids.data());
+  if (window_check_) WindowCheckAgainstMap();
+}
+
+void Backend::WindowSolve(WindowResult& r)
+{
+  int nk = 0, nl = 0, no = 0;
+  window_->Size(nk, nl, no);
+  if (nk == 0 || no == 0) return;
+  r.kf_ids.resize(nk); r.lm_ids.resize(nl); r.edge_pose.resize(no); r.edge_point.resize(no);
+  r.poses.resize(7 * (size_t)nk); r.points.resize(3 * (size_t)nl); r.edge_outlier.assign(no, 0);
+  window_->Export(r.kf_ids.data(), r.lm_ids.data(), nullptr, r.edge_pose.data(), r.edge_point.data(), nullptr);
+  ssx_ba_result res{};
+  res.poses_out = r.poses.data(); res.points_out = r.points.data(); res.edge_outlier = r.edge_outlier.data();
+  window_->Solve(res);
+  r.lm_iterations = res.n_iters;
+  r.solved = true;
+}
+
+// backend.cpp:205-244 on the map, and the same edits on the window
+void Backend::WindowApply(WindowResult& r)
+{
+  stats_.windows++; stats_.lm_iterations += r.lm_iterations; stats_.edges += (long)r.edge_outlier.size();
+  const auto& all_mps = map_->GetAllMapPoints();
+  for (size_t e = 0; e < r.edge_outlier.size(); ++e) {
+    const unsigned long kf_id = (unsigned long)r.kf_ids[r.edge_pose[e]], mp_id = (unsigned long)r.lm_ids[r.edge_point[e]];
+    auto kf_it = window_feats_.find(kf_id);
+    if (kf_it == window_feats_.end()) throw std::logic_error("Backend: the window holds an observation of keyframe " + std::to_string(kf_id) + " the backend never pushed");
+    auto f_it = kf_it->second.find(mp_id);
+    if (f_it == kf_it->second.end()) throw std::logic_error("Backend: the window holds an observation the backend never pushed");
+    const FeaturePtr& feat = f_it->second;
+    if (!r.edge_outlier[e]) { feat->is_outlier = false; continue; }
+    stats_.outlier_edges++;
+    feat->is_outlier = true;
+    auto mp_it = all_mps.find(mp_id);
+    if (mp_it != all_mps.end()) {                                     // (async: the front-end may have deleted it meanwhile)
+      MapPointPtr mp = mp_it->second;
+      mp->RemoveActiveObservation(feat);
+      mp->RemoveObservation(feat);
+      if (mp->observations.empty()) {
+        mp->is_outlier = true;
+        map_->AddOutlierMapPoint(mp->id);
+      }
+    }
+    feat->map_point = kNoMapPoint;
+    kf_it->second.erase(f_it);
+  }
+  window_->RemoveFlagged((int)r.edge_outlier.size(), r.edge_outlier.data());
+  const auto& all_kfs = map_->GetAllKeyFrames();
+  for (size_t i = 0; i < r.kf_ids.size(); ++i) all_kfs.at((unsigned long)r.kf_ids[i])->pose = SE3(&r.poses[7 * i]);
+  for (size_t j = 0; j < r.lm_ids.size(); ++j) {
+    auto it = all_mps.find((unsigned long)r.lm_ids[j]);
+    if (it != all_mps.end()) std::memcpy(it->second->position, &r.points[3 * j], 3 * sizeof(double));
+  }
+  // map points condemned during the solve (asynchronous front-end) are still in the window: out with them before the map forgets them
+  WindowDropCondemned();
+  map_->RemoveAllOutlierMapPoints();
+  map_->RemoveOldActiveMapPoints();
+  const auto& active_mps = map_->GetActiveMapPoints();
+  for (auto it = in_window_.begin(); it != in_window_.end();) it = active_mps.count(*it) ? std::next(it) : in_window_.erase(it);
+  if (window_check_) WindowCheckAgainstMap();
+}
+
+// Backend.Window.Check: the graph Marshal builds from the map against what the window exports -- keyframe ids, map-point ids,
+// fixed flags, and the observations as (keyframe, map point, pixel) triples.  Map points the front-end has condemned but
+// WindowDropCondemned has not seen yet are the one legitimate difference and are taken out of the comparison.
+void Backend::WindowCheckAgainstMap()
+{
+  Window w;
+  Marshal(w);
+  int nk = 0, nl = 0, no = 0;
+  window_->Size(nk, nl, no);
+  std::vector<int64_t> kf_ids(nk + 1), lm_ids(nl + 1);
+  std::vector<uint8_t> fixed(nl + 1);
+  std::vector<int32_t> ep(no + 1), el(no + 1);
+  std::vector<double> uv(2 * (size_t)no + 2);
+  window_->Export(kf_ids.data(), lm_ids.data(), fixed.data(), ep.data(), el.data(), uv.data());
+  auto fail = [&](const std::string& what) { throw std::logic_error("Backend.Window.Check: the resident window and the map disagree: " + what); };
+  std::unordered_set<unsigned long> pending;                          // condemned, still in the window
+  for (unsigned long id : map_->outlier_map_points()) if (in_window_.count(id)) pending.insert(id);
+  if ((size_t)nk != w.kfs.size()) fail("keyframe count " + std::to_string(nk) + " vs " + std::to_string(w.kfs.size()));
+  for (int i = 0; i < nk; ++i) if ((unsigned long)kf_ids[i] != w.kfs[i]->key_frame_id) fail("keyframe ids");
+  using Tri = std::tuple<unsigned long, unsigned long, double, double>;
+  std::vector<Tri> a, b;
+  std::vector<std::pair<unsigned long, int>> la, lb;
+  for (int j = 0; j < nl; ++j) if (!pending.count((unsigned long)lm_ids[j])) la.emplace_back((unsigned long)lm_ids[j], fixed[j]);
+  for (size_t j = 0; j < w.mps.size(); ++j) lb.emplace_back(w.mps[j]->id, w.point_fixed[j]);
+  if (la != lb) fail("map points or their fixed flags (" + std::to_string(la.size()) + " vs " + std::to_string(lb.size()) + ")");
+  for (int e = 0; e < no; ++e)
+    if (!pending.count((unsigned long)lm_ids[el[e]])) a.emplace_back((unsigned long)kf_ids[ep[e]], (unsigned long)lm_ids[el[e]], uv[2 * (size_t)e], uv[2 * (size_t)e + 1]);
+  for (size_t e = 0; e < w.edge_feature.size(); ++e)
+    b.emplace_back(w.kfs[w.edge_pose[e]]->key_frame_id, w.mps[w.edge_point[e]]->id, w.edge_uv[2 * e], w.edge_uv[2 * e + 1]);
+  std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+  if (a != b) fail("observations (" + std::to_string(a.size()) + " vs " + std::to_string(b.size()) + ")");
 }
 
 }  // namespace ssx::host

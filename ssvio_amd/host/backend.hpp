@@ -9,6 +9,17 @@
 //                           the reference takes mmutex_map_update_ (front-end: one frame; backend: insertion + read,
 //                           and the write-back of the result -- not the solve).  Results then depend on timing,
 //                           as they do in the reference.
+// The active window itself lives in one of two places (setting Backend.Window, default 1):
+//   1  RESIDENT on the device (Compute::MakeBaWindow -> ssx_ba_window): every change the reference makes to its active map --
+//      Map::InsertKeyFrame, RemoveOldActiveKeyframe, RemoveOldActiveMapPoints (map.cpp:18-58, 89-160), the outlier edges
+//      OptimizeActiveMap unlinks and the map points it deletes (backend.cpp:205-244), map points the front-end condemned
+//      (frontend.cpp:283-288) -- is mirrored as an edit of the window; a keyframe's pose, its new map points and its
+//      observations are all that crosses PCIe, and the fixed flags of backend.cpp:125-130 are kept by the window itself;
+//   0  re-marshalled from the map at every keyframe (Marshal: the reference's own way, backend.cpp:88-169).
+// Both give the same bits (the window solves in id order): tests/test_host_gpu.py runs every sequence both ways and compares
+// the per-frame logs and trajectory files byte for byte; Backend.Window.Check: 1 re-marshals the map beside the window at every
+// keyframe and throws when the two graphs differ.  An implementation without a resident window (the CPU oracle of the tests)
+// falls back to 0.
 // Loop closing is not attached.
 #pragma once
 #include <condition_variable>
@@ -16,6 +27,8 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
+#include <unordered_set>
 
 #include <exception>
 
@@ -36,6 +49,7 @@ class Backend {
   void OptimizeActiveMap();                 // synchronous: marshal + solve + apply, caller holds the map mutex
   void WaitIdle();                          // asynchronous mode: returns when the queue is empty and the worker idle
   bool async() const { return async_; }
+  bool resident_window() const { return window_ != nullptr; }
 
   struct Stats { long windows = 0, lm_iterations = 0, edges = 0, outlier_edges = 0; };
   const Stats& stats() const { return stats_; }
@@ -57,11 +71,30 @@ class Backend {
   void Apply(Window& w);                    // arrays -> map, outliers    (map mutex held)
   void Worker();
   void RethrowWorkerError();                // queue_mutex_ held
+  // the resident window (map mutex held except for WindowSolve)
+  void InsertIntoMap(const KeyFramePtr& kf);        // Map::InsertKeyFrame + its mirror on the window
+  void WindowMirrorInsert(const KeyFramePtr& kf);
+  void WindowDropCondemned();
+  struct WindowResult {
+    std::vector<int64_t> kf_ids, lm_ids;
+    std::vector<int32_t> edge_pose, edge_point;
+    std::vector<double> poses, points;
+    std::vector<uint8_t> edge_outlier;
+    int lm_iterations = 0;
+    bool solved = false;
+  };
+  void WindowSolve(WindowResult& r);        // the GPU call               (no lock)
+  void WindowApply(WindowResult& r);        // result -> map, outliers -> window and map
+  void WindowCheckAgainstMap();             // Backend.Window.Check
 
   Compute& compute_;
   std::shared_ptr<Map> map_;
   Camera camera_left_, camera_right_;
   int jac_mode_;
+  std::unique_ptr<BaWindow> window_;        // null: Marshal / Solve / Apply per keyframe
+  bool window_check_ = false;
+  std::unordered_set<unsigned long> in_window_;                                       // map points the window holds
+  std::unordered_map<unsigned long, std::unordered_map<unsigned long, FeaturePtr>> window_feats_;   // keyframe -> map point -> the feature pushed
   Stats stats_;
   bool async_ = false;
   std::thread worker_;

@@ -18,6 +18,25 @@
 
 namespace ssx::host {
 
+// The active window of the backend RESIDENT on the device (ssx_ba_window, include/ssx.h): the backend mirrors every change of
+// its map -- a keyframe in, a keyframe out, outlier observations unlinked, condemned map points deleted
+// (map.cpp:18-58, 89-194; backend.cpp:205-244) -- instead of re-marshalling the whole window at every keyframe.  Keyframes and
+// map points are named by their ids; the window solves in id order, so its result is, bit for bit, the one BundleAdjust returns
+// for the re-marshalled map (Backend::Marshal).
+class BaWindow {
+ public:
+  virtual ~BaWindow() = default;
+  virtual void Push(int64_t kf_id, const double* pose7, int n_new, const int64_t* new_ids, const double* new_xyz, const uint8_t* new_fixed,
+                    int n_obs, const int64_t* obs_lm, const double* obs_uv, const uint8_t* obs_cam) = 0;
+  virtual void Pop(int64_t kf_id) = 0;
+  virtual void RemoveLandmarks(int n, const int64_t* lm_ids) = 0;
+  virtual void RemoveFlagged(int n_obs, const uint8_t* flags) = 0;             // flags in the order of Export / of the last Solve
+  virtual void Size(int& n_keyframes, int& n_landmarks, int& n_observations) = 0;
+  // ids ascending; edge_pose / edge_point index into them; point_fixed = the flags the next solve uses (any may be null)
+  virtual void Export(int64_t* kf_ids, int64_t* lm_ids, uint8_t* point_fixed, int32_t* edge_pose, int32_t* edge_point, double* edge_uv) = 0;
+  virtual void Solve(ssx_ba_result& res) = 0;                                   // res.* in the order of Export
+};
+
 class Compute {
  public:
   virtual ~Compute() = default;
@@ -32,6 +51,13 @@ class Compute {
                            uint8_t* ok) = 0;
   // res.poses_out / points_out / edge_outlier point at caller storage
   virtual void BundleAdjust(const ssx_ba_problem& prob, const ssx_ba_options& opt, ssx_ba_result& res) = 0;
+  // a resident window with the first-observer rule of backend.cpp:125-130 switched on, or null when the implementation has
+  // none (the backend then re-marshals its map per keyframe)
+  virtual std::unique_ptr<BaWindow> MakeBaWindow(const double* K4, const double* cam_ext14, const ssx_ba_options& opt)
+  {
+    (void)K4; (void)cam_ext14; (void)opt;
+    return nullptr;
+  }
 };
 
 // device: GPU ordinal.  Three contexts (streams): per-frame work, the temporal LK chain, the backend.

@@ -71,6 +71,7 @@ MapPointPtr Map::Lock(long id) const
 void Map::InsertKeyFrame(const KeyFramePtr& kf)
 {
   current_keyframe_ = kf;
+  last_removed_keyframe_ = -1;
   if (all_key_frames_.count(kf->key_frame_id)) throw std::logic_error("Map::InsertKeyFrame: keyframe id inserted twice");
   all_key_frames_.insert({kf->key_frame_id, kf});
   active_key_frames_.insert({kf->key_frame_id, kf});
@@ -113,6 +114,7 @@ void Map::RemoveOldActiveKeyframe()
   const double min_dis_th = 0.2;
   KeyFramePtr victim = active_key_frames_.at(min_dis < min_dis_th ? min_id : max_id);
   active_key_frames_.erase(victim->key_frame_id);
+  last_removed_keyframe_ = (long)victim->key_frame_id;
   for (auto& feat : victim->features_left)
     if (MapPointPtr mp = Lock(feat)) mp->RemoveActiveObservation(feat);
 }

@@ -100,12 +100,17 @@ class Map {
   const KeyFramesType& GetAllKeyFrames() const { return all_key_frames_; }
   const MapPointsType& GetActiveMapPoints() const { return active_map_points_; }
   const KeyFramesType& GetActiveKeyFrames() const { return active_key_frames_; }
+  // for a backend that mirrors the map into a resident window: the keyframe the last InsertKeyFrame dropped from the active
+  // window (-1: none), and the map points condemned since the last RemoveAllOutlierMapPoints
+  long last_removed_keyframe() const { return last_removed_keyframe_; }
+  const std::list<unsigned long>& outlier_map_points() const { return outlier_map_points_; }
 
  private:
   MapPointsType all_map_points_, active_map_points_;
   KeyFramesType all_key_frames_, active_key_frames_;
   std::list<unsigned long> outlier_map_points_;
   KeyFramePtr current_keyframe_;
+  long last_removed_keyframe_ = -1;
   unsigned num_active_key_frames_;
   unsigned long next_frame_id_ = 0, next_key_frame_id_ = 0, next_map_point_id_ = 0;
 };

@@ -8,6 +8,39 @@
 namespace ssx::host {
 namespace {
 
+class SsxBaWindow final : public BaWindow {
+ public:
+  SsxBaWindow(ssx::Context& ctx, const double* K4, const double* cam_ext14, const ssx_ba_options& opt) : ctx_(ctx)
+  {
+    ctx_.check(ssx_ba_window_create(ctx_.get(), &opt, K4, cam_ext14, &win_));
+    ctx_.check(ssx_ba_window_set_fix_rule(win_, 1));
+  }
+  ~SsxBaWindow() override { ssx_ba_window_destroy(win_); }
+  void Push(int64_t kf_id, const double* pose7, int n_new, const int64_t* new_ids, const double* new_xyz, const uint8_t* new_fixed, int n_obs,
+            const int64_t* obs_lm, const double* obs_uv, const uint8_t* obs_cam) override
+  {
+    ctx_.check(ssx_ba_window_push_keyframe(win_, kf_id, pose7, 0, n_new, new_ids, new_xyz, new_fixed, n_obs, obs_lm, obs_uv, obs_cam));
+  }
+  void Pop(int64_t kf_id) override { ctx_.check(ssx_ba_window_pop_keyframe(win_, kf_id)); }
+  void RemoveLandmarks(int n, const int64_t* lm_ids) override { ctx_.check(ssx_ba_window_remove_landmarks(win_, n, lm_ids, nullptr)); }
+  void RemoveFlagged(int n_obs, const uint8_t* flags) override { ctx_.check(ssx_ba_window_remove_flagged(win_, n_obs, flags, nullptr)); }
+  void Size(int& nk, int& nl, int& no) override
+  {
+    int32_t a = 0, b = 0, c = 0;
+    ctx_.check(ssx_ba_window_size(win_, &a, &b, &c));
+    nk = a; nl = b; no = c;
+  }
+  void Export(int64_t* kf_ids, int64_t* lm_ids, uint8_t* point_fixed, int32_t* edge_pose, int32_t* edge_point, double* edge_uv) override
+  {
+    ctx_.check(ssx_ba_window_export(win_, kf_ids, nullptr, nullptr, lm_ids, nullptr, point_fixed, edge_pose, edge_point, edge_uv, nullptr));
+  }
+  void Solve(ssx_ba_result& res) override { ctx_.check(ssx_ba_window_solve(win_, &res)); }
+
+ private:
+  ssx::Context& ctx_;
+  ssx_ba_window* win_ = nullptr;
+};
+
 class SsxCompute final : public Compute {
  public:
   explicit SsxCompute(int device) : frame_(device), chain_(device), backend_(device) {}
@@ -68,6 +101,11 @@ class SsxCompute final : public Compute {
   void BundleAdjust(const ssx_ba_problem& prob, const ssx_ba_options& opt, ssx_ba_result& res) override
   {
     backend_.check(ssx_ba_solve(backend_.get(), &prob, &opt, &res));
+  }
+
+  std::unique_ptr<BaWindow> MakeBaWindow(const double* K4, const double* cam_ext14, const ssx_ba_options& opt) override
+  {
+    return std::make_unique<SsxBaWindow>(backend_, K4, cam_ext14, opt);    // (the window must be destroyed before this Compute)
   }
 
  private:

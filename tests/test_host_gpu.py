@@ -135,3 +135,38 @@ def test_runner_arguments(built, tmp_path):
     r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", "--max_frames=2", f"--trajectory={out}"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "Num Images: 2" in r.stdout and len(open(out).read().splitlines()) == 1
+
+
+def _run_logged(built, cfg, seq_dir, out):
+    r = subprocess.run([built["oracle_runner"], cfg, seq_dir, out], capture_output=True, text=True, timeout=900, env=dict(os.environ, SSX_HOST_TEST_GPU="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [l for l in r.stdout.splitlines() if l.startswith("frame ")]
+
+
+@pytest.mark.parametrize("case", ["lateral3", "lateral_default", "lateral4_numeric", "corridor", "corridor_long_window5"])
+def test_resident_window_backend_equals_the_remarshalling_backend(built, tmp_path, case):
+    """Backend.Window: 1 (the active window resident in HBM, every map edit of map.cpp:18-58, 89-194 and backend.cpp:205-244
+    mirrored on ssx_ba_window) against Backend.Window: 0 (the window re-marshalled from the map at every keyframe, the reference's
+    own way) on every sequence of this file: the per-frame logs -- status, feature / keyframe / map-point counts, active window
+    sizes, camera centre to 1e-6 -- and the TUM trajectory files must be IDENTICAL, byte for byte: the window solves in id order,
+    so it returns the bits of the re-marshalled solve, and the two runs never part.  A third run with Backend.Window.Check: 1
+    re-marshals the map beside the window at every edit and compares the two graphs (ids, fixed flags, observations)."""
+    overrides = {"lateral3": {"Map.ActiveMap.Size": 3, "numFeatures.trackingGood": 100000}, "lateral_default": {"numFeatures.trackingGood": 280},
+                 "lateral4_numeric": {"Map.ActiveMap.Size": 4, "numFeatures.trackingGood": 100000, "Backend.Jacobian.Numeric": 1},
+                 "corridor": {}, "corridor_long_window5": {"Map.ActiveMap.Size": 5, "numFeatures.trackingGood": 100000}}[case]
+    if case.startswith("lateral"):
+        seq = hu.write_sequence(str(tmp_path), n_frames=12, step=0.6)
+    else:
+        seq = hu.write_corridor_sequence(str(tmp_path), n_frames=24 if case == "corridor" else 36)
+    logs, files = {}, {}
+    for mode, extra in (("window", {"Backend.Window": 1}), ("marshal", {"Backend.Window": 0}), ("checked", {"Backend.Window": 1, "Backend.Window.Check": 1})):
+        cfg = hu.write_config(os.path.join(str(tmp_path), f"cfg_{mode}.yaml"), dict(overrides, **extra))
+        out = os.path.join(str(tmp_path), f"{mode}.txt")
+        logs[mode] = _run_logged(built, cfg, seq["dir"], out)
+        files[mode] = open(out).read()
+    assert len(logs["window"]) == len(seq["frames"]) and len(files["window"].splitlines()) >= 2
+    assert logs["window"] == logs["marshal"] and files["window"] == files["marshal"]
+    assert logs["checked"] == logs["window"] and files["checked"] == files["window"]
+    if case == "corridor_long_window5":
+        kfs = hu.parse_runner_log("\n".join(logs["window"]))[-1]["keyframes"]
+        assert kfs >= 30, kfs                                           # the window of 5 slid: keyframes were dropped, map points fixed by the rule
