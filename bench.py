@@ -6,8 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): "stereo frames/s (ORB+match+local-BA) on 1241x376".  One STEP = one batch of B synthetic
-1241x376 stereo pairs per GPU (already resident in HBM when the timed region starts) through the WHOLE hot path in ONE
-timed region: pyramid + grid FAST + octree + orientation + blur + BRIEF on both images (2000 features each), row-band
+1241x376 stereo pairs per GPU -- handed over as HOST images every step (a pinned ring; the upload of a step's batch
+rides the library's copy stream beside the previous kernels, test/test_system.cpp:36-47 feeds a fresh pair per step)
+-- through the WHOLE hot path in ONE timed region, the keypoint / match / triangulation counts and the optimised
+keyframe poses of every window downloaded every step: pyramid + grid FAST + octree + orientation + blur + BRIEF on both images (2000 features each), row-band
 Hamming matching, DLT triangulation (configs[1], "C2") AND one local bundle adjustment per pair -- a configs[2]-shaped
 window ("C3": 10 keyframes, 4000 landmarks, 20000 edges; Backend::OptimizeActiveMap with the reference's defaults:
 <= 5 outer rounds x optimize(10), Huber 5.891) as /root/reference/src/ssvio/frontend.cpp:546-576 ->
@@ -15,12 +17,17 @@ backend.cpp:57-76,78-245 chain them per keyframe.  `value` = pairs completed per
 N > 1 runs one process per GPU on independent pairs and windows (replicas, no data-path collective): weak scaling.
 
 Also in the same JSON line:
+  resident        the same step with images AND windows resident in HBM and nothing downloaded (rounds 1-3's `value`)
+  c1              BASELINE configs[0] at its stated size: 200 KITTI-00-shaped stereo pairs (rendered corridor drive, the
+                  reference's kitti_00.yaml settings) through the headless test_system (ssx_run_kitti): frames/s with and
+                  without PNG decoding, APE against the generator's ground truth, the CPU oracle runner beside it
   frontend        the front-end alone (the same batch, its own timed region) -- what round 1 reported as `value`
   ba              C3 alone: LM iterations/s of one window at a time (latency) and of the batched entry point
   ba_c4           BA LM iterations/s on the configs[3] shape, landmark-sharded over the N GPUs through RCCL inside
                   libssx.so (ssx_comm_*) when N > 1
-  roofline        the kernel with the largest share of the composite step: HBM, f64-flop and VALU-issue fractions from
-                  SURVEY.md 8-D's algorithmic bytes / flops and the guide's peaks (frac = the largest)
+  roofline        the kernel with the largest share of the composite step: frac = the larger of the ALGORITHMIC hbm and
+                  f64-flop fractions (SURVEY.md 8-D's bytes / flops per launch over the live launch duration, against the
+                  guide's peaks); hbm_frac, flops_frac, traffic_ratio (PMC bytes / algorithmic bytes) as scalars beside it
   cpu_baseline    the same composite on ONE host core: CPU oracle front-end (scalar C++ restatement; OpenCV cannot be
                   built here) + the reference's own g2o BA (oracle/_ref/libssvio_ref.so) when it travelled
 """
@@ -64,14 +71,24 @@ def main():
                     "18.9 / 19.8 / 20.1 k frames/s at 64 / 128 / 256 -- the latency-bound kernels of the front-end want the larger batch)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="stereo pairs + windows timed on the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--c1-frames", type=int, default=200, help="stereo pairs of the configs[0] leg (0 = skip it)")
     ap.add_argument("--lean", action="store_true", help="only the headline region + the per-kernel pass (what tools/collect_profiles.sh "
                     "profiles: every launch of a kernel then has the same shape, so rocprofv3's per-kernel averages mean something)")
     args = ap.parse_args()
 
+    rank = int(os.environ.get("RANK", "0"))
+    # configs[0] leg: the 200-pair drive is rendered + written as PNGs by a process of its own (numpy ray casting, 0.65 s per pair
+    # and core), started before this process touches the GPU and collected when the GPU regions are done
+    c1_dir = f"/tmp/ssx_c1_corridor_{args.c1_frames}"
+    c1_gen = None
+    if rank == 0 and args.gpus == 1 and args.c1_frames > 0 and not args.lean and not os.path.exists(os.path.join(c1_dir, "times.txt")):
+        import subprocess
+        c1_gen = subprocess.Popen([sys.executable, "-m", "ssvio_amd.synth", "corridor", c1_dir, str(args.c1_frames)], cwd=ROOT,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # SSX_BENCH_SINGLE_GPU_GLOO=1 is a TEST MODE for boxes with one GPU: all ranks share cuda:0, the process group is
@@ -117,6 +134,10 @@ def main():
     imgs = torch.from_numpy(host).to(dev)
     torch.cuda.synchronize(dev)
     counts = orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)   # plans, runs once, syncs
+    # the host side of the headline: a pinned ring of two batches (the same pairs in two orders: every step uploads 2 x B images)
+    ring = [torch.from_numpy(host).pin_memory(), torch.from_numpy(np.ascontiguousarray(host[::-1])).pin_memory()]
+    fe_stream = orb.StereoStream(ctx, B, KITTI_H, KITTI_W)
+    h2d_bytes_per_step = int(ring[0].numel())
     N_WIN = 16 if not args.lean else 4                                 # distinct C3 graphs, used round-robin
     # (uv_f32: the measurements are float values, as the reference's keypoints are -- cv::KeyPoint::pt; it only matters to the
     # host-buffer regions, where the library then sends 8 instead of 16 bytes of coordinates per observation)
@@ -127,9 +148,25 @@ def main():
     batch = ba.BaBatch(ctx_ba, step_windows, resident=True, with_edge_errors=False)
     batch_host = ba.BaBatch(ctx_ba, step_windows)
 
+    step_no = [0]
+
+    fe_stream.upload(ring[0].data_ptr())                               # the first batch is on its way when the first step starts
+
     def composite_step():
-        orb.stereo_batch_enqueue(ctx)                                  # asynchronous on the front-end stream
-        return batch.solve(download=False)                             # B windows on the BA stream, returns when they are done
+        # the NEXT step's batch starts crossing PCIe (the library's copy stream), this step's batch -- uploaded during the last step --
+        # goes through the front-end (asynchronous) ...
+        step_no[0] += 1
+        fe_stream.upload(ring[step_no[0] & 1].data_ptr())
+        fe_stream.run()
+        # ... B windows on the BA stream: returns when they are done, with the optimised keyframe poses of every window ...
+        batch.solve(want_edges=False, summaries=False, points=False)
+        # ... and the front-end's results of this step: keypoint / match / triangulation counts of every pair
+        c = fe_stream.wait_counts()
+        return {"n_iters_total": sum(batch.res[i].n_iters for i in range(B)), "pairs_done": int((c[:, 0] > 0).sum())}
+
+    def composite_step_resident():
+        orb.stereo_batch_enqueue(ctx)                                  # asynchronous on the front-end stream, images resident
+        return batch.solve(download=False)                             # B resident windows, nothing downloaded
 
     def composite_step_host():
         orb.stereo_batch_enqueue(ctx)
@@ -141,12 +178,29 @@ def main():
     barrier()
     t0 = time.perf_counter()
     lm_iters = 0
+    pairs_done = 0
     for _ in range(args.steps):
-        lm_iters += composite_step()["n_iters_total"]
+        r_ = composite_step()
+        lm_iters += r_["n_iters_total"]; pairs_done += r_["pairs_done"]
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     frames = world * B * args.steps
+    assert pairs_done == B * args.steps, "a stereo pair came back without keypoints"
     value = frames / elapsed
+    fe_stream.run(); fe_stream.wait_counts()                           # (the batch uploaded ahead by the last step)
+    orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)     # back to the resident images for the regions below
+
+    # ---------------- timed region 1r: rounds 1-3's headline -- images and windows resident, nothing downloaded ----------------
+    for _ in range(2):
+        composite_step_resident()
+    barrier()
+    t0 = time.perf_counter()
+    RES_STEPS = max(4, args.steps // 2)
+    for _ in range(RES_STEPS):
+        composite_step_resident()
+    barrier()
+    resident_elapsed = max_over_ranks(time.perf_counter() - t0)
+    resident_value = world * B * RES_STEPS / resident_elapsed
 
     # ---------------- timed region 1b: the same with the windows handed over as HOST buffers every step ----------------
     host_value = float("nan")
@@ -463,15 +517,16 @@ def main():
     # BA kernels: algorithmic bytes per LAUNCH of the batched kernels (B windows), the terms of SURVEY.md 8-D's bytes_iter
     # (24 B per edge, 24 B per landmark state + 72 B of Hll / bl, 56 B per pose, 288 B per non-zero block of S) by kernel.
     # The edge blocks W = Ji^T w Jj are NOT materialised any more (recomputed where needed), so they do not count.
-    # "k_schur" is the profiling id of BOTH the stand-alone Schur kernel (first slot of an optimize) and the fused
-    # linearise + Schur kernel k_lin_schur (every later slot): 9 of the 10 launches per step are the fused one.
+    # "k_lin_schur" is the fused linearise + Schur kernel of every LM slot but the first of an optimize() (9 of 10 per step);
+    # "k_schur" the stand-alone Schur kernel of the first slot.
     # (The timed regions run the batch in `ba_groups` groups of windows side by side on as many streams; the per-kernel
     # pass above runs it as ONE group, so that a launch covers the B windows and has the chip to itself.)
     lin_b = 24.0 * E3 + 24.0 * L3 + 56.0 * P3 + 72.0 * L3
     Bl = B
     algo_launch_ba = {
         "k_linearize": Bl * lin_b,
-        "k_schur": Bl * (lin_b + 72.0 * L3 + 288.0 * 55),
+        "k_lin_schur": Bl * (lin_b + 72.0 * L3 + 288.0 * 55),
+        "k_schur": Bl * (24.0 * E3 + 24.0 * L3 + 56.0 * P3 + 72.0 * L3 + 288.0 * 55),
         "k_backsub_residual": Bl * (24.0 * E3 + 72.0 * L3 + 24.0 * L3 + 56.0 * P3 + 16.0 * E3),   # edges, Hll / bl, new points, poses, trial errors
         "k_solve64": Bl * (8.0 * 61 * 60 + 56.0 * 2 * P3),
     }
@@ -498,8 +553,6 @@ def main():
         if pc.get("pairs_per_step") == B and pc.get("ba_groups", 1) == 1 and world == 1:
             base = dom.split("<")[0]
             names = [base + "_b", base] if kernels[dom]["part"] == "ba" else [base]     # the BA kernels of the step are the batched ones
-            if base == "k_schur":
-                names = ["k_lin_schur_b"] + names                                     # 9 of its 10 launches per step
             key = [k for nm in names for k in pc["per_launch"] if k.split("<")[0] == nm]
             if key:
                 rec = pc["per_launch"][key[0]]
@@ -508,17 +561,14 @@ def main():
                 pmc_src = pc.get("source")
     except (OSError, ValueError):
         pass
-    # ---- the roofline of the dominant kernel, three ways, all from ALGORITHMIC work and the guide's peaks ----
-    #   hbm         SURVEY.md 8-D's bytes per launch / live duration / 8 TB/s.  For the BA kernels the bytes are 8-D's
-    #               bytes_iter = 24 E + 48 L + 56 P + 288 nnzb(S) + t (24 L + 48 P) with t = 1 -- the WHOLE LM iteration
-    #               charged to the one kernel, exactly as 8-D defines the figure (0.785 MB per C3 window) -- times the
-    #               windows a launch covers; `by_kernel_accounting` is this script's own per-kernel split of the same terms.
-    #   flops       8-D's 23 Mflop per C3 iteration x windows per launch / duration / 78.6 TFLOP/s (f64 vector peak).
-    #   valu_issue  SQ_INSTS_VALU per launch (PMC, committed pass) / duration / 1228.8 G wave-instructions/s
-    #               (1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction, the guide's figure).
-    # `frac` = the largest of the three.  issue_utilisation_f64_mix (VALU instructions against a peak derated by the
-    # kernel's own f64 instruction mix, 3.66 cycles per instruction) is a UTILISATION figure kept as a labelled secondary:
-    # it rewards every extra instruction and is not a roofline fraction.
+    # ---- the roofline of the dominant kernel: SURVEY.md 8-D's fraction, from ALGORITHMIC work and the guide's peaks ----
+    #   hbm    8-D's bytes per launch / live duration / 8 TB/s.  For the BA kernels the bytes are 8-D's
+    #          bytes_iter = 24 E + 48 L + 56 P + 288 nnzb(S) + t (24 L + 48 P) with t = 1 -- the WHOLE LM iteration charged to the
+    #          one kernel, exactly as 8-D defines the figure (0.785 MB per C3 window) -- times the windows a launch covers;
+    #          `by_kernel_accounting` is this script's own per-kernel split of the same terms.
+    #   flops  8-D's 23 Mflop per C3 iteration x windows per launch / duration / 78.6 TFLOP/s (f64 vector peak).
+    # `frac` / `bound` = the larger of the two.  Hardware instruction counts do not enter it: the VALU-issue figures
+    # (SQ_INSTS_VALU of the committed PMC pass) are UTILISATION numbers, reported under `utilisation`, never as a roofline.
     F64_PEAK_TFLOPS = 78.6
     is_ba = kernels[dom]["part"] == "ba"
     nnzb = P3 * (P3 + 1) // 2
@@ -536,8 +586,12 @@ def main():
     if is_ba:
         own = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         hbm["by_kernel_accounting"] = {"algorithmic_bytes_per_launch": int(dom_bytes), "achieved": round(own, 3), "frac": round(own / HBM_PEAK_GBS, 6)}
-    roofline = {"kernel": dom, "avg_launch_us": round(dom_avg_s * 1e6, 2), "launches_per_step": dom_calls,
-                "algorithmic_bytes_per_launch": int(hbm_bytes), "traffic": traffic, "hbm": hbm}
+    # the name rocprofv3 prints for it: the BA kernels of the step are the batched instantiations with analytic Jacobians
+    rocprof_name = {"k_lin_schur": "k_lin_schur_b<0>", "k_linearize": "k_linearize_b<0>"}.get(dom, dom + "_b" if is_ba else dom)
+    roofline = {"kernel": rocprof_name, "profile_id": dom, "avg_launch_us": round(dom_avg_s * 1e6, 2), "launches_per_step": dom_calls,
+                "algorithmic_bytes_per_launch": int(hbm_bytes), "traffic": traffic, "hbm": hbm,
+                "hbm_frac": hbm["frac"], "flops_frac": None,
+                "traffic_ratio": None if not traffic else round(traffic / hbm_bytes, 3)}
     cands = [("hbm", hbm["achieved"], HBM_PEAK_GBS, "GB/s", hbm["frac"])]
     if flops:
         tf = flops / dom_avg_s / 1e12
@@ -545,27 +599,30 @@ def main():
                              "algorithmic_flops_per_launch": int(flops),
                              "definition": "SURVEY.md 8-D: 400 flop per edge + (60 + 108 k + 216 k (k + 1) / 2) per landmark with k = 5 "
                                            "observations = 23 Mflop per C3 iteration, x windows per launch; peak = MI355X f64 vector"}
+        roofline["flops_frac"] = roofline["flops"]["frac"]
         cands.append(("f64 flops", roofline["flops"]["achieved"], F64_PEAK_TFLOPS, "TFLOP/s", roofline["flops"]["frac"]))
     if valu_insts:
         va = valu_insts / dom_avg_s / 1e9
-        roofline["valu_issue"] = {"achieved": round(va, 2), "peak": round(VALU_PEAK_GWIPS, 1), "unit": "G wave-instr/s",
-                                  "frac": round(va / VALU_PEAK_GWIPS, 5), "wave_instructions_per_launch": int(valu_insts),
-                                  "definition": "SQ_INSTS_VALU per launch (PMC, the committed pass named in `note`, NOT this run) / live launch "
-                                                "duration; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (guide)"}
-        cands.append(("valu issue", roofline["valu_issue"]["achieved"], VALU_PEAK_GWIPS, "G wave-instr/s", roofline["valu_issue"]["frac"]))
+        util = {"valu_issue": {"value": round(va / VALU_PEAK_GWIPS, 5), "achieved_G_wave_instr_per_s": round(va, 2), "peak": round(VALU_PEAK_GWIPS, 1),
+                               "wave_instructions_per_launch": int(valu_insts),
+                               "what": "SQ_INSTS_VALU per launch (the committed PMC pass named in `note`, NOT this run) / live launch duration / "
+                                       "(1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction): how busy the issue slots are -- it "
+                                       "rewards every extra instruction and is not a roofline fraction"}}
         if is_ba:
             # f64 instructions issue over 4 cycles (tools/microbench/f64_rate.hip); 54 of the 65 VALU instructions of the block
             # loop are f64 (profiles/r02/k_lin_schur_b_block_loop.s): 3.66 cycles per instruction on average
             mix_peak = 1024 * 2.4 / 3.66
-            roofline["issue_utilisation_f64_mix"] = {"value": round(va / mix_peak, 5), "peak_G_wave_instr_per_s": round(mix_peak, 1),
-                                                     "what": "utilisation, not a roofline fraction: the same numerator against a peak derated by "
-                                                             "the kernel's own instruction mix (3.66 issue cycles per instruction)"}
+            util["issue_utilisation_f64_mix"] = {"value": round(va / mix_peak, 5), "peak_G_wave_instr_per_s": round(mix_peak, 1),
+                                                 "what": "the same numerator against a peak derated by the kernel's own instruction mix "
+                                                         "(3.66 issue cycles per instruction)"}
+        roofline["utilisation"] = util
     best = max(cands, key=lambda c: c[4])
     roofline.update(bound=best[0], achieved=best[1], peak=best[2], unit=best[3], frac=best[4])
-    roofline["note"] = ("kernel with the largest share of the composite step; achieved = ALGORITHMIC bytes / flops per launch (SURVEY.md 8-D) "
-                        "/ average launch duration measured live with HIP events on the launching stream; frac = the largest of the hbm, "
-                        "f64-flop and VALU-issue fractions at the guide's peaks; `traffic` and the VALU numerator are PMC values of the committed "
-                        "pass " + (pmc_src or "profiles/ (not available for this batch size)") + ", not of this run")
+    roofline["note"] = ("kernel with the largest share of the composite step (named as rocprofv3 prints it); achieved = ALGORITHMIC bytes / flops "
+                        "per launch (SURVEY.md 8-D) / average launch duration measured live with HIP events on the launching stream; frac = "
+                        "the larger of hbm_frac and flops_frac; `traffic` (FETCH_SIZE + WRITE_SIZE per launch) and traffic_ratio = traffic / "
+                        "algorithmic bytes are PMC values of the committed pass " + (pmc_src or "profiles/ (not available for this batch size)") +
+                        ", not of this run")
     pipeline_gbs = 12.0e6 * fe_value / world / 1e9                     # 12.0 MB algorithmic bytes per stereo pair
 
     # ---------------- global BA (C4 shape), landmark-sharded over the GPUs through RCCL inside the library ----------------
@@ -661,12 +718,27 @@ def main():
           "sharding": (f"landmarks l mod {world} + RCCL all-reduce of the banded reduced system" if world > 1 else "none"),
           "collective": comm_kind}
     c4["full_configs3"] = time_c4(80000, 2)                           # strong-scaling point: the same 480 k edges at every N
-    one_gpu_ms = 0.82                                                 # GPU ms per LM iteration of full C4 on one MI355X
-    c4["strong_scaling"] = {"target_at_8_gpus": 3.5,
-                            "this_run": {"n_gpus": world, "ms_per_lm_iteration": c4["full_configs3"]["ms_per_lm_iteration"]},
-                            "projection_at_8_gpus": "0.82 / (0.25 / 8 + 0.43 + 0.05) = 1.6x: the reduced band solve every rank repeats "
-                                                    "(0.40 ms of dependent 6x6 pivots) is the Amdahl term; DESIGN.md section 7",
-                            "one_gpu_gpu_ms_per_iteration": one_gpu_ms}
+    # Strong-scaling projection from THIS run's phases (GPU ms per LM iteration of the full configs[3] solve, profiled): the
+    # landmark-sharded kernels divide by the rank count, the reduced solve every rank repeats and the reductions do not, the
+    # collectives are this run's when it had any, else two latency-bound all-reduces of < 1 MB over xGMI (2 x 25 us).
+    ph4 = c4["full_configs3"].get("phase_ms_per_iteration") or {}
+    if ph4:
+        t_sh, t_rep, t_red, t_col = (float(ph4.get(k, 0.0)) for k in ("sharded_by_landmark", "replicated_reduced_solve", "reductions", "collective"))
+        t_sh1 = t_sh * world                                           # what one GPU would spend on all landmarks
+        col8 = t_col if world > 1 else 0.05
+        t1 = t_sh1 + t_rep + t_red
+        t8 = t_sh1 / 8.0 + t_rep + t_red + col8
+        c4["strong_scaling"] = {"target_at_8_gpus": 3.5,
+                                "this_run": {"n_gpus": world, "ms_per_lm_iteration": c4["full_configs3"]["ms_per_lm_iteration"]},
+                                "phases_one_gpu_ms": {"sharded_by_landmark": round(t_sh1, 4), "replicated_reduced_solve": round(t_rep, 4),
+                                                      "reductions": round(t_red, 4)},
+                                "assumed_collective_ms_at_8": round(col8, 4),
+                                "projection_at_8_gpus": round(t1 / t8, 2) if t8 > 0 else None,
+                                "amdahl_limit": round(t1 / (t_rep + t_red), 2) if t_rep + t_red > 0 else None,
+                                "formula": "(sharded + replicated + reductions) / (sharded / 8 + replicated + reductions + collective), all from "
+                                           "phase_ms_per_iteration of full_configs3 in this run"}
+    else:
+        c4["strong_scaling"] = {"target_at_8_gpus": 3.5, "projection_at_8_gpus": None}
     if comm_kwargs:
         try:
             from ssvio_amd import dist_ba
@@ -674,6 +746,73 @@ def main():
         except Exception as exc:                                       # noqa: BLE001
             c4["rccl_rank_world"] = f"unavailable: {exc}"
     c4["allreduces_per_lm_trial"] = "2 ([band | rhs | pose blocks | chi2] and [chi2', scale, outliers]); 3 on the first trial of an optimize()"
+
+    # ---------------- configs[0] at its stated size: 200 KITTI-00-shaped pairs through the headless test_system ----------------
+    # /root/reference/test/test_system.cpp:28-50 + config/kitti_00.yaml: load a KITTI-layout sequence, System::RunStep per pair
+    # (LK tracking, pose-only LM, keyframes: detection + stereo LK + triangulation + the local BA on the resident window), save
+    # the keyframe trajectory.  Real KITTI is not available offline: the drive is the rendered corridor of ssvio_amd.synth
+    # (forward motion 0.8 m per frame, exact stereo geometry, ground-truth poses).  A single live stream is latency-bound --
+    # one pair at a time, a handful of small dependent launches per frame -- so this is a LATENCY figure next to the
+    # throughput headline; `eight_streams` is the same loop eight times side by side on this one GPU (configs[4]'s shape).
+    c1 = None
+    if rank == 0 and world == 1 and args.c1_frames > 0 and not args.lean:
+        try:
+            import re
+            import subprocess
+            from ssvio_amd import build as sb
+            from ssvio_amd.synth import write_settings
+            if c1_gen is not None:
+                _, gen_err = c1_gen.communicate(timeout=1200)
+                if c1_gen.returncode != 0:
+                    raise RuntimeError("sequence generator failed: " + gen_err.decode()[-300:])
+            _, host_exe = sb.build_host()
+            centres = np.load(os.path.join(c1_dir, "centres.npy"))
+
+            def run_kitti(tag, overrides, extra=()):
+                cfg = write_settings(os.path.join(c1_dir, f"cfg_{tag}.yaml"), overrides)
+                traj = os.path.join(c1_dir, f"traj_{tag}.txt")
+                r = subprocess.run([host_exe, f"--config_yaml_path={cfg}", f"--kitti_dataset_path={c1_dir}", f"--trajectory={traj}", f"--device={dev_index}", *extra],
+                                   capture_output=True, text=True, timeout=1200)
+                if r.returncode != 0:
+                    raise RuntimeError(f"ssx_run_kitti [{tag}] failed: " + (r.stdout + r.stderr)[-400:])
+                return r.stdout, traj
+
+            def ape(traj):
+                tum = np.loadtxt(traj, ndmin=2)
+                idx = np.rint(tum[:, 0] / 0.1).astype(int)
+                d = (tum[:, 1:4] - tum[0, 1:4]) - (centres[idx] - centres[idx[0]])
+                e = np.linalg.norm(d, axis=1)
+                return {"keyframes": int(len(tum)), "rmse_m": round(float(np.sqrt((e ** 2).mean())), 4), "max_m": round(float(e.max()), 4),
+                        "path_length_m": round(float(np.linalg.norm(np.diff(centres, axis=0), axis=1).sum()), 1)}
+
+            def parse(out):
+                m = re.search(r"RunStep ([0-9.]+) ms/frame \(([0-9.]+) frames/s\); waiting for decoded images ([0-9.]+) ms/frame; whole loop ([0-9.]+) frames/s", out)
+                st = re.search(r"frames (\d+)  keyframes (\d+)  map points (\d+)  final status (\w+)", out)
+                bw = re.search(r"local BA: (\d+) windows, (\d+) LM iterations, (\d+) edges, (\d+) outlier edges", out)
+                kf = re.search(r"keyframe insert \+ BA\s+(\d+) calls\s+([0-9.]+) ms/call", out)
+                return {"frames_per_s_runstep_only": float(m.group(2)), "ms_per_frame_runstep": float(m.group(1)),
+                        "frames_per_s_incl_png_decode": float(m.group(4)), "ms_per_frame_waiting_for_decode": float(m.group(3)),
+                        "frames": int(st.group(1)), "keyframes": int(st.group(2)), "map_points": int(st.group(3)), "final_status": st.group(4),
+                        "ba_windows": int(bw.group(1)), "ba_lm_iterations": int(bw.group(2)), "ba_edges": int(bw.group(3)), "ba_outlier_edges": int(bw.group(4)),
+                        "ms_per_keyframe_insert_and_ba": float(kf.group(2)) if kf else None}
+
+            run_kitti("warm", {}, ("--max_frames=20",))                 # (first HIP use of the process image: page-in, code objects)
+            out_w, traj_w = run_kitti("window", {"Backend.Window": 1}, ("--decode_threads=24",))
+            out_m, traj_m = run_kitti("marshal", {"Backend.Window": 0}, ("--decode_threads=24",))
+            c1 = {"workload": f"configs[0] shape: the first {args.c1_frames} pairs of a KITTI-00-shaped drive (synthetic corridor, 1241x376, PNG files in "
+                              "KITTI layout) through ssx_run_kitti = the reference's test_system without the viewer, kitti_00.yaml settings, one stream",
+                  "resident_window": dict(parse(out_w), ape_vs_ground_truth=ape(traj_w)),
+                  "remarshalled_window": dict(parse(out_m), ape_vs_ground_truth=ape(traj_m)),
+                  "trajectories_identical": open(traj_w).read() == open(traj_m).read(),
+                  "value": parse(out_w)["frames_per_s_incl_png_decode"], "unit": "stereo frames/s (one live stream, PNG decoding on 24 host threads included)"}
+            out_8, _ = run_kitti("streams8", {}, ("--streams=8", "--preload=1"))
+            m8 = re.search(r"8 streams: aggregate ([0-9.]+) frames/s", out_8)
+            c1["eight_streams_one_gpu"] = {"aggregate_frames_per_s": float(m8.group(1)) if m8 else None,
+                                           "what": "--streams=8 --preload=1: eight independent copies of the loop in one process on this GPU (configs[4]'s "
+                                                   "shape; one stream per GPU is the driver's multi-GPU run), frames decoded beforehand"}
+        except Exception as exc:                                       # noqa: BLE001 -- an extra leg, never fatal
+            print(f"[bench] configs[0] leg skipped: {exc!r}", file=sys.stderr)
+            c1 = {"skipped": repr(exc)[:300]}
 
     # ---------------- CPU baseline (rank 0, N == 1 only): the same composite on one host core ----------------
     cpu = None
@@ -717,6 +856,30 @@ def main():
                                              "sample": f"{reported} processes x 2 pairs each, started together (one per core)"}
         except Exception as e:                                       # the baseline is informative, never fatal
             cpu["all_cores_error"] = str(e)[:200]
+        # configs[0] on the CPU: the same host loop (tests/host/oracle_runner.cpp: the product's host layer with the CPU oracle behind
+        # its Compute interface) over the same 200 pairs, one core; images decoded outside its clock
+        if c1 and "skipped" not in c1:
+            try:
+                import subprocess
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import host_util
+                from ssvio_amd.synth import write_settings
+                runner = host_util.build_test_binaries()["oracle_runner"]
+                cfg_c = write_settings(os.path.join(c1_dir, "cfg_cpu.yaml"), {})
+                tcpu = time.perf_counter()
+                rc = subprocess.run([runner, cfg_c, c1_dir, os.path.join(c1_dir, "traj_cpu.txt")], capture_output=True, text=True, timeout=1800)
+                wall = time.perf_counter() - tcpu
+                if rc.returncode != 0:
+                    raise RuntimeError(rc.stderr[-300:])
+                import re
+                mm = re.search(r"runstep_seconds first ([0-9.]+) rest ([0-9.]+)", rc.stdout)
+                t_all = float(mm.group(1)) + float(mm.group(2))
+                c1["cpu_oracle_runner"] = {"frames_per_s_runstep_only": round(args.c1_frames / t_all, 2), "cores": 1, "seconds_wall_incl_decode": round(wall, 2),
+                                           "what": "the same 200 pairs and settings through the same host loop with the CPU oracle as Compute (scalar C++ "
+                                                   "restatement of detection / LK / pose-only / BA; not the reference's OpenCV + g2o build, which cannot be built here)"}
+                c1["speedup_vs_cpu_oracle_runstep"] = round(c1["resident_window"]["frames_per_s_runstep_only"] / c1["cpu_oracle_runner"]["frames_per_s_runstep_only"], 2)
+            except Exception as e:                                   # noqa: BLE001
+                c1["cpu_oracle_runner"] = {"skipped": str(e)[:200]}
 
     if rank == 0:
         out = {
@@ -731,7 +894,17 @@ def main():
                        "avg_keypoints_per_image": round(kp_total / I, 1),
                        "avg_matches_per_pair": round(float(counts[:, 2].mean()), 1),
                        "avg_triangulated_per_pair": round(float(counts[:, 3].mean()), 1),
-                       "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2)},
+                       "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2),
+                       "images": "host -> device every step (pinned ring of 2 batches; ssx_stereo_batch_upload of step k + 1's batch on the library's "
+                                 "copy stream beside step k's kernels, ssx_stereo_batch_run on the batch uploaded during the step before)",
+                       "h2d_bytes_per_step_per_gpu": h2d_bytes_per_step,
+                       "downloaded_every_step": "keypoint / match / triangulation counts of every pair + the optimised keyframe poses of every window",
+                       "windows": "resident in HBM (ssx_ba_batch: marshalled + uploaded before the clock starts, re-solved from the uploaded state every step)"},
+            "resident": {"value": round(resident_value, 2), "unit": "stereo frames/s", "ms_per_step": round(resident_elapsed / RES_STEPS * 1e3, 4),
+                         "what": "rounds 1-3's headline: the same step with the images resident in HBM and nothing downloaded"},
+            "roofline_frac": roofline["frac"], "roofline_hbm_frac": roofline["hbm_frac"], "roofline_flops_frac": roofline["flops_frac"],
+            "roofline_traffic_ratio": roofline["traffic_ratio"],
+            "c1": c1,
             "host_buffers_inclusive": {"value": None if host_value != host_value else round(host_value, 2), "unit": "stereo frames/s",
                                        "what": "the same step with the B windows handed over as host arrays every step (ssx_ba_solve_batch: host "
                                                "marshalling on 16 threads + one PCIe upload + one download of poses / points); images still resident",

@@ -496,6 +496,26 @@ SSX_API ssx_status ssx_stereo_batch_dev(ssx_ctx* ctx, int32_t pairs, const uint8
                                         const ssx_match_params* mp, const ssx_stereo_rig* rig,
                                         int32_t* counts_out);
 SSX_API ssx_status ssx_stereo_batch_fetch(ssx_ctx* ctx, int32_t pair, ssx_stereo_frame_out* out);
+/* Batches that arrive from the HOST, as the reference's loop hands System::RunStep a fresh pair at every step
+ * (test/test_system.cpp:36-47).  imgs_host = [pairs][2][rows][stride] u8 in host memory (pinned: the upload is then
+ * asynchronous).  The images go up on a copy stream of the ctx's own into one of two device buffers; a batch's pipeline waits
+ * for its own upload only.
+ *   ssx_stereo_batch_upload  start the upload of a batch and return (at most two uploaded batches may be waiting); imgs_host
+ *                            must stay untouched until the batch has been run and a later call of these functions returned
+ *   ssx_stereo_batch_run     enqueue the whole front-end on the OLDEST uploaded batch; nothing is synchronised
+ *   ssx_stereo_batch_host    upload + run in one call
+ *   ssx_stereo_batch_counts  wait for the batch run last; counts_out = pairs x 4 int32: nL, nR, n_matched, n_triangulated
+ *                            (ssx_stereo_batch_fetch then copies one pair's keypoints / matches / points out)
+ * A server keeps one upload ahead -- upload(k + 1); run(k); ...; counts(k) -- so that batch k + 1 crosses PCIe while the
+ * kernels of batch k run (bench.py's headline region). */
+SSX_API ssx_status ssx_stereo_batch_upload(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs_host, int32_t stride, int32_t rows,
+                                           int32_t cols);
+SSX_API ssx_status ssx_stereo_batch_run(ssx_ctx* ctx, const ssx_orb_params* orb, const ssx_match_params* mp,
+                                        const ssx_stereo_rig* rig);
+SSX_API ssx_status ssx_stereo_batch_host(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs_host, int32_t stride, int32_t rows,
+                                         int32_t cols, const ssx_orb_params* orb, const ssx_match_params* mp,
+                                         const ssx_stereo_rig* rig);
+SSX_API ssx_status ssx_stereo_batch_counts(ssx_ctx* ctx, int32_t* counts_out);
 /* Timing hook: enqueue the batch again on the already-resident inputs WITHOUT any host synchronisation or
  * download (bench.py brackets a run of these with HIP events). */
 SSX_API ssx_status ssx_stereo_batch_enqueue(ssx_ctx* ctx);

@@ -348,6 +348,17 @@ def brief(blurred, x, y, angle):
     return d
 
 
+def brief_libm_census(blurred, xya, mode=0):
+    """-> (descriptor bits that differ, descriptors with a differing bit, (cos, sin) pairs that differ) between the deterministic
+    sincos_deg and libm (mode 0: cosf / sinf, 1: cos / sin of the widened angle rounded to float) over the keypoints xya [n, 3]"""
+    blurred = _img(blurred)
+    xya = np.ascontiguousarray(xya, dtype=np.float32)
+    out = np.zeros(3, np.int64)
+    oracle_lib().orc_brief_libm_census(_p(blurred, u8_p), blurred.strides[0], len(xya), _p(xya, C.POINTER(C.c_float)), int(mode),
+                                       _p(out, C.POINTER(C.c_int64)))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 def brief_pattern():
     p = oracle_lib().orc_brief_pattern()
     return np.ctypeslib.as_array(p, shape=(256, 4)).copy()

@@ -102,6 +102,10 @@ float orc_ic_angle(const uint8_t* img, int stride, float x, float y);
 float orc_fast_atan2(float y, float x);
 void orc_brief(const uint8_t* blurred, int stride, float x, float y, float angle_deg, uint8_t* desc32);
 void orc_sincos_deg(float angle_deg, float* c, float* s);
+/* the descriptor with libm's cosf / sinf (mode 0) or cos / sin rounded to float (mode 1) as orbextractor.cpp:49-50 calls them */
+void orc_brief_libm(const uint8_t* blurred, int stride, float x, float y, float angle_deg, int mode, uint8_t* desc32, float* ab_out);
+/* xya = n x (x, y, angle in degrees); out3 = differing descriptor bits, descriptors with any differing bit, (cos, sin) pairs that differ */
+void orc_brief_libm_census(const uint8_t* blurred, int stride, int n, const float* xya, int mode, int64_t* out3);
 int orc_is_fast_corner(const uint8_t* img, int stride, int x, int y, int threshold);
 const int8_t* orc_brief_pattern(void); /* 256 x 4 int8: x0 y0 x1 y1 */
 /* ScreenAndComputeKPsParams + CalcDescriptors (A8) */

@@ -628,6 +628,47 @@ float orc_ic_angle(const uint8_t* img, int stride, float x, float y)
 float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 void orc_sincos_deg(float angle_deg, float* c, float* s) { sincos_deg(angle_deg, c, s); }
 
+// computeOrbDescriptor with the reference's OWN sine / cosine (orbextractor.cpp:49-50: `(float)cos(angle)`, `(float)sin(angle)`
+// of a float angle -- cosf / sinf through <cmath>'s overloads, mode 0, or the double functions of <math.h> rounded to float,
+// mode 1): what tests/test_oracle_orb.py compares the deterministic sincos_deg with, bit by bit of the descriptor
+void orc_brief_libm(const uint8_t* blurred, int stride, float px, float py, float angle_deg, int mode, uint8_t* desc, float* ab_out)
+{
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  const float angle = angle_deg * factorPI;
+  const float a = mode == 0 ? cosf(angle) : (float)cos((double)angle), b = mode == 0 ? sinf(angle) : (float)sin((double)angle);
+  if (ab_out) { ab_out[0] = a; ab_out[1] = b; }
+  const uint8_t* center = blurred + (size_t)cv_round(py) * stride + cv_round(px);
+  for (int i = 0; i < 32; ++i) {
+    int val = 0;
+    for (int bit = 0; bit < 8; ++bit) {
+      const int8_t* t = &kPattern[(i * 8 + bit) * 4];
+      const int t0 = center[cv_round((float)t[0] * b + (float)t[1] * a) * stride + cv_round((float)t[0] * a - (float)t[1] * b)];
+      const int t1 = center[cv_round((float)t[2] * b + (float)t[3] * a) * stride + cv_round((float)t[2] * a - (float)t[3] * b)];
+      val |= (t0 < t1) << bit;
+    }
+    desc[i] = (uint8_t)val;
+  }
+}
+
+// n keypoints at once: bits of the descriptors that differ between sincos_deg and libm, and how many (cos, sin) pairs differ
+void orc_brief_libm_census(const uint8_t* blurred, int stride, int n, const float* xya, int mode, int64_t* out3)
+{
+  int64_t bits = 0, descs = 0, pairs = 0;
+  for (int i = 0; i < n; ++i) {
+    uint8_t d0[32], d1[32];
+    float ab[2], c, s;
+    Img im{blurred, stride, 0, 0};
+    brief(im, xya[3 * i], xya[3 * i + 1], xya[3 * i + 2], d0);
+    orc_brief_libm(blurred, stride, xya[3 * i], xya[3 * i + 1], xya[3 * i + 2], mode, d1, ab);
+    sincos_deg(xya[3 * i + 2], &c, &s);
+    pairs += (c != ab[0] || s != ab[1]) ? 1 : 0;
+    int diff = 0;
+    for (int k = 0; k < 32; ++k) diff += __builtin_popcount((unsigned)(d0[k] ^ d1[k]));
+    bits += diff; descs += diff ? 1 : 0;
+  }
+  out3[0] = bits; out3[1] = descs; out3[2] = pairs;
+}
+
 void orc_brief(const uint8_t* blurred, int stride, float x, float y, float angle_deg, uint8_t* desc32)
 {
   Img im{blurred, stride, 0, 0};

@@ -188,28 +188,29 @@ class BaBatch:
             self.ctx.lib.ssx_ba_batch_set_groups(self.handle, int(groups))
 
     def set_persistent(self, mode):
-        """1: one persistent workgroup per group of ~7 chunks in the linearise / Schur kernels, 0: one per chunk, -1: the
-        library decides by batch size.  Same bits either way."""
+        """1: one persistent workgroup per group of ~7 chunks in the linearise / Schur kernels; 0 or -1: one per chunk (the default;
+        there is no automatic mode).  Same bits either way."""
         if self.handle is not None:
             self.ctx.lib.ssx_ba_batch_set_persistent.restype = None
             self.ctx.lib.ssx_ba_batch_set_persistent.argtypes = [C.c_void_p, C.c_int32]
             self.ctx.lib.ssx_ba_batch_set_persistent(self.handle, int(mode))
 
-    def solve(self, want_edges=True, download=True, summaries=True):
+    def solve(self, want_edges=True, download=True, summaries=True, points=True):
         """summaries=False: the per-window dicts are not built (poses / points are in self.poses / self.points, the counters
-        in self.res): what a C caller pays -- building 128 dicts with their LM histories costs Python ~2 ms."""
+        in self.res): what a C caller pays -- building 128 dicts with their LM histories costs Python ~2 ms.
+        points=False (with want_edges=False): only the keyframe poses are downloaded (ssx_ba_result.points_out NULL)."""
         if self.handle is not None and not download:
             tot = C.c_int32(0)
             self.ctx.check(self.ctx.lib.ssx_ba_batch_solve(self.handle, None, C.byref(tot)))
             return dict(results=None, n_iters_total=tot.value)
         want_edges = want_edges and (self.handle is None or self.with_edge_errors)
-        if getattr(self, "_res_edges", None) != want_edges:             # (the output pointers of the result structs: set once)
+        if getattr(self, "_res_edges", None) != (want_edges, points):   # (the output pointers of the result structs: set once)
             for i in range(self.n):
                 r = self.res[i]
-                r.poses_out = ptr(self.poses[i], dbl_p); r.points_out = ptr(self.points[i], dbl_p)
+                r.poses_out = ptr(self.poses[i], dbl_p); r.points_out = ptr(self.points[i], dbl_p) if points else None
                 r.edge_chi2 = ptr(self.chi2[i], dbl_p) if want_edges else None
                 r.edge_outlier = ptr(self.outl[i], u8_p) if want_edges else None
-            self._res_edges = want_edges
+            self._res_edges = (want_edges, points)
         if self.handle is not None:
             self.ctx.check(self.ctx.lib.ssx_ba_batch_solve(self.handle, self.res, None))
         else:

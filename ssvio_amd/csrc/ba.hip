@@ -1634,6 +1634,16 @@ __global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* __restrict__ dv,
   }
 }
 
+// the keyframe poses of every window only (what a backend that reads its landmarks lazily needs back per keyframe): [n][7 maxP]
+__global__ __launch_bounds__(CH) void k_pack_poses_b(const BaDev* __restrict__ dv, const int* ctrl, int n, int maxP, double* out)
+{
+  const int w = blockIdx.x;
+  if (w >= n) return;
+  const BaDev& d = dv[w];
+  const double* src = d.pose[ctrl[w]];
+  for (int i = threadIdx.x; i < 7 * d.P; i += CH) out[(size_t)w * 7 * maxP + i] = src[i];
+}
+
 #include "ba_big.inc"
 #include "ba_band.inc"
 
@@ -1682,7 +1692,8 @@ class ParPool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
-  // fn(w) for w in [0, n) on up to T threads (the caller is one of them); returns when all are done
+  // fn(w) for w in [0, n) on at least T threads when the pool has them (the caller is one of them; threads created by an earlier,
+  // wider call join in as well); returns when all are done
   template <class F>
   void run(int n, int T, F&& fn)
   {
@@ -3089,8 +3100,8 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
             SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_big, dim3(1), dim3(CH), 0, ctx->stream, d));
           } else
           if (fused) {
-            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), lds_fused, ctx->stream, d));
-            else SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), lds_fused, ctx->stream, d));
+            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LIN_SCHUR, hipLaunchKernelGGL(k_lin_schur<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), lds_fused, ctx->stream, d));
+            else SSX_PROF(ctx, KID_BA_LIN_SCHUR, hipLaunchKernelGGL(k_lin_schur<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), lds_fused, ctx->stream, d));
           } else if (nCh > 0) {
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
             else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
@@ -3308,6 +3319,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
       switch (r.id) {
         case KID_BA_LINEARIZE: res->ms_linearize += t; break;
         case KID_BA_SCHUR: res->ms_schur += t; break;
+        case KID_BA_LIN_SCHUR: res->ms_schur += t; break;        // (the fused slot: linearisation + elimination in one kernel)
         case KID_BA_SOLVE: res->ms_linear_solution += t; break;
         case KID_BA_BACKSUB: res->ms_update += t; break;
         case KID_BA_COMM: res->ms_comm += t; break;
@@ -3583,8 +3595,8 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
           const BaDev* hv = dv + w0;
           const dim3 gCh(B->max_ch, hn), gWg(wg_x, hn), gRl(B->max_rl, hn), gRs(B->max_rs, hn), gOne(1, hn);
           if (fused) {
-            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_NUMERIC_G2O>, gWg, dim3(CH), lds_fused, hs, hv));
-            else SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_ANALYTIC>, gWg, dim3(CH), lds_fused, hs, hv));
+            if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_LIN_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_NUMERIC_G2O>, gWg, dim3(CH), lds_fused, hs, hv));
+            else SSX_PROF_ON(ctx, hs, KID_BA_LIN_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_ANALYTIC>, gWg, dim3(CH), lds_fused, hs, hv));
           } else {
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_NUMERIC_G2O>, gWg, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
             else SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_ANALYTIC>, gWg, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
@@ -3647,9 +3659,19 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     for (int w = 0; w < n; ++w)
       if (!wsn[w].trial_err && B->devs[w].nCh > 0)
         hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(B->devs[w].nCh), dim3(CH), LIN_LDS_BYTES, s, B->devs[w], wsn[w].cur);
-  hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, d_ooff, d_out, want_err ? 1 : 0);
+  // nobody asked for landmarks or per-edge errors: only the poses cross PCIe (560 B instead of 97 KB per C3 window)
+  bool poses_only = !want_err;
+  int maxP = 0;
+  for (int w = 0; w < n; ++w) { poses_only = poses_only && !results[w].points_out; maxP = std::max(maxP, B->P[w]); }
+  poses_only = poses_only && (size_t)n * 7 * maxP <= B->out_total;
   double* h_out = B->stage->as<double>();
+  if (poses_only) {
+    hipLaunchKernelGGL(k_pack_poses_b, dim3(n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, maxP, d_out);
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * (size_t)n * 7 * maxP, hipMemcpyDeviceToHost, s));
+  } else {
+  hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, d_ooff, d_out, want_err ? 1 : 0);
   SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * B->out_total, hipMemcpyDeviceToHost, s));
+  }
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
   float ms = 0.f;
@@ -3662,7 +3684,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     const int P = B->P[w], L = B->L[w], E = B->E[w];
     r.rounds = st.rounds; r.n_iters = st.n_iters; r.n_inliers = st.n_in; r.n_outliers = st.n_outl;
     r.ms_linearize = r.ms_schur = r.ms_linear_solution = r.ms_update = r.ms_reduce = r.ms_comm = 0.f;
-    const double* o = h_out + B->out_off[w];
+    const double* o = poses_only ? h_out + (size_t)w * 7 * maxP : h_out + B->out_off[w];
     if (r.poses_out) memcpy(r.poses_out, o, sizeof(double) * 7 * P);
     if (r.points_out && L) memcpy(r.points_out, o + 7 * (size_t)P, sizeof(double) * 3 * L);
     if (want_err && (r.edge_chi2 || r.edge_outlier) && B->devs[w].dev_prep) {

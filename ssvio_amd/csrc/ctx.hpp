@@ -95,12 +95,12 @@ struct Layout {
 enum SsxKernelId {
   KID_BA_LINEARIZE = 0, KID_BA_REDUCE_LIN, KID_BA_SCHUR, KID_BA_REDUCE_SCHUR, KID_BA_SOLVE, KID_BA_BACKSUB,
   KID_BA_REDUCE_TRIAL, KID_ORB_RESIZE, KID_ORB_FAST, KID_ORB_OCTREE, KID_ORB_ORIENT, KID_ORB_GAUSS, KID_ORB_BRIEF,
-  KID_ORB_MISC, KID_ST_BUCKET, KID_ST_MATCH, KID_ST_TRIANGULATE, KID_ST_MISC, KID_POSE_ONLY, KID_BA_COMM, KID_COUNT
+  KID_ORB_MISC, KID_ST_BUCKET, KID_ST_MATCH, KID_ST_TRIANGULATE, KID_ST_MISC, KID_POSE_ONLY, KID_BA_COMM, KID_BA_LIN_SCHUR, KID_COUNT
 };
 static const char* const kSsxKernelNames[KID_COUNT] = {
   "k_linearize", "k_reduce_lin", "k_schur", "k_reduce_schur", "k_solve", "k_backsub_residual", "k_reduce_trial",
   "k_resize", "k_fast_cells", "k_octree", "k_orient", "k_gauss7", "k_orient_brief", "orb_misc", "k_row_bucket", "k_match",
-  "k_triangulate_matches", "stereo_misc", "k_pose_only", "ba_allreduce"};
+  "k_triangulate_matches", "stereo_misc", "k_pose_only", "ba_allreduce", "k_lin_schur"};
 
 struct SsxProf {
   bool on = false;

@@ -108,6 +108,16 @@ struct OrbWorkspace {
   double* xyz = nullptr;
   uint8_t* tri_ok = nullptr;
   int* pair_counts = nullptr;   // [pairs][4]
+  // streaming batches (ssx_stereo_batch_host): two device buffers filled from the host on a copy stream of their own, so that
+  // batch k + 1 crosses PCIe while batch k is being processed
+  DevBuf ingest[2];
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  bool free_pending[2] = {false, false};
+  int up_first = 0, up_count = 0;  // uploaded batches waiting for ssx_stereo_batch_run: buffers up_first, up_first ^ 1
+  int up_shape[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // pairs, stride, rows, cols of an uploaded batch
+  HostBuf counts_pinned;        // [pairs][4] counts + [2 pairs] status words of the last enqueued batch
+  bool counts_pending = false;
 };
 
 namespace ssxorb {

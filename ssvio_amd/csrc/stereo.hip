@@ -686,6 +686,108 @@ ssx_status ssx_stereo_batch_dev(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs
   return SSX_OK;
 }
 
+// Batches that arrive from the HOST (test/test_system.cpp:36-47: the reference's loop reads a pair from disk and hands it to
+// System::RunStep at every step).  The images go up on a copy stream of the ctx's own into one of two device buffers;
+// a batch's pipeline waits for its own upload only.
+//   ssx_stereo_batch_upload   start the upload of a batch (at most two may be pending: the one being processed next and the
+//                             one after it) and return: the copy runs beside whatever the GPU is doing
+//   ssx_stereo_batch_run      enqueue the pipeline on the OLDEST uploaded batch (no synchronisation)
+//   ssx_stereo_batch_host     upload + run in one call
+//   ssx_stereo_batch_counts   wait for the batch run LAST and return its counts
+// A server keeps one upload ahead: upload(k + 1); run(k); ...; counts(k) -- batch k + 1 crosses PCIe while batch k's kernels run.
+static ssx_status batch_ingest_init(ssx_ctx* ctx, OrbWorkspace* ws)
+{
+  if (ws->copy_stream) return SSX_OK;
+  SSX_HIP_TRY(ctx, ctx->make_stream(&ws->copy_stream, false));
+  for (int b = 0; b < 2; ++b) {
+    SSX_HIP_TRY(ctx, hipEventCreateWithFlags(&ws->ev_up[b], hipEventDisableTiming));
+    SSX_HIP_TRY(ctx, hipEventCreateWithFlags(&ws->ev_free[b], hipEventDisableTiming));
+  }
+  return SSX_OK;
+}
+
+ssx_status ssx_stereo_batch_upload(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs_host, int32_t stride, int32_t rows, int32_t cols)
+{
+  if (!ctx || pairs < 1 || !imgs_host || stride < cols || rows < 1) return SSX_ERR_INVALID_ARG;
+  OrbWorkspace* ws = get_ws(ctx);
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ssx_status st = batch_ingest_init(ctx, ws);
+  if (st != SSX_OK) return st;
+  if (ws->up_count >= 2) { ctx->set_error("ssx_stereo_batch_upload: two uploaded batches are waiting for ssx_stereo_batch_run already"); return SSX_ERR_INVALID_ARG; }
+  const int b = (ws->up_first + ws->up_count) & 1;
+  const size_t bytes = 2 * (size_t)pairs * (size_t)rows * stride;
+  if (bytes > ws->ingest[b].cap) {                                    // (grows once; the batch that used the buffer last may still be read)
+    SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    SSX_HIP_TRY(ctx, ws->ingest[b].reserve(bytes));
+    ws->free_pending[b] = false;
+  }
+  if (ws->free_pending[b]) SSX_HIP_TRY(ctx, hipStreamWaitEvent(ws->copy_stream, ws->ev_free[b], 0));   // level 0 of the batch that used it is staged
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->ingest[b].p, imgs_host, bytes, hipMemcpyHostToDevice, ws->copy_stream));
+  SSX_HIP_TRY(ctx, hipEventRecord(ws->ev_up[b], ws->copy_stream));
+  ws->up_shape[b][0] = pairs; ws->up_shape[b][1] = stride; ws->up_shape[b][2] = rows; ws->up_shape[b][3] = cols;
+  ws->up_count++;
+  return SSX_OK;
+}
+
+ssx_status ssx_stereo_batch_run(ssx_ctx* ctx, const ssx_orb_params* orb, const ssx_match_params* mp, const ssx_stereo_rig* rig)
+{
+  if (!ctx || !orb || !mp || !rig) return SSX_ERR_INVALID_ARG;
+  OrbWorkspace* ws = get_ws(ctx);
+  if (ws->up_count < 1) { ctx->set_error("ssx_stereo_batch_run: no uploaded batch (ssx_stereo_batch_upload first)"); return SSX_ERR_INVALID_ARG; }
+  const int b = ws->up_first;
+  const int pairs = ws->up_shape[b][0], stride = ws->up_shape[b][1], rows = ws->up_shape[b][2], cols = ws->up_shape[b][3];
+  ssx_status st = plan(ctx, rows, cols, 2 * pairs, *orb, false, false);
+  if (st != SSX_OK) return st;
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  SSX_HIP_TRY(ctx, ws->counts_pinned.reserve(sizeof(int) * 6 * (size_t)pairs));
+  SSX_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ws->ev_up[b], 0));
+  const size_t img_bytes = (size_t)rows * stride;
+  ws->batch_imgs = ws->ingest[b].as<uint8_t>(); ws->batch_pairs = pairs; ws->batch_stride = stride;
+  ws->batch_orb = *orb; ws->batch_mp = *mp; ws->batch_rig = *rig;
+  st = stage_level0(ctx, ws->batch_imgs, stride, img_bytes, nullptr, 0, 0);
+  if (st != SSX_OK) return st;
+  SSX_HIP_TRY(ctx, hipEventRecord(ws->ev_free[b], ctx->stream));
+  ws->free_pending[b] = true;
+  ws->up_first ^= 1; ws->up_count--;
+  st = run_pipeline(ctx);
+  if (st != SSX_OK) return st;
+  MatchDev m{};
+  st = make_match_dev(ctx, pairs, *mp, *rig, nullptr, m);
+  if (st != SSX_OK) return st;
+  st = launch_stereo(ctx, m);
+  if (st != SSX_OK) return st;
+  int* hc = ws->counts_pinned.as<int>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hc, ws->pair_counts, sizeof(int) * 4 * pairs, hipMemcpyDeviceToHost, ctx->stream));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hc + 4 * (size_t)pairs, ws->dev.status, sizeof(int) * 2 * pairs, hipMemcpyDeviceToHost, ctx->stream));
+  ws->counts_pending = true;
+  return SSX_OK;
+}
+
+ssx_status ssx_stereo_batch_host(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs_host, int32_t stride, int32_t rows, int32_t cols,
+                                 const ssx_orb_params* orb, const ssx_match_params* mp, const ssx_stereo_rig* rig)
+{
+  if (!ctx || !orb || !mp || !rig) return SSX_ERR_INVALID_ARG;
+  OrbWorkspace* ws = get_ws(ctx);
+  if (ws->up_count != 0) { ctx->set_error("ssx_stereo_batch_host: %d uploaded batch(es) are waiting for ssx_stereo_batch_run", ws->up_count); return SSX_ERR_INVALID_ARG; }
+  ssx_status st = ssx_stereo_batch_upload(ctx, pairs, imgs_host, stride, rows, cols);
+  if (st != SSX_OK) return st;
+  return ssx_stereo_batch_run(ctx, orb, mp, rig);
+}
+
+// waits for the batch ssx_stereo_batch_run enqueued last: counts_out (pairs x 4: nL, nR, n_matched, n_triangulated)
+ssx_status ssx_stereo_batch_counts(ssx_ctx* ctx, int32_t* counts_out)
+{
+  if (!ctx || !ctx->orb || !ctx->orb->counts_pending) return SSX_ERR_INVALID_ARG;
+  OrbWorkspace* ws = ctx->orb;
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int pairs = ws->batch_pairs;
+  const int* hc = ws->counts_pinned.as<int>();
+  for (int i = 0; i < 2 * pairs; ++i)
+    if (hc[4 * (size_t)pairs + i]) { ctx->set_error("ssx_stereo_batch: internal capacity exceeded on image %d (bits %d)", i, hc[4 * (size_t)pairs + i]); return SSX_ERR_CAPACITY; }
+  if (counts_out) memcpy(counts_out, hc, sizeof(int) * 4 * (size_t)pairs);
+  return SSX_OK;
+}
+
 ssx_status ssx_stereo_batch_fetch(ssx_ctx* ctx, int32_t pair, ssx_stereo_frame_out* out)
 {
   if (!ctx || !ctx->orb || !out || pair < 0 || pair >= ctx->orb->batch_pairs) return SSX_ERR_INVALID_ARG;

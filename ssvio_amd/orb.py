@@ -184,6 +184,40 @@ def stereo_batch_dev(ctx: Context, imgs_dev_ptr: int, pairs: int, stride: int, r
     return counts
 
 
+class StereoStream:
+    """ssx_stereo_batch_host / ssx_stereo_batch_counts: a new batch of host images per call (pinned memory -> asynchronous upload on
+    the ctx's copy stream, double-buffered on the device), counts of the last batch on request."""
+
+    def __init__(self, ctx: Context, pairs: int, rows: int, cols: int, stride: int | None = None, orb=None, mp=None, rig=None):
+        self.ctx, self.pairs, self.rows, self.cols, self.stride = ctx, pairs, rows, cols, stride or cols
+        self.orb = orb or OrbParams(2000, 1.2, 8, 20, 7)
+        self.mp = mp or match_params(scale_factor=self.orb.scale_factor)
+        self.rig = rig or stereo_rig()
+        self.counts = np.zeros((pairs, 4), np.int32)
+        ctx.lib.ssx_stereo_batch_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(OrbParams),
+                                                  C.POINTER(MatchParams), C.POINTER(StereoRig)]
+        ctx.lib.ssx_stereo_batch_counts.argtypes = [C.c_void_p, i32_p]
+        ctx.lib.ssx_stereo_batch_upload.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        ctx.lib.ssx_stereo_batch_run.argtypes = [C.c_void_p, C.POINTER(OrbParams), C.POINTER(MatchParams), C.POINTER(StereoRig)]
+
+    def enqueue(self, host_ptr: int):
+        """host_ptr: address of [pairs][2][rows][stride] u8 in (pinned) host memory, e.g. torch.Tensor.pin_memory().data_ptr()"""
+        self.ctx.check(self.ctx.lib.ssx_stereo_batch_host(self.ctx.handle, self.pairs, C.c_void_p(host_ptr), self.stride, self.rows, self.cols,
+                                                          C.byref(self.orb), C.byref(self.mp), C.byref(self.rig)))
+
+    def upload(self, host_ptr: int):
+        """start the upload of a batch (one may be uploaded ahead of the one being run)"""
+        self.ctx.check(self.ctx.lib.ssx_stereo_batch_upload(self.ctx.handle, self.pairs, C.c_void_p(host_ptr), self.stride, self.rows, self.cols))
+
+    def run(self):
+        """enqueue the front-end on the oldest uploaded batch"""
+        self.ctx.check(self.ctx.lib.ssx_stereo_batch_run(self.ctx.handle, C.byref(self.orb), C.byref(self.mp), C.byref(self.rig)))
+
+    def wait_counts(self):
+        self.ctx.check(self.ctx.lib.ssx_stereo_batch_counts(self.ctx.handle, ptr(self.counts, i32_p)))
+        return self.counts
+
+
 def stereo_batch_enqueue(ctx: Context):
     ctx.check(ctx.lib.ssx_stereo_batch_enqueue(ctx.handle))
 

@@ -324,21 +324,42 @@ def _block_texture(a, b, salt):
     return t
 
 
-def make_corridor_sequence(n_frames=40, step=0.8, seed=0, h=KITTI_H, w=KITTI_W, K=KITTI_K, baseline=KITTI_BASELINE, lateral_amp=0.3,
-                           half_width=6.0, cam_height=1.65, wall_height=6.0, backdrop=120.0, supersample=2):
-    """A KITTI-00-shaped stereo sequence: the rig drives FORWARD (+z) by `step` metres per frame (0.8 m ~ KITTI at 10 Hz)
-    with a slow lateral sway, through a textured corridor (ground plane, two walls, a far backdrop), rendered by ray
-    casting each pixel against the planes -- exact perspective, exact stereo geometry, ground-truth poses.  Rotations
-    are identity.  The backdrop is a world plane `backdrop` metres beyond the end of the drive.
-    Returns (frames [(left, right)], T_cw [n,7], centres [n,3])."""
-    rng = np.random.default_rng(9000 + seed)
+# the keys System / FrontEnd / Backend read, with the values of the reference's config/kitti_00.yaml
+KITTI00_SETTINGS = {
+    "Camera1.fx": 718.856, "Camera1.fy": 718.856, "Camera1.cx": 607.1928, "Camera1.cy": 185.2157,
+    "Camera2.fx": 718.856, "Camera2.fy": 718.856, "Camera2.cx": 607.1928, "Camera2.cy": 185.2157,
+    "Camera.width": 1241, "Camera.height": 376, "Camera.Base.Line": 386.1448, "Camera.NeedUndistortion": 0, "Camera.fps": 10,
+    "Map.ActiveMap.Size": 12,
+    "numFeatures.initGood": 100, "numFeatures.trackingGood": 50, "numFeatures.trackingBad": 10,
+    "ORBextractor.nInitFeatures": 300, "ORBextractor.nNewFeatures": 100, "ORBextractor.scaleFactor": 1.2, "ORBextractor.nLevels": 8,
+    "ORBextractor.iniThFAST": 20, "ORBextractor.minThFAST": 7,
+    "Min.Init.Landmark.Num": 200,
+    "Viewer.ViewpointY": "1000 # a trailing comment",
+    "Backend.Open": 1,
+    "Trajectory.Save.Path": '"trajectory.txt"',
+}
+
+
+def write_settings(path, overrides=None):
+    """a settings file in the reference's format (flat %YAML:1.0 map) with kitti_00.yaml's values + overrides"""
+    cfg = dict(KITTI00_SETTINGS)
+    cfg.update(overrides or {})
+    with open(path, "w") as f:
+        f.write("%YAML:1.0\n# settings of the headless runner\n")
+        for k, v in cfg.items():
+            f.write(f"{k}: {v}\n")
+    return path
+
+
+def _corridor_frame(args):
+    """one stereo pair of make_corridor_sequence (module level: rendered by a process pool when asked for)"""
+    k, n_frames, step, seed, h, w, K, baseline, lateral_amp, half_width, cam_height, wall_height, backdrop, ss = args
+    rng = np.random.default_rng([9000 + seed, k])                       # per frame: the frames can be rendered in any order
     fx, fy, cx, cy = K
-    ss = supersample
     us = (np.arange(w * ss, dtype=np.float32) + 0.5) / ss - 0.5
     vs = (np.arange(h * ss, dtype=np.float32) + 0.5) / ss - 0.5
     dx = ((us - cx) / fx)[None, :].repeat(h * ss, 0)                   # ray direction (dx, dy, 1)
     dy = ((vs - cy) / fy)[:, None].repeat(w * ss, 1)
-
     z_end = step * n_frames + backdrop
 
     def render(c):
@@ -366,15 +387,49 @@ def make_corridor_sequence(n_frames=40, step=0.8, seed=0, h=KITTI_H, w=KITTI_W, 
         img += rng.normal(0, 1.0, img.shape)
         return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
-    frames, poses, centres = [], [], []
-    for k in range(n_frames):
-        c = np.array([lateral_amp * np.sin(0.15 * k), 0.0, step * k], dtype=np.float32)
-        left = render(c)
-        right = render(c + np.array([baseline, 0, 0], dtype=np.float32))
-        frames.append((left, right))
-        centres.append(c.astype(np.float64))
-        poses.append(np.array([0, 0, 0, 1, -c[0], -c[1], -c[2]], dtype=np.float64))   # T_cw, identity rotation
+    c = np.array([lateral_amp * np.sin(0.15 * k), 0.0, step * k], dtype=np.float32)
+    left = render(c)
+    right = render(c + np.array([baseline, 0, 0], dtype=np.float32))
+    return left, right, c.astype(np.float64)
+
+
+def make_corridor_sequence(n_frames=40, step=0.8, seed=0, h=KITTI_H, w=KITTI_W, K=KITTI_K, baseline=KITTI_BASELINE, lateral_amp=0.3,
+                           half_width=6.0, cam_height=1.65, wall_height=6.0, backdrop=120.0, supersample=2, workers=1):
+    """A KITTI-00-shaped stereo sequence: the rig drives FORWARD (+z) by `step` metres per frame (0.8 m ~ KITTI at 10 Hz)
+    with a slow lateral sway, through a textured corridor (ground plane, two walls, a far backdrop), rendered by ray
+    casting each pixel against the planes -- exact perspective, exact stereo geometry, ground-truth poses.  Rotations
+    are identity.  The backdrop is a world plane `backdrop` metres beyond the end of the drive.  workers > 1 renders the
+    frames in that many processes (0.65 s per pair on one core; same images).
+    Returns (frames [(left, right)], T_cw [n,7], centres [n,3])."""
+    jobs = [(k, n_frames, step, seed, h, w, tuple(K), baseline, lateral_amp, half_width, cam_height, wall_height, backdrop, supersample)
+            for k in range(n_frames)]
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, n_frames)) as pool:
+            out = pool.map(_corridor_frame, jobs, chunksize=1)
+    else:
+        out = [_corridor_frame(j) for j in jobs]
+    frames = [(l, r) for l, r, _ in out]
+    centres = [c for _, _, c in out]
+    poses = [np.array([0, 0, 0, 1, -c[0], -c[1], -c[2]], dtype=np.float64) for c in centres]     # T_cw, identity rotation
     return frames, np.array(poses), np.array(centres)
+
+
+def write_kitti_sequence(root, frames, dt=0.1):
+    """<root>/{times.txt, image_0/%06d.png, image_1/%06d.png}: the KITTI odometry layout the reference's loader reads
+    (include/common/read_kitii_dataset.hpp:16-60)"""
+    import os
+
+    from PIL import Image
+    for sub in ("image_0", "image_1"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    for i, (L, R) in enumerate(frames):
+        Image.fromarray(L).save(os.path.join(root, "image_0", f"{i:06d}.png"))
+        Image.fromarray(R).save(os.path.join(root, "image_1", f"{i:06d}.png"))
+    with open(os.path.join(root, "times.txt"), "w") as f:               # written last: its presence marks a complete sequence
+        for i in range(len(frames)):
+            f.write(f"{i * dt:e}\n")
+    return root
 
 
 def make_vocabulary(k=10, L=3, seed=0, stop_fraction=0.02):
@@ -408,3 +463,21 @@ def write_vocabulary_text(path, voc, scoring=0, weighting=0):
         f.write(f"{voc['k']} {voc['L']} {scoring} {weighting}\n")
         for i in range(1, len(voc["parent"])):
             f.write(f"{voc['parent'][i]} {int(voc['is_leaf'][i])} " + " ".join(str(int(b)) for b in voc["desc"][i]) + f" {float(voc['weight'][i])!r}\n")
+
+
+if __name__ == "__main__":
+    # python -m ssvio_amd.synth corridor <dir> <n_frames> [workers]: render + write a KITTI-layout corridor drive (bench.py's C1 leg
+    # starts this in a process of its own, before it touches the GPU, and collects it later)
+    import os
+    import sys
+    if len(sys.argv) >= 4 and sys.argv[1] == "corridor":
+        n = int(sys.argv[3])
+        nw = int(sys.argv[4]) if len(sys.argv) > 4 else max(1, min(os.cpu_count() or 1, 32))
+        fr, _, cen = make_corridor_sequence(n_frames=n, workers=nw)
+        os.makedirs(sys.argv[2], exist_ok=True)
+        np.save(os.path.join(sys.argv[2], "centres.npy"), cen)
+        write_kitti_sequence(sys.argv[2], fr)
+        print(f"wrote {n} stereo pairs to {sys.argv[2]}")
+    else:
+        print("usage: python -m ssvio_amd.synth corridor <dir> <n_frames> [workers]", file=sys.stderr)
+        sys.exit(2)

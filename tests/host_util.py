@@ -8,29 +8,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "host", "build")
 
-# the keys System / FrontEnd / Backend read (values of the reference's KITTI settings)
-DEFAULT_CONFIG = {
-    "Camera1.fx": 718.856, "Camera1.fy": 718.856, "Camera1.cx": 607.1928, "Camera1.cy": 185.2157,
-    "Camera2.fx": 718.856, "Camera2.fy": 718.856, "Camera2.cx": 607.1928, "Camera2.cy": 185.2157,
-    "Camera.width": 1241, "Camera.height": 376, "Camera.Base.Line": 386.1448, "Camera.NeedUndistortion": 0, "Camera.fps": 10,
-    "Map.ActiveMap.Size": 12,
-    "numFeatures.initGood": 100, "numFeatures.trackingGood": 50, "numFeatures.trackingBad": 10,
-    "ORBextractor.nInitFeatures": 300, "ORBextractor.nNewFeatures": 100, "ORBextractor.scaleFactor": 1.2, "ORBextractor.nLevels": 8,
-    "ORBextractor.iniThFAST": 20, "ORBextractor.minThFAST": 7,
-    "Min.Init.Landmark.Num": 200,
-    "Viewer.ViewpointY": "1000 # a trailing comment",
-    "Backend.Open": 1,
-    "Trajectory.Save.Path": '"trajectory.txt"',
-}
+from ssvio_amd.synth import KITTI00_SETTINGS as DEFAULT_CONFIG  # noqa: E402  (the reference's config/kitti_00.yaml values)
+from ssvio_amd.synth import write_settings  # noqa: E402
 
 
 def write_config(path, overrides):
-    cfg = dict(DEFAULT_CONFIG); cfg.update(overrides)
-    with open(path, "w") as f:
-        f.write("%YAML:1.0\n# settings of the headless runner\n")
-        for k, v in cfg.items():
-            f.write(f"{k}: {v}\n")
-    return path
+    return write_settings(path, overrides)
 
 
 def write_sequence(root, n_frames=12, step=0.12, seed=0, dt=0.1):

@@ -311,3 +311,44 @@ def test_degenerate_small_images(ctx, po):
         gk, gd = sorb.ORBextractor(ctx, nfeatures=nf, nlevels=nl).DetectAndCompute(L)
         ok, od = po.orb_extract(L, prm=po.orb_params(nfeatures=nf, nlevels=nl))
         assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+
+
+def test_streamed_batches_equal_resident_batches(ctx):
+    """ssx_stereo_batch_upload / _run / _counts (batches that arrive from the host, one upload kept ahead on the library's copy
+    stream, two device buffers): every batch's counts and per-pair results are those of ssx_stereo_batch_dev on the same images"""
+    import torch
+    from ssvio_amd.synth import make_stereo_pair
+    B, H, W = 4, 200, 320
+    prm = sorb.OrbParams(300, 1.2, 4, 20, 7)
+    batches = [np.stack([np.stack(make_stereo_pair(seed=50 + 10 * k + i, h=H, w=W, n_blobs=400)[:2]) for i in range(B)]) for k in range(3)]
+    want = []
+    for hb in batches:
+        dev = torch.from_numpy(hb).cuda()
+        c = sorb.stereo_batch_dev(ctx, dev.data_ptr(), B, W, H, W, orb=prm).copy()
+        want.append((c, [sorb.stereo_batch_fetch(ctx, p, 2048) for p in range(B)]))
+    pinned = [torch.from_numpy(hb).pin_memory() for hb in batches]
+    st = sorb.StereoStream(ctx, B, H, W, orb=prm)
+    st.upload(pinned[0].data_ptr())
+    for k in range(3):
+        if k + 1 < 3:
+            st.upload(pinned[k + 1].data_ptr())                       # one ahead
+        st.run()
+        c = st.wait_counts()
+        assert np.array_equal(c, want[k][0]), k
+        for p in range(B):
+            got, ref = sorb.stereo_batch_fetch(ctx, p, 2048), want[k][1][p]
+            for key in ("kL", "kR"):
+                assert got[key].tobytes() == ref[key].tobytes()
+            for key in ("dL", "dR", "match_idx", "match_dist", "xyz", "ok"):
+                assert np.array_equal(got[key], ref[key]), (k, p, key)
+    # the one-call form, and misuse: a third upload while two are waiting, a run without an upload
+    st.enqueue(pinned[1].data_ptr())
+    assert np.array_equal(st.wait_counts(), want[1][0])
+    from ssvio_amd._lib import SsxError
+    with pytest.raises(SsxError):
+        st.run()
+    st.upload(pinned[0].data_ptr()); st.upload(pinned[1].data_ptr())
+    with pytest.raises(SsxError):
+        st.upload(pinned[2].data_ptr())
+    st.run(); st.run()
+    assert np.array_equal(st.wait_counts(), want[1][0])
