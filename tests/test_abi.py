@@ -28,7 +28,12 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(syms) >= 10
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.ssx_version() == 100
+    from ssvio_amd import _lib
+    assert lib.ssx_version() == _lib.SSX_VERSION == 110
+    # a caller built against another header is told so (ssx_abi_check), instead of reading cu_count from garbage
+    import ctypes as C
+    assert lib.ssx_abi_check(100, C.sizeof(_lib.Config), C.sizeof(_lib.BaProblem), C.sizeof(_lib.BaOptions), C.sizeof(_lib.BaResult), C.sizeof(_lib.BaWindowUpdate)) != 0
+    assert lib.ssx_abi_check(110, C.sizeof(_lib.Config) - 8, C.sizeof(_lib.BaProblem), C.sizeof(_lib.BaOptions), C.sizeof(_lib.BaResult), C.sizeof(_lib.BaWindowUpdate)) != 0
 
 
 def test_no_cpu_fallback_without_device():
