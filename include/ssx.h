@@ -218,10 +218,8 @@ SSX_API int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch);
 /* 1 .. 4 groups for the following solves; 0 = back to the default (per-kernel profiles want 1: one launch per kernel and
    LM slot, nothing else on the chip beside it) */
 SSX_API void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups);
-/* How the linearise / Schur kernels of the following solves cover a window: 1 = one PERSISTENT workgroup per group of ~7
-   chunks (256-edge pieces of the landmark-sorted edge list) that carries the partial reduced system across its chunks and
-   writes it once (6.6x less slab traffic, but measured slower on MI355X: DESIGN.md section 4c); 0 or -1 = one workgroup
-   per chunk (the default).  The results are the same bits either way (test_persistent_groups_equal_per_chunk). */
+/* Round 3's experiment (one persistent workgroup per group of ~7 chunks; measured slower on MI355X, profiles/r03/persist_ab.md) is
+   gone; the entry point remains for callers built against that header and does nothing. */
 SSX_API void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
 
@@ -340,6 +338,11 @@ SSX_API int32_t ssx_ba_window_selftest(uint32_t seed, int32_t steps);
 /* tools hook, needs no GPU: dynamic LDS bytes a BA kernel is launched with (-1: depends on the problem); the compiler's
  * resource report and rocprofv3's dispatch rows only know static __shared__ arrays (tools/kernel_resources.py) */
 SSX_API int64_t ssx_debug_kernel_dynamic_lds(const char* kernel);
+/* tests hook: 1 = the linearise / Schur kernels write, and the reductions read, every entry of the per-chunk partial sums (round 3's
+ * dense slabs); 0 (default) = only the blocks of the reduced system and the poses a chunk contributes to; < 0 = the environment's
+ * choice (SSX_BA_DENSE_SLABS).  Same bits either way (tests/test_ba_gpu.py::test_sparse_slabs_equal_dense_slabs); applies to problems
+ * uploaded after the call. */
+SSX_API void ssx_debug_set_dense_slabs(int32_t mode);
 
 /* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */
 SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps);

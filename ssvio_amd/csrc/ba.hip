@@ -37,6 +37,7 @@
 // iteration, [S | b_s] once per trial before the (replicated, deterministic) solve, [chi2', scale, #outliers]
 // once per trial after the residual pass.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -70,9 +71,7 @@ constexpr int CH_L = 128;          // max landmarks per chunk (per-landmark LDS 
 constexpr int PL = CH_L + 1;       // their padded pitch
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
-constexpr int GRP_CH_MAX = 16;     // (experiments: SSX_BA_GRP_CH overrides GRP_CH up to this)
-constexpr int GRP_CH = 7;          // chunks per group (a function of the WINDOW only, never of the batch: results must not depend on
-                                   // how many windows share a launch).  64 C3 windows x 12 groups = 768 workgroups = 3 per CU
+constexpr int TOUCH_WORDS = (SSX_BA_SMALL_P * (SSX_BA_SMALL_P + 1) / 2 + SSX_BA_SMALL_P + 31) / 32;   // 5: bits of a chunk's touch mask
 constexpr int BSEG_PARTS = 4;      // a block's pair list is cut into at most this many parts (k_schur's block phase) ...
 constexpr int BSEG_MIN = 8;        // ... of at least this many pairs
 constexpr int MAX_PAIRS = CH_E * (SSX_BA_SMALL_P + 1) / 2 + 8;       // leader pairs of one chunk (sum k(k+1)/2, k <= 16)
@@ -112,10 +111,12 @@ struct BaDev {
                             // Jacobians, the linearize hook); 0: small windows with analytic Jacobians RECOMPUTE it where needed --
                             // 150 flops per edge instead of one 144-byte write and two reads
   int lin_stride;           // doubles per chunk in lin_slab: nP*27 + 2 (small) or 2 (big)
-  int nGrp;                 // chunk GROUPS of the window: group g = chunks [g nCh / nGrp, (g + 1) nCh / nGrp), about GRP_CH each
-  int persist;              // 1: a workgroup of the linearise / Schur kernels owns a whole GROUP and emits ONE slab for it
-                            // (slab index = group); 0: one workgroup and one slab per chunk.  Same bits either way: the group's
-                            // sum is formed chunk by chunk in chunk order in both (in the kernel, or in the reduction)
+  int dense_slabs;          // 1: every chunk writes every entry of its slabs (zeros for blocks / poses it does not touch) and the
+                            // reductions read all of them: round 3's traffic, kept as the cross-check of the sparse form (same bits)
+  GPtr<unsigned int> touch; // nCh x TOUCH_WORDS: bit b < nBlk = the chunk's landmarks contribute to block b of the reduced system,
+                            // bit nBlk + p = the chunk holds edges of free pose p.  A chunk WRITES only those parts of its slabs, the
+                            // reductions READ only those (a C3 chunk of 51 landmarks sorted by first keyframe touches 15-25 of the
+                            // 55 blocks and 5-7 of the 10 poses)
   GPtr<const int> pose_free;     // P: free index or -1
   GPtr<const uint8_t> lm_fixed;  // nLm (compact landmarks = landmarks that have edges)
   GPtr<const int> lm_id;         // nLm -> original landmark
@@ -349,37 +350,20 @@ __device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
   return acc;
 }
 
-// slab entries: the first chunk of a group stores its value, every later chunk adds to what is there (a plain read-modify-
-// write of the workgroup's own slab: 16 KB that stay in the L2 until the kernel ends).  An entry is touched by exactly ONE
-// lane per chunk and the chunks of a workgroup are separated by workgroup barriers, so the additions to an entry happen in
-// chunk order: a sequential IEEE sum, the same one the reductions form from per-chunk slabs (`first` is uniform over the
-// workgroup).  [Measured on MI355X, 64 C3 windows, profiles/r03/persist_ab.md: with fire-and-forget global_atomic_add_f64
-// instead of the load + add + store the kernel took 319 us (the L2 retires ~53 G f64 atomics/s chip-wide: 10 M of them per
-// launch), with the read-modify-write 167 us, with one workgroup and one slab per chunk 138 us.]
-__device__ __forceinline__ void slab_put(double* p, double v, bool first)
+// (Round 3 measured workgroups that walk a GROUP of chunks and keep one slab per group -- profiles/r03/persist_ab.md: 6.6x less
+// slab traffic, but the kernel lost more than the reductions won; round 4 cuts the traffic the other way: a chunk writes only the
+// parts of its slab it contributes to, see BaDev::touch.)
+__device__ __forceinline__ bool chunk_touches(const BaDev& d, int c, int bit)
 {
-  if (first) *p = v;                                  // (a branch, not a select: the select form loads the old entry speculatively
-  else *p += v;                                       // even when every chunk is a group's first -- one workgroup per chunk)
+  return d.dense_slabs || ((d.touch[(size_t)c * TOUCH_WORDS + (bit >> 5)] >> (bit & 31)) & 1u);
 }
-__device__ __forceinline__ void group_range(const BaDev& d, int g, int& c0, int& c1)
-{
-  c0 = (int)((long long)g * d.nCh / d.nGrp);
-  c1 = (int)((long long)(g + 1) * d.nCh / d.nGrp);
-}
-// what a workgroup of the linearise / Schur kernels covers: chunks [c0, c1) and the slab it writes
-__device__ __forceinline__ void wg_range(const BaDev& d, int bx, int& c0, int& c1)
-{
-  if (d.persist) group_range(d, bx, c0, c1);
-  else { c0 = bx; c1 = bx + 1; }
-}
-__device__ __forceinline__ int wg_count(const BaDev& d) { return d.persist ? d.nGrp : d.nCh; }
 
 // Wout (18, nullable): this thread's edge block W = Ji^T w Jj stays in registers for the caller; lmout (9, nullable):
 // this thread's landmark sums (Hll 6 + bl 3).  cur must be >= 0 (the device-driven checks are the wrappers').
 // erw_out (nullable): the flag word of this thread's edge record, for the Schur phase of the fused kernel.
 template <int JAC>
 __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur, char* smem, const ChunkLists& cl, double* Wout, double* lmout,
-                                                 int* erw_out, double* slab, const bool first)
+                                                 int* erw_out, double* slab)
 {
   double (*sL)[CH] = reinterpret_cast<double (*)[CH]>(smem);            // [9]: per-edge landmark contributions (6 Hll + 3 bl), edge order
   double* sV = reinterpret_cast<double*>(smem) + 9 * CH;                // [LIN_VA][PW]: per-edge pose-block terms, POSE-MAJOR order
@@ -483,9 +467,12 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
   // entries per pose (large windows build the pose blocks pose-major instead: k_pose_blocks)
   if (small) {
     const int nP = d.nP;
+    // (a pose none of whose edges lies in this chunk is not written: the reduction skips it through BaDev::touch)
+    const bool dense = d.dense_slabs != 0;
     for (int i = t; i < nP * LIN_VA; i += CH) {
       const int p = i / LIN_VA, k = i - p * LIN_VA;
-      slab_put(slab + p * 27 + k, run_sum(sV + k * PW, sPptr[p], sPptr[p + 1]), first);
+      const int s0 = sPptr[p], s1 = sPptr[p + 1];
+      if (dense || s1 > s0) slab[p * 27 + k] = run_sum(sV + k * PW, s0, s1);
     }
     __syncthreads();
     if (t < ne) {
@@ -497,7 +484,8 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     __syncthreads();
     for (int i = t; i < nP * (27 - LIN_VA); i += CH) {
       const int p = i / (27 - LIN_VA), k = i - p * (27 - LIN_VA);
-      slab_put(slab + p * 27 + LIN_VA + k, run_sum(sV + k * PW, sPptr[p], sPptr[p + 1]), first);
+      const int s0 = sPptr[p], s1 = sPptr[p + 1];
+      if (dense || s1 > s0) slab[p * 27 + LIN_VA + k] = run_sum(sV + k * PW, s0, s1);
     }
   }
   PH(3);
@@ -506,9 +494,8 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
   block_sum3_max_256(chi, z0, z1, md, sRed);
   PH(4);
   if (t == 0) {
-    slab_put(slab + d.lin_stride - 2, chi, first);
-    if (first) slab[d.lin_stride - 1] = md;
-    else slab[d.lin_stride - 1] = fmax(slab[d.lin_stride - 1], md);
+    slab[d.lin_stride - 2] = chi;
+    slab[d.lin_stride - 1] = md;
   }
 }
 
@@ -516,23 +503,13 @@ template <int JAC>
 __device__ __forceinline__ void k_linearize_entry(const BaDev& d, int bx, int cur)
 {
   extern __shared__ __attribute__((aligned(16))) char lin_smem[];
-  int c0, c1;
-  wg_range(d, bx, c0, c1);
   ChunkLists cl;
-  chunk_lists_load(d, c0, lin_smem, false, cl);
+  chunk_lists_load(d, bx, lin_smem, false, cl);
   if (cur < 0) {                                   // device-driven LM: skip when stopped or when the linearisation at the
     if (d.scal[SC_STOP] != 0.0 || d.scal[SC_NEEDLIN] == 0.0) return;   // kept state is still valid (rejected trial)
     cur = (int)d.scal[SC_CUR];
   }
-  double* slab = d.lin_slab + (size_t)bx * d.lin_stride;
-#pragma unroll 1
-  for (int c = c0; c < c1; ++c) {
-    if (c > c0) {
-      __syncthreads();                             // the previous chunk's lists and term rows are still being read
-      chunk_lists_load(d, c, lin_smem, false, cl);
-    }
-    k_linearize_body<JAC>(d, c, cur, lin_smem, cl, nullptr, nullptr, nullptr, slab, c == c0);
-  }
+  k_linearize_body<JAC>(d, bx, cur, lin_smem, cl, nullptr, nullptr, nullptr, d.lin_slab + (size_t)bx * d.lin_stride);
 }
 template <int JAC>
 __global__ __launch_bounds__(CH) void k_linearize(BaDev d, int cur) { k_linearize_entry<JAC>(d, blockIdx.x, cur); }
@@ -541,56 +518,59 @@ template <int JAC>
 __global__ __launch_bounds__(CH) void k_linearize_b(const BaDev* __restrict__ dv, int cur)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
-  if ((int)blockIdx.x >= wg_count(d)) return;
+  if ((int)blockIdx.x >= d.nCh) return;
   k_linearize_entry<JAC>(d, blockIdx.x, cur);
 }
 
-// One entry of a window's slabs summed over the window, the part of lane group j (0 .. 3): the groups g = j, j + 4, ... in
-// that order, a group's value being the sum of its chunks in chunk order -- read from the group's slab (persistent
-// workgroups formed it exactly so) or formed here from the per-chunk slabs.  The caller adds the four parts in part order.
-__device__ __forceinline__ double slab_sum_part(const BaDev& d, const double* col, size_t stride, int j)
+// One entry of a window's slabs summed over the chunks that wrote it (bit `bit` of their touch mask), the part of lane group j
+// (0 .. 3): the chunks c = j, j + 4, j + 8, ... in ascending order.  The caller adds the four parts in part order: a fixed
+// association, the same whether the slabs are sparse or dense (a chunk that does not touch the entry would add an exact zero).
+// sMask: the masks of the chunks [c_base, c_base + MASK_TILE) staged in LDS by the caller.
+constexpr int MASK_TILE = 256;
+__device__ __forceinline__ void stage_masks(const BaDev& d, int c_base, unsigned int* sMask)
 {
-  double p = 0.0;
-  if (d.persist) {
-    int g = j;
-    for (; g + 28 < d.nGrp; g += 32) {
-      double v[8];
+  const int n = min(MASK_TILE, d.nCh - c_base) * TOUCH_WORDS;
+  for (int i = threadIdx.x; i < n; i += CH) sMask[i] = d.dense_slabs ? 0xFFFFFFFFu : d.touch[(size_t)c_base * TOUCH_WORDS + i];
+}
+__device__ __forceinline__ double slab_sum_masked(const BaDev& d, const double* col, size_t stride, int j, int bit, int c_base, const unsigned int* sMask, double p)
+{
+  const int c_end = min(c_base + MASK_TILE, d.nCh);
+  const int w = bit >> 5, sh = bit & 31;
+  int c = c_base + j;                                // (MASK_TILE is a multiple of 4: the residues mod 4 continue across tiles)
+  for (; c + 12 < c_end; c += 16) {                  // four loads in flight
+    double v[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = col[(size_t)(g + 4 * i) * stride];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) p += v[i];
+    for (int i = 0; i < 4; ++i) {
+      const bool on = (sMask[(c + 4 * i - c_base) * TOUCH_WORDS + w] >> sh) & 1u;
+      v[i] = on ? col[(size_t)(c + 4 * i) * stride] : 0.0;
     }
-    for (; g < d.nGrp; g += 4) p += col[(size_t)g * stride];
-  } else {
-    for (int g = j; g < d.nGrp; g += 4) {
-      int c0, c1;
-      group_range(d, g, c0, c1);
-      double v[GRP_CH_MAX];                                     // a group holds GRP_CH chunks at most (nGrp = ceil(nCh / GRP_CH), even split)
 #pragma unroll
-      for (int i = 0; i < GRP_CH_MAX; ++i) v[i] = (c0 + i < c1) ? col[(size_t)(c0 + i) * stride] : 0.0;
-      double a = v[0];
-#pragma unroll
-      for (int i = 1; i < GRP_CH_MAX; ++i) a = (c0 + i < c1) ? a + v[i] : a;
-      p += a;
-    }
+    for (int i = 0; i < 4; ++i) p += v[i];
   }
+  for (; c < c_end; c += 4)
+    if ((sMask[(c - c_base) * TOUCH_WORDS + w] >> sh) & 1u) p += col[(size_t)c * stride];
   return p;
 }
 
 // slabs -> Hpp (21 per pose), bp, chi2, max|diag(H)|: 64 entries x 4 lane groups per 256-thread workgroup, combined in a
-// fixed order (deterministic, and the same bits whether the slabs are per chunk or per group); workgroup 0 also reduces
-// chi2 / max-diagonal.
+// fixed order (deterministic); workgroup 0 also reduces chi2 / max-diagonal.
 // (computeLambdaInit, optimization_algorithm_levenberg.cpp:152-166, wants the max over pose AND landmark
 // diagonals; with several ranks the pose diagonals need the all-reduced Hpp, see k_lambda_init.)
 __device__ __forceinline__ void k_reduce_lin_body(const BaDev& d, const int bx)
 {
   __shared__ double sAcc[CH];
+  __shared__ unsigned int sMask[MASK_TILE * TOUCH_WORDS];
   const int t = threadIdx.x;
   const int n = d.nP * 27;
   const int stride = n + 2;
   const int ent = bx * 64 + (t & 63), grp = t >> 6;
   double acc = 0.0;
-  if (ent < n) acc = slab_sum_part(d, d.lin_slab + ent, stride, grp);
+  for (int cb = 0; cb < d.nCh; cb += MASK_TILE) {
+    if (cb) __syncthreads();
+    stage_masks(d, cb, sMask);
+    __syncthreads();
+    if (ent < n) acc = slab_sum_masked(d, d.lin_slab + ent, stride, grp, d.nBlk + ent / 27, cb, sMask, acc);
+  }
   sAcc[t] = acc;
   __syncthreads();
   if (ent < n && grp == 0) {
@@ -601,23 +581,11 @@ __device__ __forceinline__ void k_reduce_lin_body(const BaDev& d, const int bx)
   }
   if (bx != 0) return;
   __syncthreads();
-  // chi2: the groups' values (chunk order inside a group) over the threads, then the fixed tree of block_sum_256
+  // chi2 / max diagonal: every chunk writes them; the chunks over the threads, then the fixed tree of block_sum_256
   double chi = 0.0, md = 0.0;
-  for (int g = t; g < d.nGrp; g += CH) {
-    if (d.persist) {
-      chi += d.lin_slab[(size_t)g * stride + n];
-      md = fmax(md, d.lin_slab[(size_t)g * stride + n + 1]);
-    } else {
-      int c0, c1;
-      group_range(d, g, c0, c1);
-      double a = d.lin_slab[(size_t)c0 * stride + n];
-      md = fmax(md, d.lin_slab[(size_t)c0 * stride + n + 1]);
-      for (int c = c0 + 1; c < c1; ++c) {
-        a += d.lin_slab[(size_t)c * stride + n];
-        md = fmax(md, d.lin_slab[(size_t)c * stride + n + 1]);
-      }
-      chi += a;
-    }
+  for (int c = t; c < d.nCh; c += CH) {
+    chi += d.lin_slab[(size_t)c * stride + n];
+    md = fmax(md, d.lin_slab[(size_t)c * stride + n + 1]);
   }
   chi = block_sum_256(chi, sAcc);
   md = block_max_256(md, sAcc);
@@ -825,13 +793,24 @@ __device__ __forceinline__ void k_build_lists_body(const BaDev& d, const int c)
       if (++pb == nP) { ++pa; pb = pa; }
     }
   }
+  // 4b. the chunk's touch mask: the blocks that have pairs, the free poses that have edges here (any edge: the pose blocks sum
+  // over fixed landmarks' edges too)
+  if (t < TOUCH_WORDS) {
+    unsigned int m = 0;
+    for (int b = 32 * t; b < min(32 * t + 32, nBlk + nP); ++b) {
+      const bool on = b < nBlk ? (sBp[b + 1] > sBp[b]) : (d.pptr[(size_t)c * (nP + 1) + (b - nBlk) + 1] > d.pptr[(size_t)c * (nP + 1) + (b - nBlk)]);
+      m |= (on || d.dense_slabs) ? 1u << (b & 31) : 0u;
+    }
+    d.touch[(size_t)c * TOUCH_WORDS + t] = m;
+  }
   // 5. work items of the block phase (prepare()'s rule: parts of at least BSEG_MIN pairs, at most BSEG_PARTS per block, sorted by
-  // part length -- ties in block order --, the parts of one block inside one group of 16 items)
+  // part length -- ties in block order --, the parts of one block inside one group of 16 items).  A block without pairs gets no
+  // item (it is not written) unless the slabs are dense.
   const int seg = max(BSEG_MIN, (sMaxLen + BSEG_PARTS - 1) / BSEG_PARTS);
   if (t < nBlk) {
-    const int n = sBp[t + 1] - sBp[t], k = max(1, (n + seg - 1) / seg);
+    const int n = sBp[t + 1] - sBp[t], k = (n == 0 && !d.dense_slabs) ? 0 : max(1, (n + seg - 1) / seg);
     sK[t] = k;
-    sLen[t] = (n + k - 1) / k;
+    sLen[t] = k ? (n + k - 1) / k : 0;
   }
   __syncthreads();
   if (t < nBlk) {
@@ -1090,7 +1069,7 @@ __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W
 // nullable): this thread's landmark sums (Hll 6 + bl 3).  The stop / state checks are the wrappers'.
 // erw_in (nullable): this thread's edge flag word from the linearisation phase (fused kernel).
 __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int cur, double lambda, char* smem, const ChunkLists& cl, const double* Win,
-                                             const double* lmin, const int* erw_in, double* slab, const bool first)
+                                             const double* lmin, const int* erw_in, double* slab)
 {
   // With D = Hll + lambda I = L L^T (3x3 Cholesky) and Y_e = W_e L^-T, the Schur term of an edge pair is
   // W_a D^-1 W_b^T = Y_a Y_b^T and W D^-1 bl = Y (L^-1 bl): ONE 6x3 array per edge in LDS instead of W and W D^-1
@@ -1242,7 +1221,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) slab_put(slab + blk * 36 + (3 * qr + i) * 6 + 3 * qc + j, acc[i][j], first);
+        for (int j = 0; j < 3; ++j) slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j] = acc[i][j];
     }
   }
   PH(8);
@@ -1261,11 +1240,11 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     const int idx = on ? item >> 2 : 0, part = item & 3;
     const int p = idx / 6, a = idx - p * 6;
     double acc = 0.0;
-    if (on)
-      for (int s = sPptr[p] + part; s < sPptr[p + 1]; s += 4) acc += sY[a * PW + s];
+    const int s0 = on ? sPptr[p] : 0, s1 = on ? sPptr[p + 1] : 0;
+    for (int s = s0 + part; s < s1; s += 4) acc += sY[a * PW + s];
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
-    if (on && part == 0) slab_put(slab + nS + idx, acc, first);
+    if (on && part == 0 && (d.dense_slabs || s1 > s0)) slab[nS + idx] = acc;     // (a pose without edges here: not written, not read)
   }
   PH(9);
 }
@@ -1276,29 +1255,19 @@ extern "C" __attribute__((visibility("default"))) void ssx_debug_phase_clock(lon
 __device__ __forceinline__ void k_schur_entry(const BaDev& d, int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
   extern __shared__ __attribute__((aligned(16))) char schur_smem[];
-  int c0, c1;
-  wg_range(d, bx, c0, c1);
   ChunkLists cl;
-  chunk_lists_load(d, c0, schur_smem, true, cl);
+  chunk_lists_load(d, bx, schur_smem, true, cl);
   if (use_dev_lambda == 2 && d.scal[SC_STOP] != 0.0) return;      // device-driven LM, already terminated
   if (cur < 0) cur = (int)d.scal[SC_CUR];
   const double lambda = use_dev_lambda ? d.scal[SC_LAMBDA] : lambda_arg;
-  double* slab = d.schur_slab + (size_t)bx * (d.nBlk * 36 + d.nP * 6);
-#pragma unroll 1
-  for (int c = c0; c < c1; ++c) {
-    if (c > c0) {
-      __syncthreads();
-      chunk_lists_load(d, c, schur_smem, true, cl);
-    }
-    k_schur_body(d, c, cur, lambda, schur_smem, cl, nullptr, nullptr, nullptr, slab, c == c0);
-  }
+  k_schur_body(d, bx, cur, lambda, schur_smem, cl, nullptr, nullptr, nullptr, d.schur_slab + (size_t)bx * (d.nBlk * 36 + d.nP * 6));
 }
 __global__ __launch_bounds__(CH) void k_schur(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_schur_entry(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
 __global__ __launch_bounds__(CH) void k_schur_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
-  if ((int)blockIdx.x >= wg_count(d)) return;
+  if ((int)blockIdx.x >= d.nCh) return;
   k_schur_entry(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
 }
 
@@ -1313,34 +1282,24 @@ __device__ __forceinline__ void k_lin_schur_entry(const BaDev& d, int bx)
 {
   extern __shared__ __attribute__((aligned(16))) char fused_smem[];
   const double stop = d.scal[SC_STOP], curd = d.scal[SC_CUR], lambda = d.scal[SC_LAMBDA], needlin = d.scal[SC_NEEDLIN];
-  int c0, c1;
-  wg_range(d, bx, c0, c1);
   ChunkLists cl;
-  chunk_lists_load(d, c0, fused_smem, true, cl);                   // issued beside the state words, not after them
+  chunk_lists_load(d, bx, fused_smem, true, cl);                   // issued beside the state words, not after them
   if (stop != 0.0) return;
   const int cur = (int)curd;
   double* lslab = d.lin_slab + (size_t)bx * d.lin_stride;
   double* sslab = d.schur_slab + (size_t)bx * (d.nBlk * 36 + d.nP * 6);
-#pragma unroll 1
-  for (int c = c0; c < c1; ++c) {
-    const bool first = c == c0;
-    if (!first) {
-      __syncthreads();                                             // the previous chunk's lists / Y rows are still being read
-      chunk_lists_load(d, c, fused_smem, true, cl);
-    }
-    if (needlin != 0.0) {
-      double W[18], lm[9];
-      int erw = 0;
+  if (needlin != 0.0) {
+    double W[18], lm[9];
+    int erw = 0;
 #pragma unroll
-      for (int k = 0; k < 18; ++k) W[k] = 0.0;
+    for (int k = 0; k < 18; ++k) W[k] = 0.0;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) lm[k] = 0.0;
-      k_linearize_body<JAC>(d, c, cur, fused_smem, cl, W, lm, &erw, lslab, first);
-      __syncthreads();                                             // the linearisation's LDS is dead: the Schur phase takes it over
-      k_schur_body(d, c, cur, lambda, fused_smem, cl, W, lm, &erw, sslab, first);
-    } else {
-      k_schur_body(d, c, cur, lambda, fused_smem, cl, nullptr, nullptr, nullptr, sslab, first);
-    }
+    for (int k = 0; k < 9; ++k) lm[k] = 0.0;
+    k_linearize_body<JAC>(d, bx, cur, fused_smem, cl, W, lm, &erw, lslab);
+    __syncthreads();                                               // the linearisation's LDS is dead: the Schur phase takes it over
+    k_schur_body(d, bx, cur, lambda, fused_smem, cl, W, lm, &erw, sslab);
+  } else {
+    k_schur_body(d, bx, cur, lambda, fused_smem, cl, nullptr, nullptr, nullptr, sslab);
   }
 }
 template <int JAC>
@@ -1349,22 +1308,29 @@ template <int JAC>
 __global__ __launch_bounds__(CH, 3) void k_lin_schur_b(const BaDev* __restrict__ dv)
 {
   const BaDev& d = dv[blockIdx.y];
-  if ((int)blockIdx.x >= wg_count(d)) return;
+  if ((int)blockIdx.x >= d.nCh) return;
   k_lin_schur_entry<JAC>(d, blockIdx.x);
 }
 
 // slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c).
-// 64 entries x 4 lane groups per workgroup (slab_sum_part), the four parts added in part order: deterministic.
+// 64 entries x 4 lane groups per workgroup (slab_sum_masked), the four parts added in part order: deterministic.
 __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx)
 {
   __shared__ double sAcc[3][64];
+  __shared__ unsigned int sMask[MASK_TILE * TOUCH_WORDS];
   const int nS = d.nBlk * 36;
   const int stride = nS + d.nP * 6;
   const int n = 6 * d.nP;
   const int t = threadIdx.x;
   const int ent = bx * 64 + (t & 63), grp = t >> 6;
+  const int bit = ent < nS ? ent / 36 : d.nBlk + (ent - nS) / 6;
   double acc = 0.0;
-  if (ent < stride) acc = slab_sum_part(d, d.schur_slab + ent, stride, grp);
+  for (int cb = 0; cb < d.nCh; cb += MASK_TILE) {
+    if (cb) __syncthreads();
+    stage_masks(d, cb, sMask);
+    __syncthreads();
+    if (ent < stride) acc = slab_sum_masked(d, d.schur_slab + ent, stride, grp, bit, cb, sMask, acc);
+  }
   if (grp > 0) sAcc[grp - 1][t & 63] = acc;
   __syncthreads();
   if (grp != 0 || ent >= stride) return;
@@ -1566,13 +1532,6 @@ __global__ __launch_bounds__(64) void k_lm_begin_batch(const BaDev* __restrict__
   k_lm_begin_body(d, 0, ctrl[w], iters, ctrl[n + w], ctrl[2 * n + w]);
 }
 
-// batch_run switches all windows of a batch between one workgroup per chunk and one per group of chunks
-__global__ __launch_bounds__(CH) void k_set_persist_b(BaDev* dv, int n, int persist)
-{
-  const int w = blockIdx.x * CH + threadIdx.x;
-  if (w < n) dv[w].persist = dv[w].big ? 0 : persist;
-}
-
 // after the upload of a batch: the second state buffer (and a resident batch's pristine copy) from the uploaded one
 __global__ __launch_bounds__(CH) void k_dup_state_b(const BaDev* __restrict__ dv)
 {
@@ -1653,6 +1612,18 @@ __global__ __launch_bounds__(CH) void k_pack_poses_b(const BaDev* __restrict__ d
 // host side
 // ------------------------------------------------------------------------------------------------
 namespace {
+// 1: round 3's dense slabs (every chunk writes and the reductions read every entry), the cross-check of the sparse form;
+// SSX_BA_DENSE_SLABS=1 in the environment or ssx_debug_set_dense_slabs
+std::atomic<int> g_dense_slabs{-1};
+inline int dense_slabs_mode()
+{
+  int m = g_dense_slabs.load(std::memory_order_relaxed);
+  if (m < 0) {
+    m = getenv("SSX_BA_DENSE_SLABS") ? 1 : 0;
+    g_dense_slabs.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
 struct HostPrep {
   int P, L, E, nP, nLm, nCh, nBlk;
   int E_raw = 0;                     // entries of the caller's edge arrays (E of them alive; see BaDev::E_raw)
@@ -1666,6 +1637,7 @@ struct HostPrep {
   bool big = false;
   std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr;
   std::vector<int> bseg, bseg_ptr;   // see BaDev
+  std::vector<unsigned int> touch;   // host-built lists only: BaDev::touch
   bool dev_lists = false;            // small window: pair lists + work items are built by k_build_lists, not here
   bool dev_prep = false;             // small window: the edge sort by (landmark, pose), the packed records, the pose-major order and the
                                      // sorted uv columns are built ON THE DEVICE (k_prep_scatter / k_prep_chunk) from the caller's raw
@@ -1673,7 +1645,7 @@ struct HostPrep {
   std::vector<uint8_t> slot8;
   std::vector<int> lm_compact;       // caller's landmark -> compact landmark or -1
   std::vector<int> pose_rank;        // empty, or BaDev::pose_rank (a window's keyframes in the order of their ids)
-  std::vector<int> cnt_tmp, start_tmp;
+  std::vector<int> cnt_tmp, start_tmp, first_pf_tmp, visit_tmp, visit2_tmp;
   std::vector<uint32_t> tmp_pairs;   // scratch of prepare(), kept between calls
   std::vector<std::pair<int, int>> tmp_order;
   std::vector<int> ch_desc, e_rec, l_rec;   // packed records (4 ints each), see BaDev
@@ -1849,6 +1821,8 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   // counting sort of the edges by landmark
   std::vector<int>& cnt = h.cnt_tmp;
   cnt.assign(L + 1, 0);
+  std::vector<int>& first_pf = h.first_pf_tmp;            // per landmark: the first free pose (in free-pose order) that observes it
+  first_pf.assign((size_t)L + 1, h.nP + 1);
   if (h.dev_prep) h.slot8.resize((size_t)std::max(E, 1));
   int n_dead = 0;
   const bool big_dev = h.big && h.dev_prep;               // large window, device-marshalled: the host also counts edges per free pose
@@ -1862,6 +1836,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
     }
     if (h.dev_prep) h.slot8[e] = (uint8_t)cnt[l + 1];      // (a count beyond CH_E is reported below: the wrapped value is never used)
     cnt[l + 1]++;
+    { const int pfk = h.pose_free[p] >= 0 ? h.pose_free[p] : h.nP; if (pfk < first_pf[l]) first_pf[l] = pfk; }
     if (big_dev) { const int pf = h.pose_free[p]; if (pf >= 0) h.pe_ptr[pf + 1]++; }
   }
   if (n_dead && !h.dev_prep) { ctx->set_error("ssx_ba: dead observations need the device-side marshalling"); return SSX_ERR_UNSUPPORTED; }
@@ -1883,10 +1858,15 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   std::vector<int>& lm_compact = h.lm_compact;
   std::vector<int>& start = h.start_tmp;
   lm_compact.assign(L, -1); start.assign(L + 1, 0);
-  const bool lm_ordered = ext && ext->lm_order;           // a window: compact landmarks in the order of the caller's ids
-  if (!lm_ordered) for (int l = 0; l < L; ++l) start[l + 1] = start[l] + cnt[l + 1];
+  // The compact order of the landmarks: the caller's order (a window: ascending ids), then -- stable -- by the FIRST free pose that
+  // observes a landmark.  Map points are created keyframe by keyframe, so real windows arrive almost sorted already; what the
+  // sort buys is locality for every input: the landmarks of a chunk then share their poses, a chunk contributes to 15-25 of the
+  // 55 blocks of a 10-keyframe reduced system instead of all of them, and writes / the reductions read only those (BaDev::touch).
+  const bool lm_ordered = ext && ext->lm_order;
+  static const bool no_lm_sort = getenv("SSX_BA_NO_LM_SORT") != nullptr;   // (experiments)
   const int n_visit = lm_ordered ? ext->n_lm_order : L;
-  int run = 0;
+  std::vector<int>& visit = h.visit_tmp;
+  visit.clear();
   for (int i = 0; i < n_visit; ++i) {
     const int l = lm_ordered ? ext->lm_order[i] : i;
     if (cnt[l + 1] == 0) continue;
@@ -1894,13 +1874,26 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
       ctx->set_error("ssx_ba: landmark %d has %d observations (> %d per landmark unsupported)", l, cnt[l + 1], CH_E);
       return SSX_ERR_UNSUPPORTED;
     }
+    visit.push_back(l);
+  }
+  if (!no_lm_sort && !h.big) {
+    std::vector<int>& out = h.visit2_tmp;
+    int bucket[SSX_BA_SMALL_P + 3] = {0};
+    for (int l : visit) bucket[first_pf[l] + 1]++;
+    for (int b = 0; b < SSX_BA_SMALL_P + 2; ++b) bucket[b + 1] += bucket[b];
+    out.resize(visit.size());
+    for (int l : visit) out[bucket[first_pf[l]]++] = l;
+    visit.swap(out);
+  }
+  int run = 0;
+  for (int l : visit) {
     lm_compact[l] = (int)h.lm_id.size();
     h.lm_id.push_back(l);
-    h.lm_ptr.push_back(lm_ordered ? run : start[l]);
+    h.lm_ptr.push_back(run);
     run += cnt[l + 1];
     h.lm_fixed.push_back(pr->point_fixed ? (pr->point_fixed[l] ? 1 : 0) : 0);
   }
-  if (lm_ordered && run != E - n_dead) { ctx->set_error("ssx_ba_window: an observation refers to a landmark that is not in the window's order list"); return SSX_ERR_INVALID_ARG; }
+  if (run != E - n_dead) { ctx->set_error("ssx_ba_window: an observation refers to a landmark that is not in the window's order list"); return SSX_ERR_INVALID_ARG; }
   h.lm_ptr.push_back(h.E);
   h.nLm = (int)h.lm_id.size();
   if (h.dev_prep) {
@@ -1932,7 +1925,8 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   }
   h.perm.assign(E, 0);
   {
-    std::vector<int> fill(start.begin(), start.end() - 1);
+    std::vector<int> fill((size_t)L, 0);
+    for (int l = 0; l < L; ++l) if (lm_compact[l] >= 0) fill[l] = h.lm_ptr[lm_compact[l]];
     for (int e = 0; e < E; ++e) h.perm[fill[pr->edge_point[e]]++] = e;
   }
   // inside a landmark: stable sort by pose so that duplicates of a (landmark,pose) pair are adjacent
@@ -2005,6 +1999,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   h.pair_ptr.assign((size_t)h.nCh * (nBlk + 1) + 1, 0);
   h.pair_a.clear(); h.pair_b.clear();
   h.bseg.clear(); h.bseg_ptr.assign(2 * (size_t)h.nCh + 2, 0);
+  h.touch.assign(TOUCH_WORDS * (size_t)(h.nCh + 1), 0u);
   std::vector<int> blk_of((size_t)std::max(nP, 1) * std::max(nP, 1), -1);
   for (int b = 0; b < nBlk; ++b) blk_of[(size_t)h.blk_pa[b] * nP + h.blk_pb[b]] = b;
   std::vector<int> pc(nP + 1), bc(nBlk + 1);
@@ -2069,16 +2064,23 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
       int maxlen = 0;
       for (int b = 0; b < nBlk; ++b) maxlen = std::max(maxlen, bp[b + 1] - bp[b]);
       const int seg = std::max(BSEG_MIN, (maxlen + BSEG_PARTS - 1) / BSEG_PARTS);
+      const bool dense = dense_slabs_mode() != 0;
+      // (BaDev::touch, as k_build_lists writes it: blocks with pairs, poses with edges)
+      unsigned int* tm = &h.touch[(size_t)c * TOUCH_WORDS];
+      for (int b = 0; b < nBlk + nP; ++b) {
+        const bool on = b < nBlk ? (bp[b + 1] > bp[b]) : (pp[b - nBlk + 1] > pp[b - nBlk]);
+        if (on || dense) tm[b >> 5] |= 1u << (b & 31);
+      }
       order.clear();
       for (int b = 0; b < nBlk; ++b) {
-        const int n = bp[b + 1] - bp[b], k = std::max(1, (n + seg - 1) / seg);
-        order.push_back({-((n + k - 1) / k), b});
+        const int n = bp[b + 1] - bp[b], k = (n == 0 && !dense) ? 0 : std::max(1, (n + seg - 1) / seg);
+        order.push_back({k ? -((n + k - 1) / k) : 0, b});
       }
       std::stable_sort(order.begin(), order.end());
       h.bseg_ptr[2 * c] = (int)(h.bseg.size() / 4);
       int pos = 0;                                // in items (16 per wave: four lanes each)
       for (const auto& ob : order) {
-        const int b = ob.second, n = bp[b + 1] - bp[b], k = std::max(1, (n + seg - 1) / seg), len = (n + k - 1) / k;
+        const int b = ob.second, n = bp[b + 1] - bp[b], k = (n == 0 && !dense) ? 0 : std::max(1, (n + seg - 1) / seg), len = k ? (n + k - 1) / k : 0;
         while ((pos & 15) + k > 16) { h.bseg.push_back(-1); h.bseg.push_back(0); h.bseg.push_back(0); h.bseg.push_back(1 << 4); ++pos; }
         for (int i = 0; i < k; ++i) {
           const int q0 = bp[b] - base + std::min(n, i * len), q1 = bp[b] - base + std::min(n, (i + 1) * len);
@@ -2189,6 +2191,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   size_t o_pair_ptr = dev_lists ? 0 : in.take(sizeof(int) * (h.pair_ptr.size() + 1));
   size_t o_bseg = dev_lists ? 0 : in.take(sizeof(int) * (h.bseg.size() + 4));
   size_t o_bseg_ptr = dev_lists ? 0 : in.take(sizeof(int) * (h.bseg_ptr.size() + 1));
+  const size_t touch_bytes = big ? 0 : sizeof(unsigned int) * TOUCH_WORDS * (size_t)(nCh + 1);
+  size_t o_touch = (dev_lists || big) ? 0 : in.take(touch_bytes);
   const size_t o_pe_ptr = in.take(rz ? 0 : sizeof(int) * (h.pe_ptr.size() + 1));
   const size_t o_pe_edge = in.take(rz ? 0 : sizeof(int) * (h.pe_edge.size() + 1));
   const size_t o_sblk_pa = in.take(sizeof(int) * (nBlkS + 1));
@@ -2225,6 +2229,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     o_pair_ptr = all.take(sizeof(int) * ((size_t)(nCh + 1) * (nBlk + 1) + 1));
     o_bseg = all.take(sizeof(int) * 4 * ((size_t)(nCh + 1) * bseg_cap + 1));
     o_bseg_ptr = all.take(sizeof(int) * (2 * (size_t)nCh + 2));
+    o_touch = all.take(touch_bytes);
   }
   const size_t o_W = all.take(sizeof(double) * 18 * (size_t)E);
   const size_t o_err_lin = all.take(sizeof(double) * 2 * (size_t)E);
@@ -2331,6 +2336,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
     if (!h.pair_ptr.empty()) memcpy(hs + o_pair_ptr, h.pair_ptr.data(), sizeof(int) * h.pair_ptr.size());
     if (!h.bseg.empty()) memcpy(hs + o_bseg, h.bseg.data(), sizeof(int) * h.bseg.size());
     if (!h.bseg_ptr.empty()) memcpy(hs + o_bseg_ptr, h.bseg_ptr.data(), sizeof(int) * h.bseg_ptr.size());
+    if (!big && !h.touch.empty()) memcpy(hs + o_touch, h.touch.data(), sizeof(unsigned int) * h.touch.size());
   }
   if (big && !rz) {
     memcpy(hs + o_pe_ptr, h.pe_ptr.data(), sizeof(int) * h.pe_ptr.size());
@@ -2366,9 +2372,8 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
 
   d.P = P; d.L = L; d.E = E; d.nP = nP; d.nLm = nLm; d.nCh = nCh; d.nBlk = nBlk; d.world = world; d.rank = rank;
   d.big = big ? 1 : 0; d.lin_stride = lin_stride;
-  static const int grp_ch = getenv("SSX_BA_GRP_CH") ? std::min(std::max(atoi(getenv("SSX_BA_GRP_CH")), 1), GRP_CH_MAX) : GRP_CH;
-  d.nGrp = (nCh > 0 && !big) ? (nCh + grp_ch - 1) / grp_ch : (big ? nCh : 0);   // (large windows: one chunk per group, never persistent)
-  d.persist = 0;                                 // batch_run switches it on for batches that fill the chip (see there)
+  d.dense_slabs = dense_slabs_mode();
+  d.touch = (unsigned int*)(at(o_touch));
   d.store_w = 1;                                 // the caller clears it for small windows with analytic Jacobians
   d.pose_free = (const int*)(at(o_pose_free));
   d.lm_fixed = (const uint8_t*)(at(o_lm_fixed));
@@ -3354,9 +3359,7 @@ struct ssx_ba_batch {
   const ssx_ba_problem* probs = nullptr;             // (valid during a one-shot call: the dead entries of a window's storage)
   std::vector<size_t> out_off;
   size_t out_total = 0, a_out = 0, a_gather = 0, a_head = 0, in_total = 0, o_dv = 0, o_ctrl = 0, o_ooff = 0;
-  int max_ch = 1, max_rl = 1, max_rs = 1, max_grp = 1, total_ch = 0;
-  int persist = -1;                                  // ssx_ba_batch_set_persist: -1 auto, 0 / 1 forced
-  int persist_dev = 0;                               // what the device copies of the window descriptors currently say
+  int max_ch = 1, max_rl = 1, max_rs = 1, total_ch = 0;
   bool any_solve64 = false, any_solve80 = false, any_solve = false, with_err = false, fresh = false;
   int threads = 1;
   int groups = 0;                                    // ssx_ba_batch_set_groups; 0: batch_groups(n)
@@ -3470,7 +3473,6 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   for (int w = 0; w < n; ++w) {
     const BaDev& d = B->devs[w];
     B->max_ch = std::max(B->max_ch, d.nCh);
-    B->max_grp = std::max(B->max_grp, d.nGrp);
     B->total_ch += d.nCh;
     B->max_rl = std::max(B->max_rl, (d.nP * 27 + 63) / 64);
     B->max_rs = std::max(B->max_rs, (d.nBlk * 36 + d.nP * 6 + 63) / 64);
@@ -3538,17 +3540,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   double* d_out = reinterpret_cast<double*>(dev_base + B->a_out);
   double* d_gather = reinterpret_cast<double*>(dev_base + B->a_gather);
   hipStream_t s = ctx->stream;
-  // Persistent workgroups (one per GROUP of ~7 chunks, one slab each) only on request (ssx_ba_batch_set_persistent): measured
-  // on 64 C3 windows they cut the slab traffic 6.6x and the two slab reductions from 29 to 14 us per LM slot, but the fused
-  // kernel itself goes from 138 to 167 us -- a chunk's tail (read-modify-write of the slab) and the next chunk's head
-  // (lists, edge records) are serialised inside one workgroup where independent workgroups overlap them -- so the default
-  // stays one workgroup per chunk.  The results do not depend on the choice (bit for bit).
-  const int want_persist = B->persist > 0 ? 1 : 0;
-  if (want_persist != B->persist_dev) {
-    hipLaunchKernelGGL(k_set_persist_b, dim3((n + CH - 1) / CH), dim3(CH), 0, s, const_cast<BaDev*>(dv), n, want_persist);
-    B->persist_dev = want_persist;
-  }
-  const int wg_x = want_persist ? B->max_grp : B->max_ch;             // workgroups per window of the linearise / Schur kernels
+  const int wg_x = B->max_ch;                                        // workgroups per window of the linearise / Schur kernels
   if (!B->fresh) hipLaunchKernelGGL(k_reset_state_b, dim3(16, n), dim3(CH), 0, s, dv);
   B->fresh = false;
   // per-window host state of Backend::OptimizeActiveMap's outer loop (backend.cpp:175-203)
@@ -3726,6 +3718,11 @@ extern "C" {
 
 // tools hook (no GPU needed): dynamic LDS bytes a kernel of this file is launched with (the compiler's resource report only
 // knows static __shared__ arrays, and rocprofv3's dispatch rows show 0 for these); -1 = depends on the problem / unknown
+// tests hook: 1 = the per-chunk slabs of the linearise / Schur kernels are written and read in full (round 3), 0 = only the blocks and
+// poses a chunk touches (default), < 0 = the environment's choice (SSX_BA_DENSE_SLABS).  Same bits either way.  Applies to problems
+// uploaded after the call.
+void ssx_debug_set_dense_slabs(int32_t mode) { g_dense_slabs.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
+
 int64_t ssx_debug_kernel_dynamic_lds(const char* kernel)
 {
   if (!kernel) return -1;
@@ -3814,7 +3811,9 @@ int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch) { return !batch ? 0 : (ba
 
 void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups) { if (batch) batch->groups = groups > 0 ? groups : 0; }
 
-void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode) { if (batch) batch->persist = mode < 0 ? -1 : (mode ? 1 : 0); }
+// (round 3's experiment -- workgroups that walk a group of chunks -- is gone: measured slower, profiles/r03/persist_ab.md; the entry
+// point stays so that callers built against the round-3 header keep linking, and does nothing)
+void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode) { (void)batch; (void)mode; }
 
 void ssx_ba_batch_destroy(ssx_ba_batch* batch)
 {

@@ -491,28 +491,43 @@ def test_batch_groups_do_not_change_the_bits(ctx):
     assert ba.BaBatch(ctx, probs[:3], resident=True).groups == 1
 
 
-def test_persistent_groups_equal_per_chunk(ctx):
-    """ssx_ba_batch_set_persistent: a workgroup of the linearise / Schur kernels owns a GROUP of ~7 chunks and adds its chunks'
-    partial reduced systems into one slab (global_atomic_add_f64, chunk order), or one chunk and one slab (the reductions then
-    form the same sums in the same order).  Per window the same bits, and the bits of ssx_ba_solve -- windows of 1 .. 80
-    chunks, 4 .. 16 keyframes, fixed poses, rejected trials, several outer rounds, numeric Jacobians."""
+def test_sparse_slabs_equal_dense_slabs(ctx):
+    """A chunk's workgroup writes only the blocks of the reduced system its landmarks contribute to and the pose blocks of the
+    poses it holds edges of (BaDev::touch), and the reductions read only those; ssx_debug_set_dense_slabs(1) brings back round 3's
+    dense slabs (every entry written, zeros included, every entry read).  The sums are formed in the same order either way: per
+    window the same bits, single call and resident batch, every batch grouping -- windows of 1 .. 80 chunks, 4 .. 16 keyframes,
+    fixed poses, rejected trials, several outer rounds, numeric Jacobians, landmarks that arrive sorted by keyframe or shuffled."""
+    import ssvio_amd
+    lib = ssvio_amd.load()
+    lib.ssx_debug_set_dense_slabs.argtypes = [C.c_int32]; lib.ssx_debug_set_dense_slabs.restype = None
     probs = [make_ba_problem(P=10, L=4000, seed=601), make_ba_problem(P=10, L=380, seed=602), make_ba_problem(P=16, L=1700, obs_per_lm=5, seed=603),
              make_ba_problem(P=12, L=1500, obs_per_lm=4, seed=604), make_ba_problem(P=4, L=60, obs_per_lm=4, seed=605),
              make_ba_problem(P=10, L=2000, seed=606, pose_t_noise=0.3, pose_r_noise=0.03), make_ba_problem(P=10, L=600, seed=607, frac_gross=0.45),
              make_ba_problem(P=7, L=800, obs_per_lm=3, seed=608, fix_first_pose=True), make_ba_problem(P=10, L=4000, seed=609)]
-    for jac in (ba.JAC_ANALYTIC, ba.JAC_NUMERIC_G2O):
-        ones = [ba.ba_solve(ctx, pr, jac_mode=jac) for pr in probs]
-        assert max(o["rounds"] for o in ones) >= 2
-        res = ba.BaBatch(ctx, probs, resident=True, jac_mode=jac)
-        for mode, groups in ((1, 1), (0, 2), (1, 2), (-1, 0), (1, 3)):
-            res.set_persistent(mode)
-            res.set_groups(groups)
-            out = res.solve()
-            for b, one in zip(out["results"], ones):
-                for k in ("poses", "points", "chi2", "lam", "trials", "edge_chi2", "edge_outlier"):
-                    assert np.array_equal(b[k], one[k]), (mode, groups, k)
-                assert b["rounds"] == one["rounds"]
-        res.close()
+    keys = ("poses", "points", "chi2", "lam", "trials", "edge_chi2", "edge_outlier")
+    try:
+        for jac in (ba.JAC_ANALYTIC, ba.JAC_NUMERIC_G2O):
+            lib.ssx_debug_set_dense_slabs(1)
+            dense = [ba.ba_solve(ctx, pr, jac_mode=jac) for pr in probs]
+            lib.ssx_debug_set_dense_slabs(0)
+            ones = [ba.ba_solve(ctx, pr, jac_mode=jac) for pr in probs]
+            assert max(o["rounds"] for o in ones) >= 2
+            for a, b in zip(dense, ones):
+                for k in keys:
+                    assert np.array_equal(a[k], b[k]), ("dense vs sparse", jac, k)
+            for mode in (0, 1):
+                lib.ssx_debug_set_dense_slabs(mode)
+                res = ba.BaBatch(ctx, probs, resident=True, jac_mode=jac)
+                for groups in (1, 2, 3):
+                    res.set_groups(groups)
+                    out = res.solve()
+                    for b, one in zip(out["results"], ones):
+                        for k in keys:
+                            assert np.array_equal(b[k], one[k]), (mode, groups, k)
+                        assert b["rounds"] == one["rounds"]
+                res.close()
+    finally:
+        lib.ssx_debug_set_dense_slabs(-1)
 
 
 _LISTS_SCRIPT = r"""
