@@ -8,6 +8,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "host", "build")
 
+import sys  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 from ssvio_amd.synth import KITTI00_SETTINGS as DEFAULT_CONFIG  # noqa: E402  (the reference's config/kitti_00.yaml values)
 from ssvio_amd.synth import write_settings  # noqa: E402
 
