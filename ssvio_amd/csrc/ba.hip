@@ -353,6 +353,14 @@ __device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
 // (Round 3 measured workgroups that walk a GROUP of chunks and keep one slab per group -- profiles/r03/persist_ab.md: 6.6x less
 // slab traffic, but the kernel lost more than the reductions won; round 4 cuts the traffic the other way: a chunk writes only the
 // parts of its slab it contributes to, see BaDev::touch.)
+// -DSSX_EXP_SKIP_{SLAB_WRITES,POSE_BLOCKS,BLOCKS,CVEC} (tools/build_variant.py, profiles/r04/schur_phase_ab.md): the kernels with one
+// of their phases left out -- wrong results, meaningful times: what a phase costs UNDER LOAD, which the one-workgroup cycle stamps of
+// SSX_PHASE_CLOCK cannot say.  EXP_STORE(x) is the store of a slab entry.
+#ifdef SSX_EXP_SKIP_SLAB_WRITES
+#define EXP_STORE(dst, v) do { if ((v) == 1.2345e300) (dst) = (v); } while (0)
+#else
+#define EXP_STORE(dst, v) do { (dst) = (v); } while (0)
+#endif
 __device__ __forceinline__ bool chunk_touches(const BaDev& d, int c, int bit)
 {
   return d.dense_slabs || ((d.touch[(size_t)c * TOUCH_WORDS + (bit >> 5)] >> (bit & 31)) & 1u);
@@ -465,14 +473,18 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
 
   // pose blocks: owned entries, each the sum of ITS pose's run of the pose-major term rows, in two rounds of 14 and 13
   // entries per pose (large windows build the pose blocks pose-major instead: k_pose_blocks)
+#ifdef SSX_EXP_SKIP_POSE_BLOCKS
+  if (small && d.nP > 100) {
+#else
   if (small) {
+#endif
     const int nP = d.nP;
     // (a pose none of whose edges lies in this chunk is not written: the reduction skips it through BaDev::touch)
     const bool dense = d.dense_slabs != 0;
     for (int i = t; i < nP * LIN_VA; i += CH) {
       const int p = i / LIN_VA, k = i - p * LIN_VA;
       const int s0 = sPptr[p], s1 = sPptr[p + 1];
-      if (dense || s1 > s0) slab[p * 27 + k] = run_sum(sV + k * PW, s0, s1);
+      if (dense || s1 > s0) EXP_STORE(slab[p * 27 + k], run_sum(sV + k * PW, s0, s1));
     }
     __syncthreads();
     if (t < ne) {
@@ -485,7 +497,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     for (int i = t; i < nP * (27 - LIN_VA); i += CH) {
       const int p = i / (27 - LIN_VA), k = i - p * (27 - LIN_VA);
       const int s0 = sPptr[p], s1 = sPptr[p + 1];
-      if (dense || s1 > s0) slab[p * 27 + LIN_VA + k] = run_sum(sV + k * PW, s0, s1);
+      if (dense || s1 > s0) EXP_STORE(slab[p * 27 + LIN_VA + k], run_sum(sV + k * PW, s0, s1));
     }
   }
   PH(3);
@@ -1176,7 +1188,11 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   // through DPP -- half the LDS traffic; an explicit software pipeline of index / operands / multiply.)
   PH(7);
   const int nS = d.nBlk * 36;
+#ifdef SSX_EXP_SKIP_BLOCKS
+  for (int base = 0; base < n_items && d.nP > 100; base += CH) {
+#else
   for (int base = 0; base < n_items; base += CH) {
+#endif
     const int4 ir = item_rec;
     if (base + CH < n_items) item_rec = base + CH + t < n_items ? d.bseg[it0 + ((base + CH + t) >> 2)] : make_int4(-1, 0, 0, 1 << 4);
     const int blk = ir.x, qr = (t >> 1) & 1, qc = t & 1;                 // rows 3 qr .. 3 qr + 2, columns 3 qc .. 3 qc + 2
@@ -1221,7 +1237,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j] = acc[i][j];
+        for (int j = 0; j < 3; ++j) EXP_STORE(slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j], acc[i][j]);
     }
   }
   PH(8);
@@ -1234,7 +1250,11 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     for (int a = 0; a < 6; ++a) sY[a * PW + zpos] = z[a];
   }
   __syncthreads();
+#ifdef SSX_EXP_SKIP_CVEC
+  for (int base = 0; base < nP * 6 * 4 && d.nP > 100; base += CH) {
+#else
   for (int base = 0; base < nP * 6 * 4; base += CH) {
+#endif
     const int item = base + t;
     const bool on = item < nP * 6 * 4;
     const int idx = on ? item >> 2 : 0, part = item & 3;
@@ -1244,7 +1264,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     for (int s = s0 + part; s < s1; s += 4) acc += sY[a * PW + s];
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
-    if (on && part == 0 && (d.dense_slabs || s1 > s0)) slab[nS + idx] = acc;     // (a pose without edges here: not written, not read)
+    if (on && part == 0 && (d.dense_slabs || s1 > s0)) EXP_STORE(slab[nS + idx], acc);     // (a pose without edges here: not written, not read)
   }
   PH(9);
 }
