@@ -66,3 +66,58 @@ def test_two_ranks_on_one_gpu_match_the_single_rank_solve(ctx):
         pts = np.zeros_like(one["points"])
         pts[a["lm_global"]] = a["points"]; pts[b["lm_global"]] = b["points"]
         np.testing.assert_allclose(pts, one["points"], rtol=0, atol=1e-8)
+
+
+def _worker_native(rank, world, port, out_dir):
+    """one rank per GPU, RCCL inside libssx.so (ncclCommInitRank with world_size > 1 through ssx_comm_init)"""
+    import torch
+    import torch.distributed as dist
+    import ssvio_amd
+    from ssvio_amd import ba, dist_ba
+    from ssvio_amd.synth import make_ba_problem
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    res = {}
+    ctx = ssvio_amd.Context(rank)
+    comm = dist_ba.init_native_comm(ctx, rank, world)
+    res["info"] = dist_ba.native_comm_info(ctx, comm)
+    for name, c in CASES.items():
+        pr = make_ba_problem(**c["cfg"])
+        loc = dist_ba.shard_problem(pr, rank, world)
+        r = ba.ba_solve(ctx, loc, comm=comm, rank=rank, world_size=world, **c["kw"])
+        res[name] = dict(poses=r["poses"], points=r["points"], chi2=r["chi2"], trials=r["trials"], lm_global=loc["lm_global"])
+    dist_ba.destroy_native_comm(ctx, comm)
+    ctx.close()
+    pickle.dump(res, open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_rccl_two_gpus_match_the_single_gpu_solve(ctx):
+    """The first execution of ncclCommInitRank(world_size > 1) inside libssx.so that hardware allows: needs TWO GPUs in the box
+    (skipped otherwise -- the builder's boxes have one).  One rank per GPU, landmark shards l mod 2, ncclAllReduce(f64, sum) on
+    the ctx stream for the pose blocks / the reduced system (small window, band, tiles) / the trial scalars: both ranks take the
+    single-GPU solve's LM decisions and end on its poses and points (1e-9: the two partial sums are added in another order)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    import torch.multiprocessing as mp
+    from ssvio_amd import ba
+    from ssvio_amd.synth import make_ba_problem
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_native, args=(2, 29763, d), nprocs=2, join=True)
+        r0 = pickle.load(open(os.path.join(d, "rank0.pkl"), "rb")); r1 = pickle.load(open(os.path.join(d, "rank1.pkl"), "rb"))
+    assert tuple(r0["info"]) == (0, 2) and tuple(r1["info"]) == (1, 2)
+    for name, c in CASES.items():
+        pr = make_ba_problem(**c["cfg"])
+        one = ba.ba_solve(ctx, pr, **c["kw"])
+        a, b = r0[name], r1[name]
+        assert np.array_equal(a["trials"], b["trials"]) and np.array_equal(a["chi2"], b["chi2"]) and np.array_equal(a["poses"], b["poses"])
+        assert np.array_equal(a["trials"], one["trials"]), name
+        np.testing.assert_allclose(a["chi2"], one["chi2"], rtol=1e-9)
+        np.testing.assert_allclose(a["poses"], one["poses"], rtol=0, atol=1e-9)
+        pts = np.zeros_like(one["points"])
+        pts[a["lm_global"]] = a["points"]; pts[b["lm_global"]] = b["points"]
+        np.testing.assert_allclose(pts, one["points"], rtol=0, atol=1e-8)
