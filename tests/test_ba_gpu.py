@@ -915,7 +915,7 @@ def test_window_storage_is_rewritten_when_mostly_dead(ctx):
 
 
 def test_window_misuse(ctx):
-    pr = make_ba_problem(P=4, L=60, obs_per_lm=4, seed=2)
+    pr = make_ba_problem(P=6, L=90, obs_per_lm=3, seed=2)
     feed = _window_feed(pr)
     from ssvio_amd._lib import SsxError
     win = ba.BaWindow(ctx, pr["K"], pr["cam_ext"])
@@ -927,7 +927,28 @@ def test_window_misuse(ctx):
     with pytest.raises(SsxError):
         win.pop(77)
     assert win.size() == (1, len(feed[0]["new_ids"]), len(feed[0]["obs_lm"]))   # nothing was changed by the failures
-    win.pop(1)
+    # the removal calls: a wrong flag count and an unknown keyframe are refused; unknown landmarks / pairs are skipped
+    n_obs = win.size()[2]
+    with pytest.raises(SsxError):
+        win.remove_flagged(np.zeros(n_obs + 1, np.uint8))
+    with pytest.raises(SsxError):
+        win.remove_observations(77, [int(feed[0]["new_ids"][0])])
+    assert win.remove_landmarks([10 ** 12]) == 0 and win.remove_observations(1, [10 ** 12]) == 0
+    assert win.size() == (1, len(feed[0]["new_ids"]), n_obs)
+    with pytest.raises(SsxError):
+        ctx.check(ctx.lib.ssx_ba_window_set_fix_rule(win.handle, 7))
+    # every observation removed: the landmarks go with them, the keyframe stays, and a solve of the empty graph returns the state
+    assert win.remove_flagged(np.ones(n_obs, np.uint8)) == n_obs
+    assert win.size() == (1, 0, 0)
+    r = win.solve()
+    assert r["n_iters"] == 0 and np.array_equal(r["poses"][0], np.asarray(feed[0]["pose"], dtype=np.float64))
+    own = np.isin(feed[1]["obs_lm"], feed[1]["new_ids"])                      # ... and the window goes on (the landmarks of keyframe 1 went with it)
+    win.push(2, feed[1]["pose"], new_ids=feed[1]["new_ids"], new_xyz=feed[1]["new_xyz"], new_fixed=feed[1]["new_fixed"],
+             obs_lm=feed[1]["obs_lm"][own], obs_uv=feed[1]["obs_uv"][own], obs_cam=feed[1]["obs_cam"][own])
+    assert own.sum() > 5 and win.size()[0] == 2 and win.size()[2] == int(own.sum())
+    g = win.solve()
+    assert g["n_iters"] > 0 and np.isfinite(g["poses"]).all()
+    win.pop(1); win.pop(2)
     assert win.size() == (0, 0, 0)
     win.close()
 
