@@ -150,17 +150,21 @@ def main():
 
     step_no = [0]
 
-    fe_stream.upload(ring[0].data_ptr())                               # the first batch is on its way when the first step starts
+    # A streaming server's steady state: the batch of step k + 1 is crossing PCIe, the batch of step k is in the front-end, the
+    # windows of step k are being optimised, and the host collects the front-end's results ONE STEP BEHIND (batch k - 1: they are
+    # there, nothing waits).  Every batch is uploaded, processed and its results downloaded exactly once; a result is available
+    # one step (6 ms) after its batch entered the front-end.
+    fe_stream.upload(ring[0].data_ptr()); fe_stream.run()              # batch 0 is in the front-end ...
+    fe_stream.upload(ring[1].data_ptr())                               # ... batch 1 on its way when the first step starts
+    step_no[0] = 1
 
     def composite_step():
-        # the NEXT step's batch starts crossing PCIe (the library's copy stream), this step's batch -- uploaded during the last step --
-        # goes through the front-end (asynchronous) ...
+        fe_stream.run()                                                # batch k (uploaded during the last step) -> front-end, asynchronous
         step_no[0] += 1
-        fe_stream.upload(ring[step_no[0] & 1].data_ptr())
-        fe_stream.run()
-        # ... B windows on the BA stream: returns when they are done, with the optimised keyframe poses of every window ...
+        fe_stream.upload(ring[step_no[0] & 1].data_ptr())              # batch k + 1 starts crossing PCIe (the library's copy stream)
+        # B windows on the BA stream: returns when they are done, with the optimised keyframe poses of every window ...
         batch.solve(want_edges=False, summaries=False, points=False)
-        # ... and the front-end's results of this step: keypoint / match / triangulation counts of every pair
+        # ... and the front-end's results of batch k - 1: keypoint / match / triangulation counts of every pair
         c = fe_stream.wait_counts()
         return {"n_iters_total": sum(batch.res[i].n_iters for i in range(B)), "pairs_done": int((c[:, 0] > 0).sum())}
 
@@ -187,7 +191,8 @@ def main():
     frames = world * B * args.steps
     assert pairs_done == B * args.steps, "a stereo pair came back without keypoints"
     value = frames / elapsed
-    fe_stream.run(); fe_stream.wait_counts()                           # (the batch uploaded ahead by the last step)
+    fe_stream.wait_counts()                                            # drain: the last batch that was run ...
+    fe_stream.run(); fe_stream.wait_counts()                           # ... and the one uploaded ahead by the last step
     orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)     # back to the resident images for the regions below
 
     # ---------------- timed region 1r: rounds 1-3's headline -- images and windows resident, nothing downloaded ----------------
@@ -898,7 +903,8 @@ def main():
                        "images": "host -> device every step (pinned ring of 2 batches; ssx_stereo_batch_upload of step k + 1's batch on the library's "
                                  "copy stream beside step k's kernels, ssx_stereo_batch_run on the batch uploaded during the step before)",
                        "h2d_bytes_per_step_per_gpu": h2d_bytes_per_step,
-                       "downloaded_every_step": "keypoint / match / triangulation counts of every pair + the optimised keyframe poses of every window",
+                       "downloaded_every_step": "keypoint / match / triangulation counts of every pair (collected one step behind: the batch of step "
+                                                "k - 1 while batch k is in the front-end) + the optimised keyframe poses of every window",
                        "windows": "resident in HBM (ssx_ba_batch: marshalled + uploaded before the clock starts, re-solved from the uploaded state every step)"},
             "resident": {"value": round(resident_value, 2), "unit": "stereo frames/s", "ms_per_step": round(resident_elapsed / RES_STEPS * 1e3, 4),
                          "what": "rounds 1-3's headline: the same step with the images resident in HBM and nothing downloaded"},

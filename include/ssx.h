@@ -507,10 +507,12 @@ SSX_API ssx_status ssx_stereo_batch_fetch(ssx_ctx* ctx, int32_t pair, ssx_stereo
  *                            must stay untouched until the batch has been run and a later call of these functions returned
  *   ssx_stereo_batch_run     enqueue the whole front-end on the OLDEST uploaded batch; nothing is synchronised
  *   ssx_stereo_batch_host    upload + run in one call
- *   ssx_stereo_batch_counts  wait for the batch run last; counts_out = pairs x 4 int32: nL, nR, n_matched, n_triangulated
- *                            (ssx_stereo_batch_fetch then copies one pair's keypoints / matches / points out)
- * A server keeps one upload ahead -- upload(k + 1); run(k); ...; counts(k) -- so that batch k + 1 crosses PCIe while the
- * kernels of batch k run (bench.py's headline region). */
+ *   ssx_stereo_batch_counts  the counts of the OLDEST batch that was run and not collected yet (at most two may be waiting): waits
+ *                            for that batch only; counts_out = pairs x 4 int32: nL, nR, n_matched, n_triangulated.
+ *                            (ssx_stereo_batch_fetch copies one pair's keypoints / matches / points of the batch run LAST.)
+ * A server keeps one upload ahead and collects one batch behind -- upload(k + 1); run(k); ...; counts() -> batch k - 1 -- so that
+ * batch k + 1 crosses PCIe and batch k's front-end runs while the host waits for nothing but its own backend (bench.py's
+ * headline region); counts() right after run(k) returns batch k's counts once it is done. */
 SSX_API ssx_status ssx_stereo_batch_upload(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs_host, int32_t stride, int32_t rows,
                                            int32_t cols);
 SSX_API ssx_status ssx_stereo_batch_run(ssx_ctx* ctx, const ssx_orb_params* orb, const ssx_match_params* mp,

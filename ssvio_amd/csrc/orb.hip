@@ -935,7 +935,7 @@ static void orb_ws_free(OrbWorkspace* w)
   if (!w) return;
   w->arena.release(); w->input.release(); w->stereo.release(); w->stage.release(); w->fetch.release();
   w->ingest[0].release(); w->ingest[1].release(); w->counts_pinned.release();
-  for (int b = 0; b < 2; ++b) { if (w->ev_up[b]) (void)hipEventDestroy(w->ev_up[b]); if (w->ev_free[b]) (void)hipEventDestroy(w->ev_free[b]); }
+  for (int b = 0; b < 2; ++b) { if (w->ev_up[b]) (void)hipEventDestroy(w->ev_up[b]); if (w->ev_free[b]) (void)hipEventDestroy(w->ev_free[b]); if (w->ev_counts[b]) (void)hipEventDestroy(w->ev_counts[b]); }
   if (w->copy_stream) { (void)hipStreamSynchronize(w->copy_stream); (void)hipStreamDestroy(w->copy_stream); }
   delete w;
 }

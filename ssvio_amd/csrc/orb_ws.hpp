@@ -117,7 +117,8 @@ struct OrbWorkspace {
   int up_first = 0, up_count = 0;  // uploaded batches waiting for ssx_stereo_batch_run: buffers up_first, up_first ^ 1
   int up_shape[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // pairs, stride, rows, cols of an uploaded batch
   HostBuf counts_pinned;        // [pairs][4] counts + [2 pairs] status words of the last enqueued batch
-  bool counts_pending = false;
+  hipEvent_t ev_counts[2] = {nullptr, nullptr};   // per run batch: its counts have reached counts_pinned
+  int cnt_first = 0, cnt_count = 0, cnt_pairs[2] = {0, 0};
 };
 
 namespace ssxorb {

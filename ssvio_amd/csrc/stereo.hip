@@ -739,7 +739,10 @@ ssx_status ssx_stereo_batch_run(ssx_ctx* ctx, const ssx_orb_params* orb, const s
   ssx_status st = plan(ctx, rows, cols, 2 * pairs, *orb, false, false);
   if (st != SSX_OK) return st;
   SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  SSX_HIP_TRY(ctx, ws->counts_pinned.reserve(sizeof(int) * 6 * (size_t)pairs));
+  if (ws->cnt_count >= 2) { ctx->set_error("ssx_stereo_batch_run: the counts of two batches are waiting for ssx_stereo_batch_counts already"); return SSX_ERR_INVALID_ARG; }
+  if (ws->cnt_count > 0 && ws->cnt_pairs[ws->cnt_first] != pairs) { ctx->set_error("ssx_stereo_batch_run: collect the counts of the batches that were run before changing the batch size"); return SSX_ERR_INVALID_ARG; }
+  SSX_HIP_TRY(ctx, ws->counts_pinned.reserve(2 * sizeof(int) * 6 * (size_t)pairs));
+  for (int q = 0; q < 2; ++q) if (!ws->ev_counts[q]) SSX_HIP_TRY(ctx, hipEventCreateWithFlags(&ws->ev_counts[q], hipEventDisableTiming));
   SSX_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ws->ev_up[b], 0));
   const size_t img_bytes = (size_t)rows * stride;
   ws->batch_imgs = ws->ingest[b].as<uint8_t>(); ws->batch_pairs = pairs; ws->batch_stride = stride;
@@ -756,10 +759,15 @@ ssx_status ssx_stereo_batch_run(ssx_ctx* ctx, const ssx_orb_params* orb, const s
   if (st != SSX_OK) return st;
   st = launch_stereo(ctx, m);
   if (st != SSX_OK) return st;
-  int* hc = ws->counts_pinned.as<int>();
+  // the counts of this batch leave the device before the next batch's kernels overwrite them (stream order); an event per batch
+  // lets ssx_stereo_batch_counts wait for THIS batch only -- a caller may run the next batch first and collect one batch behind
+  const int slot = (ws->cnt_first + ws->cnt_count) & 1;
+  int* hc = ws->counts_pinned.as<int>() + (size_t)slot * 6 * pairs;
   SSX_HIP_TRY(ctx, hipMemcpyAsync(hc, ws->pair_counts, sizeof(int) * 4 * pairs, hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipMemcpyAsync(hc + 4 * (size_t)pairs, ws->dev.status, sizeof(int) * 2 * pairs, hipMemcpyDeviceToHost, ctx->stream));
-  ws->counts_pending = true;
+  SSX_HIP_TRY(ctx, hipEventRecord(ws->ev_counts[slot], ctx->stream));
+  ws->cnt_pairs[slot] = pairs;
+  ws->cnt_count++;
   return SSX_OK;
 }
 
@@ -774,14 +782,17 @@ ssx_status ssx_stereo_batch_host(ssx_ctx* ctx, int32_t pairs, const uint8_t* img
   return ssx_stereo_batch_run(ctx, orb, mp, rig);
 }
 
-// waits for the batch ssx_stereo_batch_run enqueued last: counts_out (pairs x 4: nL, nR, n_matched, n_triangulated)
+// the counts of the OLDEST batch that was run and not collected yet (at most two can be waiting): waits for that batch only
 ssx_status ssx_stereo_batch_counts(ssx_ctx* ctx, int32_t* counts_out)
 {
-  if (!ctx || !ctx->orb || !ctx->orb->counts_pending) return SSX_ERR_INVALID_ARG;
+  if (!ctx || !ctx->orb) return SSX_ERR_INVALID_ARG;
   OrbWorkspace* ws = ctx->orb;
-  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const int pairs = ws->batch_pairs;
-  const int* hc = ws->counts_pinned.as<int>();
+  if (ws->cnt_count < 1) { ctx->set_error("ssx_stereo_batch_counts: no batch has been run (ssx_stereo_batch_run first)"); return SSX_ERR_INVALID_ARG; }
+  const int slot = ws->cnt_first;
+  SSX_HIP_TRY(ctx, hipEventSynchronize(ws->ev_counts[slot]));
+  ws->cnt_first ^= 1; ws->cnt_count--;
+  const int pairs = ws->cnt_pairs[slot];
+  const int* hc = ws->counts_pinned.as<int>() + (size_t)slot * 6 * pairs;
   for (int i = 0; i < 2 * pairs; ++i)
     if (hc[4 * (size_t)pairs + i]) { ctx->set_error("ssx_stereo_batch: internal capacity exceeded on image %d (bits %d)", i, hc[4 * (size_t)pairs + i]); return SSX_ERR_CAPACITY; }
   if (counts_out) memcpy(counts_out, hc, sizeof(int) * 4 * (size_t)pairs);

@@ -341,6 +341,17 @@ def test_streamed_batches_equal_resident_batches(ctx):
                 assert got[key].tobytes() == ref[key].tobytes()
             for key in ("dL", "dR", "match_idx", "match_dist", "xyz", "ok"):
                 assert np.array_equal(got[key], ref[key]), (k, p, key)
+    # collecting one batch behind: run(k + 1) before counts(k) -- counts() returns the OLDEST uncollected batch
+    st.upload(pinned[0].data_ptr())
+    st.run()
+    for k in range(1, 3):
+        st.upload(pinned[k].data_ptr())
+        st.run()                                                      # batch k runs ...
+        assert np.array_equal(st.wait_counts(), want[k - 1][0]), k    # ... while the counts of batch k - 1 are collected
+    assert np.array_equal(st.wait_counts(), want[2][0])
+    from ssvio_amd._lib import SsxError
+    with pytest.raises(SsxError):
+        st.wait_counts()                                              # nothing left to collect
     # the one-call form, and misuse: a third upload while two are waiting, a run without an upload
     st.enqueue(pinned[1].data_ptr())
     assert np.array_equal(st.wait_counts(), want[1][0])
@@ -351,4 +362,8 @@ def test_streamed_batches_equal_resident_batches(ctx):
     with pytest.raises(SsxError):
         st.upload(pinned[2].data_ptr())
     st.run(); st.run()
-    assert np.array_equal(st.wait_counts(), want[1][0])
+    with pytest.raises(SsxError):
+        st.upload(pinned[2].data_ptr()); st.run()                     # a third run while the counts of two batches are waiting
+    assert np.array_equal(st.wait_counts(), want[0][0]) and np.array_equal(st.wait_counts(), want[1][0])
+    st.run()
+    assert np.array_equal(st.wait_counts(), want[2][0])
