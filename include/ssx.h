@@ -58,7 +58,10 @@ typedef struct {
   /* Partition the chip between contexts that run side by side (the front-end's ctx and the backend's): when cu_count > 0
    * every stream the ctx CREATES (stream == NULL above, its auxiliary and group streams) is restricted to cu_count
    * compute units starting at cu_first (hipExtStreamCreateWithCUMask; bit i of the mask lands on XCD i mod 8, so any
-   * contiguous range is spread evenly over the eight XCDs).  0 / 0 = the whole chip.  Ignored for a caller's stream. */
+   * contiguous range is spread evenly over the eight XCDs).  0 / 0 = the whole chip.  Ignored for a caller's stream.
+   * NOTE: hipExtStreamCreateWithCUMask takes no flags -- the streams of a masked ctx have default flags and normal priority:
+   * they are not hipStreamNonBlocking (they synchronise implicitly with the legacy NULL stream, e.g. torch's default stream) and
+   * the auxiliary stream loses the lowest priority an unmasked ctx gives it. */
   int cu_first, cu_count;
 } ssx_config;
 
