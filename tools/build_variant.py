@@ -16,6 +16,8 @@ from ssvio_amd import build as b  # noqa: E402
 
 name, flags = sys.argv[1], sys.argv[2:]
 src = "ba.hip"
+if flags and flags[0].endswith(".hip"):                      # python tools/build_variant.py <name> orb.hip -D...: another source file
+    src, flags = flags[0], flags[1:]
 b.build()
 cc = b.hipcc()
 obj = f"/tmp/ssx_variant_{name}.o"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # fe_k.sh <lib suffix or "">: bench --lean, print front-end + per-kernel times
 L=$1
-if [ -n "$L" ]; then export SSX_LIB=$PWD/ssvio_amd/libssx_$L.so; fi
+if [ -n "$L" ]; then export SSX_LIB=$PWD/ssvio_amd/libssx.so.$L; fi
 python bench.py --lean --steps 20 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']
