@@ -443,63 +443,33 @@ __device__ __forceinline__ uint32_t udot2(uint32_t pair, uint32_t w, uint32_t ac
 constexpr int GT_RUN = 4;                       // consecutive tiles of one tile row per workgroup of a batch (OrbDev::gauss_run): the next tile's loads fly during this tile's passes
 constexpr int GT_NLD = ((GT_H + 6) * (GT_PITCH / 4) + 255) / 256;   // dwords of an input tile per thread (6)
 
-// the dwords thread t holds of input tile (x0, y0).  Tiles inside the image: aligned loads.  Tiles at its border (a third of
-// level 0's tiles, all of the small levels'): the same aligned loads from the reflected row at a clamped column, and the
-// dwords that straddle the left / right edge of the image -- at most three per tile row -- are assembled from reflected bytes by
-// the first 3 x 38 threads (`fix` = the four bytes, `fix_at` = the dword's index in the tile or -1) and replace the clamped ones when the tile is
-// written to LDS.  (Each thread used to branch into the byte gather for each of its six dwords: every wave holds an edge dword,
-// so every wave took six dependent round trips per border tile.  Alone on the chip: 0.345 -> 0.326 ms per 256 images; 0.28 without
-// the fix-up threads, 0.21 with every tile read like an interior one -- 45 % of the tiles touch the border.)  One reflection is exact for the rows / columns that reach a stored
-// pixel of the image (at most 3 outside it); the ones further out only feed outputs that are never stored or land in the row
-// padding, and are clamped.
-__device__ __forceinline__ bool gauss_fixed_dword(int cols, int x0, int dwi)
-{
-  const int gx = x0 - 4 + 4 * dwi, gxa = cols & ~3;
-  return gx < 0 || gx == gxa || gx == gxa + 4;
-}
-__device__ __forceinline__ void gauss_load_tile(const uint8_t* __restrict__ src, int rows, int cols, int pitch, int x0, int y0, int t, uint32_t (&v)[GT_NLD],
-                                                uint32_t (&fix)[4], int& fix_at)
+// the dwords thread t holds of input tile (x0, y0): aligned loads, every tile alike.  Rows outside the image: the load goes to the
+// BORDER_REFLECT_101 row.  Columns outside it: the dword index is clamped into the row, and the (at most three) bytes left of
+// column 0 / right of the last column are mirrored INSIDE LDS once the tile is there (gauss_fix_edges: 38 x 6 byte copies and
+// one more barrier, only in tiles that touch the left / right edge).  One reflection is exact for the rows / columns that reach a
+// stored pixel of the image (at most 3 outside it); what lies further out only feeds outputs that are never stored or land in
+// the row padding.
+// [Until round 4 the first 3 x 38 threads of a border tile -- 45 % of all tiles -- assembled the dwords that straddle the left /
+// right edge from single reflected bytes read from global memory, and interior tiles took a branch of their own: 108 VGPRs,
+// 0.326 ms per 256 images alone on the chip against 0.21 with every tile read like an interior one.]
+__device__ __forceinline__ void gauss_load_tile(const uint8_t* __restrict__ src, int rows, int cols, int pitch, int x0, int y0, int t, uint32_t (&v)[GT_NLD])
 {
   constexpr int NDW = GT_PITCH / 4;   // 34 dwords per tile row
-  const bool interior = y0 >= 3 && y0 + GT_H + 3 <= rows && x0 >= 4 && x0 + GT_W + 4 <= cols;   // block-uniform
-  fix[0] = fix[1] = fix[2] = fix[3] = 0u; fix_at = -1;
-  if (interior) {
-    const uint8_t* base = src + (size_t)(y0 - 3) * pitch + (x0 - 4);
+  if (rows >= 8 && cols >= 8) {
+    const int gx_max = (cols - 1) & ~3;                     // the dword of the last column (the pitch is a multiple of 128: it is inside the row)
 #pragma unroll
     for (int k = 0; k < GT_NLD; ++k) {
       const int i = t + 256 * k;
       const int r = i / NDW, dwi = i - r * NDW;
-      v[k] = i < (GT_H + 6) * NDW ? *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * dwi) : 0u;
-    }
-  } else if (rows >= 8 && cols >= 8) {
-    auto refl_row = [&](int y) { y = y < 0 ? -y : y; y = y >= rows ? 2 * rows - 2 - y : y; return min(max(y, 0), rows - 1); };
-    const int gx_max = (cols - 4) & ~3;
-#pragma unroll
-    for (int k = 0; k < GT_NLD; ++k) {
-      const int i = t + 256 * k;
-      const int r = i / NDW, dwi = i - r * NDW;
+      int gy = y0 + r - 3;
+      gy = gy < 0 ? -gy : gy;
+      gy = gy >= rows ? 2 * rows - 2 - gy : gy;
+      gy = min(max(gy, 0), rows - 1);
       const int gx = min(max(x0 - 4 + 4 * dwi, 0), gx_max);
-      v[k] = i < (GT_H + 6) * NDW ? *reinterpret_cast<const uint32_t*>(src + (size_t)refl_row(y0 + r - 3) * pitch + gx) : 0u;
-    }
-    if (t < 3 * (GT_H + 6)) {
-      const int r = t / 3, which = t - 3 * r;
-      const int gx = which == 0 ? -4 : (cols & ~3) + 4 * (which - 1);
-      const int dwi = (gx - (x0 - 4)) >> 2;
-      if (gx >= x0 - 4 && dwi < NDW && (which > 0 || x0 == 0)) {
-        const uint8_t* row = src + (size_t)refl_row(y0 + r - 3) * pitch;
-        // (the four bytes stay in four registers until the tile is written to LDS: combining them here would wait for the loads)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          int x = gx + b;
-          x = x < 0 ? -x : x;
-          x = x >= cols ? 2 * cols - 2 - x : x;
-          fix[b] = row[min(max(x, 0), cols - 1)];
-        }
-        fix_at = r * NDW + dwi;
-      }
+      v[k] = i < (GT_H + 6) * NDW ? *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx) : 0u;
     }
   } else {
-    // (images of a few pixels: the general reflection)
+    // (levels of a few pixels: the general reflection, byte by byte)
 #pragma unroll 1
     for (int k = 0; k < GT_NLD; ++k) {
       const int i = t + 256 * k;
@@ -514,6 +484,23 @@ __device__ __forceinline__ void gauss_load_tile(const uint8_t* __restrict__ src,
       }
       v[k] = w;
     }
+  }
+}
+
+// does tile x0 hold a column left of 0 or right of cols - 1 that a stored output needs?  (block-uniform)
+__device__ __forceinline__ bool gauss_tile_at_edge(int rows, int cols, int x0)
+{
+  return rows >= 8 && cols >= 8 && (x0 == 0 || x0 + GT_W + 4 > cols);
+}
+// mirror the bytes of columns -3 .. -1 and cols .. cols + 2 inside the LDS tile (tile byte b of a row = column x0 - 4 + b)
+__device__ __forceinline__ void gauss_fix_edges(uint8_t* sIn, int cols, int x0, int t)
+{
+  if (t < 6 * (GT_H + 6)) {
+    const int r = t / 6, k = t - 6 * r;
+    const int x = k < 3 ? k - 3 : cols + k - 3;             // the column to fill
+    const int xs = k < 3 ? -x : 2 * cols - 2 - x;           // its BORDER_REFLECT_101 source (inside the image: cols >= 8)
+    const int b = x - x0 + 4, bs = xs - x0 + 4;
+    if (b >= 0 && b < GT_PITCH && bs >= 0 && bs < GT_PITCH) sIn[r * GT_PITCH + b] = sIn[r * GT_PITCH + bs];
   }
 }
 
@@ -537,8 +524,7 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
   uint8_t* dst = o.blur + (size_t)img * o.pyr_bytes + o.lvl_off[level];
   constexpr int NDW = GT_PITCH / 4;   // 34 dwords per tile row
   uint32_t ld[GT_NLD];
-  uint32_t fix[4]; int fix_at;
-  gauss_load_tile(src, rows, cols, pitch, tx0 * GT_W, y0, t, ld, fix, fix_at);
+  gauss_load_tile(src, rows, cols, pitch, tx0 * GT_W, y0, t, ld);
   // The results of a tile stay in registers and are stored one tile LATE, behind the next tile's loads: loads and stores share
   // one counter on this target (vmcnt) and complete out of order with respect to each other, so the wait for a tile's input is
   // s_waitcnt vmcnt(0) -- with the stores issued right after the column pass it also waited for their completion, every tile.
@@ -556,17 +542,18 @@ __global__ __launch_bounds__(256) void k_gauss7(OrbDev o)
 #pragma unroll 1
   for (int tx_ = tx0; tx_ < tx1; ++tx_) {
   const int x0 = tx_ * GT_W;
-  const bool border_fix = rows >= 8 && cols >= 8 && !(y0 >= 3 && y0 + GT_H + 3 <= rows && x0 >= 4 && x0 + GT_W + 4 <= cols);
   if (tx_ > tx0) __syncthreads();                                  // the previous tile's column pass has read sRowP, its row pass sIn
 #pragma unroll
   for (int k = 0; k < GT_NLD; ++k) {
     const int i = t + 256 * k;
-    // (a dword that straddles the image's edge comes from the fix-up threads; fix_at >= 0 only in border tiles of images >= 8 x 8)
-    if (i < (GT_H + 6) * NDW && !(border_fix && gauss_fixed_dword(cols, x0, i % NDW))) reinterpret_cast<uint32_t*>(sIn)[i] = ld[k];
+    if (i < (GT_H + 6) * NDW) reinterpret_cast<uint32_t*>(sIn)[i] = ld[k];
   }
-  if (fix_at >= 0) reinterpret_cast<uint32_t*>(sIn)[fix_at] = fix[0] | (fix[1] << 8) | (fix[2] << 16) | (fix[3] << 24);
-  if (tx_ + 1 < tx1) gauss_load_tile(src, rows, cols, pitch, x0 + GT_W, y0, t, ld, fix, fix_at);   // in flight during the two passes below
+  if (tx_ + 1 < tx1) gauss_load_tile(src, rows, cols, pitch, x0 + GT_W, y0, t, ld);   // in flight during the two passes below
   if (tx_ > tx0) store_tile(x0 - GT_W);
+  if (gauss_tile_at_edge(rows, cols, x0)) {                        // (block-uniform)
+    __syncthreads();
+    gauss_fix_edges(sIn, cols, x0, t);
+  }
   __syncthreads();
   // row pass: tile column x sits at byte x + 4 of a tile row, so the taps of pixels 4g .. 4g+3 are bytes
   // 4g+1 .. 4g+10 = bytes 1 .. 10 of the dwords g, g+1, g+2
