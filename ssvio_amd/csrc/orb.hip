@@ -29,7 +29,7 @@
 
 namespace ssxorb {
 
-__constant__ int8_t c_pattern[256 * 4] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[256 * 4] = {
 #include "brief_pattern.inc"
 };
 // umax of the circular patch (orbextractor.cpp:176-191): closed form checked in tests
@@ -644,7 +644,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 // (MUL, SH): i / NDW == (i * MUL) >> SH for i < 64 (the first round; later rounds advance row / dword / byte offset
 // incrementally: 64 = (64 / NDW) rows + (64 % NDW) dwords).
 template <int ROWS, int NDW, int MUL, int SH>
-__device__ __forceinline__ int stage_patch(uint32_t* sp, const uint8_t* src, int pitch, int x0, int y0, int lane)
+__device__ __forceinline__ int load_patch(uint32_t (&v)[(ROWS * NDW + 63) / 64], const uint8_t* src, int pitch, int x0, int y0, int lane)
 {
   const int ax = x0 & ~3;
   const uint8_t* base = src + (size_t)y0 * pitch + ax;
@@ -658,12 +658,27 @@ __device__ __forceinline__ int stage_patch(uint32_t* sp, const uint8_t* src, int
 #pragma unroll
   for (int i0 = 0; i0 < ROWS * NDW; i0 += 64) {
     const int i = i0 + lane;
-    if (i < ROWS * NDW) sp[i] = *reinterpret_cast<const uint32_t*>(base);
+    v[i0 / 64] = i < ROWS * NDW ? *reinterpret_cast<const uint32_t*>(base) : 0u;
     d += 64 % NDW;
     base += step;
     if (d >= NDW) { d -= NDW; base += wrap; }
   }
   return x0 - ax;
+}
+template <int ROWS, int NDW>
+__device__ __forceinline__ void write_patch(uint32_t* sp, const uint32_t (&v)[(ROWS * NDW + 63) / 64], int lane)
+{
+#pragma unroll
+  for (int i0 = 0; i0 < ROWS * NDW; i0 += 64)
+    if (i0 + lane < ROWS * NDW) sp[i0 + lane] = v[i0 / 64];
+}
+template <int ROWS, int NDW, int MUL, int SH>
+__device__ __forceinline__ int stage_patch(uint32_t* sp, const uint8_t* src, int pitch, int x0, int y0, int lane)
+{
+  uint32_t v[(ROWS * NDW + 63) / 64];
+  const int off = load_patch<ROWS, NDW, MUL, SH>(v, src, pitch, x0, y0, lane);
+  write_patch<ROWS, NDW>(sp, v, lane);
+  return off;
 }
 
 constexpr int OP_NDW = 9;            // orientation patch: 31 rows x 9 dwords (31 bytes + <= 3 bytes of alignment)
@@ -756,15 +771,21 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float* c, float* s)
 
 // steered BRIEF: lane l evaluates tests l, 64+l, 128+l, 192+l on the staged blurred patch (byte offset `off` in
 // each row of 4 * BP_NDW bytes); the four ballots ARE the descriptor's four 64-bit words (bit i = test i).
-__device__ __forceinline__ void brief_words(const uint8_t* sp, int off, float angle, int lane, unsigned long long words[4])
+// pat[j] = the four signed bytes (x0, y0, x1, y1) of test 64 j + lane (brief_pattern_of_lane).
+__device__ __forceinline__ void brief_pattern_of_lane(int lane, uint32_t pat[4])
+{
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pat[j] = *reinterpret_cast<const uint32_t*>(&c_pattern[(j * 64 + lane) * 4]);
+}
+__device__ __forceinline__ void brief_words(const uint8_t* sp, int off, float angle, const uint32_t pat[4], unsigned long long words[4])
 {
   float a, b;
   sincos_deg(angle, &a, &b);
   const uint8_t* c = sp + BR * (4 * BP_NDW) + BR + off;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int8_t* tp = &c_pattern[(j * 64 + lane) * 4];
-    const float x0 = (float)tp[0], y0 = (float)tp[1], x1 = (float)tp[2], y1 = (float)tp[3];
+    const int w = (int)pat[j];
+    const float x0 = (float)((w << 24) >> 24), y0 = (float)((w << 16) >> 24), x1 = (float)((w << 8) >> 24), y1 = (float)(w >> 24);
     const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
     const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
     const int t0 = c[r0 * (4 * BP_NDW) + c0];
@@ -773,9 +794,20 @@ __device__ __forceinline__ void brief_words(const uint8_t* sp, int off, float an
   }
 }
 
-// One wave per OUTPUT SLOT (levels concatenated in order, orbextractor.cpp:722-752): orientation from the raw
-// 31x31 patch, descriptor from the blurred 37x37 patch, keypoint record.  No workgroup barrier: a wave owns its
-// LDS patches.
+// One wave per OB_KPW consecutive OUTPUT SLOTS (levels concatenated in order, orbextractor.cpp:722-752): orientation from the raw
+// 31x31 patch, descriptor from the blurred 37x37 patch, keypoint record.  No workgroup barrier: a wave owns its LDS patches.
+// The counts and the OB_KPW candidate records are fetched once per wave, the lane's four BRIEF tests once per wave; the patches
+// of keypoint j + 1 are requested into registers BEFORE keypoint j is worked on (they reach LDS when j is done), and the results
+// of keypoint j are stored one keypoint late, behind the next patch request (loads and stores share the vmcnt counter: a wait for
+// the patches right after the stores would wait for the stores' completion as well).
+// What bounds it (round 4, profiles/r04/orient_brief_bound.md): the PATCH LOADS.  Per 256 images: 0.49 ms; 0.24 with the loads
+// replaced by constants; 0.50 with the loads but without BRIEF or without IC_Angle; 0.08 with none of the three.  A keypoint is
+// 68 row segments of 36-40 bytes, each its own 128-byte line; the time does not depend on the batch (64 images = 196 MB, inside
+// the 256 MB MALL: the same per image) nor on which XCD's L2 an image lands in -- it is the L2 -> L1 line traffic of ~11 KB per
+// keypoint for 2.3 KB of pixels.  Variants measured and not kept: 8 keypoints per wave with the slot -> level search on vector
+// lanes, per-lane IC_Angle weights in registers instead of the LDS table, one 32-bit offset per load (330 -> 60 scalar
+// instructions per keypoint, but 74 VGPRs = 6 waves per SIMD): 0.487 ms; the same forced to 64 VGPRs (40 B of scratch): 0.84.
+constexpr int OB_KPW = 4;
 __global__ __launch_bounds__(256) void k_orient_brief(OrbDev o)
 {
   __shared__ uint32_t sPatch[4][PATCH_LDS_DW];
@@ -784,53 +816,84 @@ __global__ __launch_bounds__(256) void k_orient_brief(OrbDev o)
   __syncthreads();                                      // the only workgroup barrier; waves leave only after it
   const int img = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
-  const int slot = blockIdx.x * 4 + wave;
-  // level of this output slot: all per-level counts are fetched at once (independent scalar loads) -- a search loop
-  // that loads one count per iteration costs one dependent memory round trip per level, and this kernel is bound
-  // by exactly such round trips
+  const int slot0 = (blockIdx.x * 4 + wave) * OB_KPW;
+  // levels of the output slots: all per-level counts are fetched at once (independent scalar loads) -- a search loop
+  // that loads one count per iteration costs one dependent memory round trip per level
   int cnt[MAX_LEVELS];
 #pragma unroll
   for (int l = 0; l < MAX_LEVELS; ++l) cnt[l] = l < o.nlevels ? o.sel_count[img * o.nlevels + l] : 0;
-  int level = 0, base = 0, n = cnt[0];
+  uint32_t pat[4];
+  brief_pattern_of_lane(lane, pat);
+  int lvl_of[OB_KPW];
+  uint32_t cand[OB_KPW];
+  bool ok[OB_KPW];
 #pragma unroll
-  for (int l = 1; l < MAX_LEVELS; ++l) {
-    const bool next = l < o.nlevels && level == l - 1 && slot >= base + n;
-    base = next ? base + n : base;
-    level = next ? l : level;
-    n = next ? cnt[l] : n;
+  for (int j = 0; j < OB_KPW; ++j) {
+    const int slot = slot0 + j;
+    int level = 0, base = 0, n = cnt[0];
+#pragma unroll
+    for (int l = 1; l < MAX_LEVELS; ++l) {
+      const bool next = l < o.nlevels && level == l - 1 && slot >= base + n;
+      base = next ? base + n : base;
+      level = next ? l : level;
+      n = next ? cnt[l] : n;
+    }
+    const int k = slot - base;
+    ok[j] = k < n && slot < o.out_cap;                  // (wave-uniform; false from the first slot past the last level's keypoints on)
+    if (k < n && slot >= o.out_cap && lane == 0) atomicOr(&o.status[img], 4);   // a keypoint past the output capacity
+    lvl_of[j] = level;
+    cand[j] = ok[j] ? o.sel[(size_t)(img * o.nlevels + level) * SEL_CAP + k] : 0u;
   }
-  const int k = slot - base;
-  if (k >= n) return;                                   // past the last level's keypoints (wave-uniform)
-  if (slot >= o.out_cap) { if (lane == 0) atomicOr(&o.status[img], 4); return; }
-  const int il = img * o.nlevels + level;
-  const uint32_t p = o.sel[(size_t)il * SEL_CAP + k];
-  const int minB = EDGE_THRESHOLD - 3;
-  const int cx = (int)(p & 0xFFF) + minB, cy = (int)((p >> 12) & 0xFFF) + minB;   // cvRound of integral coords
-  const size_t lvl = (size_t)img * o.pyr_bytes + o.lvl_off[level];
-  const int pitch = o.lvl_pitch[level];
   uint32_t* sp = sPatch[wave];
-  const int off_o = stage_patch<31, OP_NDW, 57, 9>(sp, o.pyr + lvl, pitch, cx - 15, cy - 15, lane);
-  const int off_b = stage_patch<BP, BP_NDW, 205, 11>(sp + 31 * OP_NDW, o.blur + lvl, pitch, cx - BR, cy - BR, lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  const float angle = ic_angle(sp, off_o, lane, sIc);
-  unsigned long long words[4];
-  brief_words(reinterpret_cast<const uint8_t*>(sp + 31 * OP_NDW), off_b, angle, lane, words);
-  if (lane < 4) {
-    unsigned long long* dd = reinterpret_cast<unsigned long long*>(o.out_desc + ((size_t)img * o.out_cap + slot) * 32);
-    dd[lane] = words[lane];
-  }
-  if (lane == 0) {
-    ssx_keypoint kp;
-    const float sc = o.scale[level];
-    kp.x = (float)cx; kp.y = (float)cy;
-    if (level != 0) { kp.x *= sc; kp.y *= sc; }
-    kp.size = (float)(int)(31 * sc);
-    kp.angle = angle;
-    kp.response = (float)(p >> 24);
-    kp.octave = level;
-    kp.class_id = -1;
-    reinterpret_cast<ssx_keypoint*>(o.out_kps)[(size_t)img * o.out_cap + slot] = kp;
+  const int minB = EDGE_THRESHOLD - 3;
+  uint32_t vr[(31 * OP_NDW + 63) / 64], vb[(BP * BP_NDW + 63) / 64];
+  int off_o = 0, off_b = 0;
+  auto request = [&](int j) {
+    const uint32_t p = cand[j];
+    const int cx = (int)(p & 0xFFF) + minB, cy = (int)((p >> 12) & 0xFFF) + minB;   // cvRound of integral coords
+    const size_t lvl = (size_t)img * o.pyr_bytes + o.lvl_off[lvl_of[j]];
+    const int pitch = o.lvl_pitch[lvl_of[j]];
+    off_o = load_patch<31, OP_NDW, 57, 9>(vr, o.pyr + lvl, pitch, cx - 15, cy - 15, lane);
+    off_b = load_patch<BP, BP_NDW, 205, 11>(vb, o.blur + lvl, pitch, cx - BR, cy - BR, lane);
+  };
+  unsigned long long word_prev = 0;                     // lane < 4: word `lane` of the previous keypoint's descriptor
+  float angle_prev = 0.f;
+  auto store = [&](int j) {                             // results of slot j (held in word_prev / angle_prev)
+    const int slot = slot0 + j, level = lvl_of[j];
+    const uint32_t p = cand[j];
+    if (lane < 4) reinterpret_cast<unsigned long long*>(o.out_desc + ((size_t)img * o.out_cap + slot) * 32)[lane] = word_prev;
+    if (lane == 0) {
+      ssx_keypoint kp;
+      const float sc = o.scale[level];
+      kp.x = (float)((int)(p & 0xFFF) + minB); kp.y = (float)((int)((p >> 12) & 0xFFF) + minB);
+      if (level != 0) { kp.x *= sc; kp.y *= sc; }
+      kp.size = (float)(int)(31 * sc);
+      kp.angle = angle_prev;
+      kp.response = (float)(p >> 24);
+      kp.octave = level;
+      kp.class_id = -1;
+      reinterpret_cast<ssx_keypoint*>(o.out_kps)[(size_t)img * o.out_cap + slot] = kp;
+    }
+  };
+  if (!ok[0]) return;
+  request(0);
+#pragma unroll
+  for (int j = 0; j < OB_KPW; ++j) {
+    if (!ok[j]) break;
+    const int oo = off_o, ob = off_b;
+    write_patch<31, OP_NDW>(sp, vr, lane);
+    write_patch<BP, BP_NDW>(sp + 31 * OP_NDW, vb, lane);
+    if (j + 1 < OB_KPW && ok[j + 1]) request(j + 1);
+    if (j > 0) store(j - 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const float angle = ic_angle(sp, oo, lane, sIc);
+    unsigned long long words[4];
+    brief_words(reinterpret_cast<const uint8_t*>(sp + 31 * OP_NDW), ob, angle, pat, words);
+    word_prev = (lane & 2) ? ((lane & 1) ? words[3] : words[2]) : ((lane & 1) ? words[1] : words[0]);
+    angle_prev = angle;
+    __builtin_amdgcn_wave_barrier();                    // every lane has read the patches before the next keypoint's overwrite them
+    if (j + 1 == OB_KPW || !ok[j + 1]) store(j);
   }
 }
 
@@ -891,7 +954,9 @@ __global__ __launch_bounds__(256) void k_describe_at(OrbDev o, DescribeAt a)
   __syncthreads();
   if (!active) { if (k < a.n_in && lane == 0) a.keep[k] = 0; return; }
   unsigned long long words[4];
-  brief_words(reinterpret_cast<const uint8_t*>(sp + 31 * OP_NDW), off_b, angle, lane, words);
+  uint32_t pat[4];
+  brief_pattern_of_lane(lane, pat);
+  brief_words(reinterpret_cast<const uint8_t*>(sp + 31 * OP_NDW), off_b, angle, pat, words);
   if (lane < 4) reinterpret_cast<unsigned long long*>(a.desc + (size_t)k * 32)[lane] = words[lane];
   if (lane == 0) {
     ssx_keypoint okp = kp;
@@ -1274,8 +1339,8 @@ ssx_status run_pipeline(ssx_ctx* ctx)
   if (d.detect_only) {
     SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_finalize_detect, dim3((SEL_CAP + 255) / 256, d.I), dim3(256), 0, s, d));
   } else {
-    // one wave per output slot; a keypoint past out_cap raises the capacity flag from the first wave beyond it
-    const dim3 kgrid((d.out_cap + 4 + 3) / 4, d.I);
+    // one wave per OB_KPW output slots; a keypoint past out_cap raises the capacity flag from the wave that holds its slot
+    const dim3 kgrid((d.out_cap + 4 + 4 * OB_KPW - 1) / (4 * OB_KPW), d.I);
     if (fork) SSX_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     SSX_PROF(ctx, KID_ORB_BRIEF, hipLaunchKernelGGL(k_orient_brief, kgrid, dim3(256), 0, s, d));
   }
