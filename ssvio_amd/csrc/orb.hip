@@ -136,9 +136,19 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
     const int valid = cols - x;   // >= 1
     if (valid < 8) { const uint64_t keep = (~0ull) >> (8 * (8 - valid)); w[0] &= (uint32_t)keep; w[1] &= (uint32_t)(keep >> 32); }
   } else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (x + k < cols) w[k >> 2] |= (uint32_t)srow[x + k] << (8 * (k & 3));
+    // rows that start anywhere (a 1241-pixel row): the three ALIGNED dwords that hold the eight bytes, cut with v_alignbyte
+    // (eight byte loads per thread before: 0.10 ms per 256 images for 0.03 ms of traffic).  A dword that holds one valid byte is
+    // inside the allocation; the ones behind it are clamped to the dword of the input's last byte.
+    const uintptr_t p = reinterpret_cast<uintptr_t>(srow + x), a = p & ~uintptr_t(3);
+    const uintptr_t last = (reinterpret_cast<uintptr_t>(in) + (size_t)(gridDim.z - 1) * in_img_bytes + (size_t)(rows - 1) * in_stride + (size_t)(cols - 1)) & ~uintptr_t(3);
+    const uint32_t d0 = *reinterpret_cast<const uint32_t*>(a);
+    const uint32_t d1 = *reinterpret_cast<const uint32_t*>(a + 4 < last ? a + 4 : last);
+    const uint32_t d2 = *reinterpret_cast<const uint32_t*>(a + 8 < last ? a + 8 : last);
+    const uint32_t sh = (uint32_t)(p & 3);
+    w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const int valid = cols - x;   // >= 1
+    if (valid < 8) { const uint64_t keep = (~0ull) >> (8 * (8 - valid)); w[0] &= (uint32_t)keep; w[1] &= (uint32_t)(keep >> 32); }
   }
   *reinterpret_cast<uint2*>(dst_base + (size_t)blockIdx.z * img_stride_bytes + (size_t)y * dpitch + x) = make_uint2(w[0], w[1]);
 }
