@@ -1674,6 +1674,13 @@ struct HostPrep {
 };
 }  // namespace
 
+// upper bound of the host threads a batched call spreads its per-window work over (SSX_HOST_THREADS overrides it)
+static int host_threads_cap()
+{
+  static const int cap = [] { const char* e = getenv("SSX_HOST_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? std::min(v, 128) : 16; }();
+  return cap;
+}
+
 // A few persistent host threads for the per-window host work of a batched call (staging copies, result unpacking): created
 // on first use, parked on a condition variable between calls (the former code spawned up to 16 std::threads twice per call).
 class ParPool {
@@ -3407,7 +3414,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   if ((int)ws->preps.size() < n) ws->preps.resize(n);
   std::vector<HostPrep>& preps = ws->preps;
   const int hw = (int)std::thread::hardware_concurrency();
-  const int T = std::max(1, std::min({n, 16, hw > 1 ? hw / 2 : 1}));
+  const int T = std::max(1, std::min({n, host_threads_cap(), hw > 1 ? hw / 2 : 1}));
   B->ctx = ctx; B->device = ctx->device; B->n = n; B->opt = opt; B->threads = T; B->with_err = with_err;
   static const int timing_mode = getenv("SSX_BATCH_TIMING") ? std::max(atoi(getenv("SSX_BATCH_TIMING")), 1) : 0;   // phase times on stderr
   const bool timing = timing_mode == 1;                              // 1: with synchronisations (tools/batch_time.py), 2: host clocks only
