@@ -188,8 +188,8 @@ class BaBatch:
             self.ctx.lib.ssx_ba_batch_set_groups(self.handle, int(groups))
 
     def set_persistent(self, mode):
-        """1: one persistent workgroup per group of ~7 chunks in the linearise / Schur kernels; 0 or -1: one per chunk (the default;
-        there is no automatic mode).  Same bits either way."""
+        """No effect since round 4: round 3's persistent chunk groups (measured slower, profiles/r03/persist_ab.md) are gone and the
+        library entry point does nothing; kept so that round-3 callers and tools still run."""
         if self.handle is not None:
             self.ctx.lib.ssx_ba_batch_set_persistent.restype = None
             self.ctx.lib.ssx_ba_batch_set_persistent.argtypes = [C.c_void_p, C.c_int32]
