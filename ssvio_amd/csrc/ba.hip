@@ -1334,9 +1334,14 @@ __global__ __launch_bounds__(CH, 3) void k_lin_schur_b(const BaDev* __restrict__
 
 // slabs -> dense reduced system WITHOUT lambda:  S = Hpp - sum(schur),  bs = bp - sum(c).
 // 64 entries x 4 lane groups per workgroup (slab_sum_masked), the four parts added in part order: deterministic.
+// OWN_LIN: the entry's share of Hpp / bp is summed HERE from the linearisation's slabs, with the grouping and the order of
+// k_reduce_lin (the same value to the last bit), instead of being read from k_reduce_lin's output -- the two reductions then do
+// not depend on each other and run as ONE launch (k_reduce_both: one launch boundary less per LM slot).
+template <bool OWN_LIN>
 __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx)
 {
   __shared__ double sAcc[3][64];
+  __shared__ double sAccL[3][64];
   __shared__ unsigned int sMask[MASK_TILE * TOUCH_WORDS];
   const int nS = d.nBlk * 36;
   const int stride = nS + d.nP * 6;
@@ -1344,17 +1349,37 @@ __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx
   const int t = threadIdx.x;
   const int ent = bx * 64 + (t & 63), grp = t >> 6;
   const int bit = ent < nS ? ent / 36 : d.nBlk + (ent - nS) / 6;
-  double acc = 0.0;
+  // my entry of the linearisation's slabs (pose p, entry k of its 27): the diagonal blocks' entries and the right-hand side
+  int lin_ent = -1, lin_pose = 0;
+  if (OWN_LIN && ent < stride) {
+    if (ent < nS) {
+      const int blk = ent / 36, rc = ent - blk * 36;
+      const int r = rc / 6, cc = rc - r * 6;
+      const int pa = d.blk_pa[blk];
+      if (pa == d.blk_pb[blk]) {
+        const int rr = r < cc ? r : cc, c2 = r < cc ? cc : r;
+        lin_pose = pa;
+        lin_ent = pa * 27 + rr * 6 - (rr * (rr - 1)) / 2 + (c2 - rr);
+      }
+    } else {
+      const int j = ent - nS;
+      lin_pose = j / 6;
+      lin_ent = lin_pose * 27 + UPPER6 + (j - 6 * lin_pose);
+    }
+  }
+  double acc = 0.0, accl = 0.0;
   for (int cb = 0; cb < d.nCh; cb += MASK_TILE) {
     if (cb) __syncthreads();
     stage_masks(d, cb, sMask);
     __syncthreads();
     if (ent < stride) acc = slab_sum_masked(d, d.schur_slab + ent, stride, grp, bit, cb, sMask, acc);
+    if (OWN_LIN && lin_ent >= 0) accl = slab_sum_masked(d, d.lin_slab + lin_ent, d.nP * 27 + 2, grp, d.nBlk + lin_pose, cb, sMask, accl);
   }
-  if (grp > 0) sAcc[grp - 1][t & 63] = acc;
+  if (grp > 0) { sAcc[grp - 1][t & 63] = acc; if (OWN_LIN) sAccL[grp - 1][t & 63] = accl; }
   __syncthreads();
   if (grp != 0 || ent >= stride) return;
   acc = ((acc + sAcc[0][t]) + sAcc[1][t]) + sAcc[2][t];
+  if (OWN_LIN) accl = ((accl + sAccL[0][t]) + sAccL[1][t]) + sAccL[2][t];
   double* S = d.trial_comm;
   double* bs = d.trial_comm + (size_t)n * n;
   if (ent < nS) {
@@ -1365,24 +1390,42 @@ __device__ __forceinline__ void k_reduce_schur_body(const BaDev& d, const int bx
     if (pa == pb) {
       const int rr = r < cc ? r : cc, c2 = r < cc ? cc : r;
       const int k = rr * 6 - (rr * (rr - 1)) / 2 + (c2 - rr);   // index of (rr,c2) in the 21-entry upper layout
-      h = d.Hpp[pa * UPPER6 + k];
+      h = OWN_LIN ? accl : d.Hpp[pa * UPPER6 + k];
     }
     const double v = h - acc;
     S[(size_t)(6 * pa + r) * n + 6 * pb + cc] = v;
     if (pa != pb) S[(size_t)(6 * pb + cc) * n + 6 * pa + r] = v;
   } else {
     const int j = ent - nS;
-    bs[j] = d.bp[j] - acc;
+    bs[j] = (OWN_LIN ? accl : d.bp[j]) - acc;
   }
 }
 
-__global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d) { k_reduce_schur_body(d, blockIdx.x); }
+__global__ __launch_bounds__(CH) void k_reduce_schur(BaDev d) { k_reduce_schur_body<false>(d, blockIdx.x); }
+// both reductions of an LM slot in one launch: blocks [0, n_rl) reduce the linearisation's slabs, the others the Schur slabs
+__global__ __launch_bounds__(CH) void k_reduce_both(BaDev d, int n_rl)
+{
+  if ((int)blockIdx.x < n_rl) k_reduce_lin_body(d, blockIdx.x);
+  else k_reduce_schur_body<true>(d, blockIdx.x - n_rl);
+}
+__global__ __launch_bounds__(CH) void k_reduce_both_b(const BaDev* __restrict__ dv, int max_rl)
+{
+  const BaDev& d = dv[blockIdx.y];
+  if ((int)blockIdx.x < max_rl) {
+    if ((int)blockIdx.x >= ((d.nP * 27 + 63) / 64 > 0 ? (d.nP * 27 + 63) / 64 : 1)) return;
+    k_reduce_lin_body(d, blockIdx.x);
+  } else {
+    const int bx = (int)blockIdx.x - max_rl;
+    if (bx >= ((d.nBlk * 36 + d.nP * 6 + 63) / 64)) return;
+    k_reduce_schur_body<true>(d, bx);
+  }
+}
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
 __global__ __launch_bounds__(CH) void k_reduce_schur_b(const BaDev* __restrict__ dv)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= ((d.nBlk * 36 + d.nP * 6 + 63) / 64)) return;
-  k_reduce_schur_body(d, blockIdx.x);
+  k_reduce_schur_body<false>(d, blockIdx.x);
 }
 
 // (the reduced solve of a small window -- k_solve64 for <= 10 free keyframes, k_solve80 for 11 .. 13, k_solve for 14 .. 16
@@ -3138,7 +3181,12 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_NUMERIC_G2O>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
             else SSX_PROF(ctx, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(nCh), dim3(CH), LIN_LDS_BYTES, ctx->stream, d, -1));
           }
-          if (!d.big) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(std::max(1, (d.nP * 27 + 63) / 64)), dim3(CH), 0, ctx->stream, d));
+          // later slots of a single-rank solve: the two reductions as one launch (the first slot needs lambda between them, ranks an all-reduce)
+          static const bool no_both_env = getenv("SSX_BA_SPLIT_REDUCE") != nullptr;   // (tools: the two launches, for A/B timing)
+          const bool both = !d.big && fused && !first_slot && !cm.fn && n > 0 && !no_both_env;
+          const int n_rl = std::max(1, (d.nP * 27 + 63) / 64);
+          if (both) SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_both, dim3(n_rl + (nSchurEntries + 63) / 64), dim3(CH), 0, ctx->stream, d, n_rl));
+          else if (!d.big) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin, dim3(n_rl), dim3(CH), 0, ctx->stream, d));
           // (band solver, later slots: lambda is known, so the linearisation's sums travel with the trial's reduced system)
           static const bool no_fuse_env = getenv("SSX_BA_NO_FUSED_ALLREDUCE") != nullptr;
           const bool fuse_iter = d.big && bnd.on && cm.fn && !first_slot && !no_fuse_env;
@@ -3154,7 +3202,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
           } else {
           if (n > 0) {
             if (nCh > 0 && !fused) SSX_PROF(ctx, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur, dim3(nCh), dim3(CH), lds_schur, ctx->stream, d, -1, 0.0, 2));
-            SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 63) / 64), dim3(CH), 0, ctx->stream, d));
+            if (!both) SSX_PROF(ctx, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur, dim3((nSchurEntries + 63) / 64), dim3(CH), 0, ctx->stream, d));
             st = allreduce(ctx, cm, d.trial_comm, (size_t)n * n + n);
             if (st != SSX_OK) return st;
           }
@@ -3620,10 +3668,13 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_NUMERIC_G2O>, gWg, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
             else SSX_PROF_ON(ctx, hs, KID_BA_LINEARIZE, hipLaunchKernelGGL(k_linearize_b<SSX_JAC_ANALYTIC>, gWg, dim3(CH), LIN_LDS_BYTES, hs, hv, -1));
           }
-          SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_b, gRl, dim3(CH), 0, hs, hv));
+          static const bool no_both_env = getenv("SSX_BA_SPLIT_REDUCE") != nullptr;   // (tools: the two launches, for A/B timing)
+          const bool both = fused && !first_slot && !no_both_env;    // (the first slot needs lambda between the two reductions)
+          if (both) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_both_b, dim3(B->max_rl + B->max_rs, hn), dim3(CH), 0, hs, hv, B->max_rl));
+          else SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_reduce_lin_b, gRl, dim3(CH), 0, hs, hv));
           if (first_slot) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init_b, gOne, dim3(64), 0, hs, hv, 1));
           if (!fused) SSX_PROF_ON(ctx, hs, KID_BA_SCHUR, hipLaunchKernelGGL(k_schur_b, gWg, dim3(CH), lds_schur, hs, hv, -1, 0.0, 2));
-          SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, hs, hv));
+          if (!both) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_SCHUR, hipLaunchKernelGGL(k_reduce_schur_b, gRs, dim3(CH), 0, hs, hv));
           if (B->any_solve64) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve80) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
