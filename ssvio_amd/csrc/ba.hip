@@ -1662,7 +1662,7 @@ __global__ __launch_bounds__(CH) void k_pack_poses_b(const BaDev* __restrict__ d
   const int w = blockIdx.x;
   if (w >= n) return;
   const BaDev& d = dv[w];
-  const double* src = d.pose[ctrl[w]];
+  const double* src = d.pose[ctrl ? ctrl[w] : (int)d.scal[SC_CUR]];   // (no host word: the state buffer the window's own LM loop ended on)
   for (int i = threadIdx.x; i < 7 * d.P; i += CH) out[(size_t)w * 7 * maxP + i] = src[i];
 }
 
@@ -3621,6 +3621,12 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   // per-window host state of Backend::OptimizeActiveMap's outer loop (backend.cpp:175-203)
   struct WinState { int cur = 0, round = 0, rounds = 0, n_iters = 0, n_in = 0, n_outl = 0; bool done = false, trial_err = false; double n_out = 0; };
   std::vector<WinState> wsn(n);
+  // nobody asked for landmarks or per-edge errors: only the poses cross PCIe (560 B instead of 97 KB per C3 window), and they are
+  // requested speculatively at the end of every outer round (below)
+  bool spec_poses = results != nullptr && !B->with_err;
+  int spec_maxP = 0;
+  if (results) for (int w = 0; w < n; ++w) { spec_poses = spec_poses && !results[w].points_out; spec_maxP = std::max(spec_maxP, B->P[w]); }
+  spec_poses = spec_poses && (size_t)n * 7 * spec_maxP <= B->out_total;
   double* hscal = B->scal->as<double>();                             // n x SC_N, then n x 3 x MAX_STATS, then the ctrl words
   int* h_ctrl = reinterpret_cast<int*>(hscal + (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS));
   for (int w = 0; w < n; ++w) wsn[w].done = !(B->devs[w].nCh > 0) || opt.outer_rounds <= 0;
@@ -3691,6 +3697,16 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
       SSX_HIP_TRY(ctx, hipGetLastError());
       hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 0);
       SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d_gather, sizeof(double) * (size_t)n * SC_N, hipMemcpyDeviceToHost, s));
+      if (spec_poses) {
+        // poses-only results ride behind the control words of this round, before the host has looked at them: if the round turns
+        // out to be the last one (the usual case) the solve ends on ONE synchronisation instead of two; otherwise the next round
+        // overwrites them.  The packing kernel takes the state buffer index from the window's own control block.
+        hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 1);
+        SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal + (size_t)n * SC_N, d_gather, sizeof(double) * (size_t)n * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_pack_poses_b, dim3(n), dim3(CH), 0, s, dv, (const int*)nullptr, n, spec_maxP, d_out);
+        SSX_HIP_TRY(ctx, hipMemcpyAsync(B->stage->as<double>(), d_out, sizeof(double) * (size_t)n * 7 * spec_maxP, hipMemcpyDeviceToHost, s));
+        SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+      }
       SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
       bool stopped = true;
       for (int w = 0; w < n; ++w) if (!wsn[w].done && hscal[(size_t)w * SC_N + SC_STOP] == 0.0) stopped = false;
@@ -3721,6 +3737,10 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   }
   // ---- statistics + results: one packing kernel, one download
   const bool want_err = B->with_err;
+  bool poses_only = spec_poses;
+  const int maxP = spec_maxP;
+  double* h_out = B->stage->as<double>();
+  if (!spec_poses) {
   for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = wsn[w].trial_err ? 1 : 0; h_ctrl[2 * n + w] = 1; }
   hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 1);
   SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal + (size_t)n * SC_N, d_gather, sizeof(double) * (size_t)n * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, s));
@@ -3729,26 +3749,17 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     for (int w = 0; w < n; ++w)
       if (!wsn[w].trial_err && B->devs[w].nCh > 0)
         hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(B->devs[w].nCh), dim3(CH), LIN_LDS_BYTES, s, B->devs[w], wsn[w].cur);
-  // nobody asked for landmarks or per-edge errors: only the poses cross PCIe (560 B instead of 97 KB per C3 window)
-  bool poses_only = !want_err;
-  int maxP = 0;
-  for (int w = 0; w < n; ++w) { poses_only = poses_only && !results[w].points_out; maxP = std::max(maxP, B->P[w]); }
-  poses_only = poses_only && (size_t)n * 7 * maxP <= B->out_total;
-  double* h_out = B->stage->as<double>();
-  if (poses_only) {
-    hipLaunchKernelGGL(k_pack_poses_b, dim3(n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, maxP, d_out);
-    SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * (size_t)n * 7 * maxP, hipMemcpyDeviceToHost, s));
-  } else {
   hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, d_ooff, d_out, want_err ? 1 : 0);
   SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * B->out_total, hipMemcpyDeviceToHost, s));
-  }
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  }   // (!spec_poses)
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   static const bool timing = getenv("SSX_BATCH_TIMING") != nullptr;
   const auto t_unpack = std::chrono::steady_clock::now();
-  ctx->ba->pool.run(n, B->threads, [&](int w) {
+  // (poses only: 560 bytes per window -- waking the worker threads costs more than copying them here)
+  ctx->ba->pool.run(n, poses_only ? 1 : B->threads, [&](int w) {
     ssx_ba_result& r = results[w];
     const WinState& st = wsn[w];
     const int P = B->P[w], L = B->L[w], E = B->E[w];
