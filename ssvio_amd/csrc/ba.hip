@@ -1726,14 +1726,11 @@ static int host_threads_cap()
 
 // A few persistent host threads for the per-window host work of a batched call (staging copies, result unpacking): created
 // on first use, parked on a condition variable between calls (the former code spawned up to 16 std::threads twice per call).
-// A batched call runs several jobs in quick succession (fill, marshal, upload pieces, unpack) and a futex wake-up is 50-130 us --
-// as much as a small job -- so a worker SPINS for a short while after a job before it parks, and the caller spins for the last
-// worker instead of sleeping on it: the jobs of one call find the workers awake.
 class ParPool {
  public:
   ~ParPool()
   {
-    { std::lock_guard<std::mutex> lk(mu_); stop_.store(true); }
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
@@ -1747,27 +1744,16 @@ class ParPool {
     {
       std::unique_lock<std::mutex> lk(mu_);
       while ((int)th_.size() < T - 1) th_.emplace_back([this] { loop(); });
-      job_ = &f; n_ = n; next_ = 0; pending_.store(n);
-      gen_.fetch_add(1, std::memory_order_release);
+      job_ = &f; n_ = n; next_ = 0; pending_ = n; ++gen_;
     }
     cv_.notify_all();
     work();
-    const auto t0 = std::chrono::steady_clock::now();
-    while (pending_.load(std::memory_order_acquire) != 0) {          // (the last items are in other threads' hands)
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) {
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [this] { return pending_.load() == 0; });
-        break;
-      }
-      relax();
-    }
-    std::lock_guard<std::mutex> lk(mu_);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
     job_ = nullptr;
   }
 
  private:
-  static constexpr int SPIN_US = 400;
-  static void relax() { __builtin_ia32_pause(); }
   void work()
   {
     for (;;) {
@@ -1779,27 +1765,20 @@ class ParPool {
         w = next_++; f = job_;
       }
       (*f)(w);
-      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-        std::lock_guard<std::mutex> lk(mu_);
-        done_cv_.notify_all();
-      }
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_cv_.notify_all();
     }
   }
   void loop()
   {
     unsigned long seen = 0;
     for (;;) {
-      const auto t0 = std::chrono::steady_clock::now();
-      while (gen_.load(std::memory_order_acquire) == seen && !stop_.load()) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) {
-          std::unique_lock<std::mutex> lk(mu_);
-          cv_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
-          break;
-        }
-        relax();
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
       }
-      if (stop_.load()) return;
-      seen = gen_.load(std::memory_order_acquire);
       work();
     }
   }
@@ -1807,10 +1786,9 @@ class ParPool {
   std::condition_variable cv_, done_cv_;
   std::vector<std::thread> th_;
   const std::function<void(int)>* job_ = nullptr;
-  int n_ = 0, next_ = 0;
-  std::atomic<int> pending_{0};
-  std::atomic<unsigned long> gen_{0};
-  std::atomic<bool> stop_{false};
+  int n_ = 0, next_ = 0, pending_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
 };
 
 struct BaWorkspace {
