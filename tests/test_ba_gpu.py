@@ -611,6 +611,31 @@ def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
         assert np.array_equal(outs["device"][k], outs["splitreduce"][k]), k
 
 
+def test_poses_only_download_equals_the_full_download(ctx):
+    """BaBatch.solve(points=False, want_edges=False): only the keyframe poses cross PCIe -- requested behind the LM control words of
+    every outer round, packed from the state buffer the window's own control block names (batch_run's speculative download).  Same
+    poses, iteration counts and LM histories as the full download: windows of 4 .. 12 keyframes, one that needs several outer
+    rounds (the speculative copies of the earlier rounds are overwritten), rejected trials, both batch groupings, solved twice."""
+    probs = [make_ba_problem(P=10, L=800, seed=801), make_ba_problem(P=7, L=300, obs_per_lm=4, seed=802), make_ba_problem(P=12, L=900, obs_per_lm=4, seed=803),
+             make_ba_problem(P=10, L=600, seed=804, frac_gross=0.45), make_ba_problem(P=4, L=60, obs_per_lm=4, seed=805),
+             make_ba_problem(P=10, L=2000, seed=806, pose_t_noise=0.3, pose_r_noise=0.03)]
+    full = ba.BaBatch(ctx, probs, resident=True)
+    ref = full.solve()["results"]
+    full.close()
+    assert max(o["rounds"] for o in ref) >= 2 and max(int(o["trials"].max()) for o in ref) >= 2
+    lean = ba.BaBatch(ctx, probs, resident=True, with_edge_errors=False)
+    for groups in (1, 2):
+        lean.set_groups(groups)
+        for _ in range(2):
+            lean.solve(want_edges=False, summaries=False, points=False)
+            for i, one in enumerate(ref):
+                assert np.array_equal(lean.poses[i][:probs[i]["P"]], one["poses"]), (groups, i)
+                assert lean.res[i].n_iters == one["n_iters"] and lean.res[i].rounds == one["rounds"]
+                k = min(one["n_iters"], len(one["chi2"]))
+                assert np.array_equal(np.array(lean.res[i].iter_chi2[:k]), one["chi2"][:k])
+    lean.close()
+
+
 def test_bench_size_batch_equals_single_calls(ctx):
     """The bench's own configuration (BASELINE configs[2]: 10 keyframes x 4000 landmarks x 20 000 edges per window), eight
     windows resident in two groups: every window returns the bits of ssx_ba_solve, and solving again from the uploaded
