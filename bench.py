@@ -6,18 +6,28 @@
         bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): "stereo frames/s (ORB+match+local-BA) on 1241x376".  One STEP = one batch of B synthetic
-1241x376 stereo pairs per GPU -- handed over as HOST images every step (a pinned ring; the upload of a step's batch
-rides the library's copy stream beside the previous kernels, test/test_system.cpp:36-47 feeds a fresh pair per step)
--- through the WHOLE hot path in ONE timed region, the keypoint / match / triangulation counts and the optimised
-keyframe poses of every window downloaded every step: pyramid + grid FAST + octree + orientation + blur + BRIEF on both images (2000 features each), row-band
-Hamming matching, DLT triangulation (configs[1], "C2") AND one local bundle adjustment per pair -- a configs[2]-shaped
-window ("C3": 10 keyframes, 4000 landmarks, 20000 edges; Backend::OptimizeActiveMap with the reference's defaults:
-<= 5 outer rounds x optimize(10), Huber 5.891) as /root/reference/src/ssvio/frontend.cpp:546-576 ->
-backend.cpp:57-76,78-245 chain them per keyframe.  `value` = pairs completed per second, whole job, all GPUs.
-N > 1 runs one process per GPU on independent pairs and windows (replicas, no data-path collective): weak scaling.
+1241x376 stereo pairs per GPU through the WHOLE hot path, in ONE timed region, the way a live system produces it:
+
+  front-end   the batch is handed over as HOST images (a pinned ring; the upload of step k + 1's batch rides the library's
+              copy stream beside step k's kernels, test/test_system.cpp:36-47 feeds a fresh pair per step): pyramid + grid
+              FAST + octree + orientation + blur + BRIEF on both images (2000 features each), row-band Hamming matching, DLT
+              triangulation (configs[1], "C2"); keypoint / match / triangulation counts of every pair downloaded
+  backend     one local bundle adjustment per pair on a window that MOVES: B resident sliding windows (ssx_ba_window), each
+              of which, per step, drops its oldest keyframe and takes a new one -- pose, ~400 new landmarks, 2000
+              observations, the only data that crosses PCIe on the way in (ssx_ba_window_update_batch) -- is optimised
+              where it lies (ssx_ba_window_solve_batch: Backend::OptimizeActiveMap with the reference's defaults, <= 5
+              outer rounds x optimize(10), Huber 5.891) and returns the poses AND landmarks of the window to the host:
+              /root/reference/src/ssvio/frontend.cpp:546-576 -> backend.cpp:57-76, 78-245, map.cpp:27-56, 89-160.
+              10 keyframes x 20 000 observations per window (configs[2], "C3", on a window that moves: ~5200 landmarks,
+              the partially observed ones at both ends included).  tools/bench_live.py drives it.
+
+`value` = pairs completed per second, whole job, all GPUs.  N > 1 runs one process per GPU on independent pairs and
+windows (replicas, no data-path collective): weak scaling.
 
 Also in the same JSON line:
-  resident        the same step with images AND windows resident in HBM and nothing downloaded (rounds 1-3's `value`)
+  frozen_batch    rounds 2-4's headline: the same front-end step beside a FROZEN batch of C3 windows (ssx_ba_batch: marshalled
+                  and uploaded before the clock starts, re-solved from the same state every step, poses downloaded)
+  resident        the frozen batch with the images resident in HBM too and nothing downloaded (rounds 1-3's `value`)
   c1              BASELINE configs[0] at its stated size: 200 KITTI-00-shaped stereo pairs (rendered corridor drive, the
                   reference's kitti_00.yaml settings) through the headless test_system (ssx_run_kitti): frames/s with and
                   without PNG decoding, APE against the generator's ground truth, the CPU oracle runner beside it
@@ -25,6 +35,8 @@ Also in the same JSON line:
   ba              C3 alone: LM iterations/s of one window at a time (latency) and of the batched entry point
   ba_c4           BA LM iterations/s on the configs[3] shape, landmark-sharded over the N GPUs through RCCL inside
                   libssx.so (ssx_comm_*) when N > 1
+  next_rows       SURVEY.md 8-F's rows with their own lines: LK points/s, pose-only solves/s, vocabulary transform
+                  descriptors/s, pose-graph iterations/s, each with algorithmic bytes / flops and the CPU time beside it
   roofline        the kernel with the largest share of the composite step: frac = the larger of the ALGORITHMIC hbm and
                   f64-flop fractions (SURVEY.md 8-D's bytes / flops per launch over the live launch duration, against the
                   guide's peaks); hbm_frac, flops_frac, traffic_ratio (PMC bytes / algorithmic bytes) as scalars beside it
@@ -83,7 +95,7 @@ def main():
     c1_gen = None
     if rank == 0 and args.gpus == 1 and args.c1_frames > 0 and not args.lean and not os.path.exists(os.path.join(c1_dir, "times.txt")):
         import subprocess
-        c1_gen = subprocess.Popen([sys.executable, "-m", "ssvio_amd.synth", "corridor", c1_dir, str(args.c1_frames)], cwd=ROOT,
+        c1_gen = subprocess.Popen([sys.executable, "-m", "tools.synth", "corridor", c1_dir, str(args.c1_frames)], cwd=ROOT,
                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
 
     import torch
@@ -115,7 +127,7 @@ def main():
 
     import ssvio_amd
     from ssvio_amd import _lib, ba, orb
-    from ssvio_amd.synth import KITTI_H, KITTI_W, make_ba_problem, make_stereo_pair
+    from tools.synth import KITTI_H, KITTI_W, make_ba_problem, make_stereo_pair
 
     stream = torch.cuda.Stream(device=dev)
     ctx = ssvio_amd.Context(dev_index, stream=stream.cuda_stream)     # front-end
@@ -151,22 +163,83 @@ def main():
     step_no = [0]
 
     # A streaming server's steady state: the batch of step k + 1 is crossing PCIe, the batch of step k is in the front-end, the
-    # windows of step k are being optimised, and the host collects the front-end's results ONE STEP BEHIND (batch k - 1: they are
-    # there, nothing waits).  Every batch is uploaded, processed and its results downloaded exactly once; a result is available
-    # one step (6 ms) after its batch entered the front-end.
+    # windows of step k are being edited / optimised, and the host collects the front-end's results ONE STEP BEHIND (batch k - 1:
+    # they are there, nothing waits).  Every batch is uploaded, processed and its results downloaded exactly once; a result is
+    # available one step (6 ms) after its batch entered the front-end.
     fe_stream.upload(ring[0].data_ptr()); fe_stream.run()              # batch 0 is in the front-end ...
     fe_stream.upload(ring[1].data_ptr())                               # ... batch 1 on its way when the first step starts
     step_no[0] = 1
+    fe_pairs = [0]
 
-    def composite_step():
+    def frontend_step():
         fe_stream.run()                                                # batch k (uploaded during the last step) -> front-end, asynchronous
         step_no[0] += 1
         fe_stream.upload(ring[step_no[0] & 1].data_ptr())              # batch k + 1 starts crossing PCIe (the library's copy stream)
+
+    def frontend_collect():
+        c = fe_stream.wait_counts()                                    # the front-end's results of batch k - 1
+        fe_pairs[0] += int((c[:, 0] > 0).sum())
+
+    # ---------------- timed region 1 (the headline): front-end + one local BA per pair on B live sliding windows ----------------
+    from tools import bench_live
+    LIVE_THREADS = int(os.environ.get("SSX_BENCH_WINDOW_THREADS", "2"))
+    live_steps = args.warmup + args.steps
+    live = bench_live.LiveBackend(ssvio_amd, dev_index, B, live_steps, threads=LIVE_THREADS, seed=900 + 1000 * rank)
+
+    def live_steps_run(n):
+        # per step: the front-end's enqueue, the release of the step's keyframes to the backend groups, the front-end's results of
+        # the batch before; the groups' step is awaited one step late (bench_live.LiveBackend.run: their host phases overlap each
+        # other's kernels)
+        def fe_part():
+            frontend_step()
+        for i in range(n):
+            fe_part()
+            live.release()
+            frontend_collect()
+            if i >= 1:
+                live.wait_done()
+        for _ in range(min(1, n)):
+            live.wait_done()
+
+    def sync_all():
+        live.synchronize()
+        barrier()
+
+    live_steps_run(args.warmup)
+    sync_all()
+    live.reset_counters(); fe_pairs[0] = 0
+    t0 = time.perf_counter()
+    live_steps_run(args.steps)
+    sync_all()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    frames = world * B * args.steps
+    assert fe_pairs[0] == B * args.steps, "a stereo pair came back without keypoints"
+    assert min(live.steps_done) == args.steps, "a backend group did not finish its steps"
+    lm_iters = sum(live.iters)
+    value = frames / elapsed
+    nkf_w, nlm_w, nob_w = live.window_size()
+    live_info = {"host_threads": live.G, "ms_per_step_inside_solve_calls": round(max(live.t_solve) / args.steps * 1e3, 4),
+                 "ms_per_step_inside_update_calls": round(max(live.t_edit) / args.steps * 1e3, 4),
+                 "window": {"keyframes": nkf_w, "landmarks": nlm_w, "observations": nob_w},
+                 "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2),
+                 "what": "ms_per_step_inside_solve_calls / _update_calls = the busiest group thread's time inside ssx_ba_window_solve_batch "
+                         "(pending uploads, counting tables, device-side marshalling, solve, download of poses + landmarks) / inside "
+                         "ssx_ba_window_update_batch, per step of the whole batch; the groups work side by side, so the calls of one group "
+                         "wait for the GPU while the others' kernels run"}
+    live.close()
+    fe_stream.wait_counts()                                            # drain: the last batch that was run ...
+    fe_stream.run(); fe_stream.wait_counts()                           # ... and the one uploaded ahead by the last step
+
+    # ---------------- timed region 1f: rounds 2-4's headline -- the same front-end step beside a FROZEN batch of C3 windows ----------------
+    fe_stream.upload(ring[0].data_ptr()); fe_stream.run()
+    fe_stream.upload(ring[1].data_ptr())
+    step_no[0] = 1
+
+    def composite_step():
+        frontend_step()
         # B windows on the BA stream: returns when they are done, with the optimised keyframe poses of every window ...
         batch.solve(want_edges=False, summaries=False, points=False)
-        # ... and the front-end's results of batch k - 1: keypoint / match / triangulation counts of every pair
-        c = fe_stream.wait_counts()
-        return {"n_iters_total": sum(batch.res[i].n_iters for i in range(B)), "pairs_done": int((c[:, 0] > 0).sum())}
+        frontend_collect()
 
     def composite_step_resident():
         orb.stereo_batch_enqueue(ctx)                                  # asynchronous on the front-end stream, images resident
@@ -176,23 +249,18 @@ def main():
         orb.stereo_batch_enqueue(ctx)
         return batch_host.solve(want_edges=False, summaries=False)                      # marshal + upload + solve + download poses / points
 
-    # ---------------- timed region 1 (the headline): front-end + one local BA per pair ----------------
-    for _ in range(args.warmup):
+    FROZEN_STEPS = max(4, args.steps // 2)
+    for _ in range(2):
         composite_step()
     barrier()
     t0 = time.perf_counter()
-    lm_iters = 0
-    pairs_done = 0
-    for _ in range(args.steps):
-        r_ = composite_step()
-        lm_iters += r_["n_iters_total"]; pairs_done += r_["pairs_done"]
+    for _ in range(FROZEN_STEPS):
+        composite_step()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    frames = world * B * args.steps
-    assert pairs_done == B * args.steps, "a stereo pair came back without keypoints"
-    value = frames / elapsed
-    fe_stream.wait_counts()                                            # drain: the last batch that was run ...
-    fe_stream.run(); fe_stream.wait_counts()                           # ... and the one uploaded ahead by the last step
+    frozen_elapsed = max_over_ranks(time.perf_counter() - t0)
+    frozen_value = world * B * FROZEN_STEPS / frozen_elapsed
+    fe_stream.wait_counts()
+    fe_stream.run(); fe_stream.wait_counts()
     orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)     # back to the resident images for the regions below
 
     # ---------------- timed region 1r: rounds 1-3's headline -- images and windows resident, nothing downloaded ----------------
@@ -256,184 +324,6 @@ def main():
     except Exception as exc:                                           # noqa: BLE001 -- an extra figure, never fatal
         if not args.lean:
             print(f"[bench] pipelined host-buffer region skipped: {exc}", file=sys.stderr)
-
-    # ---------------- timed region 1d: resident sliding windows (ssx_ba_window), one keyframe replaced per step ----------------
-    # What a live backend hands over at every keyframe (backend.cpp:88-169, map.cpp:52-56, 89-160): the window it optimised
-    # last time minus its oldest keyframe plus the new one.  B window objects stay in HBM; per step every window pops one
-    # keyframe and pushes one (its pose, ~400 new landmarks, ~2000 observations: ~75 KB over PCIe), then all B windows are
-    # optimised in ONE call (ssx_ba_window_solve_batch) and their poses / landmarks come back.  10 keyframes x ~5600 landmarks
-    # (partially observed ones included) x 20 000 observations per window: configs[2]'s edge count on a moving window.
-    churn = None
-    try:
-        if args.lean:
-            raise RuntimeError("--lean")
-        import ctypes as C
-        from ssvio_amd._lib import BaResult, dbl_p, u8_p, ptr
-        CH_STEPS = max(3, args.steps // 4)
-        CH_WARM = 12                                                     # untimed steps: one full turnover of the windows (their storage has been rewritten once, every buffer has its final size)
-        n_kf_total = 10 + CH_WARM + CH_STEPS + 1
-        N_TRAJ = 4                                                       # distinct trajectories (the generator is a Python loop over observations)
-        traj = [make_ba_problem(P=n_kf_total, L=400 * (n_kf_total - 4), seed=900 + k + 1000 * rank) for k in range(N_TRAJ)]
-        i64_p = C.POINTER(C.c_int64)
-
-        def feed_of(pr):
-            first = np.full(pr["L"], 10 ** 9, dtype=np.int64)
-            np.minimum.at(first, pr["edge_point"], pr["edge_pose"])
-            out = []
-            for k in range(pr["P"]):
-                new = np.nonzero(first == k)[0]
-                e = np.nonzero(pr["edge_pose"] == k)[0]
-                a = dict(pose=np.ascontiguousarray(pr["poses"][k]), new_ids=np.ascontiguousarray(new.astype(np.int64)),
-                         new_xyz=np.ascontiguousarray(pr["points"][new]), new_fixed=np.ascontiguousarray(pr["point_fixed"][new]),
-                         obs_lm=np.ascontiguousarray(pr["edge_point"][e].astype(np.int64)), obs_uv=np.ascontiguousarray(pr["edge_uv"][e]))
-                # the ctypes argument tuple, built once: the timed loop only makes the library call
-                a["args"] = (ptr(a["pose"], dbl_p), 0, len(new), ptr(a["new_ids"], i64_p), ptr(a["new_xyz"], dbl_p), ptr(a["new_fixed"], u8_p),
-                             len(e), ptr(a["obs_lm"], i64_p), ptr(a["obs_uv"], dbl_p), None)
-                out.append(a)
-            return out
-        feeds = [feed_of(t) for t in traj]
-        # A backend keeps, with every map point, the slot the window gave it (ssx_ba_window_push_keyframe_slots).  The slots of
-        # a push / pop sequence are deterministic: one untimed pass over a scratch window per trajectory records them, and the
-        # timed loop passes slot arrays instead of ids (what a C++ caller reads out of its MapPoint objects).
-        i32p = C.POINTER(C.c_int32)
-        for q, fd in enumerate(feeds):
-            scratch = ba.BaWindow(ctx_ba, traj[q]["K"], traj[q]["cam_ext"])
-            slot_of = np.full(traj[q]["L"], -10 ** 9, dtype=np.int64)
-            for k, a in enumerate(fd):
-                if k >= 10:
-                    scratch.pop(k - 10)
-                is_new = np.zeros(traj[q]["L"], dtype=bool); is_new[a["new_ids"]] = True
-                rank_new = np.zeros(traj[q]["L"], dtype=np.int64); rank_new[a["new_ids"]] = np.arange(len(a["new_ids"]))
-                lm = a["obs_lm"]
-                a["obs_slot"] = np.ascontiguousarray(np.where(is_new[lm], -1 - rank_new[lm], slot_of[lm]).astype(np.int32))
-                a["slots_out"] = np.zeros(len(a["new_ids"]), dtype=np.int32)
-                a["args_slots"] = (ptr(a["pose"], dbl_p), 0, len(a["new_ids"]), ptr(a["new_ids"], i64_p), ptr(a["new_xyz"], dbl_p), ptr(a["new_fixed"], u8_p),
-                                   ptr(a["slots_out"], i32p), len(lm), ptr(a["obs_slot"], i32p), ptr(a["obs_uv"], dbl_p), None)
-                ctx_ba.check(ctx_ba.lib.ssx_ba_window_push_keyframe_slots(scratch.handle, k, *a["args_slots"]))
-                slot_of[a["new_ids"]] = a["slots_out"]
-            scratch.close()
-        # G_W groups of windows, each owned by one host thread with its own context (the backend threads of concurrent streams):
-        # a group's pop / push and the host side of its solve overlap the other groups' kernels
-        G_W = max(1, min(int(os.environ.get("SSX_BENCH_WINDOW_THREADS", "2")), B))
-        ctx_w = [ssvio_amd.Context(dev_index) for _ in range(G_W)]
-        grp_of = [i * G_W // B for i in range(B)]
-        wins_r = [ba.BaWindow(ctx_w[grp_of[i]], traj[i % N_TRAJ]["K"], traj[i % N_TRAJ]["cam_ext"]) for i in range(B)]
-        lib = ctx_ba.lib
-        for i, w in enumerate(wins_r):
-            for k in range(10):
-                w.ctx.check(lib.ssx_ba_window_push_keyframe_slots(w.handle, k, *feeds[i % N_TRAJ][k]["args_slots"]))
-        groups = []
-        keep_out = []
-        for g in range(G_W):
-            idx = [i for i in range(B) if grp_of[i] == g]
-            hs_arr = (C.c_void_p * len(idx))(*[wins_r[i].handle for i in idx])
-            res_arr = (BaResult * len(idx))()
-            for j in range(len(idx)):                                   # result buffers sized for the largest window state
-                po = np.zeros((16, 7)); pt = np.zeros((400 * 16, 3))
-                keep_out.append((po, pt))
-                res_arr[j].poses_out = ptr(po, dbl_p); res_arr[j].points_out = ptr(pt, dbl_p)
-            groups.append((idx, hs_arr, res_arr))
-        it_count = [0] * G_W
-        t_solve = [0.0] * G_W
-        t_edit = [0.0] * G_W
-        err_box = []
-        # the edits of a step, one ssx_ba_window_update per (window, step), built once (a C caller fills them from its map);
-        # every window gets its own output array for the slots of its new landmarks
-        from ssvio_amd._lib import BaWindowUpdate
-        lib.ssx_ba_window_update_batch.restype = C.c_int32
-        lib.ssx_ba_window_update_batch.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(BaWindowUpdate), C.POINTER(C.c_int32)]
-        upd = {}
-        for g in range(G_W):
-            idx = groups[g][0]
-            for k in range(10, 10 + CH_WARM + CH_STEPS):
-                arr = (BaWindowUpdate * len(idx))()
-                for j, i in enumerate(idx):
-                    a = feeds[i % N_TRAJ][k]
-                    so = np.zeros(len(a["new_ids"]), dtype=np.int32)
-                    keep_out.append(so)
-                    u = arr[j]
-                    u.pop = 1; u.pop_kf_id = k - 10; u.push = 1; u.kf_id = k
-                    u.pose7 = ptr(a["pose"], dbl_p); u.pose_fixed = 0; u.n_new = len(a["new_ids"]); u.new_ids = ptr(a["new_ids"], i64_p)
-                    u.new_xyz = ptr(a["new_xyz"], dbl_p); u.new_fixed = ptr(a["new_fixed"], u8_p); u.new_slots_out = ptr(so, i32p)
-                    u.n_obs = len(a["obs_slot"]); u.obs_slot = ptr(a["obs_slot"], i32p); u.obs_uv = ptr(a["obs_uv"], dbl_p)
-                upd[(g, k)] = arr
-
-        def group_steps(g, k0, k1):
-            idx, hs_arr, res_arr = groups[g]
-            try:
-                for k in range(k0, k1):
-                    tq = time.perf_counter()
-                    ctx_w[g].check(lib.ssx_ba_window_update_batch(len(idx), hs_arr, upd[(g, k)], None))
-                    t_edit[g] += time.perf_counter() - tq
-                    tq = time.perf_counter()
-                    ctx_w[g].check(lib.ssx_ba_window_solve_batch(len(idx), hs_arr, res_arr))
-                    t_solve[g] += time.perf_counter() - tq
-                    if os.environ.get("SSX_WIN_TIMING"):
-                        print(f"[bench] group {g} step {k}: solve call {1e3 * (time.perf_counter() - tq):.3f} ms (Python's clock)", file=sys.stderr)
-                    it_count[g] += sum(res_arr[j].n_iters for j in range(len(idx)))
-                    step_bar.wait()
-            except Exception as exc_:                                  # noqa: BLE001
-                err_box.append(exc_)
-                step_bar.abort()
-
-        # (the group threads live through warm-up and timed steps: a new thread's first HIP call costs ~10 ms of runtime set-up)
-        import concurrent.futures as cf
-        pool_w = cf.ThreadPoolExecutor(max_workers=G_W)
-
-        # one front-end batch per step, enqueued when the step starts (as in region 1: it runs beside the step's window solves);
-        # enqueueing all of them up front puts 100 ms of front-end kernels ahead of the solves' streams
-        step_bar = threading.Barrier(G_W + 1)
-
-        def run_steps(k0, k1):
-            fut = [pool_w.submit(group_steps, g, k0, k1) for g in range(G_W)]
-            try:
-                for _ in range(k1 - k0):
-                    orb.stereo_batch_enqueue(ctx)
-                    step_bar.wait()
-            except threading.BrokenBarrierError:
-                pass
-            for f_ in fut:
-                f_.result()
-            if err_box:
-                raise err_box[0]
-
-        for g in range(G_W):
-            ctx_w[g].check(lib.ssx_ba_window_solve_batch(len(groups[g][0]), groups[g][1], groups[g][2]))
-        run_steps(10, 10 + CH_WARM)
-        for c_ in ctx_w:
-            c_.synchronize()
-        barrier()
-        it_count = [0] * G_W
-        t_solve = [0.0] * G_W
-        t_edit = [0.0] * G_W
-        t0 = time.perf_counter()
-        run_steps(10 + CH_WARM, 10 + CH_WARM + CH_STEPS)
-        for c_ in ctx_w:
-            c_.synchronize()
-        torch.cuda.synchronize(dev)
-        ch_elapsed = time.perf_counter() - t0
-        it_ch = sum(it_count)
-        nkf, nlm, nob = wins_r[0].size()
-        churn = {"value": round(world * B * CH_STEPS / ch_elapsed, 2), "unit": "stereo frames/s", "ms_per_step": round(ch_elapsed / CH_STEPS * 1e3, 4),
-                 "host_threads": G_W, "ms_per_step_inside_solve_calls": round(max(t_solve) / CH_STEPS * 1e3, 4),
-                 "ms_per_step_inside_update_calls": round(max(t_edit) / CH_STEPS * 1e3, 4), "window": {"keyframes": nkf, "landmarks": nlm, "observations": nob},
-                 "lm_iterations_per_window": round(it_ch / (CH_STEPS * B), 2),
-                 "what": "front-end batch + B resident sliding windows (ssx_ba_window) in G groups, one host thread + context per group: per step "
-                         "every window pops its oldest keyframe and pushes a new one by landmark slots (pose, ~400 landmarks, ~2000 observations: "
-                         "the only data that crosses PCIe on the way in) -- one ssx_ba_window_update_batch call per group, the windows spread over "
-                         "the library's host threads -- then ssx_ba_window_solve_batch optimises the group's windows where they lie and returns "
-                         "poses + landmarks; rank 0's own clock.  ms_per_step_inside_solve_calls / _update_calls = the busiest thread's time inside "
-                         "ssx_ba_window_solve_batch (pending uploads, counting tables, device-side marshalling, solve, download) / inside "
-                         "ssx_ba_window_update_batch"}
-        pool_w.shutdown()
-        for w in wins_r:
-            w.close()
-        for c_ in ctx_w:
-            c_.close()
-
-    except Exception as exc:                                           # noqa: BLE001 -- an extra figure, never fatal
-        if not args.lean:
-            print(f"[bench] resident-window region skipped: {exc!r}", file=sys.stderr)
 
     # ---------------- timed region 2: the front-end alone (round 1's `value`) ----------------
     barrier()
@@ -755,7 +645,7 @@ def main():
     # ---------------- configs[0] at its stated size: 200 KITTI-00-shaped pairs through the headless test_system ----------------
     # /root/reference/test/test_system.cpp:28-50 + config/kitti_00.yaml: load a KITTI-layout sequence, System::RunStep per pair
     # (LK tracking, pose-only LM, keyframes: detection + stereo LK + triangulation + the local BA on the resident window), save
-    # the keyframe trajectory.  Real KITTI is not available offline: the drive is the rendered corridor of ssvio_amd.synth
+    # the keyframe trajectory.  Real KITTI is not available offline: the drive is the rendered corridor of tools.synth
     # (forward motion 0.8 m per frame, exact stereo geometry, ground-truth poses).  A single live stream is latency-bound --
     # one pair at a time, a handful of small dependent launches per frame -- so this is a LATENCY figure next to the
     # throughput headline; `eight_streams` is the same loop eight times side by side on this one GPU (configs[4]'s shape).
@@ -765,7 +655,7 @@ def main():
             import re
             import subprocess
             from ssvio_amd import build as sb
-            from ssvio_amd.synth import write_settings
+            from tools.synth import write_settings
             if c1_gen is not None:
                 _, gen_err = c1_gen.communicate(timeout=1200)
                 if c1_gen.returncode != 0:
@@ -819,6 +709,16 @@ def main():
             print(f"[bench] configs[0] leg skipped: {exc!r}", file=sys.stderr)
             c1 = {"skipped": repr(exc)[:300]}
 
+    # ---------------- SURVEY.md 8-F's "next" rows + A11, each with its own line (tools/bench_next.py) ----------------
+    next_rows = None
+    if rank == 0 and world == 1 and not args.lean:
+        try:
+            from tools import bench_next
+            next_rows = bench_next.next_rows(ssvio_amd, ctx_ba, cpu=not args.no_cpu_baseline)
+        except Exception as exc:                                       # noqa: BLE001 -- extra lines, never fatal
+            print(f"[bench] next_rows skipped: {exc!r}", file=sys.stderr)
+            next_rows = {"skipped": repr(exc)[:300]}
+
     # ---------------- CPU baseline (rank 0, N == 1 only): the same composite on one host core ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.lean:
@@ -868,7 +768,7 @@ def main():
                 import subprocess
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import host_util
-                from ssvio_amd.synth import write_settings
+                from tools.synth import write_settings
                 runner = host_util.build_test_binaries()["oracle_runner"]
                 cfg_c = write_settings(os.path.join(c1_dir, "cfg_cpu.yaml"), {})
                 tcpu = time.perf_counter()
@@ -893,7 +793,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (front-end) + f64 (BA)", "data": "synthetic",
             "config": {"workload": "C2 + C3: 1241x376 synthetic stereo, 2000 ORB feats/img, 8 levels, extract+match+triangulate, then one "
-                                   "local BA (10 KF x 4000 landmarks x 20000 edges, <= 5 x optimize(10), analytic Jacobians) per pair",
+                                   "local BA per pair on a live sliding window (10 KF x 20000 edges, one keyframe replaced per step, <= 5 x "
+                                   "optimize(10), analytic Jacobians)",
                        "pairs_per_step_per_gpu": B, "ba_windows_per_step_per_gpu": B, "ba_groups": ba_groups,
                        "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
                        "avg_keypoints_per_image": round(kp_total / I, 1),
@@ -904,18 +805,25 @@ def main():
                                  "copy stream beside step k's kernels, ssx_stereo_batch_run on the batch uploaded during the step before)",
                        "h2d_bytes_per_step_per_gpu": h2d_bytes_per_step,
                        "downloaded_every_step": "keypoint / match / triangulation counts of every pair (collected one step behind: the batch of step "
-                                                "k - 1 while batch k is in the front-end) + the optimised keyframe poses of every window",
-                       "windows": "resident in HBM (ssx_ba_batch: marshalled + uploaded before the clock starts, re-solved from the uploaded state every step)"},
+                                                "k - 1 while batch k is in the front-end) + the optimised keyframe poses AND landmarks of every window",
+                       "windows": "B live sliding windows (ssx_ba_window) resident in HBM: per step every window pops its oldest keyframe and pushes a "
+                                  "new one by landmark slots (pose, ~400 landmarks, 2000 observations -- one ssx_ba_window_update_batch call per group), "
+                                  "then ssx_ba_window_solve_batch optimises the group's windows where they lie (backend.cpp:88-169, map.cpp:27-56, 89-160)",
+                       "window": live_info["window"], "backend_groups": live_info["host_threads"]},
+            "live_backend": live_info,
+            "frozen_batch": {"value": round(frozen_value, 2), "unit": "stereo frames/s", "ms_per_step": round(frozen_elapsed / FROZEN_STEPS * 1e3, 4),
+                             "what": "rounds 2-4's headline: the same front-end step (host images in, counts out) beside a FROZEN batch of B C3 windows "
+                                     "(ssx_ba_batch: marshalled + uploaded before the clock starts, re-solved from the same state every step, poses "
+                                     "downloaded) -- no keyframe enters or leaves a window"},
             "resident": {"value": round(resident_value, 2), "unit": "stereo frames/s", "ms_per_step": round(resident_elapsed / RES_STEPS * 1e3, 4),
-                         "what": "rounds 1-3's headline: the same step with the images resident in HBM and nothing downloaded"},
+                         "what": "rounds 1-3's headline: the frozen batch with the images resident in HBM too and nothing downloaded"},
             "roofline_frac": roofline["frac"], "roofline_hbm_frac": roofline["hbm_frac"], "roofline_flops_frac": roofline["flops_frac"],
             "roofline_traffic_ratio": roofline["traffic_ratio"],
             "c1": c1,
             "host_buffers_inclusive": {"value": None if host_value != host_value else round(host_value, 2), "unit": "stereo frames/s",
                                        "what": "the same step with the B windows handed over as host arrays every step (ssx_ba_solve_batch: host "
                                                "marshalling on 16 threads + one PCIe upload + one download of poses / points); images still resident",
-                                       "two_batches_in_flight": None if pipe_value is None else round(pipe_value, 2),
-                                       "resident_windows_one_keyframe_replaced_per_step": churn},
+                                       "two_batches_in_flight": None if pipe_value is None else round(pipe_value, 2)},
             "roofline": roofline,
             "frontend": {"metric": "stereo frames/s (ORB extract + row-band match + triangulate), no BA", "value": round(fe_value, 2),
                          "ms_per_step": round(fe_elapsed / args.steps * 1e3, 4),
@@ -930,6 +838,7 @@ def main():
                    "note": "batched = resident windows (ssx_ba_batch_solve, no PCIe traffic but the LM control words); one_window = ssx_ba_solve "
                            "incl. host marshalling and host<->device transfer of the window and its result"},
             "ba_c4": c4,
+            "next_rows": next_rows,
             "cpu_baseline": cpu,
         }
         if cpu:

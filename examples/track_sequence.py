@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from ssvio_amd import synth  # noqa: E402
-from ssvio_amd.synth import KITTI_BASELINE, KITTI_K, pose_inv, pose_mul, quat_rot  # noqa: E402
+from tools import synth  # noqa: E402
+from tools.synth import KITTI_BASELINE, KITTI_K, pose_inv, pose_mul, quat_rot  # noqa: E402
 
 
 class GpuProvider:

@@ -225,6 +225,13 @@ SSX_API void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups);
    gone; the entry point remains for callers built against that header and does nothing. */
 SSX_API void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
+/* Process-wide: batched solves (ssx_ba_solve_batch, ssx_ba_batch_solve, ssx_ba_window_solve_batch) of DIFFERENT contexts take turns on
+ * the device (FIFO) for their device phase -- the LM slots, enqueued at once, and the one synchronisation behind them; the host phase
+ * in front of it (pending uploads, counting tables) and the unpacking behind it stay outside the turn.  For servers that drive groups of
+ * windows from several host threads, one context each (the backend threads of concurrent streams, backend.cpp:57-76): without turns the
+ * device phases of the groups interleave, end together, and the groups' host phases then coincide with the device idle; with turns one
+ * group's host phase lies beside the other's kernels.  Off by default; no effect on results. */
+SSX_API void ssx_ba_device_turns(int32_t enable);
 
 /* ------------------------------------------------------------------------------------------------
  * A sliding local-BA window that STAYS in HBM.  Backend::OptimizeActiveMap (src/ssvio/backend.cpp:88-169) rebuilds its
@@ -512,7 +519,10 @@ SSX_API ssx_status ssx_stereo_batch_fetch(ssx_ctx* ctx, int32_t pair, ssx_stereo
  *   ssx_stereo_batch_host    upload + run in one call
  *   ssx_stereo_batch_counts  the counts of the OLDEST batch that was run and not collected yet (at most two may be waiting): waits
  *                            for that batch only; counts_out = pairs x 4 int32: nL, nR, n_matched, n_triangulated.
- *                            (ssx_stereo_batch_fetch copies one pair's keypoints / matches / points of the batch run LAST.)
+ *                            A run that failed after it consumed its batch still owns its place in this FIFO: the counts call
+ *                            that collects it returns the run's status, and the batches around it keep their own counts.
+ *                            ssx_stereo_batch_fetch copies one pair's keypoints / matches / points of the batch run LAST -- after
+ *                            run(k + 1); counts() -> batch k, a fetch reads batch k + 1: fetch a batch before the next one is run.
  * A server keeps one upload ahead and collects one batch behind -- upload(k + 1); run(k); ...; counts() -> batch k - 1 -- so that
  * batch k + 1 crosses PCIe and batch k's front-end runs while the host waits for nothing but its own backend (bench.py's
  * headline region); counts() right after run(k) returns batch k's counts once it is done. */

@@ -15,7 +15,7 @@ def _work(idx, pairs, start_at):
     import numpy as np
 
     from oracle import pyoracle as po
-    from ssvio_amd.synth import make_stereo_pair
+    from tools.synth import make_stereo_pair
     imgs = [make_stereo_pair(seed=50000 + idx * pairs + i)[:2] for i in range(pairs)]
     po.orb_extract(imgs[0][0][:64, :96].copy())                       # load the library before the clock starts
     late = time.time() > start_at

@@ -106,7 +106,7 @@ def _ba_args(pr, poses, points):
 
 def ba_solve(pr, which="oracle", outer_rounds=5, iters=10, chi2_th=5.891, huber_delta=5.891,
              inlier_ratio=0.7, jac_mode=1):
-    """Run the BA on a problem dict (ssvio_amd.synth.make_ba_problem layout). which = oracle | ref."""
+    """Run the BA on a problem dict (tools.synth.make_ba_problem layout). which = oracle | ref."""
     poses = np.ascontiguousarray(pr["poses"], dtype=np.float64).copy()
     points = np.ascontiguousarray(pr["points"], dtype=np.float64).copy()
     E = pr["E"]

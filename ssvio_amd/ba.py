@@ -2,7 +2,7 @@
 (/root/reference/src/ssvio/backend.cpp:78-245).
 
 `problem` is a dict of flat arrays in the layout of ssx_ba_problem (include/ssx.h); see
-ssvio_amd.synth.make_ba_problem.  Every function here calls the HIP library; nothing is computed in
+tools.synth.make_ba_problem.  Every function here calls the HIP library; nothing is computed in
 Python.
 """
 from __future__ import annotations

@@ -1791,6 +1791,41 @@ class ParPool {
   bool stop_ = false;
 };
 
+// ssx_ba_device_turns: batched solves of DIFFERENT contexts take turns on the device.  A batched solve is a host phase (pending
+// uploads, counting tables, marshalling) followed by a device phase (the LM slots, enqueued at once, one synchronisation).  Two
+// host threads that drive two contexts side by side fall into lock step when their device phases interleave -- both finish together,
+// both then sit in their host phases with the device idle.  With turns the device phases run one after the other (FIFO), so one
+// context's host phase lies beside the other's kernels: the whole point of driving groups of windows from several threads.
+class DeviceTurns {
+ public:
+  void enable(bool on) { on_.store(on, std::memory_order_relaxed); }
+  bool enabled() const { return on_.load(std::memory_order_relaxed); }
+  void acquire()
+  {
+    std::unique_lock<std::mutex> lk(mu_);
+    const unsigned long my = next_ticket_++;
+    cv_.wait(lk, [&] { return serving_ == my; });
+  }
+  void release()
+  {
+    { std::lock_guard<std::mutex> lk(mu_); ++serving_; }
+    cv_.notify_all();
+  }
+ private:
+  std::atomic<bool> on_{false};
+  std::mutex mu_;
+  std::condition_variable cv_;
+  unsigned long next_ticket_ = 0, serving_ = 0;
+};
+static DeviceTurns g_turns;
+struct TurnGuard {
+  bool held = false;
+  TurnGuard() { if (g_turns.enabled()) { g_turns.acquire(); held = true; } }
+  ~TurnGuard() { if (held) g_turns.release(); }
+  TurnGuard(const TurnGuard&) = delete;
+  TurnGuard& operator=(const TurnGuard&) = delete;
+};
+
 struct BaWorkspace {
   DevBuf arena;      // everything on the device
   HostBuf stage;     // pinned upload / download staging
@@ -3627,6 +3662,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   int spec_maxP = 0;
   if (results) for (int w = 0; w < n; ++w) { spec_poses = spec_poses && !results[w].points_out; spec_maxP = std::max(spec_maxP, B->P[w]); }
   spec_poses = spec_poses && (size_t)n * 7 * spec_maxP <= B->out_total;
+  bool spec_done = false;                                            // a speculative poses download was really enqueued (no LM round may run at all)
   double* hscal = B->scal->as<double>();                             // n x SC_N, then n x 3 x MAX_STATS, then the ctrl words
   int* h_ctrl = reinterpret_cast<int*>(hscal + (size_t)n * (SC_N + 3 * SSX_BA_MAX_STATS));
   for (int w = 0; w < n; ++w) wsn[w].done = !(B->devs[w].nCh > 0) || opt.outer_rounds <= 0;
@@ -3706,6 +3742,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
         hipLaunchKernelGGL(k_pack_poses_b, dim3(n), dim3(CH), 0, s, dv, (const int*)nullptr, n, spec_maxP, d_out);
         SSX_HIP_TRY(ctx, hipMemcpyAsync(B->stage->as<double>(), d_out, sizeof(double) * (size_t)n * 7 * spec_maxP, hipMemcpyDeviceToHost, s));
         SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+        spec_done = true;
       }
       SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
       bool stopped = true;
@@ -3737,10 +3774,12 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   }
   // ---- statistics + results: one packing kernel, one download
   const bool want_err = B->with_err;
-  bool poses_only = spec_poses;
+  // (iters <= 0, outer_rounds <= 0 or windows without a single chunk: no round ran, nothing was staged -- the ordinary
+  // gather / pack / download returns the input state)
+  const bool poses_only = spec_poses && spec_done;
   const int maxP = spec_maxP;
   double* h_out = B->stage->as<double>();
-  if (!spec_poses) {
+  if (!poses_only) {
   for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = wsn[w].trial_err ? 1 : 0; h_ctrl[2 * n + w] = 1; }
   hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 1);
   SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal + (size_t)n * SC_N, d_gather, sizeof(double) * (size_t)n * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, s));
@@ -3753,7 +3792,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * B->out_total, hipMemcpyDeviceToHost, s));
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
-  }   // (!spec_poses)
+  }   // (!poses_only)
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   static const bool timing = getenv("SSX_BATCH_TIMING") != nullptr;
@@ -3864,6 +3903,7 @@ ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* pro
   ssx_status st = batch_build(ctx, n, probs, opt, with_err, false, &B);
   if (st == SSX_ERR_UNSUPPORTED) return sequential();                 // a large window in the batch
   if (st != SSX_OK) return st;
+  TurnGuard turn;                                                     // (ssx_ba_device_turns: the device phase, one context at a time)
   return batch_run(&B, results, nullptr);
 }
 
@@ -3891,8 +3931,11 @@ ssx_status ssx_ba_batch_create(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* pr
 ssx_status ssx_ba_batch_solve(ssx_ba_batch* batch, ssx_ba_result* results, int32_t* lm_iterations_total)
 {
   if (!batch) return SSX_ERR_INVALID_ARG;
+  TurnGuard turn;
   return batch_run(batch, results, lm_iterations_total);
 }
+
+void ssx_ba_device_turns(int32_t enable) { g_turns.enable(enable != 0); }
 
 int32_t ssx_ba_batch_size(const ssx_ba_batch* batch) { return batch ? batch->n : 0; }
 

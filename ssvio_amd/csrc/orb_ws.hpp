@@ -119,6 +119,7 @@ struct OrbWorkspace {
   HostBuf counts_pinned;        // [pairs][4] counts + [2 pairs] status words of the last enqueued batch
   hipEvent_t ev_counts[2] = {nullptr, nullptr};   // per run batch: its counts have reached counts_pinned
   int cnt_first = 0, cnt_count = 0, cnt_pairs[2] = {0, 0};
+  ssx_status cnt_fail[2] = {SSX_OK, SSX_OK};           // a run that failed after consuming its batch still owns a slot of the FIFO
 };
 
 namespace ssxorb {

@@ -693,7 +693,8 @@ ssx_status ssx_stereo_batch_dev(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs
 //                             one after it) and return: the copy runs beside whatever the GPU is doing
 //   ssx_stereo_batch_run      enqueue the pipeline on the OLDEST uploaded batch (no synchronisation)
 //   ssx_stereo_batch_host     upload + run in one call
-//   ssx_stereo_batch_counts   wait for the batch run LAST and return its counts
+//   ssx_stereo_batch_counts   wait for the OLDEST batch that was run and not collected yet (at most two wait) and return its counts
+//   ssx_stereo_batch_fetch    one pair's arrays of the batch run LAST (after run(k + 1); counts() -> k the two name different batches)
 // A server keeps one upload ahead: upload(k + 1); run(k); ...; counts(k) -- batch k + 1 crosses PCIe while batch k's kernels run.
 static ssx_status batch_ingest_init(ssx_ctx* ctx, OrbWorkspace* ws)
 {
@@ -752,23 +753,32 @@ ssx_status ssx_stereo_batch_run(ssx_ctx* ctx, const ssx_orb_params* orb, const s
   SSX_HIP_TRY(ctx, hipEventRecord(ws->ev_free[b], ctx->stream));
   ws->free_pending[b] = true;
   ws->up_first ^= 1; ws->up_count--;
-  st = run_pipeline(ctx);
-  if (st != SSX_OK) return st;
-  MatchDev m{};
-  st = make_match_dev(ctx, pairs, *mp, *rig, nullptr, m);
-  if (st != SSX_OK) return st;
-  st = launch_stereo(ctx, m);
-  if (st != SSX_OK) return st;
-  // the counts of this batch leave the device before the next batch's kernels overwrite them (stream order); an event per batch
-  // lets ssx_stereo_batch_counts wait for THIS batch only -- a caller may run the next batch first and collect one batch behind
+  // From here on the batch is CONSUMED (its buffer is promised to the next upload): whatever happens below, it takes its slot in
+  // the counts FIFO, so a caller that pipelines upload / run / counts stays aligned -- a failure is reported by this call AND by
+  // the ssx_stereo_batch_counts call that collects this batch, never as another batch's counts.
   const int slot = (ws->cnt_first + ws->cnt_count) & 1;
-  int* hc = ws->counts_pinned.as<int>() + (size_t)slot * 6 * pairs;
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hc, ws->pair_counts, sizeof(int) * 4 * pairs, hipMemcpyDeviceToHost, ctx->stream));
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hc + 4 * (size_t)pairs, ws->dev.status, sizeof(int) * 2 * pairs, hipMemcpyDeviceToHost, ctx->stream));
-  SSX_HIP_TRY(ctx, hipEventRecord(ws->ev_counts[slot], ctx->stream));
+  auto rest = [&]() -> ssx_status {
+    ssx_status r = run_pipeline(ctx);
+    if (r != SSX_OK) return r;
+    MatchDev m{};
+    r = make_match_dev(ctx, pairs, *mp, *rig, nullptr, m);
+    if (r != SSX_OK) return r;
+    r = launch_stereo(ctx, m);
+    if (r != SSX_OK) return r;
+    // the counts of this batch leave the device before the next batch's kernels overwrite them (stream order); an event per batch
+    // lets ssx_stereo_batch_counts wait for THIS batch only -- a caller may run the next batch first and collect one batch behind
+    int* hc = ws->counts_pinned.as<int>() + (size_t)slot * 6 * pairs;
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(hc, ws->pair_counts, sizeof(int) * 4 * pairs, hipMemcpyDeviceToHost, ctx->stream));
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(hc + 4 * (size_t)pairs, ws->dev.status, sizeof(int) * 2 * pairs, hipMemcpyDeviceToHost, ctx->stream));
+    return SSX_OK;
+  };
+  st = rest();
+  const hipError_t ev_err = hipEventRecord(ws->ev_counts[slot], ctx->stream);
+  if (st == SSX_OK && ev_err != hipSuccess) { ctx->set_error("ssx_stereo_batch_run: hipEventRecord: %s", hipGetErrorString(ev_err)); st = SSX_ERR_HIP; }
   ws->cnt_pairs[slot] = pairs;
+  ws->cnt_fail[slot] = st;
   ws->cnt_count++;
-  return SSX_OK;
+  return st;
 }
 
 ssx_status ssx_stereo_batch_host(ssx_ctx* ctx, int32_t pairs, const uint8_t* imgs_host, int32_t stride, int32_t rows, int32_t cols,
@@ -789,8 +799,10 @@ ssx_status ssx_stereo_batch_counts(ssx_ctx* ctx, int32_t* counts_out)
   OrbWorkspace* ws = ctx->orb;
   if (ws->cnt_count < 1) { ctx->set_error("ssx_stereo_batch_counts: no batch has been run (ssx_stereo_batch_run first)"); return SSX_ERR_INVALID_ARG; }
   const int slot = ws->cnt_first;
-  SSX_HIP_TRY(ctx, hipEventSynchronize(ws->ev_counts[slot]));
-  ws->cnt_first ^= 1; ws->cnt_count--;
+  const hipError_t sync_err = hipEventSynchronize(ws->ev_counts[slot]);
+  ws->cnt_first ^= 1; ws->cnt_count--;                               // (collected either way: the FIFO stays aligned with the runs)
+  if (ws->cnt_fail[slot] != SSX_OK) { ctx->set_error("ssx_stereo_batch_counts: the run of this batch failed (status %d)", (int)ws->cnt_fail[slot]); return ws->cnt_fail[slot]; }
+  SSX_HIP_TRY(ctx, sync_err);
   const int pairs = ws->cnt_pairs[slot];
   const int* hc = ws->counts_pinned.as<int>() + (size_t)slot * 6 * pairs;
   for (int i = 0; i < 2 * pairs; ++i)

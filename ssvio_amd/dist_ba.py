@@ -13,7 +13,7 @@ import numpy as np
 
 
 def shard_problem(pr: dict, rank: int, world: int) -> dict:
-    """The shard of `pr` (ssvio_amd.synth.make_ba_problem layout) owned by `rank`: landmarks l % world == rank,
+    """The shard of `pr` (tools.synth.make_ba_problem layout) owned by `rank`: landmarks l % world == rank,
     re-indexed compactly, with all their edges; poses unchanged.  `lm_global` maps local -> global landmark ids."""
     lm_global = np.nonzero(np.arange(pr["points"].shape[0]) % world == rank)[0]
     remap = -np.ones(pr["points"].shape[0], dtype=np.int64)

@@ -265,7 +265,10 @@ void Backend::WindowMirrorInsert(const KeyFramePtr& kf)
     obs_lm.push_back((int64_t)mp->id);
     obs_uv.push_back(feat->x); obs_uv.push_back(feat->y);
     obs_cam.push_back(feat->is_on_left_frame ? 0 : 1);
-    feats[mp->id] = feat;
+    // (one left feature per (keyframe, map point): WindowApply resolves an edge to its Feature through this pair; a keyframe that
+    // carried two would leave the second one's flags stale, so the assumption is enforced instead of overwritten silently)
+    if (!feats.emplace(mp->id, feat).second)
+      throw std::logic_error("Backend: keyframe " + std::to_string(kf->key_frame_id) + " holds two left features of map point " + std::to_string(mp->id));
   }
   window_->Push((int64_t)kf->key_frame_id, kf->pose.data(), (int)new_ids.size(), new_ids.data(), new_xyz.data(), new_fixed.data(), (int)obs_lm.size(),
                 obs_lm.data(), obs_uv.data(), obs_cam.data());

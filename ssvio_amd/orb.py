@@ -100,8 +100,11 @@ def match_params(band_px=2.0, min_disp=0.0, max_disp=120.0, max_dist=80, max_oct
     return MatchParams(band_px, min_disp, max_disp, max_dist, max_octave_diff, scale_factor)
 
 
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)   # fx fy cx cy  (/root/reference/config/kitti_00.yaml:3-6)
+KITTI_BASELINE = 386.1448 / KITTI_K[0]               # bf / fx (kitti_00.yaml:26, system.cpp:69-70)
+
+
 def stereo_rig(K=None, baseline=None):
-    from .synth import KITTI_BASELINE, KITTI_K
     K = KITTI_K if K is None else K
     return StereoRig(float(K[0]), float(K[1]), float(K[2]), float(K[3]), float(KITTI_BASELINE if baseline is None else baseline))
 

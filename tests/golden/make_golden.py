@@ -6,7 +6,7 @@ Run in the BUILD container (where /root/reference is mounted and oracle/_ref/lib
 
 ref_*.npz hold outputs of the REAL reference arithmetic (oracle/ref_driver.cpp linked against the
 reference's g2otypes.hpp / algorithm.hpp / g2o / Sophus / Eigen): they pin the CPU oracle and travel to the
-GPU box, where /root/reference does not exist.  Inputs are regenerated from seeds by ssvio_amd.synth (the
+GPU box, where /root/reference does not exist.  Inputs are regenerated from seeds by tools.synth (the
 arrays that cannot be regenerated bit-for-bit are stored).  self_orb.npz holds outputs of OUR restatement
 of the ORB path (no reference implementation of that half can run anywhere: OpenCV is absent) -- it is a
 regression pin of the oracle, not a reference vector.
@@ -19,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle as po  # noqa: E402
-from ssvio_amd import synth  # noqa: E402
+from tools import synth  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -103,9 +103,9 @@ def make_window_golden():
     """ref_window.npz: the reference's backend over a DRIVE -- fourteen keyframes through a five-keyframe active map, every
     window optimised by the REAL g2o classes (po.ba_solve "ref"), every result written back the way backend.cpp:205-244 does
     (outlier observations unlinked, condemned map points deleted, the first-observer rule of backend.cpp:125-130 deciding which
-    map points are fixed): the map bookkeeping is ssvio_amd.mapmodel.ActiveMap, the arithmetic is the reference's.  The GPU test
+    map points are fixed): the map bookkeeping is tools.mapmodel.ActiveMap, the arithmetic is the reference's.  The GPU test
     replays the same drive on an ssx_ba_window and must take the same decisions at every keyframe."""
-    from ssvio_amd.mapmodel import ActiveMap, make_window_scenario
+    from tools.mapmodel import ActiveMap, make_window_scenario
     frames = make_window_scenario(**WINDOW_SCENARIO)
     m = ActiveMap(WINDOW_SCENARIO["n_active"])
     g = {"cfg": np.array([WINDOW_SCENARIO[k] for k in ("n_kf", "n_active", "new_per_kf", "track_len", "seed")])}

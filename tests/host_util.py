@@ -11,8 +11,8 @@ OUT = os.path.join(ROOT, "tests", "host", "build")
 import sys  # noqa: E402
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from ssvio_amd.synth import KITTI00_SETTINGS as DEFAULT_CONFIG  # noqa: E402  (the reference's config/kitti_00.yaml values)
-from ssvio_amd.synth import write_settings  # noqa: E402
+from tools.synth import KITTI00_SETTINGS as DEFAULT_CONFIG  # noqa: E402  (the reference's config/kitti_00.yaml values)
+from tools.synth import write_settings  # noqa: E402
 
 
 def write_config(path, overrides):
@@ -23,7 +23,7 @@ def write_sequence(root, n_frames=12, step=0.12, seed=0, dt=0.1):
     """make_lateral_sequence as <root>/seq/{times.txt,image_0,image_1}.  Returns dir, dt, camera centres [n,3]."""
     from PIL import Image
 
-    from ssvio_amd.synth import KITTI_BASELINE, make_lateral_sequence
+    from tools.synth import KITTI_BASELINE, make_lateral_sequence
     frames, gt, _ = make_lateral_sequence(n_frames=n_frames, step=step, seed=seed)
     d = os.path.join(root, "seq")
     for sub in ("image_0", "image_1"):
@@ -41,7 +41,7 @@ def write_corridor_sequence(root, n_frames=30, step=0.8, seed=0, dt=0.1):
     """make_corridor_sequence (forward drive, KITTI-00-shaped) as <root>/seq/..."""
     from PIL import Image
 
-    from ssvio_amd.synth import make_corridor_sequence
+    from tools.synth import make_corridor_sequence
     frames, gt, centres = make_corridor_sequence(n_frames=n_frames, step=step, seed=seed)
     d = os.path.join(root, "seq")
     for sub in ("image_0", "image_1"):

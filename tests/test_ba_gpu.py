@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from ssvio_amd import ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -164,7 +164,7 @@ def test_pose_only_matches_reference_golden_and_oracle(ctx, po, name):
     """FrontEnd::EstimateCurrentPose (frontend.cpp:184-270): the one-launch kernel against the vectors produced by the
     REAL reference (g2o + EdgeProjectionPoseOnly) and against the CPU oracle."""
     import os
-    from ssvio_amd.synth import make_pose_only_problem
+    from tools.synth import make_pose_only_problem
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz"))
     M, seed, fg = [int(v) for v in G[f"{name}_cfg"]]
     pp = make_pose_only_problem(M=M, seed=seed, frac_gross=fg / 100.0)
@@ -178,7 +178,7 @@ def test_pose_only_matches_reference_golden_and_oracle(ctx, po, name):
 
 
 def test_pose_only_edge_cases(ctx, po):
-    from ssvio_amd.synth import make_pose_only_problem
+    from tools.synth import make_pose_only_problem
     pp = make_pose_only_problem(M=700, seed=11, frac_gross=0.3)        # more edges than threads; many outliers
     g = ba.pose_only_opt(ctx, pp["pose"], pp["K"], pp["xyz"], pp["uv"])
     o = po.pose_only(pp)
@@ -538,7 +538,7 @@ import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
 import ssvio_amd
 from ssvio_amd import ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 ctx = ssvio_amd.Context(0)
 out = {}
 def with_duplicates(pr, n):   # right-camera observations of the first n landmarks from the pose of their first edge
@@ -634,6 +634,26 @@ def test_poses_only_download_equals_the_full_download(ctx):
                 k = min(one["n_iters"], len(one["chi2"]))
                 assert np.array_equal(np.array(lean.res[i].iter_chi2[:k]), one["chi2"][:k])
     lean.close()
+
+
+@pytest.mark.parametrize("knob", ["iters", "outer_rounds"])
+def test_poses_only_download_without_any_lm_round_returns_the_input(ctx, knob):
+    """No LM round runs (iters = 0 or outer_rounds = 0): batch_run's speculative poses download is never enqueued, and the call
+    must fall back to the ordinary gather -- the INPUT poses come back, not what the staging block held after an earlier solve."""
+    probs = [make_ba_problem(P=10, L=500, seed=811), make_ba_problem(P=6, L=200, obs_per_lm=4, seed=812)]
+    warm = ba.BaBatch(ctx, probs, resident=True, with_edge_errors=False)
+    warm.solve(want_edges=False, summaries=False, points=False)          # leaves optimised poses in the ctx's staging memory
+    assert not np.array_equal(warm.poses[0], probs[0]["poses"])
+    warm.close()
+    kw = dict(iters=0) if knob == "iters" else dict(outer_rounds=0)
+    idle = ba.BaBatch(ctx, probs, resident=True, with_edge_errors=False, **kw)
+    one = ba.BaBatch(ctx, probs, **kw)
+    for b in (idle, one):
+        b.solve(want_edges=False, summaries=False, points=False)
+        for i, pr in enumerate(probs):
+            assert np.array_equal(b.poses[i], pr["poses"]), (knob, i)
+            assert b.res[i].n_iters == 0
+    idle.close()
 
 
 def test_bench_size_batch_equals_single_calls(ctx):
@@ -986,7 +1006,7 @@ def test_window_misuse(ctx):
 # ---- the window driven like the reference's backend drives its map (backend.cpp:205-244, map.cpp:89-194) -----------------------
 
 def _drive(ctx, frames, n_active, jac, golden=None, open_loop=False):
-    """Replays a drive (ssvio_amd.mapmodel.make_window_scenario) the way ssvio's backend would: per keyframe the map changes
+    """Replays a drive (tools.mapmodel.make_window_scenario) the way ssvio's backend would: per keyframe the map changes
     (insert, drop a keyframe, drop unobserved map points, delete condemned ones), the window receives those edits, and is
     solved; the SAME graph re-marshalled from the map (keyframes / map points ascending by id, backend.cpp:88-169) goes through
     a fresh ssx_ba_solve.  Window and fresh solve must agree BIT FOR BIT at every keyframe -- contents, fixed flags, result --
@@ -995,7 +1015,7 @@ def _drive(ctx, frames, n_active, jac, golden=None, open_loop=False):
     with the reference is about decisions (and drifts by what a gauge-free window amplifies).  open_loop: the map advances
     with the REFERENCE's results (and the window's estimate is overwritten with them), so every keyframe's optimisation starts
     from the reference's own state and is compared one to one."""
-    from ssvio_amd.mapmodel import ActiveMap, apply_edits
+    from tools.mapmodel import ActiveMap, apply_edits
     m = ActiveMap(n_active)
     win = ba.BaWindow(ctx, m.K, m.cam_ext, jac_mode=jac, fix_rule=1)
     # worst over the keyframes whose window is pinned by at least one fixed map point | over the gauge-free ones (the first
@@ -1069,7 +1089,7 @@ def _drive(ctx, frames, n_active, jac, golden=None, open_loop=False):
 def test_window_driven_like_the_backend_equals_the_remarshalled_map(ctx):
     """ssx_ba_window_remove_* / pop with the first-observer rule / landmarks that come back: 14-keyframe drives through windows
     of 4 .. 7 keyframes, non-oldest keyframes dropped now and then, 4 % gross outliers, map points condemned by the frontend"""
-    from ssvio_amd.mapmodel import make_window_scenario
+    from tools.mapmodel import make_window_scenario
     for seed, n_active, jac in ((1, 5, ba.JAC_ANALYTIC), (2, 4, ba.JAC_NUMERIC_G2O), (5, 7, ba.JAC_ANALYTIC)):
         frames = make_window_scenario(n_kf=14, n_active=n_active, seed=seed)
         stats, _ = _drive(ctx, frames, n_active, jac)
@@ -1077,7 +1097,7 @@ def test_window_driven_like_the_backend_equals_the_remarshalled_map(ctx):
 
 
 def _golden_drive():
-    from ssvio_amd.mapmodel import make_window_scenario
+    from tools.mapmodel import make_window_scenario
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_window.npz"))
     n_kf, n_active, new_per_kf, track_len, seed = (int(x) for x in G["cfg"])
     frames = make_window_scenario(n_kf=n_kf, n_active=n_active, new_per_kf=new_per_kf, track_len=track_len, seed=seed)

@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     from oracle import pyoracle as po
     from ssvio_amd.dist_ba import shard_problem
-    from ssvio_amd.synth import make_ba_problem
+    from tools.synth import make_ba_problem
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     pr = make_ba_problem(P=6, L=240, obs_per_lm=4, seed=21)
     sh = shard_problem(pr, rank, world)
@@ -83,7 +83,7 @@ def test_landmark_sharding_is_additive_world2(po):
 
 def test_shard_edge_cases():
     from ssvio_amd.dist_ba import shard_problem
-    from ssvio_amd.synth import make_ba_problem
+    from tools.synth import make_ba_problem
     pr = make_ba_problem(P=4, L=5, obs_per_lm=3, seed=1)
     tot = 0
     for r in range(8):                       # more ranks than landmarks: some shards are empty

@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
     import ssvio_amd
     from ssvio_amd import ba, dist_ba
-    from ssvio_amd.synth import make_ba_problem
+    from tools.synth import make_ba_problem
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
@@ -50,7 +50,7 @@ def _worker(rank, world, port, out_dir):
 def test_two_ranks_on_one_gpu_match_the_single_rank_solve(ctx):
     import torch.multiprocessing as mp
     from ssvio_amd import ba
-    from ssvio_amd.synth import make_ba_problem
+    from tools.synth import make_ba_problem
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, 29751, d), nprocs=2, join=True)
         r0 = pickle.load(open(os.path.join(d, "rank0.pkl"), "rb")); r1 = pickle.load(open(os.path.join(d, "rank1.pkl"), "rb"))
@@ -74,7 +74,7 @@ def _worker_native(rank, world, port, out_dir):
     import torch.distributed as dist
     import ssvio_amd
     from ssvio_amd import ba, dist_ba
-    from ssvio_amd.synth import make_ba_problem
+    from tools.synth import make_ba_problem
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(rank)
@@ -110,7 +110,7 @@ def test_native_rccl_two_gpus_match_the_single_gpu_solve(ctx):
         pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
     import torch.multiprocessing as mp
     from ssvio_amd import ba
-    from ssvio_amd.synth import make_ba_problem
+    from tools.synth import make_ba_problem
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_native, args=(2, 29763, d), nprocs=2, join=True)
         r0 = pickle.load(open(os.path.join(d, "rank0.pkl"), "rb")); r1 = pickle.load(open(os.path.join(d, "rank1.pkl"), "rb"))

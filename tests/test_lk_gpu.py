@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from ssvio_amd import lk
-from ssvio_amd.synth import make_stereo_pair
+from tools.synth import make_stereo_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -100,7 +100,7 @@ def test_chained_tracking_reuses_the_previous_pyramid(ctx, po):
     two-image call and as the oracle, over a 4-frame sequence; refused without a matching previous call"""
     from ssvio_amd import Context
     from ssvio_amd._lib import SsxError
-    from ssvio_amd.synth import make_lateral_sequence
+    from tools.synth import make_lateral_sequence
     frames = [f[0] for f in make_lateral_sequence(n_frames=4, seed=2)[0]]
     pts = _points(po, frames[0], 600)
     fresh = Context(0)

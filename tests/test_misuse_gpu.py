@@ -9,7 +9,7 @@ import pytest
 
 from ssvio_amd import _lib, ba, lk, orb
 from ssvio_amd._lib import SsxError
-from ssvio_amd.synth import make_ba_problem, make_pose_graph_problem, make_pose_only_problem, make_stereo_pair
+from tools.synth import make_ba_problem, make_pose_graph_problem, make_pose_only_problem, make_stereo_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -141,7 +141,7 @@ def test_ba_and_pose_graph_reject_bad_problems(ctx, po):
 
 def test_vocabulary_entry_points_reject_bad_arguments(ctx, po):
     from ssvio_amd import voc as svoc
-    from ssvio_amd.synth import make_vocabulary
+    from tools.synth import make_vocabulary
     lib, h = ctx.lib, ctx.handle
     vv = make_vocabulary(k=4, L=2, seed=1)
     out = C.c_void_p()

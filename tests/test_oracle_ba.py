@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from ssvio_amd import synth
+from tools import synth
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz"))
 BA_CASES = ["tiny", "mid", "C3", "gauge", "win12", "win16"]

@@ -3,7 +3,7 @@ OpenCV is not available anywhere, so these are known-answer and property tests o
 (oracle/src/lk_oracle.cpp): PARITY UNPINNED vs OpenCV, like the other OpenCV-resident arithmetic."""
 import numpy as np
 
-from ssvio_amd.synth import make_stereo_pair
+from tools.synth import make_stereo_pair
 
 
 def test_pyr_down_known_answers(po):

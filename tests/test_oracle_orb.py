@@ -132,7 +132,7 @@ def test_deterministic_sincos_never_moves_a_brief_bit(po):
     as fastAtan2 produces them: any float in [0, 360)) count the descriptor BITS that differ between the two -- for cosf / sinf and
     for cos / sin of the widened angle rounded to float.  A differing (cos, sin) pair is a 1-ulp difference; it moves a bit only
     if it flips a cvRound of a rotated tap."""
-    from ssvio_amd.synth import make_stereo_pair
+    from tools.synth import make_stereo_pair
     img = po.gauss7(make_stereo_pair(seed=21)[0])
     rng = np.random.default_rng(5)
     n = 100000

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from ssvio_amd import synth
+from tools import synth
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_pg.npz"))
 PG_CASES = {

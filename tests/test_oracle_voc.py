@@ -60,7 +60,7 @@ def test_l1_score_known_answers():
 
 def test_random_vocabulary_properties():
     """a 10^3 vocabulary: every descent ends in a leaf, the leaf is the arg-min path, values are L1-normalised, score in [0, 1]"""
-    from ssvio_amd.synth import make_vocabulary
+    from tools.synth import make_vocabulary
     po.build()
     voc = make_vocabulary(k=10, L=3, seed=1)
     rng = np.random.default_rng(0)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from ssvio_amd import orb as sorb
-from ssvio_amd.synth import KITTI_BASELINE, KITTI_K, make_stereo_pair
+from tools.synth import KITTI_BASELINE, KITTI_K, make_stereo_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -210,7 +210,7 @@ def test_tiny_budgets_return_more_than_the_budget(ctx, po):
     """a wide image with a handful of features per level: the first quadtree subdivision already makes up to
     4 * nIni nodes, so a level returns more keypoints than its budget + 3 (found by tools/fuzz_parity.py: the output
     arrays used to be sized for budget + 4 per level)"""
-    from ssvio_amd.synth import make_stereo_pair
+    from tools.synth import make_stereo_pair
     L = make_stereo_pair(seed=1008, h=368, w=1341, n_blobs=4100)[0]
     for nfeat, nlev, sf in ((50, 8, 1.1), (8, 8, 1.2), (20, 3, 1.5)):
         ex = sorb.ORBextractor(ctx, nfeatures=nfeat, scaleFactor=sf, nlevels=nlev, iniThFAST=35, minThFAST=3)
@@ -241,7 +241,7 @@ def test_triangulation_without_positive_disparity(ctx, po):
 def test_more_levels_than_the_image_has_pixels_for(ctx, po):
     """48x79 at scale 2.0 has no pixels left from level 6 on (OpenCV's resize would throw in the reference): the empty
     levels contribute nothing, the others are as always (found by tools/fuzz_parity.py)"""
-    from ssvio_amd.synth import make_stereo_pair
+    from tools.synth import make_stereo_pair
     for (h, w, nfeat, nlev, sf) in ((48, 79, 300, 8, 2.0), (63, 69, 2000, 8, 2.0), (40, 40, 100, 8, 1.5)):
         L = make_stereo_pair(seed=h + w, h=h, w=w, n_blobs=max(h * w // 100, 8))[0]
         ex = sorb.ORBextractor(ctx, nfeatures=nfeat, scaleFactor=sf, nlevels=nlev, iniThFAST=10, minThFAST=3)
@@ -317,7 +317,7 @@ def test_streamed_batches_equal_resident_batches(ctx):
     """ssx_stereo_batch_upload / _run / _counts (batches that arrive from the host, one upload kept ahead on the library's copy
     stream, two device buffers): every batch's counts and per-pair results are those of ssx_stereo_batch_dev on the same images"""
     import torch
-    from ssvio_amd.synth import make_stereo_pair
+    from tools.synth import make_stereo_pair
     B, H, W = 4, 200, 320
     prm = sorb.OrbParams(300, 1.2, 4, 20, 7)
     batches = [np.stack([np.stack(make_stereo_pair(seed=50 + 10 * k + i, h=H, w=W, n_blobs=400)[:2]) for i in range(B)]) for k in range(3)]

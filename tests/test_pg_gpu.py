@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from ssvio_amd import ba, synth
+from ssvio_amd import ba
+from tools import synth
 
 pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_pg.npz"))

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def test_tracked_sequence_gpu_equals_oracle(ctx, po):
     import track_sequence as ts
-    from ssvio_amd import synth
+    from tools import synth
     frames, gt, _ = synth.make_lateral_sequence(n_frames=12, step=0.25)
     g = ts.run(ts.GpuProvider(ctx), frames, kf_below=300)
     o = ts.run(ts.OracleProvider(po), frames, kf_below=300)

@@ -6,7 +6,7 @@ import pytest
 
 from ssvio_amd import voc as svoc
 from ssvio_amd._lib import SsxError
-from ssvio_amd.synth import make_stereo_pair, make_vocabulary, write_vocabulary_text
+from tools.synth import make_stereo_pair, make_vocabulary, write_vocabulary_text
 
 pytestmark = pytest.mark.gpu
 

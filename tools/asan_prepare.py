@@ -6,7 +6,7 @@ pair lists, work items), no GPU needed:
 import sys, ctypes as C
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ssvio_amd import _lib, ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 lib=_lib.load()
 lib.ssx_ba_debug_prepare_seconds.restype=C.c_double
 keep=[]

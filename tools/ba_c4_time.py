@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ssvio_amd
 from ssvio_amd import ba, _lib
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 ctx = ssvio_amd.Context(0)
 t = time.time(); pr = make_ba_problem(P=500, L=80000, obs_per_lm=6, seed=4, loop=True, fix_first_pose=True); print('gen s', time.time() - t, 'E', pr['E'])
 for _ in range(2): r = ba.ba_solve(ctx, pr, outer_rounds=1, iters=10, want_edges=False)

@@ -5,7 +5,7 @@ import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssvio_amd
 from ssvio_amd import ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 REP = 20
 for nthr in (1, 2, 4, 8, 16):
     ctxs = [ssvio_amd.Context(0) for _ in range(nthr)]

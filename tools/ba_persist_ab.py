@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssvio_amd
 from ssvio_amd import ba, _lib
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 REP = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ctx = ssvio_amd.Context(0)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ssvio_amd
 from ssvio_amd import ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 ctx = ssvio_amd.Context(0)
 pr = make_ba_problem(seed=3)
 def dump(tag):

@@ -2,7 +2,7 @@ import sys, time, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssvio_amd
 from ssvio_amd import ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 ctx = ssvio_amd.Context(0)
 for cfg in [dict(P=10, L=4000, seed=1), dict(P=12, L=1500, obs_per_lm=4, seed=5)]:
     pr = make_ba_problem(**cfg)

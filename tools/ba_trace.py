@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssvio_amd
 from ssvio_amd import ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 ctx = ssvio_amd.Context(0)
 pr = make_ba_problem(P=10, L=4000, seed=1)
 for _ in range(3): r = ba.ba_solve(ctx, pr, want_edges=False)

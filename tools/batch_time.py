@@ -9,7 +9,7 @@ if os.environ.get("PHASES"):
     os.environ["SSX_BATCH_TIMING"] = "1"
 import ssvio_amd
 from ssvio_amd import ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 ctx = ssvio_amd.Context(0)
 probs = [make_ba_problem(P=10, L=4000, seed=100 + i, uv_f32=not os.environ.get("UV_F64")) for i in range(min(B, 8))]
 wins = [probs[i % len(probs)] for i in range(B)]

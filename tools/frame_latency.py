@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssvio_amd
 from ssvio_amd import orb
-from ssvio_amd.synth import make_stereo_pair
+from tools.synth import make_stereo_pair
 ctx = ssvio_amd.Context(0)
 L, R, _ = make_stereo_pair(seed=0)
 for _ in range(5): r = orb.stereo_frame(ctx, L, R)

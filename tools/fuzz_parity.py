@@ -9,7 +9,7 @@ import numpy as np
 import ssvio_amd
 from oracle import pyoracle as po
 from ssvio_amd import ba, lk, orb
-from ssvio_amd.synth import make_ba_problem, make_pose_graph_problem, make_pose_only_problem, make_stereo_pair
+from tools.synth import make_ba_problem, make_pose_graph_problem, make_pose_only_problem, make_stereo_pair
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 20

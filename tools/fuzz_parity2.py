@@ -8,7 +8,7 @@ import numpy as np
 import ssvio_amd
 from oracle import pyoracle as po
 from ssvio_amd import ba, lk, orb
-from ssvio_amd.synth import KITTI_BASELINE, KITTI_K, make_ba_problem, make_lateral_sequence, make_stereo_pair
+from tools.synth import KITTI_BASELINE, KITTI_K, make_ba_problem, make_lateral_sequence, make_stereo_pair
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -93,7 +93,7 @@ for r in range(rounds):
             c2.close()
         # bag of words on a random vocabulary
         from ssvio_amd import voc as svoc
-        from ssvio_amd.synth import make_vocabulary
+        from tools.synth import make_vocabulary
         vk = int(rng.integers(2, 21)); vL = int(rng.integers(1, 5 if vk > 8 else 7)); wt = int(rng.integers(0, 4))
         vv = make_vocabulary(k=vk, L=vL, seed=int(rng.integers(1000)), stop_fraction=float(rng.choice([0.0, 0.05, 0.5])))
         V = svoc.Vocabulary.from_arrays(ctx, vk, vL, vv["parent"], vv["is_leaf"], vv["desc"], vv["weight"], weighting=wt)
@@ -110,7 +110,7 @@ for r in range(rounds):
         if rng.random() < 0.5:
             # right-camera observations: re-measure those edges through the right extrinsic (from the initial estimate
             # + the noise already in the data) so that the problem stays a sane BA
-            from ssvio_amd.synth import quat_rot
+            from tools.synth import quat_rot
             cam = rng.integers(0, 2, pr["E"]).astype(np.uint8)
             uv = np.array(pr["edge_uv"], dtype=np.float64)
             for e in np.nonzero(cam)[0]:

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ssvio_amd
 from ssvio_amd import lk, orb
-from ssvio_amd.synth import make_stereo_pair
+from tools.synth import make_stereo_pair
 ctx = ssvio_amd.Context(0)
 L, R, _ = make_stereo_pair(seed=0)
 k, _ = orb.ORBextractor(ctx, nfeatures=2000, nlevels=1).DetectAndCompute(L)

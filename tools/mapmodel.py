@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import synth
+from tools import synth
 
 
 class _Feature:

@@ -2,7 +2,7 @@ import sys, time, numpy as np, os
 sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/ssvio_amd") else os.getcwd())
 import ssvio_amd
 from ssvio_amd import ba
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 ctx = ssvio_amd.Context(0)
 for f32 in (True, False):
     pr = make_ba_problem(P=10, L=4000, seed=1, uv_f32=f32)

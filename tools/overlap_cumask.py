@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ssvio_amd
 from ssvio_amd import ba, orb
-from ssvio_amd.synth import KITTI_H, KITTI_W, make_ba_problem, make_stereo_pair
+from tools.synth import KITTI_H, KITTI_W, make_ba_problem, make_stereo_pair
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 dev = torch.device("cuda:0")

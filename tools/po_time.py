@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssvio_amd
 from ssvio_amd import ba
-from ssvio_amd.synth import make_pose_only_problem
+from tools.synth import make_pose_only_problem
 ctx = ssvio_amd.Context(0)
 for M in (100, 300, 500, 1000, 1500, 3000):
     pp = make_pose_only_problem(M=M, seed=1, frac_gross=0.05)

@@ -466,7 +466,7 @@ def write_vocabulary_text(path, voc, scoring=0, weighting=0):
 
 
 if __name__ == "__main__":
-    # python -m ssvio_amd.synth corridor <dir> <n_frames> [workers]: render + write a KITTI-layout corridor drive (bench.py's C1 leg
+    # python -m tools.synth corridor <dir> <n_frames> [workers]: render + write a KITTI-layout corridor drive (bench.py's C1 leg
     # starts this in a process of its own, before it touches the GPU, and collects it later)
     import os
     import sys
@@ -479,5 +479,5 @@ if __name__ == "__main__":
         write_kitti_sequence(sys.argv[2], fr)
         print(f"wrote {n} stereo pairs to {sys.argv[2]}")
     else:
-        print("usage: python -m ssvio_amd.synth corridor <dir> <n_frames> [workers]", file=sys.stderr)
+        print("usage: python -m tools.synth corridor <dir> <n_frames> [workers]", file=sys.stderr)
         sys.exit(2)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ssvio_amd
 from ssvio_amd import orb
-from ssvio_amd.synth import KITTI_H, KITTI_W, make_stereo_pair
+from tools.synth import KITTI_H, KITTI_W, make_stereo_pair
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 NC = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20

@@ -5,7 +5,7 @@ import numpy as np
 import ssvio_amd
 from ssvio_amd import ba
 from ssvio_amd._lib import BaResult, dbl_p, u8_p, ptr
-from ssvio_amd.synth import make_ba_problem
+from tools.synth import make_ba_problem
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 ctx = ssvio_amd.Context(0)
