@@ -180,9 +180,18 @@ def main():
         c = fe_stream.wait_counts()                                    # the front-end's results of batch k - 1
         fe_pairs[0] += int((c[:, 0] > 0).sum())
 
+    # (the configs[0] drive is rendered by worker processes on the host cores: finished before any clock starts -- the backend
+    # groups' host phases of the headline region run on those cores)
+    c1_gen_err = None
+    if c1_gen is not None:
+        _, c1_gen_err = c1_gen.communicate(timeout=1800)
+
     # ---------------- timed region 1 (the headline): front-end + one local BA per pair on B live sliding windows ----------------
     from tools import bench_live
-    LIVE_THREADS = int(os.environ.get("SSX_BENCH_WINDOW_THREADS", "2"))
+    # three backend groups (host thread + context each), one stream per context, a group may be two steps behind the front-end's
+    # release: measured best of the sweep in profiles/r05/live_backend_orchestration.md (the GPU has four hardware queues)
+    LIVE_THREADS = int(os.environ.get("SSX_BENCH_WINDOW_THREADS", "3"))
+    LIVE_LAG = max(1, int(os.environ.get("SSX_BENCH_LAG", "2")))       # steps a backend group may be behind the front-end's release
     live_steps = args.warmup + args.steps
     live = bench_live.LiveBackend(ssvio_amd, dev_index, B, live_steps, threads=LIVE_THREADS, seed=900 + 1000 * rank)
 
@@ -196,9 +205,9 @@ def main():
             fe_part()
             live.release()
             frontend_collect()
-            if i >= 1:
+            if i >= LIVE_LAG:
                 live.wait_done()
-        for _ in range(min(1, n)):
+        for _ in range(min(LIVE_LAG, n)):
             live.wait_done()
 
     def sync_all():
@@ -218,7 +227,7 @@ def main():
     lm_iters = sum(live.iters)
     value = frames / elapsed
     nkf_w, nlm_w, nob_w = live.window_size()
-    live_info = {"host_threads": live.G, "ms_per_step_inside_solve_calls": round(max(live.t_solve) / args.steps * 1e3, 4),
+    live_info = {"host_threads": live.G, "streams_per_group": live.batch_groups or 2, "steps_a_group_may_lag": LIVE_LAG, "ms_per_step_inside_solve_calls": round(max(live.t_solve) / args.steps * 1e3, 4),
                  "ms_per_step_inside_update_calls": round(max(live.t_edit) / args.steps * 1e3, 4),
                  "window": {"keyframes": nkf_w, "landmarks": nlm_w, "observations": nob_w},
                  "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2),
@@ -656,10 +665,8 @@ def main():
             import subprocess
             from ssvio_amd import build as sb
             from tools.synth import write_settings
-            if c1_gen is not None:
-                _, gen_err = c1_gen.communicate(timeout=1200)
-                if c1_gen.returncode != 0:
-                    raise RuntimeError("sequence generator failed: " + gen_err.decode()[-300:])
+            if c1_gen is not None and c1_gen.returncode != 0:
+                raise RuntimeError("sequence generator failed: " + (c1_gen_err or b"").decode()[-300:])
             _, host_exe = sb.build_host()
             centres = np.load(os.path.join(c1_dir, "centres.npy"))
 

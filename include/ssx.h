@@ -225,13 +225,20 @@ SSX_API void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups);
    gone; the entry point remains for callers built against that header and does nothing. */
 SSX_API void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
-/* Process-wide: batched solves (ssx_ba_solve_batch, ssx_ba_batch_solve, ssx_ba_window_solve_batch) of DIFFERENT contexts take turns on
- * the device (FIFO) for their device phase -- the LM slots, enqueued at once, and the one synchronisation behind them; the host phase
- * in front of it (pending uploads, counting tables) and the unpacking behind it stay outside the turn.  For servers that drive groups of
- * windows from several host threads, one context each (the backend threads of concurrent streams, backend.cpp:57-76): without turns the
- * device phases of the groups interleave, end together, and the groups' host phases then coincide with the device idle; with turns one
- * group's host phase lies beside the other's kernels.  Off by default; no effect on results. */
+/* Process-wide: the device phases of batched solves (ssx_ba_solve_batch, ssx_ba_batch_solve, ssx_ba_window_solve_batch) of DIFFERENT
+ * contexts run one after the other on the device, in the order they were enqueued: the kernels of an LM round wait, on the device
+ * (hipStreamWaitEvent), for the end of the round enqueued before it, whichever context that was.  Nothing is serialised on the host
+ * but the enqueueing.  For servers that drive groups of windows from several host threads, one context each (the backend threads of
+ * concurrent streams, backend.cpp:57-76): without turns the device phases of the groups interleave on the chip, end together, and
+ * the groups' host phases (pending uploads, counting tables, unpacking) then coincide with the device idle; with turns one group's
+ * host phase lies beside the other's kernels.  Off by default; no effect on results. */
 SSX_API void ssx_ba_device_turns(int32_t enable);
+/* Groups of windows (1 .. 4, each on a stream of its own; 0 = the default, 2 from 8 windows on) the ONE-SHOT batched solves of this ctx
+ * -- ssx_ba_solve_batch, ssx_ba_window_solve_batch -- are run in, as ssx_ba_batch_set_groups does for a resident batch.  A server that
+ * already drives several contexts side by side wants 1: the GPU has four hardware queues, and three backend contexts of one stream
+ * each beside the front-end's measured 18 k stereo frames/s where three contexts of two streams each measured 14 k
+ * (profiles/r05/live_backend_orchestration.md).  No effect on results. */
+SSX_API ssx_status ssx_ba_set_batch_groups(ssx_ctx* ctx, int32_t groups);
 
 /* ------------------------------------------------------------------------------------------------
  * A sliding local-BA window that STAYS in HBM.  Backend::OptimizeActiveMap (src/ssvio/backend.cpp:88-169) rebuilds its

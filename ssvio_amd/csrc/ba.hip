@@ -200,17 +200,37 @@ enum { SC_CHI2_CUR = 0, SC_MAXDIAG = 1, SC_SOLVE_OK = 2, SC_SCALE_P = 3, SC_TEMP
 
 // Workgroup reductions (256 threads), fixed shape, hence deterministic: an xor tree inside each wave, then the four wave
 // results in wave order.  `s` needs 16 doubles; two barriers per call (the tree of barriers it replaces took ten).
+// Wave-wide reductions on the VALU: a butterfly through DPP inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror: every lane of a row then holds the row's result), then the four rows through v_readlane, in row order.  `__shfl_xor`
+// compiles to ds_bpermute_b32 -- two of them per double and step, 12 per wave_sum -- which are LDS-pipeline instructions with an LDS
+// round trip each: the fused linearise + Schur kernel spent a fifth of its LDS cycles on them (140 static sites).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+__device__ __forceinline__ double lane_f64(double v, int lane)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f64<DPP_QUAD_XOR1>(v);
+  v += dpp_f64<DPP_QUAD_XOR2>(v);
+  v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_f64<DPP_ROW_MIRROR>(v);
+  return ((lane_f64(v, 0) + lane_f64(v, 16)) + lane_f64(v, 32)) + lane_f64(v, 48);
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+  v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
+  v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
+  v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
+  v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
+  return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
 }
 __device__ __forceinline__ double block_sum_256(double v, double* s)
 {
@@ -253,16 +273,6 @@ __device__ __forceinline__ void block_sum3_max_256(double& a, double& b, double&
 // ------------------------------------------------------------------------------------------------
 // LDS of the linearisation (carved from the workgroup's dynamic LDS so that the fused k_lin_schur can reuse the same
 // bytes for the Schur phase)
-// -DSSX_PHASE_CLOCK (tools/ba_phase_clock.py): shader-clock stamps of one workgroup at the phase boundaries of the
-// linearise / Schur bodies, read back through ssx_debug_phase_clock -- how the per-phase cycle counts in DESIGN.md were taken
-#ifdef SSX_PHASE_CLOCK
-__device__ long long g_ph[16];
-#define PH(i) do { if (threadIdx.x == 0 && bx == 7 && blockIdx.y == 0) g_ph[i] = clock64(); } while (0)
-#define PHS(i) do { if (threadIdx.x == 0 && bx == 0 && blockIdx.y == 0) g_ph[i] = clock64(); } while (0)
-#else
-#define PH(i) do {} while (0)
-#define PHS(i) do {} while (0)
-#endif
 constexpr int LIN_VA = 14;           // pose-block entries per round: 27 = 14 + 13
 // One LDS layout for k_linearize, k_schur and the fused k_lin_schur: [0, BA_PHASE_BYTES) belongs to the running phase
 // (linearise: sL 9 x CH + sV 14 x PW doubles; Schur: sY 18 x PW + sG, sGb 9 x PL doubles + sLm CH ints), the lists above
@@ -353,14 +363,6 @@ __device__ __forceinline__ double run_sum(const double* row, int s0, int s1)
 // (Round 3 measured workgroups that walk a GROUP of chunks and keep one slab per group -- profiles/r03/persist_ab.md: 6.6x less
 // slab traffic, but the kernel lost more than the reductions won; round 4 cuts the traffic the other way: a chunk writes only the
 // parts of its slab it contributes to, see BaDev::touch.)
-// -DSSX_EXP_SKIP_{SLAB_WRITES,POSE_BLOCKS,BLOCKS,CVEC} (tools/build_variant.py, profiles/r04/schur_phase_ab.md): the kernels with one
-// of their phases left out -- wrong results, meaningful times: what a phase costs UNDER LOAD, which the one-workgroup cycle stamps of
-// SSX_PHASE_CLOCK cannot say.  EXP_STORE(x) is the store of a slab entry.
-#ifdef SSX_EXP_SKIP_SLAB_WRITES
-#define EXP_STORE(dst, v) do { if ((v) == 1.2345e300) (dst) = (v); } while (0)
-#else
-#define EXP_STORE(dst, v) do { (dst) = (v); } while (0)
-#endif
 __device__ __forceinline__ bool chunk_touches(const BaDev& d, int c, int bit)
 {
   return d.dense_slabs || ((d.touch[(size_t)c * TOUCH_WORDS + (bit >> 5)] >> (bit & 31)) & 1u);
@@ -387,7 +389,6 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
   const bool small = !d.big;
 
   double rho0 = 0.0;
-  PH(0);
   double Ji[12], wq = 0.0, r0 = 0.0, r1 = 0.0;
   int pos = 0;
 #pragma unroll
@@ -447,7 +448,6 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     }
   }
   __syncthreads();
-  PH(1);
 
   // per-landmark sums in edge order (one thread per landmark of the chunk)
   double maxd = 0.0;
@@ -469,22 +469,17 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     }
     maxd = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
   }
-  PH(2);
 
   // pose blocks: owned entries, each the sum of ITS pose's run of the pose-major term rows, in two rounds of 14 and 13
   // entries per pose (large windows build the pose blocks pose-major instead: k_pose_blocks)
-#ifdef SSX_EXP_SKIP_POSE_BLOCKS
-  if (small && d.nP > 100) {
-#else
   if (small) {
-#endif
     const int nP = d.nP;
     // (a pose none of whose edges lies in this chunk is not written: the reduction skips it through BaDev::touch)
     const bool dense = d.dense_slabs != 0;
     for (int i = t; i < nP * LIN_VA; i += CH) {
       const int p = i / LIN_VA, k = i - p * LIN_VA;
       const int s0 = sPptr[p], s1 = sPptr[p + 1];
-      if (dense || s1 > s0) EXP_STORE(slab[p * 27 + k], run_sum(sV + k * PW, s0, s1));
+      if (dense || s1 > s0) slab[p * 27 + k] = run_sum(sV + k * PW, s0, s1);
     }
     __syncthreads();
     if (t < ne) {
@@ -497,14 +492,12 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     for (int i = t; i < nP * (27 - LIN_VA); i += CH) {
       const int p = i / (27 - LIN_VA), k = i - p * (27 - LIN_VA);
       const int s0 = sPptr[p], s1 = sPptr[p + 1];
-      if (dense || s1 > s0) EXP_STORE(slab[p * 27 + LIN_VA + k], run_sum(sV + k * PW, s0, s1));
+      if (dense || s1 > s0) slab[p * 27 + LIN_VA + k] = run_sum(sV + k * PW, s0, s1);
     }
   }
-  PH(3);
   if (!small) __syncthreads();                   // sRed lies over sL: every landmark sum must have been read
   double chi = rho0, md = maxd, z0 = 0.0, z1 = 0.0;
   block_sum3_max_256(chi, z0, z1, md, sRed);
-  PH(4);
   if (t == 0) {
     slab[d.lin_stride - 2] = chi;
     slab[d.lin_stride - 1] = md;
@@ -816,8 +809,8 @@ __device__ __forceinline__ void k_build_lists_body(const BaDev& d, const int c)
     d.touch[(size_t)c * TOUCH_WORDS + t] = m;
   }
   // 5. work items of the block phase (prepare()'s rule: parts of at least BSEG_MIN pairs, at most BSEG_PARTS per block, sorted by
-  // part length -- ties in block order --, the parts of one block inside one group of 16 items).  A block without pairs gets no
-  // item (it is not written) unless the slabs are dense.
+  // part length -- ties in block order --, the parts of one block inside one group of FOUR items = one row of 16 lanes, so that the
+  // parts meet through DPP row shifts).  A block without pairs gets no item (it is not written) unless the slabs are dense.
   const int seg = max(BSEG_MIN, (sMaxLen + BSEG_PARTS - 1) / BSEG_PARTS);
   if (t < nBlk) {
     const int n = sBp[t + 1] - sBp[t], k = (n == 0 && !d.dense_slabs) ? 0 : max(1, (n + seg - 1) / seg);
@@ -840,7 +833,7 @@ __device__ __forceinline__ void k_build_lists_body(const BaDev& d, const int c)
     int pos = 0;
     for (int r = 0; r < nBlk; ++r) {
       const int k = sKr[r];
-      if ((pos & 15) + k > 16) pos = (pos + 15) & ~15;
+      if ((pos & 3) + k > 4) pos = (pos + 3) & ~3;
       sPosR[r] = pos;
       pos += k;
     }
@@ -1105,7 +1098,6 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   double Wm[18];
   double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // this edge's term of c = sum W D^-1 bl: Y (L^-1 bl)
   int zpos = 0;                                  // its position in the chunk's pose-major order
-  PH(5);
   const int it0 = cl.it0, n_items = cl.n_items;
   int4 item_rec = cl.item_rec;
   if (t < ne) {
@@ -1157,7 +1149,6 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     sGb[t] = g0; sGb[PL + t] = g1; sGb[2 * PL + t] = g2;
   }
   __syncthreads();
-  PH(6);
   if (t < ne) {
     if (leader) {
       const int l = sLm[t];
@@ -1182,17 +1173,12 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
   // the block's (edge a, edge b) pairs in landmark order with 9 independent accumulators: 18 LDS doubles per pair feed
   // 27 fused multiply-adds.  A wave takes as long as its longest list and nine tenths of the kernel's VALU
   // instructions are issued here, so the host cuts the lists (0 .. 40 pairs) into parts of equal length, sorts the
-  // items by length and keeps the parts of one block in one wave (d.bseg): the first part collects the partial sums
-  // through wave shuffles, in part order.
+  // items by length and keeps the parts of one block in one row of 16 lanes (d.bseg): the first part collects the partial
+  // sums through DPP row shifts, in part order.
   // (Tried and slower: reading only one 3x3 operand per lane and passing the other between the lanes of the quad
   // through DPP -- half the LDS traffic; an explicit software pipeline of index / operands / multiply.)
-  PH(7);
   const int nS = d.nBlk * 36;
-#ifdef SSX_EXP_SKIP_BLOCKS
-  for (int base = 0; base < n_items && d.nP > 100; base += CH) {
-#else
   for (int base = 0; base < n_items; base += CH) {
-#endif
     const int4 ir = item_rec;
     if (base + CH < n_items) item_rec = base + CH + t < n_items ? d.bseg[it0 + ((base + CH + t) >> 2)] : make_int4(-1, 0, 0, 1 << 4);
     const int blk = ir.x, qr = (t >> 1) & 1, qc = t & 1;                 // rows 3 qr .. 3 qr + 2, columns 3 qc .. 3 qc + 2
@@ -1220,12 +1206,14 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = fma(bd[i][2], w[j][2], fma(bd[i][1], w[j][1], fma(bd[i][0], w[j][0], acc[i][j])));
     }
-    if (__any(parts > 1)) {                                              // wave-uniform: every lane takes part in the shuffles
+    if (__any(parts > 1)) {                                              // wave-uniform
+      // the parts of a block sit in consecutive items of ONE row of 16 lanes (k_build_lists): part q's sums are 4 q lanes up the
+      // row -- DPP row shifts on the VALU (the __shfl_down they replace were 54 ds_bpermute_b32 per pass: LDS-pipeline instructions)
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const double v1 = __shfl_down(acc[i][j], 4), v2 = __shfl_down(acc[i][j], 8), v3 = __shfl_down(acc[i][j], 12);
+          const double v1 = dpp_f64<0x104>(acc[i][j]), v2 = dpp_f64<0x108>(acc[i][j]), v3 = dpp_f64<0x10C>(acc[i][j]);   // row_shl:4 / 8 / 12
           if (part == 0) {
             if (parts > 1) acc[i][j] += v1;
             if (parts > 2) acc[i][j] += v2;
@@ -1237,10 +1225,9 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) EXP_STORE(slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j], acc[i][j]);
+        for (int j = 0; j < 3; ++j) slab[blk * 36 + (3 * qr + i) * 6 + 3 * qc + j] = acc[i][j];
     }
   }
-  PH(8);
   // c: the per-edge terms z go to LDS in POSE-MAJOR positions (Y is dead), four threads per entry share the pose's run,
   // partial sums folded inside the quad (the former loop chased the pose's edge list: three dependent LDS round trips
   // per edge)
@@ -1250,11 +1237,7 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     for (int a = 0; a < 6; ++a) sY[a * PW + zpos] = z[a];
   }
   __syncthreads();
-#ifdef SSX_EXP_SKIP_CVEC
-  for (int base = 0; base < nP * 6 * 4 && d.nP > 100; base += CH) {
-#else
   for (int base = 0; base < nP * 6 * 4; base += CH) {
-#endif
     const int item = base + t;
     const bool on = item < nP * 6 * 4;
     const int idx = on ? item >> 2 : 0, part = item & 3;
@@ -1262,15 +1245,11 @@ __device__ __forceinline__ void k_schur_body(const BaDev& d, const int bx, int c
     double acc = 0.0;
     const int s0 = on ? sPptr[p] : 0, s1 = on ? sPptr[p + 1] : 0;
     for (int s = s0 + part; s < s1; s += 4) acc += sY[a * PW + s];
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    if (on && part == 0 && (d.dense_slabs || s1 > s0)) EXP_STORE(slab[nS + idx], acc);     // (a pose without edges here: not written, not read)
+    acc += dpp_f64<DPP_QUAD_XOR1>(acc);                              // (the sums of __shfl_xor(acc, 1), (acc, 2): same pairs, same bits)
+    acc += dpp_f64<DPP_QUAD_XOR2>(acc);
+    if (on && part == 0 && (d.dense_slabs || s1 > s0)) slab[nS + idx] = acc;     // (a pose without edges here: not written, not read)
   }
-  PH(9);
 }
-#ifdef SSX_PHASE_CLOCK
-extern "C" __attribute__((visibility("default"))) void ssx_debug_phase_clock(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ph), sizeof(long long) * 16); }
-#endif
 
 __device__ __forceinline__ void k_schur_entry(const BaDev& d, int bx, int cur, double lambda_arg, int use_dev_lambda)
 {
@@ -1791,40 +1770,42 @@ class ParPool {
   bool stop_ = false;
 };
 
-// ssx_ba_device_turns: batched solves of DIFFERENT contexts take turns on the device.  A batched solve is a host phase (pending
-// uploads, counting tables, marshalling) followed by a device phase (the LM slots, enqueued at once, one synchronisation).  Two
-// host threads that drive two contexts side by side fall into lock step when their device phases interleave -- both finish together,
-// both then sit in their host phases with the device idle.  With turns the device phases run one after the other (FIFO), so one
-// context's host phase lies beside the other's kernels: the whole point of driving groups of windows from several threads.
+// ssx_ba_device_turns: the device phases of batched solves of DIFFERENT contexts run one after the other on the device (FIFO).
+// A batched solve is a host phase (pending uploads, counting tables, marshalling) followed by a device phase (the LM slots of a
+// round, enqueued at once, one synchronisation behind them).  Two host threads that drive two contexts side by side fall into lock
+// step when their device phases interleave on the chip -- both end together, both threads then sit in their host phases with the
+// device idle.  With turns a round's kernels WAIT (hipStreamWaitEvent, on the device) for the end of the round that was enqueued
+// before it, whichever context that was: nothing is serialised on the host but the enqueueing itself, one context's kernels finish
+// early, and its host phase lies beside the other's kernels.
 class DeviceTurns {
  public:
   void enable(bool on) { on_.store(on, std::memory_order_relaxed); }
   bool enabled() const { return on_.load(std::memory_order_relaxed); }
-  void acquire()
+  // (mutex held from begin to end: the rounds of different contexts are enqueued one after the other, in the order of the chain)
+  void begin(const void* owner, int device, hipStream_t s)
   {
-    std::unique_lock<std::mutex> lk(mu_);
-    const unsigned long my = next_ticket_++;
-    cv_.wait(lk, [&] { return serving_ == my; });
+    mu_.lock();
+    if (last_ && owner_ != owner && device_ == device) (void)hipStreamWaitEvent(s, last_, 0);
   }
-  void release()
+  void end(const void* owner, int device, hipEvent_t ev, hipStream_t s)
   {
-    { std::lock_guard<std::mutex> lk(mu_); ++serving_; }
-    cv_.notify_all();
+    if (ev && hipEventRecord(ev, s) == hipSuccess) { last_ = ev; owner_ = owner; device_ = device; }
+    else { (void)hipGetLastError(); last_ = nullptr; owner_ = nullptr; }
+    mu_.unlock();
+  }
+  void forget(const void* owner)                       // the owner's event is about to be destroyed
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (owner_ == owner) { last_ = nullptr; owner_ = nullptr; }
   }
  private:
   std::atomic<bool> on_{false};
   std::mutex mu_;
-  std::condition_variable cv_;
-  unsigned long next_ticket_ = 0, serving_ = 0;
+  hipEvent_t last_ = nullptr;
+  const void* owner_ = nullptr;
+  int device_ = -1;
 };
 static DeviceTurns g_turns;
-struct TurnGuard {
-  bool held = false;
-  TurnGuard() { if (g_turns.enabled()) { g_turns.acquire(); held = true; } }
-  ~TurnGuard() { if (held) g_turns.release(); }
-  TurnGuard(const TurnGuard&) = delete;
-  TurnGuard& operator=(const TurnGuard&) = delete;
-};
 
 struct BaWorkspace {
   DevBuf arena;      // everything on the device
@@ -1843,11 +1824,14 @@ struct BaWorkspace {
   HostBuf recs_h;
   DevBuf win_stage_d;                 // ssx_ba_window: pending uploads of the windows of a call, one block (ba_window.inc)
   HostBuf win_stage_h;
+  hipEvent_t ev_turn = nullptr;       // ssx_ba_device_turns: the end of this context's last device phase
 };
 
 static void ssx_ba_workspace_free(BaWorkspace* w)
 {
   if (!w) return;
+  g_turns.forget(w);
+  if (w->ev_turn) (void)hipEventDestroy(w->ev_turn);
   w->arena.release();
   w->stage.release();
   w->scal.release();
@@ -2183,10 +2167,10 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
       }
       std::stable_sort(order.begin(), order.end());
       h.bseg_ptr[2 * c] = (int)(h.bseg.size() / 4);
-      int pos = 0;                                // in items (16 per wave: four lanes each)
+      int pos = 0;                                // in items (16 per wave, four lanes each; a block's parts inside one row of 16 lanes)
       for (const auto& ob : order) {
         const int b = ob.second, n = bp[b + 1] - bp[b], k = (n == 0 && !dense) ? 0 : std::max(1, (n + seg - 1) / seg), len = k ? (n + k - 1) / k : 0;
-        while ((pos & 15) + k > 16) { h.bseg.push_back(-1); h.bseg.push_back(0); h.bseg.push_back(0); h.bseg.push_back(1 << 4); ++pos; }
+        while ((pos & 3) + k > 4) { h.bseg.push_back(-1); h.bseg.push_back(0); h.bseg.push_back(0); h.bseg.push_back(1 << 4); ++pos; }
         for (int i = 0; i < k; ++i) {
           const int q0 = bp[b] - base + std::min(n, i * len), q1 = bp[b] - base + std::min(n, (i + 1) * len);
           h.bseg.push_back(b); h.bseg.push_back(q0); h.bseg.push_back(q1); h.bseg.push_back(i | (k << 4));
@@ -3499,6 +3483,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   const int hw = (int)std::thread::hardware_concurrency();
   const int T = std::max(1, std::min({n, host_threads_cap(), hw > 1 ? hw / 2 : 1}));
   B->ctx = ctx; B->device = ctx->device; B->n = n; B->opt = opt; B->threads = T; B->with_err = with_err;
+  if (!own) B->groups = ctx->ba_batch_groups;                       // (a resident batch has its own setting: ssx_ba_batch_set_groups)
   static const int timing_mode = getenv("SSX_BATCH_TIMING") ? std::max(atoi(getenv("SSX_BATCH_TIMING")), 1) : 0;   // phase times on stderr
   const bool timing = timing_mode == 1;                              // 1: with synchronisations (tools/batch_time.py), 2: host clocks only
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -3675,6 +3660,8 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     if (!ctx->grp_ev[g] && hipEventCreateWithFlags(&ctx->grp_ev[g], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G = g + 1; break; }
   }
   const bool split = G > 1;
+  const bool turns_on = g_turns.enabled() && ctx->ba != nullptr;
+  if (turns_on && !ctx->ba->ev_turn && hipEventCreateWithFlags(&ctx->ba->ev_turn, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->ba->ev_turn = nullptr; }
   auto all_done = [&] { for (int w = 0; w < n; ++w) if (!wsn[w].done) return false; return true; };
   while (!all_done() && opt.iters > 0) {
     for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = wsn[w].n_iters; h_ctrl[2 * n + w] = wsn[w].done ? 1 : 0; }
@@ -3683,6 +3670,13 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
     int slots_total = 0;
     bool first_slot = true;
     for (;;) {
+      // ssx_ba_device_turns: this round's kernels run after the round enqueued before it, whichever context enqueued that
+      struct TurnScope {
+        bool on; BaWorkspace* w; int dev; hipStream_t st;
+        TurnScope(bool o, BaWorkspace* w_, int d, hipStream_t s_) : on(o), w(w_), dev(d), st(s_) { if (on) g_turns.begin(w, dev, st); }
+        void close() { if (on) { g_turns.end(w, dev, w->ev_turn, st); on = false; } }
+        ~TurnScope() { close(); }
+      } turn(turns_on, ctx->ba, ctx->device, s);
       int slots = opt.iters;
       if (slots_total > 0) {
         slots = 1;
@@ -3744,6 +3738,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
         SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
         spec_done = true;
       }
+      turn.close();
       SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
       bool stopped = true;
       for (int w = 0; w < n; ++w) if (!wsn[w].done && hscal[(size_t)w * SC_N + SC_STOP] == 0.0) stopped = false;
@@ -3903,7 +3898,6 @@ ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* pro
   ssx_status st = batch_build(ctx, n, probs, opt, with_err, false, &B);
   if (st == SSX_ERR_UNSUPPORTED) return sequential();                 // a large window in the batch
   if (st != SSX_OK) return st;
-  TurnGuard turn;                                                     // (ssx_ba_device_turns: the device phase, one context at a time)
   return batch_run(&B, results, nullptr);
 }
 
@@ -3931,11 +3925,17 @@ ssx_status ssx_ba_batch_create(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* pr
 ssx_status ssx_ba_batch_solve(ssx_ba_batch* batch, ssx_ba_result* results, int32_t* lm_iterations_total)
 {
   if (!batch) return SSX_ERR_INVALID_ARG;
-  TurnGuard turn;
   return batch_run(batch, results, lm_iterations_total);
 }
 
 void ssx_ba_device_turns(int32_t enable) { g_turns.enable(enable != 0); }
+
+ssx_status ssx_ba_set_batch_groups(ssx_ctx* ctx, int32_t groups)
+{
+  if (!ctx || groups < 0 || groups > 4) return SSX_ERR_INVALID_ARG;
+  ctx->ba_batch_groups = groups;
+  return SSX_OK;
+}
 
 int32_t ssx_ba_batch_size(const ssx_ba_batch* batch) { return batch ? batch->n : 0; }
 

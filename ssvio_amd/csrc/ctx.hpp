@@ -149,6 +149,7 @@ struct ssx_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pyr = nullptr, ev_fast0 = nullptr;
   hipStream_t grp[3] = {nullptr, nullptr, nullptr};   // batched BA: the groups of windows beside the main stream (created on first use)
   hipEvent_t grp_ev[3] = {nullptr, nullptr, nullptr};
+  int ba_batch_groups = 0;                   // ssx_ba_set_batch_groups: groups of windows of this ctx's one-shot batched solves (0: the default)
   SsxProf prof;
   DevBuf po_arena;                           // pose-only optimisation scratch
   HostBuf po_stage;

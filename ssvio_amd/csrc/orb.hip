@@ -240,12 +240,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
   const int cell = cell_begin + blockIdx.x * (blockDim.x >> 6) + wave, img = blockIdx.y;   // 1..4 cells per workgroup
   if (cell >= cell_end) return;
   const Cell c = o.cells[cell];
-  // -DSSX_EXP_FAST_STOP=1..4 (tools/build_variant.py <name> orb.hip -D...): the kernel cut short after the cell record / the ROI
-  // staging / the quick test / the segment test -- wrong results, meaningful times (profiles/r04/fast_cells_phases.md)
-#if SSX_EXP_FAST_STOP == 1
-  if (lane == 0) o.cell_count[(size_t)img * o.n_cells + cell] = c.w & 1;
-  return;
-#endif
   const uint8_t* lvl = o.pyr + (size_t)img * o.pyr_bytes + o.lvl_off[c.level];
   const int pitch = o.lvl_pitch[c.level];
   const int w = c.w, h = c.h;
@@ -288,10 +282,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
   const uint8_t* mk = o.has_mask ? o.maskpyr + (size_t)img * o.pyr_bytes + o.lvl_off[c.level] : nullptr;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-#if SSX_EXP_FAST_STOP == 2
-  if (lane == 0) *cell_count = sImg[(h - 1) * tw + 5] & 1;
-  return;
-#endif
   int n_out = 0;
   for (int pass = 0; pass < 2; ++pass) {
     const int th = min(max(pass == 0 ? o.ini_th : o.min_th, 0), 255);
@@ -361,10 +351,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
         n_surv += total;
       }
     }
-#if SSX_EXP_FAST_STOP == 3
-    if (lane == 0) *cell_count = min(n_surv, 1) + (n_surv > 0 ? (sList[n_surv - 1] & 1) : 0);
-    return;
-#endif
     // -- stage 2: full segment test + score on the survivors; corners compacted in place (order kept) --
     int n_corner = 0;
     for (int base = 0; base < n_surv; base += 64) {
@@ -384,10 +370,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbDev o, int cell_begin, in
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-#if SSX_EXP_FAST_STOP == 4
-    if (lane == 0) *cell_count = min(n_corner, 1) + (n_corner > 0 ? (sList[n_corner - 1] & 1) : 0);
-    return;
-#endif
     // -- stage 3: NMS (strict >), emptiness test BEFORE the mask (orbextractor.cpp:803-808), mask test at the
     //    UN-bordered coordinates (orbextractor.cpp:816-823, reference quirk), ordered output --
     int n_keep_pre = 0;

@@ -1,7 +1,7 @@
 """Per-phase shader-clock counts of ONE workgroup of the fused linearise + Schur kernel (k_lin_schur / k_lin_schur_b).
 Needs a library built with the stamps compiled in:
-    SSX_EXTRA_HIPCC_FLAGS=-DSSX_PHASE_CLOCK python -c "from ssvio_amd import build; build.build(force=True)"
-(rebuild without the flag afterwards).  Run on the GPU box: python tools/ba_phase_clock.py"""
+    python tools/build_variant.py clock --patch tools/patches/ba_experiment_switches.diff -DSSX_PHASE_CLOCK   (then SSX_LIB=$PWD/ssvio_amd/libssx.so.clock)
+Run on the GPU box: python tools/ba_phase_clock.py"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -19,6 +19,7 @@ the partially observed ones at both ends included).  Test / bench infrastructure
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 import time
 
@@ -92,9 +93,13 @@ class LiveBackend:
         lib = self.lib = self.ctx[0].lib
         lib.ssx_ba_device_turns.restype = None
         lib.ssx_ba_device_turns.argtypes = [C.c_int32]
-        import os
-        self.turns = G > 1 and os.environ.get("SSX_BENCH_NO_TURNS") is None
+        self.turns = G > 1 and os.environ.get("SSX_BENCH_TURNS") is not None   # (measured: no gain, profiles/r05/live_backend_orchestration.md)
         lib.ssx_ba_device_turns(1 if self.turns else 0)
+        lib.ssx_ba_set_batch_groups.restype = C.c_int32
+        lib.ssx_ba_set_batch_groups.argtypes = [C.c_void_p, C.c_int32]
+        self.batch_groups = int(os.environ.get("SSX_BENCH_BATCH_GROUPS", "1" if G > 1 else "0"))
+        for c in self.ctx:
+            c.check(lib.ssx_ba_set_batch_groups(c.handle, self.batch_groups))
         lib.ssx_ba_window_update_batch.restype = C.c_int32
         lib.ssx_ba_window_update_batch.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(BaWindowUpdate), C.POINTER(C.c_int32)]
         # A backend keeps, with every map point, the slot the window gave it (ssx_ba_window_push_keyframe_slots).  The slots of a
