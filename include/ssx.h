@@ -347,28 +347,8 @@ SSX_API ssx_status ssx_ba_window_solve(ssx_ba_window* win, ssx_ba_result* res);
  * The options of the first window apply. */
 SSX_API ssx_status ssx_ba_window_solve_batch(int32_t n, ssx_ba_window* const* wins, ssx_ba_result* results);
 
-/* test hook, needs no GPU: `steps` random pushes / pops / removals of observations and landmarks on a window without a device (fix
- * rule 1), its contents, order and fixed flags checked against a plain model after every step, and two twin windows that receive the same edits through ssx_ba_window_update_batch (two windows per call: the
- * threaded path) against the window itself; 0 = all steps agree, else the first step that does not */
-SSX_API int32_t ssx_ba_window_selftest(uint32_t seed, int32_t steps);
-
-/* tools hook, needs no GPU: dynamic LDS bytes a BA kernel is launched with (-1: depends on the problem); the compiler's
- * resource report and rocprofv3's dispatch rows only know static __shared__ arrays (tools/kernel_resources.py) */
-SSX_API int64_t ssx_debug_kernel_dynamic_lds(const char* kernel);
-/* tests hook: 1 = the linearise / Schur kernels write, and the reductions read, every entry of the per-chunk partial sums (round 3's
- * dense slabs); 0 (default) = only the blocks of the reduced system and the poses a chunk contributes to; < 0 = the environment's
- * choice (SSX_BA_DENSE_SLABS).  Same bits either way (tests/test_ba_gpu.py::test_sparse_slabs_equal_dense_slabs); applies to problems
- * uploaded after the call. */
-SSX_API void ssx_debug_set_dense_slabs(int32_t mode);
-
-/* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */
-SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps);
-
-/* tools / tests hook, needs no GPU: how ssx_ba_solve / ssx_ba_solve_batch would send this problem's observation arrays
- * across PCIe (lossless narrowing): bit 0 = keyframe indices as bytes, bit 1 = landmark indices as 16-bit words, bit 2 =
- * pixel coordinates as floats (every edge_uv value is a float's value, as the reference's cv::KeyPoint::pt measurements
- * are); 0 = as handed over (large windows, SSX_BA_WIDE_UPLOAD / SSX_BA_HOST_PREP set); -1 = invalid problem */
-SSX_API int32_t ssx_ba_debug_upload_format(const ssx_ba_problem* prob);
+/* (test and tools hooks -- ssx_ba_window_selftest, ssx_debug_*, ssx_ba_debug_* -- are NOT part of this ABI: include/ssx_test_hooks.h,
+ * compiled out of the library by -DSSX_NO_TEST_HOOKS / SSX_PRODUCT_BUILD=1 python -m ssvio_amd.build) */
 
 /* One linearisation of the problem at its current state (no update): the blocks the kernels build,
  * for kernel-level parity tests and profiling.  Any output may be NULL.
@@ -424,6 +404,13 @@ SSX_API void ssx_orb_default_params(ssx_orb_params* p); /* 2000, 1.2, 8, 20, 7 (
 SSX_API ssx_status ssx_orb_detect(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
                                   const uint8_t* mask, int32_t mask_stride, const ssx_orb_params* prm,
                                   int32_t cap, ssx_keypoint* kps_out, int32_t* n);
+/* The same with the mask of FrontEnd::DetectFeatures (src/ssvio/frontend.cpp:302-312: 255 everywhere, a FILLED cv::rectangle of
+ * pt -+ (10, 10) set to 0 per tracked feature) handed over as its rectangles: boxes_xyxy = n_boxes x (x0, y0, x1, y1), corners
+ * INCLUSIVE (cv::rectangle's convention), clipped to the image by the library.  16 bytes per tracked feature cross PCIe instead
+ * of rows x cols bytes; the mask is rasterised on the device.  Same keypoints as ssx_orb_detect on the rasterised mask. */
+SSX_API ssx_status ssx_orb_detect_boxes(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
+                                        const int32_t* boxes_xyxy, int32_t n_boxes, const ssx_orb_params* prm,
+                                        int32_t cap, ssx_keypoint* kps_out, int32_t* n);
 
 /* ORBextractor::DetectAndCompute: 8-level pyramid ORB.  desc_out: cap x 32 bytes (CV_8U N x 32). */
 SSX_API ssx_status ssx_orb_extract(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,

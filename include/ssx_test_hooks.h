@@ -1,0 +1,40 @@
+/* include/ssx_test_hooks.h -- hooks of the TESTS and TOOLS of this repository into libssx.so.  NOT part of the product ABI
+ * (include/ssx.h): they may change or disappear at any time, and a product build leaves them out altogether
+ * (-DSSX_NO_TEST_HOOKS, which `SSX_PRODUCT_BUILD=1 python -m ssvio_amd.build` passes).  The default build carries them because the
+ * driver's GPU tests load the very library that ships (tests/test_ba_gpu.py, tests/test_window_host.py, tools/kernel_resources.py,
+ * tools/asan_prepare.py). */
+#ifndef SSX_TEST_HOOKS_H
+#define SSX_TEST_HOOKS_H
+#include "ssx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* test hook, needs no GPU: `steps` random pushes / pops / removals of observations and landmarks on a window without a device (fix
+ * rule 1), its contents, order and fixed flags checked against a plain model after every step, and two twin windows that receive the same edits through ssx_ba_window_update_batch (two windows per call: the
+ * threaded path) against the window itself; 0 = all steps agree, else the first step that does not */
+SSX_API int32_t ssx_ba_window_selftest(uint32_t seed, int32_t steps);
+
+/* tools hook, needs no GPU: dynamic LDS bytes a BA kernel is launched with (-1: depends on the problem); the compiler's
+ * resource report and rocprofv3's dispatch rows only know static __shared__ arrays (tools/kernel_resources.py) */
+SSX_API int64_t ssx_debug_kernel_dynamic_lds(const char* kernel);
+/* tests hook: 1 = the linearise / Schur kernels write, and the reductions read, every entry of the per-chunk partial sums (round 3's
+ * dense slabs); 0 (default) = only the blocks of the reduced system and the poses a chunk contributes to; < 0 = the environment's
+ * choice (SSX_BA_DENSE_SLABS).  Same bits either way (tests/test_ba_gpu.py::test_sparse_slabs_equal_dense_slabs); applies to problems
+ * uploaded after the call. */
+SSX_API void ssx_debug_set_dense_slabs(int32_t mode);
+
+/* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */
+SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps);
+
+/* tools / tests hook, needs no GPU: how ssx_ba_solve / ssx_ba_solve_batch would send this problem's observation arrays
+ * across PCIe (lossless narrowing): bit 0 = keyframe indices as bytes, bit 1 = landmark indices as 16-bit words, bit 2 =
+ * pixel coordinates as floats (every edge_uv value is a float's value, as the reference's cv::KeyPoint::pt measurements
+ * are); 0 = as handed over (large windows, SSX_BA_WIDE_UPLOAD / SSX_BA_HOST_PREP set); -1 = invalid problem */
+SSX_API int32_t ssx_ba_debug_upload_format(const ssx_ba_problem* prob);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSX_TEST_HOOKS_H */

@@ -21,6 +21,10 @@ ARCH = "gfx950"
 
 COMMON = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-fvisibility=hidden", "-DSSX_BUILD"]
+# SSX_PRODUCT_BUILD=1: the library without the hooks of this repository's tests and tools (include/ssx_test_hooks.h); the default
+# build keeps them, because the GPU tests must load the very library that ships
+if os.environ.get("SSX_PRODUCT_BUILD"):
+    COMMON.append("-DSSX_NO_TEST_HOOKS")
 # files whose results must be bit-identical to the CPU oracle (integer / f32 image arithmetic): forbid
 # fused multiply-add contraction so every float operation rounds exactly like the scalar C++ restatement
 PER_FILE = {

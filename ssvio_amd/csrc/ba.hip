@@ -57,6 +57,7 @@
 
 #include "ctx.hpp"
 #include "se3.hpp"
+#include "../../include/ssx_test_hooks.h"
 
 int ssx_comm_allreduce_f64(void* user, double* buf_dev, size_t count, void* stream);   // comm.hip
 
@@ -3839,6 +3840,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
 
 extern "C" {
 
+#ifndef SSX_NO_TEST_HOOKS   // include/ssx_test_hooks.h: hooks of this repository's tests / tools, not part of the product ABI
 // tools hook (no GPU needed): dynamic LDS bytes a kernel of this file is launched with (the compiler's resource report only
 // knows static __shared__ arrays, and rocprofv3's dispatch rows show 0 for these); -1 = depends on the problem / unknown
 // tests hook: 1 = the per-chunk slabs of the linearise / Schur kernels are written and read in full (round 3), 0 = only the blocks and
@@ -3877,6 +3879,7 @@ int32_t ssx_ba_debug_upload_format(const ssx_ba_problem* prob)
   if (prepare(&dummy, prob, h) != SSX_OK) return -1;
   return h.raw_fmt;
 }
+#endif  // SSX_NO_TEST_HOOKS
 
 ssx_status ssx_ba_solve_batch(ssx_ctx* ctx, int32_t n, const ssx_ba_problem* probs, const ssx_ba_options* opt_in, ssx_ba_result* results)
 {

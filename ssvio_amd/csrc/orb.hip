@@ -153,6 +153,21 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
   *reinterpret_cast<uint2*>(dst_base + (size_t)blockIdx.z * img_stride_bytes + (size_t)y * dpitch + x) = make_uint2(w[0], w[1]);
 }
 
+// A4, the mask of FrontEnd::DetectFeatures (frontend.cpp:302-312) rasterised on the device: level 0 of the mask pyramid was
+// set to 255; one workgroup per box clears its rectangle [x0, x1] x [y0, y1] (inclusive, already clipped by the caller's
+// contract -- clipped again here).  16 bytes per tracked feature cross PCIe instead of rows x cols bytes of mask.
+__global__ __launch_bounds__(64) void k_mask_boxes(const int4* __restrict__ boxes, int n_boxes, uint8_t* __restrict__ mask0, int rows, int cols, int pitch)
+{
+  const int4 b = boxes[blockIdx.x];
+  const int x0 = max(b.x, 0), y0 = max(b.y, 0), x1 = min(b.z, cols - 1), y1 = min(b.w, rows - 1);
+  const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+  if (w <= 0 || h <= 0) return;
+  for (int i = threadIdx.x; i < w * h; i += 64) {
+    const int r = i / w, c = i - r * w;
+    mask0[(size_t)(y0 + r) * pitch + x0 + c] = 0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // A1+A2: grid FAST.  One workgroup per cell.
 // ------------------------------------------------------------------------------------------------
@@ -1423,6 +1438,43 @@ ssx_status ssx_orb_detect(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int3
     return SSX_ERR_INVALID_ARG;
   }
   ssx_status st = run_host_image(ctx, img, stride, rows, cols, mask, mask_stride, *prm, true);
+  if (st != SSX_OK) return st;
+  return fetch_image_result(ctx, 0, cap, kps_out, nullptr, n);
+}
+
+// ORBextractor::Detect with the mask of FrontEnd::DetectFeatures given as its RECTANGLES (frontend.cpp:302-312: 255 everywhere,
+// cv::rectangle(mask, pt - (10, 10), pt + (10, 10), 0, FILLED) per tracked feature): boxes_xyxy = n_boxes x (x0, y0, x1, y1), corners
+// inclusive.  The mask is built on the device (k_mask_boxes); results equal ssx_orb_detect on the rasterised mask bit for bit.
+ssx_status ssx_orb_detect_boxes(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols, const int32_t* boxes_xyxy,
+                                int32_t n_boxes, const ssx_orb_params* prm, int32_t cap, ssx_keypoint* kps_out, int32_t* n)
+{
+  if (!ctx || !prm || !n) return SSX_ERR_INVALID_ARG;
+  *n = 0;
+  if (!img || rows <= 0 || cols <= 0) return SSX_OK;   // `if (_image.empty()) return;` orbextractor.cpp:758
+  if (stride < cols || cap < 0 || (cap > 0 && !kps_out) || n_boxes < 0 || (n_boxes > 0 && !boxes_xyxy)) {
+    ctx->set_error("ssx_orb_detect_boxes: stride smaller than the image width, negative capacity / box count or a missing array");
+    return SSX_ERR_INVALID_ARG;
+  }
+  ssx_status st = plan(ctx, rows, cols, 1, *prm, true, true);
+  if (st != SSX_OK) return st;
+  OrbWorkspace* ws = get_ws(ctx);
+  const OrbDev& d = ws->dev;
+  const size_t bytes = (size_t)rows * cols, box_off = (bytes + 15) & ~size_t(15), box_bytes = sizeof(int32_t) * 4 * (size_t)n_boxes;
+  SSX_HIP_TRY(ctx, ws->input.reserve(box_off + box_bytes + 512));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(box_off + box_bytes + 512));
+  uint8_t* hs = ws->stage.as<uint8_t>();
+  for (int y = 0; y < rows; ++y) memcpy(hs + (size_t)y * cols, img + (size_t)y * stride, cols);
+  if (n_boxes) memcpy(hs + box_off, boxes_xyxy, box_bytes);
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->input.p, hs, box_off + box_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const dim3 grid((d.lvl_cols[0] + 511) / 512, (d.lvl_rows[0] + 3) / 4, 1);
+  SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_copy_level0, grid, dim3(64, 4), 0, ctx->stream, ws->input.as<uint8_t>(), cols, bytes, d.pyr, d.pyr_bytes,
+                     d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0]));
+  SSX_HIP_TRY(ctx, hipMemsetAsync(d.maskpyr + d.lvl_off[0], 255, (size_t)d.lvl_pitch[0] * d.lvl_rows[0], ctx->stream));
+  if (n_boxes)
+    SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_mask_boxes, dim3(n_boxes), dim3(64), 0, ctx->stream, reinterpret_cast<const int4*>(ws->input.as<uint8_t>() + box_off),
+                       n_boxes, d.maskpyr + d.lvl_off[0], d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0]));
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  st = run_pipeline(ctx);
   if (st != SSX_OK) return st;
   return fetch_image_result(ctx, 0, cap, kps_out, nullptr, n);
 }

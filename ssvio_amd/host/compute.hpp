@@ -41,6 +41,17 @@ class Compute {
  public:
   virtual ~Compute() = default;
   virtual void Detect(const Image& img, const uint8_t* mask, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) = 0;
+  // FrontEnd::DetectFeatures' mask (frontend.cpp:302-312) as its rectangles: boxes = n x (x0, y0, x1, y1), corners inclusive and inside
+  // the image.  Default: rasterise on the host and call Detect (the CPU oracle's Compute); the GPU library takes the rectangles
+  // themselves (ssx_orb_detect_boxes: 16 bytes per tracked feature over PCIe instead of a 466 KB mask).
+  virtual void DetectBoxes(const Image& img, const std::vector<int32_t>& boxes, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps)
+  {
+    std::vector<uint8_t> mask((size_t)img.rows * img.cols, 255);
+    for (size_t b = 0; b + 3 < boxes.size(); b += 4)
+      for (long y = boxes[b + 1]; y <= boxes[b + 3]; ++y)
+        for (long x = boxes[b]; x <= boxes[b + 2]; ++x) mask[(size_t)y * img.cols + x] = 0;
+    Detect(img, mask.data(), prm, kps);
+  }
   // 11x11 window, 3 levels, (COUNT+EPS, 30, 0.01), OPTFLOW_USE_INITIAL_FLOW: next_pts holds the guesses going in.
   // `temporal` marks the frame-to-frame call (the implementation may keep the previous frame's pyramid).
   virtual void TrackLK(const Image& prev, const Image& next, const std::vector<float>& prev_pts, std::vector<float>& next_pts,

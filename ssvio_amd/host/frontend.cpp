@@ -169,17 +169,19 @@ int FrontEnd::EstimateCurrentPose()
 int FrontEnd::DetectFeatures()
 {
   const Image& img = *current_frame_->left_image;
-  mask_.assign((size_t)img.rows * img.cols, 255);
+  // cv::Mat mask(size, CV_8UC1, 255); cv::rectangle(mask, pt - (10, 10), pt + (10, 10), 0, FILLED) per tracked feature
+  // (frontend.cpp:304-311): the rectangles themselves go to the compute layer, corners inclusive as cv::rectangle draws them
+  boxes_.clear();
   for (const auto& feat : current_frame_->features_left) {
     const long x0 = std::max(0l, std::lrintf(feat->x - 10.f)), x1 = std::min((long)img.cols - 1, std::lrintf(feat->x + 10.f));
     const long y0 = std::max(0l, std::lrintf(feat->y - 10.f)), y1 = std::min((long)img.rows - 1, std::lrintf(feat->y + 10.f));
-    for (long y = y0; y <= y1; ++y)
-      for (long x = x0; x <= x1; ++x) mask_[(size_t)y * img.cols + x] = 0;
+    if (x1 < x0 || y1 < y0) continue;
+    boxes_.push_back((int32_t)x0); boxes_.push_back((int32_t)y0); boxes_.push_back((int32_t)x1); boxes_.push_back((int32_t)y1);
   }
   std::vector<ssx_keypoint> kps;
   {
     Stopwatch sw(times_.detect, times_.n_detect);
-    compute_.Detect(img, mask_.data(), track_status_ == FrontendStatus::INITING ? orb_init_ : orb_, kps);
+    compute_.DetectBoxes(img, boxes_, track_status_ == FrontendStatus::INITING ? orb_init_ : orb_, kps);
   }
   for (const auto& kp : kps) {
     auto f = std::make_shared<Feature>();

@@ -69,7 +69,7 @@ class FrontEnd {
   int num_features_init_good_, num_features_tracking_good_, num_features_tracking_bad_;
   unsigned min_init_landmark_;
   bool open_backend_optimization_;
-  std::vector<uint8_t> mask_;
+  std::vector<int32_t> boxes_;               // DetectFeatures: the mask's rectangles (x0, y0, x1, y1)
   StageTimes times_;
 };
 

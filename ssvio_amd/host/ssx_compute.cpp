@@ -61,6 +61,20 @@ class SsxCompute final : public Compute {
     kps.resize(n);
   }
 
+  void DetectBoxes(const Image& img, const std::vector<int32_t>& boxes, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
+  {
+    kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});
+    int32_t n = 0;
+    const int32_t nb = (int32_t)(boxes.size() / 4);
+    ssx_status st = ssx_orb_detect_boxes(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, boxes.data(), nb, &prm, (int32_t)kps.size(), kps.data(), &n);
+    if (st == SSX_ERR_CAPACITY && n > (int32_t)kps.size()) {
+      kps.assign((size_t)n, ssx_keypoint{});
+      st = ssx_orb_detect_boxes(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, boxes.data(), nb, &prm, (int32_t)kps.size(), kps.data(), &n);
+    }
+    frame_.check(st);
+    kps.resize(n);
+  }
+
   void TrackLK(const Image& prev, const Image& next, const std::vector<float>& prev_pts, std::vector<float>& next_pts,
                std::vector<uint8_t>& status, bool temporal) override
   {

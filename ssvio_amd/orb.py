@@ -48,6 +48,22 @@ class ORBextractor:
             0 if mask is None else mask.strides[0], C.byref(self.prm), cap, kps.ctypes.data_as(C.c_void_p), C.byref(n)))
         return kps[:n.value].copy()
 
+    def DetectBoxes(self, image, boxes):
+        """ssx_orb_detect_boxes: ORBextractor::Detect under the mask of FrontEnd::DetectFeatures (frontend.cpp:302-312) given as its
+        rectangles -- boxes [n, 4] int32 (x0, y0, x1, y1), corners inclusive; the mask is rasterised on the device."""
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, dtype=KP_DTYPE)
+        image = _img(image)
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
+        cap = self._cap()
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.ssx_orb_detect_boxes(
+            self.ctx.handle, ptr(image, u8_p), image.strides[0], image.shape[0], image.shape[1], boxes.ctypes.data_as(C.POINTER(C.c_int32)),
+            len(boxes), C.byref(self.prm), cap, kps.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return kps[:n.value].copy()
+
     def DetectAndCompute(self, image, mask=None):
         """ORBextractor::DetectAndCompute (orbextractor.cpp:687-753): (keypoints, N x 32 uint8 descriptors)."""
         image = np.asarray(image)

@@ -42,7 +42,7 @@ def write_corridor_sequence(root, n_frames=30, step=0.8, seed=0, dt=0.1):
     from PIL import Image
 
     from tools.synth import make_corridor_sequence
-    frames, gt, centres = make_corridor_sequence(n_frames=n_frames, step=step, seed=seed)
+    frames, gt, centres = make_corridor_sequence(n_frames=n_frames, step=step, seed=seed, workers=min(12, os.cpu_count() or 1))   # (same images as one worker)
     d = os.path.join(root, "seq")
     for sub in ("image_0", "image_1"):
         os.makedirs(os.path.join(d, sub), exist_ok=True)

@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "ssx.h")
 
 
-def declared_symbols():
-    src = open(HDR).read()
+HOOKS = os.path.join(ROOT, "include", "ssx_test_hooks.h")
+
+
+def declared_symbols(path=HDR):
+    src = open(path).read()
     return sorted(set(re.findall(r"SSX_API[^;(]*?\b(ssx_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -28,6 +31,11 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(syms) >= 10
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
+    # the product header declares no test / tools hook; those live in include/ssx_test_hooks.h (present in the default build only)
+    assert not [s for s in syms if "debug" in s or "selftest" in s]
+    hooks = declared_symbols(HOOKS)
+    assert len(hooks) >= 5 and all(("debug" in s or "selftest" in s) for s in hooks)
+    assert not [s for s in hooks if not hasattr(lib, s)]
     from ssvio_amd import _lib
     assert lib.ssx_version() == _lib.SSX_VERSION == 110
     # a caller built against another header is told so (ssx_abi_check), instead of reading cu_count from garbage

@@ -48,27 +48,124 @@ def test_runner_matches_the_oracle(built, tmp_path, overrides):
     assert err.max() < 0.03
 
 
-def test_forward_drive_matches_the_oracle(built, tmp_path):
-    """BASELINE configs[0] shape (forward drive through a rendered corridor, the reference's own settings): GPU and
-    oracle runs take the same decisions on every frame and end with the same trajectory file"""
-    # (seed: the first window holds ONE keyframe and nothing fixed -- its solution is set by rounding along seven directions, in the GPU
-    # solver and the oracle alike -- and on the drive of seed 0 one LK track of frame 1 sits so close to its acceptance threshold that
-    # the two runs keep 217 and 218 features; seeds 1 .. 5 take identical decisions throughout)
-    seq = hu.write_corridor_sequence(str(tmp_path), n_frames=24, seed=1)
+def _strip(log):
+    return [{k: v for k, v in f.items() if k != "centre"} for f in log]
+
+
+def _run_both(built, cfg, seq_dir, t_gpu, t_cpu):
+    cpu = subprocess.run([built["oracle_runner"], cfg, seq_dir, t_cpu], capture_output=True, text=True, timeout=1800)
+    gpu = subprocess.run([built["oracle_runner"], cfg, seq_dir, t_gpu], capture_output=True, text=True, timeout=1800,
+                         env=dict(os.environ, SSX_HOST_TEST_GPU="1"))
+    assert cpu.returncode == 0 and gpu.returncode == 0, cpu.stderr[-2000:] + gpu.stderr[-2000:]
+    return hu.parse_runner_log(gpu.stdout), hu.parse_runner_log(cpu.stdout)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_forward_drive_matches_the_oracle(built, tmp_path, seed):
+    """BASELINE configs[0] shape (forward drive through a rendered corridor, the reference's own settings), six drives: GPU and
+    oracle runs take the same decisions on every frame and end with the same trajectory file -- up to ONE kind of difference, which
+    is asserted as such.  Detection, LK and the map bookkeeping are bit-exact between the two; the pose-only LM and the window BA
+    are not (different summation orders), and the reference's window BA has no fixed vertex and left-image edges only, so gauge AND
+    scale are free inside a window and its solution along those seven directions is set by rounding: keyframe poses of two
+    faithful implementations agree to ~1e-4 m after the first optimisation, LK's initial guesses (projected map points) then differ
+    by ~1e-3 px, and a track that sits on one of LK's acceptance thresholds is kept by one run and dropped by the other.  On the
+    drive of seed 0 that happens to one track of frame 1 (217 / 218 features); seeds 1 .. 5 see no such track in 24 frames.  So:
+    every frame identical, or -- a difference of at most two in the feature count of some frames (and, from the next keyframe on,
+    in the map-point counts: the extra track becomes an extra map point), nothing else (same status, keyframes, window
+    keyframes), camera centres within 1e-3 m."""
+    seq = hu.write_corridor_sequence(str(tmp_path), n_frames=24, seed=seed)
     cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {})
     t_gpu, t_cpu = os.path.join(str(tmp_path), "gpu.txt"), os.path.join(str(tmp_path), "cpu.txt")
-    cpu = subprocess.run([built["oracle_runner"], cfg, seq["dir"], t_cpu], capture_output=True, text=True, timeout=600)
-    gpu = subprocess.run([built["oracle_runner"], cfg, seq["dir"], t_gpu], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, SSX_HOST_TEST_GPU="1"))
-    assert cpu.returncode == 0 and gpu.returncode == 0, cpu.stderr + gpu.stderr
-    lg, lc = hu.parse_runner_log(gpu.stdout), hu.parse_runner_log(cpu.stdout)
-    assert [{k: v for k, v in f.items() if k != "centre"} for f in lg] == [{k: v for k, v in f.items() if k != "centre"} for f in lc]
-    assert np.abs(np.array([f["centre"] for f in lg]) - np.array([f["centre"] for f in lc])).max() < 1e-4
+    lg, lc = _run_both(built, cfg, seq["dir"], t_gpu, t_cpu)
+    assert len(lg) == len(lc) == 24
+    n_diff = 0
+    for fg, fc in zip(_strip(lg), _strip(lc)):
+        if fg != fc:
+            n_diff += 1
+            # the extra track is an extra feature, and at the next keyframe an extra map point; decisions stay the same
+            soft = ("features", "points", "active_points")
+            assert {k: v for k, v in fg.items() if k not in soft} == {k: v for k, v in fc.items() if k not in soft}, (fg, fc)
+            assert all(abs(fg[k] - fc[k]) <= 2 for k in soft), (fg, fc)
+    if seed != 0:
+        assert n_diff == 0, n_diff                                   # (five of the six drives: nothing differs at all)
+    assert np.abs(np.array([f["centre"] for f in lg]) - np.array([f["centre"] for f in lc])).max() < 1e-3
     assert lg[-1]["keyframes"] >= 2 and all(f["status"] in (1, 2) for f in lg)
-    # the window BA of the reference has no fixed vertex and left-image edges only: gauge AND scale are free, so the
-    # solution along those 7 directions is set by rounding; keyframe poses of the two runs agree to ~1e-4 m, not 1e-6
     a, b = np.loadtxt(t_gpu, ndmin=2), np.loadtxt(t_cpu, ndmin=2)
     assert a.shape == b.shape and np.abs(a - b).max() <= 1e-3, np.abs(a - b).max()
+
+
+def _umeyama(X, Y):
+    """similarity (s, R, t) minimising |s R X + t - Y| (what `evo_ape -as` aligns with)"""
+    mx, my = X.mean(0), Y.mean(0)
+    Xc, Yc = X - mx, Y - my
+    U, D, Vt = np.linalg.svd(Yc.T @ Xc / len(X))
+    S = np.eye(3); S[2, 2] = np.sign(np.linalg.det(U) * np.linalg.det(Vt))
+    R = U @ S @ Vt
+    s = np.trace(np.diag(D) @ S) / (Xc ** 2).sum() * len(X)
+    return s, R, my - s * R @ mx
+
+
+def test_c1_200_pairs_through_test_system(built, tmp_path):
+    """BASELINE configs[0] AT ITS STATED SIZE (/root/reference/test/test_system.cpp:36-49: 200 stereo pairs, kitti_00.yaml, no loop
+    closure): the rendered 200-pair corridor drive (159 m; real KITTI frames do not exist offline) through the headless test_system
+    on the GPU library and through the same host code on the CPU oracle.
+
+    What CAN be asserted over 200 frames, and why not more.  The two runs are identical frame by frame until a single LK track
+    lands on different sides of an acceptance threshold (see test_forward_drive_matches_the_oracle: inevitable once the gauge-free
+    window BA has run; it happens once per ~60 frames on these drives -- frame 1 here); from the next keyframe decision on they are
+    two different, equally valid runs of a chaotic system (keyframes at different frames, trajectories ~1 m apart).  So the
+    assertions are (1) identity up to the first difference, which must be a feature count off by at most two and nothing else;
+    (2) both runs complete without ever losing track, with keyframe counts within two of each other; (3) ACCURACY against the
+    generator's ground truth, for both: the reference's window BA holds no fixed vertex and only left-image observations, i.e. it is
+    a monocular BA whose scale drifts (measured here: 2-3 %) -- the keyframe trajectory is within 3 % of the path length of the
+    truth when merely anchored at the first keyframe, within 0.7 m RMSE (0.45 % of 159 m) after the similarity alignment `evo_ape
+    -as` applies, at a scale within 4 % of one; (4) the product executable writes the instrumented GPU run's trajectory file byte
+    for byte, twice (determinism)."""
+    from tools.synth import make_corridor_sequence, write_kitti_sequence
+    d = "/tmp/ssx_c1_corridor_200"                                  # (bench.py's configs[0] leg renders and keeps the same drive)
+    if not os.path.exists(os.path.join(d, "times.txt")) or not os.path.exists(os.path.join(d, "centres.npy")):
+        frames, _, centres = make_corridor_sequence(n_frames=200, workers=min(32, os.cpu_count() or 1))
+        write_kitti_sequence(d, frames)
+        np.save(os.path.join(d, "centres.npy"), centres)
+    centres = np.load(os.path.join(d, "centres.npy"))
+    path_len = float(np.linalg.norm(np.diff(centres, axis=0), axis=1).sum())
+    cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {})
+    t_gpu, t_cpu = os.path.join(str(tmp_path), "gpu.txt"), os.path.join(str(tmp_path), "cpu.txt")
+    lg, lc = _run_both(built, cfg, d, t_gpu, t_cpu)
+    assert len(lg) == len(lc) == 200
+    # (1) identical up to the first difference; the first difference is a feature count
+    sg, sc = _strip(lg), _strip(lc)
+    first = next((i for i in range(200) if sg[i] != sc[i]), None)
+    if first is not None:
+        fg, fc = sg[first], sc[first]
+        assert {k: v for k, v in fg.items() if k != "features"} == {k: v for k, v in fc.items() if k != "features"}, (fg, fc)
+        assert abs(fg["features"] - fc["features"]) <= 2, (fg, fc)
+        assert np.abs(np.array([f["centre"] for f in lg[:first + 1]]) - np.array([f["centre"] for f in lc[:first + 1]])).max() < 1e-3
+    # (2) both runs track throughout
+    for log in (lg, lc):
+        assert all(f["status"] in (1, 2) for f in log) and log[-1]["keyframes"] >= 8
+    assert abs(lg[-1]["keyframes"] - lc[-1]["keyframes"]) <= 2
+    # (3) accuracy against the ground truth
+    for name, tfile in (("gpu", t_gpu), ("cpu", t_cpu)):
+        tum = np.loadtxt(tfile, ndmin=2)
+        idx = np.rint(tum[:, 0] / 0.1).astype(int)
+        est, gt = tum[:, 1:4], centres[idx]
+        anchored = np.linalg.norm((est - est[0]) - (gt - gt[0]), axis=1)
+        s, R, t = _umeyama(est, gt)
+        aligned = np.linalg.norm((s * (R @ est.T).T + t) - gt, axis=1)
+        print(f"[c1 {name}] keyframes {len(tum)}, path {path_len:.1f} m: anchored APE rmse {np.sqrt((anchored ** 2).mean()):.3f} max {anchored.max():.3f} m; "
+              f"Sim3-aligned rmse {np.sqrt((aligned ** 2).mean()):.3f} max {aligned.max():.3f} m, scale {s:.4f}")
+        assert anchored.max() < 0.03 * path_len, (name, anchored.max())
+        assert np.sqrt((aligned ** 2).mean()) < 0.7 and abs(s - 1.0) < 0.04, (name, np.sqrt((aligned ** 2).mean()), s)
+    # (4) the product executable: the same file, twice
+    outs = []
+    for rep in range(2):
+        out = os.path.join(str(tmp_path), f"exe{rep}.txt")
+        r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={d}", f"--trajectory={out}", "--decode_threads=16"],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "Num Images: 200" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] == open(t_gpu).read()
 
 
 def test_asynchronous_backend(built, tmp_path):
