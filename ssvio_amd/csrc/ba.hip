@@ -164,6 +164,8 @@ struct BaDev {
   GPtr<double> c2_out;            // E: edge chi2 in the CALLER's order (results of a device-marshalled window)
   Cam K;
   double ext[14];
+  double extR[18];               // quat_to_R of the two camera extrinsics (row-major), filled by upload(): every kernel that needs the
+                                 // Jacobians takes the rotations from here (21 f64 operations per edge not repeated)
   double huber_delta, chi2_th;
   // state
   GPtr<double> pose[2];          // [P*7]
@@ -411,7 +413,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     double er[2], p1[3], pc[3], Jj[6];
     ssx::edge_error(T, X, ext, d.K, u, v, er, p1, pc);
     if (JAC == SSX_JAC_NUMERIC_G2O) ssx::edge_jac_numeric(T, X, ext, d.K, u, v, Ji, Jj);
-    else ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
+    else ssx::edge_jac_analytic_R(T, d.extR + 9 * (er4.w & 1), d.K, p1, pc, Ji, Jj);
     double w;
     ssx::huber(er[0] * er[0] + er[1] * er[1], d.huber_delta, rho0, w);
     if (!d.no_err) {
@@ -421,14 +423,17 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     // an edge whose vertices are both fixed is not active in g2o (sparse_optimizer.cpp:237): no chi2 term
     if (pf < 0 && !lfree) rho0 = 0.0;
     wq = w; r0 = -er[0] * w; r1 = -er[1] * w;
-    // W = Ji^T w Jj  (6x3), only when both vertices are free (block_solver.hpp:196-222)
+    // W = Ji^T w Jj  (6x3), only when both vertices are free (block_solver.hpp:196-222).  The conditions go into the WEIGHT (one
+    // select each) instead of into every entry (27 selects of a double = 54 v_cndmask): a vanishing weight gives (signed) zeros.
     const bool both = (pf >= 0) && lfree;
+    const double wb = both ? w : 0.0, wl = lfree ? w : 0.0;
+    const double r0l = -er[0] * wl, r1l = -er[1] * wl;
     if (d.store_w || Wout) {
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-          const double wv = both ? (Ji[a] * w * Jj[b] + Ji[6 + a] * w * Jj[3 + b]) : 0.0;
+          const double wv = Ji[a] * wb * Jj[b] + Ji[6 + a] * wb * Jj[3 + b];
           if (d.store_w) d.W[(size_t)(a * 3 + b) * d.E + e] = wv;
           if (Wout) Wout[a * 3 + b] = wv;
         }
@@ -438,9 +443,9 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = a; b < 3; ++b) sL[q++][t] = lfree ? (Jj[a] * w * Jj[b] + Jj[3 + a] * w * Jj[3 + b]) : 0.0;
+      for (int b = a; b < 3; ++b) sL[q++][t] = Jj[a] * wl * Jj[b] + Jj[3 + a] * wl * Jj[3 + b];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) sL[6 + a][t] = lfree ? (Jj[a] * r0 + Jj[3 + a] * r1) : 0.0;
+    for (int a = 0; a < 3; ++a) sL[6 + a][t] = Jj[a] * r0l + Jj[3 + a] * r1l;
     if (small) {
       double V[LIN_VA];
       pose_terms<0, LIN_VA>(Ji, wq, r0, r1, V);
@@ -477,7 +482,8 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     const int nP = d.nP;
     // (a pose none of whose edges lies in this chunk is not written: the reduction skips it through BaDev::touch)
     const bool dense = d.dense_slabs != 0;
-    for (int i = t; i < nP * LIN_VA; i += CH) {
+    // (entries dealt from the LAST thread down: the landmark sums above kept the first threads busy)
+    for (int i = CH - 1 - t; i < nP * LIN_VA; i += CH) {
       const int p = i / LIN_VA, k = i - p * LIN_VA;
       const int s0 = sPptr[p], s1 = sPptr[p + 1];
       if (dense || s1 > s0) slab[p * 27 + k] = run_sum(sV + k * PW, s0, s1);
@@ -490,7 +496,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
       for (int k = 0; k < 27 - LIN_VA; ++k) sV[k * PW + pos] = V[k];
     }
     __syncthreads();
-    for (int i = t; i < nP * (27 - LIN_VA); i += CH) {
+    for (int i = CH - 1 - t; i < nP * (27 - LIN_VA); i += CH) {
       const int p = i / (27 - LIN_VA), k = i - p * (27 - LIN_VA);
       const int s0 = sPptr[p], s1 = sPptr[p + 1];
       if (dense || s1 > s0) slab[p * 27 + LIN_VA + k] = run_sum(sV + k * PW, s0, s1);
@@ -1058,7 +1064,7 @@ __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W
   const double* ext = d.ext + 7 * (er4.w & 1);
   double er[2], p1[3], pc[3], Ji[12], Jj[6], rho0, w;
   ssx::edge_error(T, X, ext, d.K, d.e_uv[e], d.e_uv[d.E + e], er, p1, pc);
-  ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
+  ssx::edge_jac_analytic_R(T, d.extR + 9 * (er4.w & 1), d.K, p1, pc, Ji, Jj);
   ssx::huber(er[0] * er[0] + er[1] * er[1], d.huber_delta, rho0, w);
 #pragma unroll
   for (int a = 0; a < 6; ++a)
@@ -2499,6 +2505,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.pose_rank = (const int*)(have_rank ? at(o_pose_rank) : nullptr);
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
+  ssx::quat_to_R(d.ext, d.extR); ssx::quat_to_R(d.ext + 7, d.extR + 9);   // every kernel takes the extrinsics' rotations from here
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
   d.pose_init = keep_init ? (const double*)(at(o_pose_init)) : nullptr;
   d.point_init = keep_init ? (const double*)(at(o_point_init)) : nullptr;

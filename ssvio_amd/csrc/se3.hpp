@@ -201,15 +201,16 @@ SSX_HD void edge_error(const double* T, const double* p, const double* ext, cons
 
 // analytic Jacobians (the formula commented out at g2otypes.hpp:133-153, generalised to ext != I):
 //   Ji (2x6) = A * R_ext * [ I | -[p1]x ],  Jj (2x3) = A * R_ext * R_T,  A = d e / d pc
-SSX_HD void edge_jac_analytic(const double* T, const double* ext, const Cam& K, const double* p1,
-                              const double* pc, double* Ji, double* Jj)
+// (Re = quat_to_R(ext), row-major: the rotation of the camera extrinsic is the same for every edge of a camera -- callers that
+// linearise thousands of edges keep it, see BaDev::extR)
+SSX_HD void edge_jac_analytic_R(const double* T, const double* Re, const Cam& K, const double* p1,
+                                const double* pc, double* Ji, double* Jj)
 {
   const double X = pc[0], Y = pc[1], Z = pc[2];
   const double Zinv = 1.0 / (Z + 1e-18);
   const double Zinv2 = Zinv * Zinv;
   const double A[6] = {-K.fx * Zinv, 0.0, K.fx * X * Zinv2, 0.0, -K.fy * Zinv, K.fy * Y * Zinv2};
-  double Re[9], Rt[9];
-  quat_to_R(ext, Re);
+  double Rt[9];
   quat_to_R(T, Rt);
   double AR[6];
 #pragma unroll
@@ -227,6 +228,13 @@ SSX_HD void edge_jac_analytic(const double* T, const double* ext, const Cam& K, 
       Jj[r * 3 + c] = AR[r * 3] * Rt[c] + AR[r * 3 + 1] * Rt[3 + c] + AR[r * 3 + 2] * Rt[6 + c];
     }
   }
+}
+SSX_HD void edge_jac_analytic(const double* T, const double* ext, const Cam& K, const double* p1,
+                              const double* pc, double* Ji, double* Jj)
+{
+  double Re[9];
+  quat_to_R(ext, Re);
+  edge_jac_analytic_R(T, Re, K, p1, pc, Ji, Jj);
 }
 
 // g2o's numeric Jacobians: central differences, delta = 1e-9, through oplus
