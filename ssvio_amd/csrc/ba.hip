@@ -164,8 +164,6 @@ struct BaDev {
   GPtr<double> c2_out;            // E: edge chi2 in the CALLER's order (results of a device-marshalled window)
   Cam K;
   double ext[14];
-  double extR[18];               // quat_to_R of the two camera extrinsics (row-major), filled by upload(): every kernel that needs the
-                                 // Jacobians takes the rotations from here (21 f64 operations per edge not repeated)
   double huber_delta, chi2_th;
   // state
   GPtr<double> pose[2];          // [P*7]
@@ -413,7 +411,7 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     double er[2], p1[3], pc[3], Jj[6];
     ssx::edge_error(T, X, ext, d.K, u, v, er, p1, pc);
     if (JAC == SSX_JAC_NUMERIC_G2O) ssx::edge_jac_numeric(T, X, ext, d.K, u, v, Ji, Jj);
-    else ssx::edge_jac_analytic_R(T, d.extR + 9 * (er4.w & 1), d.K, p1, pc, Ji, Jj);
+    else ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
     double w;
     ssx::huber(er[0] * er[0] + er[1] * er[1], d.huber_delta, rho0, w);
     if (!d.no_err) {
@@ -1064,7 +1062,7 @@ __device__ __forceinline__ void edge_W(const BaDev& d, int cur, int e, double* W
   const double* ext = d.ext + 7 * (er4.w & 1);
   double er[2], p1[3], pc[3], Ji[12], Jj[6], rho0, w;
   ssx::edge_error(T, X, ext, d.K, d.e_uv[e], d.e_uv[d.E + e], er, p1, pc);
-  ssx::edge_jac_analytic_R(T, d.extR + 9 * (er4.w & 1), d.K, p1, pc, Ji, Jj);
+  ssx::edge_jac_analytic(T, ext, d.K, p1, pc, Ji, Jj);
   ssx::huber(er[0] * er[0] + er[1] * er[1], d.huber_delta, rho0, w);
 #pragma unroll
   for (int a = 0; a < 6; ++a)
@@ -2505,7 +2503,6 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.pose_rank = (const int*)(have_rank ? at(o_pose_rank) : nullptr);
   d.K = Cam{pr->K[0], pr->K[1], pr->K[2], pr->K[3]};
   for (int i = 0; i < 14; ++i) d.ext[i] = pr->cam_ext[i];
-  ssx::quat_to_R(d.ext, d.extR); ssx::quat_to_R(d.ext + 7, d.extR + 9);   // every kernel takes the extrinsics' rotations from here
   d.huber_delta = huber_delta; d.chi2_th = chi2_th;
   d.pose_init = keep_init ? (const double*)(at(o_pose_init)) : nullptr;
   d.point_init = keep_init ? (const double*)(at(o_point_init)) : nullptr;
