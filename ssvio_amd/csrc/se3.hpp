@@ -202,7 +202,7 @@ SSX_HD void edge_error(const double* T, const double* p, const double* ext, cons
 // analytic Jacobians (the formula commented out at g2otypes.hpp:133-153, generalised to ext != I):
 //   Ji (2x6) = A * R_ext * [ I | -[p1]x ],  Jj (2x3) = A * R_ext * R_T,  A = d e / d pc
 // (Re = quat_to_R(ext), row-major: the rotation of the camera extrinsic is the same for every edge of a camera -- callers that
-// linearise thousands of edges keep it, see BaDev::extR)
+// linearise thousands of edges keep it, k_linearize measured no gain from it: profiles/r05/lin_schur_ab.md)
 SSX_HD void edge_jac_analytic_R(const double* T, const double* Re, const Cam& K, const double* p1,
                                 const double* pc, double* Ji, double* Jj)
 {
