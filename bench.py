@@ -84,6 +84,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16, help="stereo pairs + windows timed on the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--c1-frames", type=int, default=200, help="stereo pairs of the configs[0] leg (0 = skip it)")
+    ap.add_argument("--profile-kernels", action="store_true", help="for the rocprofv3 passes (tools/collect_profiles.sh): the live-backend region "
+                    "is left out, so that every batched BA kernel is launched in ONE shape (B windows per launch: the frozen batch and the "
+                    "per-kernel pass) and rocprofv3's per-kernel averages can be set beside roofline.avg_launch_us; `value` is then the "
+                    "frozen-batch composite and the line says so")
     ap.add_argument("--lean", action="store_true", help="only the headline region + the per-kernel pass (what tools/collect_profiles.sh "
                     "profiles: every launch of a kernel then has the same shape, so rocprofv3's per-kernel averages mean something)")
     args = ap.parse_args()
@@ -187,57 +191,64 @@ def main():
         _, c1_gen_err = c1_gen.communicate(timeout=1800)
 
     # ---------------- timed region 1 (the headline): front-end + one local BA per pair on B live sliding windows ----------------
-    from tools import bench_live
-    # three backend groups (host thread + context each), one stream per context, a group may be two steps behind the front-end's
-    # release: measured best of the sweep in profiles/r05/live_backend_orchestration.md (the GPU has four hardware queues)
-    LIVE_THREADS = int(os.environ.get("SSX_BENCH_WINDOW_THREADS", "3"))
-    LIVE_LAG = max(1, int(os.environ.get("SSX_BENCH_LAG", "2")))       # steps a backend group may be behind the front-end's release
-    live_steps = args.warmup + args.steps
-    live = bench_live.LiveBackend(ssvio_amd, dev_index, B, live_steps, threads=LIVE_THREADS, seed=900 + 1000 * rank)
+    if not args.profile_kernels:
+        from tools import bench_live
+        # three backend groups (host thread + context each), one stream per context, a group may be two steps behind the front-end's
+        # release: measured best of the sweep in profiles/r05/live_backend_orchestration.md (the GPU has four hardware queues)
+        LIVE_THREADS = int(os.environ.get("SSX_BENCH_WINDOW_THREADS", "3"))
+        LIVE_LAG = max(1, int(os.environ.get("SSX_BENCH_LAG", "2")))       # steps a backend group may be behind the front-end's release
+        live_steps = args.warmup + args.steps
+        live = bench_live.LiveBackend(ssvio_amd, dev_index, B, live_steps, threads=LIVE_THREADS, seed=900 + 1000 * rank)
 
-    def live_steps_run(n):
-        # per step: the front-end's enqueue, the release of the step's keyframes to the backend groups, the front-end's results of
-        # the batch before; the groups' step is awaited one step late (bench_live.LiveBackend.run: their host phases overlap each
-        # other's kernels)
-        def fe_part():
-            frontend_step()
-        for i in range(n):
-            fe_part()
-            live.release()
-            frontend_collect()
-            if i >= LIVE_LAG:
+        def live_steps_run(n):
+            # per step: the front-end's enqueue, the release of the step's keyframes to the backend groups, the front-end's results of
+            # the batch before; the groups' step is awaited one step late (bench_live.LiveBackend.run: their host phases overlap each
+            # other's kernels)
+            def fe_part():
+                frontend_step()
+            for i in range(n):
+                fe_part()
+                live.release()
+                frontend_collect()
+                if i >= LIVE_LAG:
+                    live.wait_done()
+            for _ in range(min(LIVE_LAG, n)):
                 live.wait_done()
-        for _ in range(min(LIVE_LAG, n)):
-            live.wait_done()
 
-    def sync_all():
-        live.synchronize()
-        barrier()
+        def sync_all():
+            live.synchronize()
+            barrier()
 
-    live_steps_run(args.warmup)
-    sync_all()
-    live.reset_counters(); fe_pairs[0] = 0
-    t0 = time.perf_counter()
-    live_steps_run(args.steps)
-    sync_all()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    frames = world * B * args.steps
-    assert fe_pairs[0] == B * args.steps, "a stereo pair came back without keypoints"
-    assert min(live.steps_done) == args.steps, "a backend group did not finish its steps"
-    lm_iters = sum(live.iters)
-    value = frames / elapsed
-    nkf_w, nlm_w, nob_w = live.window_size()
-    live_info = {"host_threads": live.G, "streams_per_group": live.batch_groups or 2, "steps_a_group_may_lag": LIVE_LAG, "ms_per_step_inside_solve_calls": round(max(live.t_solve) / args.steps * 1e3, 4),
-                 "ms_per_step_inside_update_calls": round(max(live.t_edit) / args.steps * 1e3, 4),
-                 "window": {"keyframes": nkf_w, "landmarks": nlm_w, "observations": nob_w},
-                 "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2),
-                 "what": "ms_per_step_inside_solve_calls / _update_calls = the busiest group thread's time inside ssx_ba_window_solve_batch "
-                         "(pending uploads, counting tables, device-side marshalling, solve, download of poses + landmarks) / inside "
-                         "ssx_ba_window_update_batch, per step of the whole batch; the groups work side by side, so the calls of one group "
-                         "wait for the GPU while the others' kernels run"}
-    live.close()
-    fe_stream.wait_counts()                                            # drain: the last batch that was run ...
-    fe_stream.run(); fe_stream.wait_counts()                           # ... and the one uploaded ahead by the last step
+        live_steps_run(args.warmup)
+        sync_all()
+        live.reset_counters(); fe_pairs[0] = 0
+        t0 = time.perf_counter()
+        live_steps_run(args.steps)
+        sync_all()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        frames = world * B * args.steps
+        assert fe_pairs[0] == B * args.steps, "a stereo pair came back without keypoints"
+        assert min(live.steps_done) == args.steps, "a backend group did not finish its steps"
+        lm_iters = sum(live.iters)
+        value = frames / elapsed
+        nkf_w, nlm_w, nob_w = live.window_size()
+        live_info = {"host_threads": live.G, "streams_per_group": live.batch_groups or 2, "steps_a_group_may_lag": LIVE_LAG, "ms_per_step_inside_solve_calls": round(max(live.t_solve) / args.steps * 1e3, 4),
+                     "ms_per_step_inside_update_calls": round(max(live.t_edit) / args.steps * 1e3, 4),
+                     "window": {"keyframes": nkf_w, "landmarks": nlm_w, "observations": nob_w},
+                     "lm_iterations_per_window": round(lm_iters / (args.steps * B), 2),
+                     "what": "ms_per_step_inside_solve_calls / _update_calls = the busiest group thread's time inside ssx_ba_window_solve_batch "
+                             "(pending uploads, counting tables, device-side marshalling, solve, download of poses + landmarks) / inside "
+                             "ssx_ba_window_update_batch, per step of the whole batch; the groups work side by side, so the calls of one group "
+                             "wait for the GPU while the others' kernels run"}
+        live.close()
+        fe_stream.wait_counts()                                            # drain: the last batch that was run ...
+        fe_stream.run(); fe_stream.wait_counts()                           # ... and the one uploaded ahead by the last step
+
+    else:
+        live_info = {"skipped": "--profile-kernels: value is the frozen-batch composite", "host_threads": 0, "window": None}
+        lm_iters = 0
+        fe_stream.wait_counts()
+        fe_stream.run(); fe_stream.wait_counts()
 
     # ---------------- timed region 1f: rounds 2-4's headline -- the same front-end step beside a FROZEN batch of C3 windows ----------------
     fe_stream.upload(ring[0].data_ptr()); fe_stream.run()
@@ -268,6 +279,9 @@ def main():
     barrier()
     frozen_elapsed = max_over_ranks(time.perf_counter() - t0)
     frozen_value = world * B * FROZEN_STEPS / frozen_elapsed
+    if args.profile_kernels:
+        value, elapsed, frames = frozen_value, frozen_elapsed * args.steps / FROZEN_STEPS, world * B * args.steps
+        lm_iters = 10 * args.steps * B
     fe_stream.wait_counts()
     fe_stream.run(); fe_stream.wait_counts()
     orb.stereo_batch_dev(ctx, imgs.data_ptr(), B, KITTI_W, KITTI_H, KITTI_W)     # back to the resident images for the regions below
@@ -449,7 +463,7 @@ def main():
         dom_bytes = algo_launch_ba.get(dom.split("<")[0], 0.0)
     # PMC counters per launch from the committed passes (tools/collect_profiles.sh -> profiles/pmc_counters.json:
     # separate FETCH_SIZE / WRITE_SIZE / SQ passes); only valid for the batch size they were taken at
-    traffic = valu_insts = None
+    traffic = valu_insts = rocprof_avg_us = None
     pmc_src = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
@@ -460,6 +474,7 @@ def main():
             key = [k for nm in names for k in pc["per_launch"] if k.split("<")[0] == nm]
             if key:
                 rec = pc["per_launch"][key[0]]
+                rocprof_avg_us = rec.get("avg_us_rocprof_stats")
                 traffic = rec.get("hbm_bytes")
                 valu_insts = rec.get("SQ_INSTS_VALU")
                 pmc_src = pc.get("source")
@@ -522,6 +537,12 @@ def main():
         roofline["utilisation"] = util
     best = max(cands, key=lambda c: c[4])
     roofline.update(bound=best[0], achieved=best[1], peak=best[2], unit=best[3], frac=best[4])
+    # the two durations the fraction can be taken with, named: this run's HIP events around the kernel ALONE on the chip (one group of
+    # B windows, nothing beside it: avg_launch_us, what `frac` uses), and the average of the committed rocprofv3 --kernel-trace
+    # --stats pass of `bench.py --lean --profile-kernels` (the same launch shape with the front-end's kernels beside it)
+    roofline["frac_alone_on_chip"] = best[4]
+    roofline["rocprof_avg_launch_us"] = rocprof_avg_us
+    roofline["frac_from_rocprof_avg"] = (round(best[4] * dom_avg_s * 1e6 / rocprof_avg_us, 5) if rocprof_avg_us else None)
     roofline["note"] = ("kernel with the largest share of the composite step (named as rocprofv3 prints it); achieved = ALGORITHMIC bytes / flops "
                         "per launch (SURVEY.md 8-D) / average launch duration measured live with HIP events on the launching stream; frac = "
                         "the larger of hbm_frac and flops_frac; `traffic` (FETCH_SIZE + WRITE_SIZE per launch) and traffic_ratio = traffic / "
@@ -796,6 +817,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "stereo frames/s (ORB extract + row-band match + triangulate + one local BA per frame) on 1241x376",
+            **({"profiling_mode": "--profile-kernels: the live-backend region was left out; value = frozen_batch"} if args.profile_kernels else {}),
             "value": round(value, 2), "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (front-end) + f64 (BA)", "data": "synthetic",

@@ -17,7 +17,7 @@ cd /tmp
 # one group of BA windows per launch while the counters run: a batched kernel then covers the whole batch and has the chip
 # to itself (the default, two groups on two streams, is what the bench line after the passes is taken with)
 export SSX_BA_GROUPS=1
-CMD="python $R/bench.py --steps 5 --warmup 2 --lean"
+CMD="python $R/bench.py --steps 5 --warmup 2 --lean --profile-kernels"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1

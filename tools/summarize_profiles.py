@@ -104,7 +104,7 @@ for sub in ("sq1", "sq2"):
 CLK_GHZ, SIMDS = 2.4, 1024
 per_launch = {}
 for k in set(list(traffic) + list(sq)):
-    per_launch[k] = {"hbm_bytes": round(traffic[k]) if k in traffic else None}
+    per_launch[k] = {"hbm_bytes": round(traffic[k]) if k in traffic else None, "avg_us_rocprof_stats": round(avg_ns.get(k, 0) / 1e3, 2) or None}
     for c, v in sq.get(k, {}).items():
         per_launch[k][c] = round(v)
 if sq:
