@@ -1652,6 +1652,7 @@ __global__ __launch_bounds__(CH) void k_pack_poses_b(const BaDev* __restrict__ d
 
 #include "ba_big.inc"
 #include "ba_band.inc"
+#include "ba_bcr.inc"
 
 }  // namespace
 
@@ -2193,6 +2194,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
 struct BandPlan {
   int w = 0, K = 1;
   std::vector<int> seg_p0, seg_m;
+  BcrPlan bcr;                       // bcr.on: block cyclic reduction (ba_bcr.inc) solves the band instead of the segments
 };
 
 void plan_band(int nP, int w, BandPlan& bp)
@@ -2295,6 +2297,9 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const bool band = big && bp.w > 0;
   const size_t o_seg_p0 = in.take(sizeof(int) * (bp.seg_p0.size() + 1));
   const size_t o_seg_m = in.take(sizeof(int) * (bp.seg_m.size() + 1));
+  const bool bcr = band && bp.bcr.on;                                 // block cyclic reduction of the band (ba_bcr.inc)
+  const size_t o_bcr_p0 = in.take(bcr ? sizeof(int) * (bp.bcr.p0.size() + 1) : 0);
+  const size_t o_bcr_elim = in.take(bcr ? sizeof(int) * (bp.bcr.elim.size() + 4) : 0);
   if (ext && !dev_prep) { ctx->set_error("ssx_ba: a window needs the device-side marshalling (<= %d free keyframes, no SSX_BA_HOST_PREP)", SSX_BA_SMALL_P); return SSX_ERR_UNSUPPORTED; }
   const size_t o_pose0 = in.take(ext ? 0 : sizeof(double) * 7 * P);
   const size_t o_point0 = in.take(ext ? 0 : sizeof(double) * 3 * (L + 1));
@@ -2357,6 +2362,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_Ls0 = all.take((band && bK > 1) ? sizeof(double) * (size_t)nP * LS0 : 256);
   const size_t o_Sr = all.take(sizeof(double) * (sr_count + 1));
   const size_t o_Ls1 = all.take(band ? sizeof(double) * (size_t)(bK > 1 ? bnPr : nP) * LS1 : 256);
+  const size_t o_bcr_mem = all.take(bcr ? sizeof(double) * (bcr_mem_doubles(bp.bcr.N, bp.bcr.m) + 8) : 256);
   const size_t o_xr = all.take(sizeof(double) * (6 * (size_t)bnPr + 8));
   const size_t o_x = all.take(sizeof(double) * (n_pad + 8));
   const size_t o_Ld = all.take(sizeof(double) * NB * NB);
@@ -2444,6 +2450,10 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   if (band) {
     memcpy(hs + o_seg_p0, bp.seg_p0.data(), sizeof(int) * bp.seg_p0.size());
     memcpy(hs + o_seg_m, bp.seg_m.data(), sizeof(int) * bp.seg_m.size());
+    if (bcr) {
+      memcpy(hs + o_bcr_p0, bp.bcr.p0.data(), sizeof(int) * bp.bcr.p0.size());
+      memcpy(hs + o_bcr_elim, bp.bcr.elim.data(), sizeof(int) * bp.bcr.elim.size());
+    }
   }
   if (!ext) {
     memcpy(hs + o_pose0, pr->poses, sizeof(double) * 7 * P);
@@ -2549,6 +2559,16 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
       bnd.seg_p0 = (const int*)(at(o_seg_p0)); bnd.seg_m = (const int*)(at(o_seg_m));
       bnd.U = (double*)(at(o_U)); bnd.Ls0 = (double*)(at(o_Ls0)); bnd.Sr = (double*)(at(o_Sr));
       bnd.Ls1 = (double*)(at(o_Ls1)); bnd.xr = (double*)(at(o_xr)); bnd.LS0 = LS0; bnd.LS1 = LS1;
+      bnd.bcr = BcrDev{};
+      if (bcr) {
+        BcrDev& q = bnd.bcr;
+        q.on = 1; q.N = bp.bcr.N; q.m = bp.bcr.m;
+        q.p0 = (const int*)(at(o_bcr_p0)); q.elim = (const int4*)(at(o_bcr_elim));
+        const size_t mmN = (size_t)q.N * q.m * q.m, mN = (size_t)q.N * q.m;
+        double* base = (double*)(at(o_bcr_mem));
+        q.D = base; q.E = q.D + mmN; q.DL = q.E + mmN; q.DR = q.DL + mmN; q.Lf = q.DR + mmN; q.Ul = q.Lf + mmN; q.Ur = q.Ul + mmN;
+        q.R = q.Ur + mmN; q.RL = q.R + mN; q.RR = q.RL + mN; q.Y = q.RR + mN; q.X = q.Y + mN;
+      }
     }
     bd.S = (double*)(at(o_S)); bd.x = (double*)(at(o_x)); bd.Ld = (double*)(at(o_Ld)); bd.invd = (double*)(at(o_invd)); bd.Ninv = (double*)(at(o_Ninv)); bd.scale_part = (double*)(at(o_scale_part));
   }
@@ -3055,7 +3075,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
       SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       for (int i = 1; i <= BAND_WMAX + 1; ++i) if (hist[i] != 0.0) w = i;
     }
-    if (w <= BAND_WMAX && h.nP >= 2 * w + 2) plan_band(h.nP, w, bp);
+    if (w <= BAND_WMAX && h.nP >= 2 * w + 2) { plan_band(h.nP, w, bp); plan_bcr(h.nP, w, bp.bcr); }
   }
   if (h.big && opt.large_solver == SSX_LARGE_SOLVER_BAND && bp.w == 0) {
     ctx->set_error("ssx_ba_solve: the band solver was requested but the co-visibility bandwidth is %d poses (> %d)", h.band_w, BAND_WMAX);
@@ -3118,6 +3138,24 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
       ssx_status st2 = allreduce(ctx, cm, bnd.Sb, band_doubles + (size_t)bd.n + (fuse_iter ? (size_t)d.nP * 27 + 1 + d.world : 0));
       if (st2 != SSX_OK) return st2;
       if (fuse_iter) SSX_PROF(ctx, KID_BA_REDUCE_LIN, hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, s, d, 0));   // the global chi2 of the linearisation
+      if (bnd.bcr.on) {
+        // block cyclic reduction: log2(N) levels of concurrent super-block eliminations, then as many of back-substitution
+        const std::vector<int>& lv = bp.bcr.lvl;
+        const int dlm = dev_lambda == 2 ? 1 : 0;
+        SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_bcr_build, dim3(bnd.bcr.N), dim3(256), 0, s, d, bnd, bnd.bcr, lambda, dev_lambda));
+        const bool m24 = bnd.bcr.m == 24;
+        const std::vector<int>& lm = bp.bcr.lvM;
+        for (size_t q = 0; q < lm.size(); ++q) {
+          const int cnt = lv[q + 1] - lv[q], sh = (int)q;
+          if (m24) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_bcr_fwd<24>, dim3(cnt, BCR_S), dim3(BCR_T), 0, s, d, bnd.bcr, sh, lm[q], dlm));
+          else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_bcr_fwd<36>, dim3(cnt, BCR_S), dim3(BCR_T), 0, s, d, bnd.bcr, sh, lm[q], dlm));
+        }
+        for (size_t q = lm.size(); q-- > 0;) {
+          const int cnt = lv[q + 1] - lv[q], sh = (int)q;
+          if (m24) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_bcr_bwd<24>, dim3(cnt), dim3(256), 0, s, d, bnd.bcr, bd, sh, lm[q], dlm));
+          else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_bcr_bwd<36>, dim3(cnt), dim3(256), 0, s, d, bnd.bcr, bd, sh, lm[q], dlm));
+        }
+      } else {
       if (bnd.K > 1) {
         SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_seg, dim3(bnd.K), dim3(BAND_T), lds_seg, s, d, bnd, lambda, dev_lambda));
         const int total = bnd.nPr * (bnd.wr + 1) * 36 + 6 * bnd.nPr;
@@ -3125,6 +3163,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
       }
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_top, dim3(1), dim3(BAND_TOP_T), lds_top, s, d, bnd, bd, lambda, dev_lambda));
       if (bnd.K > 1) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_band_back, dim3(bnd.K), dim3(BAND_T), lds_back, s, d, bnd, bd, dev_lambda == 2 ? 1 : 0));
+      }
       const int nparts = std::min(32, (d.P + CH - 1) / CH);
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_pose_update_big, dim3(nparts), dim3(CH), 0, s, d, bd, cur_, lambda, dev_lambda));
       SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_scale_finish, dim3(1), dim3(64), 0, s, d, bd, nparts));
