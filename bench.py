@@ -619,6 +619,14 @@ def main():
                 n_it4 += r4["n_iters"]
             barrier()
             el = max_over_ranks(time.perf_counter() - tb)
+            # the slope: the same solve with 20 iterations; (t20 - t10) / (trials20 - trials10) is what one more LM trial costs once
+            # the call's fixed part (host marshalling of the observations, upload, pair lists, download) is paid
+            tb = time.perf_counter()
+            r20 = ba.ba_solve(ctx, pr4_local, outer_rounds=1, iters=20, want_edges=False, **dkw)
+            barrier()
+            el20 = max_over_ranks(time.perf_counter() - tb)
+            tr10, tr20 = int(np.sum(r4["trials"])), int(np.sum(r20["trials"]))
+            steady = (el20 - el / reps) / max(tr20 - tr10, 1) * 1e3
             # one more solve with every launch and every all-reduce between HIP events (ssx_ba_options.collect_stats): where an
             # LM iteration's GPU time goes -- landmark-sharded kernels, the reduced solve every rank repeats, reductions, collectives
             rs = ba.ba_solve(ctx, pr4_local, outer_rounds=1, iters=10, want_edges=False, collect_stats=True, **dkw)
@@ -632,6 +640,9 @@ def main():
         return {"landmarks": n_landmarks, "edges": int(pr4["E"]), "iters_per_s": round(n_it4 / el, 2),
                 "edge_iters_per_s": round(float(pr4["E"]) * n_it4 / el, 1), "ms_per_lm_iteration": round(el / max(n_it4, 1) * 1e3, 3),
                 "lm_trials": int(np.sum(r4["trials"])), "chi2_first_last": [float(r4["chi2"][0]), float(r4["chi2"][-1])],
+                "ms_per_lm_trial_steady_state": round(steady, 3), "fixed_ms_per_call": round(el / reps * 1e3 - steady * tr10, 3),
+                "steady_state_what": "(wall of a 20-iteration call - wall of a 10-iteration call) / (their LM trials' difference); "
+                                     "fixed = the 10-iteration wall minus its trials at that rate (marshalling, upload, pair lists, download)",
                 "phase_ms_per_iteration": split}
 
     C4_LM_PER_GPU = 10000

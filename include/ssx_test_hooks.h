@@ -34,6 +34,11 @@ SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t 
  * are); 0 = as handed over (large windows, SSX_BA_WIDE_UPLOAD / SSX_BA_HOST_PREP set); -1 = invalid problem */
 SSX_API int32_t ssx_ba_debug_upload_format(const ssx_ba_problem* prob);
 
+/* test hook, needs no GPU: FNV-1a digest of the host marshalling of a LARGE window (per-landmark offsets, every observation's rank
+ * inside its landmark, per-keyframe counts, chunk cuts) with the observation pass on `threads` host threads (>= 65 536 observations
+ * take it on the worker pool; SSX_BA_PREP_THREADS, default min(8, cores)).  The digest must not depend on `threads`.  0 = invalid. */
+SSX_API uint64_t ssx_ba_debug_prepare_digest(const ssx_ba_problem* prob, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1685,6 +1685,7 @@ struct HostPrep {
   bool big = false;
   std::vector<int> pe_ptr, pe_edge, sblk_pa, sblk_pb, spair_ptr;
   std::vector<int> bseg, bseg_ptr;   // see BaDev
+  std::vector<int> thr_cnt, thr_pe;  // prepare() of a large window on several threads: per-thread landmark / pose counts
   std::vector<unsigned int> touch;   // host-built lists only: BaDev::touch
   bool dev_lists = false;            // small window: pair lists + work items are built by k_build_lists, not here
   bool dev_prep = false;             // small window: the edge sort by (landmark, pose), the packed records, the pose-major order and the
@@ -1884,6 +1885,8 @@ struct WinExt {
   const int* lm_order = nullptr; int n_lm_order = 0;
 };
 
+static int g_prep_threads_override = 0;   // test hook (ssx_ba_debug_prepare_digest): threads of the large-window observation pass
+
 // allow_dev_prep: small windows leave everything beyond counting to the device (see HostPrep::dev_prep); SSX_BA_HOST_PREP=1
 // keeps the host marshalling below as the reference of the tests (same bits: test_device_marshalling_equals_host_marshalling)
 ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool allow_dev_prep = true, const WinExt* ext = nullptr)
@@ -1922,6 +1925,49 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   int n_dead = 0;
   const bool big_dev = h.big && h.dev_prep;               // large window, device-marshalled: the host also counts edges per free pose
   if (big_dev) h.pe_ptr.assign((size_t)h.nP + 1, 0);
+  // The one pass over the observations.  A large window (480 000 observations at BASELINE configs[3]: 1.05 ms on one core, a sixth of
+  // a 10-iteration solve) takes it on the worker pool: every thread counts its range into tables of its own (slot8 = the rank
+  // inside the range), the per-landmark offsets of the ranges are summed landmark-parallel, a second pass adds them -- the same
+  // ranks as the serial loop, whatever the number of threads.
+  static const int prep_threads = [] { const char* e = getenv("SSX_BA_PREP_THREADS"); const int v = e ? atoi(e) : 0;
+                                       return v > 0 ? std::min(v, 32) : std::min(8, std::max(1, (int)std::thread::hardware_concurrency())); }();
+  const int T = (big_dev && !dead_ok && E >= (1 << 16) && ctx->ba) ? (g_prep_threads_override > 0 ? g_prep_threads_override : prep_threads) : 1;
+  if (T > 1) {
+    h.thr_cnt.resize((size_t)T * L); h.thr_pe.resize((size_t)T * (h.nP + 1));
+    std::vector<int> bad(T, -1);
+    auto lo = [&](int t, int n) { return (int)((long long)n * t / T); };
+    ctx->ba->pool.run(T, T, [&](int t) {
+      int* c = h.thr_cnt.data() + (size_t)t * L; int* pe = h.thr_pe.data() + (size_t)t * (h.nP + 1);
+      std::fill(c, c + L, 0); std::fill(pe, pe + h.nP + 1, 0);
+      for (int e = lo(t, E), e1 = lo(t + 1, E); e < e1; ++e) {
+        const int l = pr->edge_point[e], p = pr->edge_pose[e];
+        if (l < 0 || l >= L || p < 0 || p >= P) { bad[t] = e; return; }
+        h.slot8[e] = (uint8_t)c[l];
+        c[l]++;
+        const int pf = h.pose_free[p];
+        if (pf >= 0) pe[pf + 1]++;
+      }
+    });
+    for (int t = 0; t < T; ++t)
+      if (bad[t] >= 0) {
+        ctx->set_error("ssx_ba: edge %d references pose %d / point %d out of range", bad[t], pr->edge_pose[bad[t]], pr->edge_point[bad[t]]);
+        return SSX_ERR_INVALID_ARG;
+      }
+    ctx->ba->pool.run(T, T, [&](int t) {
+      for (int l = lo(t, L), l1 = lo(t + 1, L); l < l1; ++l) {
+        int run = 0;
+        for (int tt = 0; tt < T; ++tt) { int& c = h.thr_cnt[(size_t)tt * L + l]; const int k = c; c = run; run += k; }
+        cnt[l + 1] = run;
+      }
+    });
+    ctx->ba->pool.run(T - 1, T - 1, [&](int t1) {
+      const int t = t1 + 1;
+      const int* c = h.thr_cnt.data() + (size_t)t * L;
+      for (int e = lo(t, E), e1 = lo(t + 1, E); e < e1; ++e) h.slot8[e] = (uint8_t)(h.slot8[e] + c[pr->edge_point[e]]);
+    });
+    for (int t = 0; t < T; ++t)
+      for (int p = 0; p < h.nP; ++p) h.pe_ptr[p + 1] += h.thr_pe[(size_t)t * (h.nP + 1) + p + 1];
+  } else
   for (int e = 0; e < E; ++e) {
     const int l = pr->edge_point[e], p = pr->edge_pose[e];
     if (dead_ok && l < 0) { ++n_dead; continue; }           // a window's storage: observation of a removed keyframe
@@ -3012,8 +3058,13 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   // ~20 vectors of up to E entries are not re-allocated and re-faulted every solve
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
   HostPrep& h = ctx->ba->prep1;
+  static const bool timing = getenv("SSX_BA_TIMING") != nullptr;       // host phases of the call on stderr (tools/ba_c4_slope.py)
+  const auto tc0 = std::chrono::steady_clock::now();
+  auto tc_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(); };
+  double tph[6] = {0, 0, 0, 0, 0, 0};
   ssx_status st = prepare(ctx, prob, h, true, ext);
   if (st != SSX_OK) return st;
+  tph[0] = tc_ms();
   if (ext && (!h.dev_prep || h.big)) {
     ctx->set_error("ssx_ba_window: %d free keyframes (a window holds at most %d) or the device-side marshalling is switched off", h.nP, SSX_BA_SMALL_P);
     return SSX_ERR_UNSUPPORTED;
@@ -3057,6 +3108,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
     st = build_pairs(ctx, h, &pairs_dev, big_dev ? &recs : nullptr);
     if (st != SSX_OK) return st;
   }
+  tph[1] = tc_ms();
   BandPlan bp;
   if (h.big && opt.large_solver != SSX_LARGE_SOLVER_TILES) {
     int w = std::max(h.band_w, 1);
@@ -3084,6 +3136,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   BandDev bnd;
   st = upload(ctx, prob, h, opt.huber_delta, opt.chi2_th, cm.world, cm.fn ? opt.rank : 0, d, bd, bp, bnd, nullptr, ext, big_dev ? &recs : nullptr, pe_ptr_dev, pe_edge_dev);
   if (st != SSX_OK) return st;
+  tph[2] = tc_ms();
   d.store_w = (d.big || opt.jac_mode == SSX_JAC_NUMERIC_G2O) ? 1 : 0;
   d.no_err = (!d.big && !(res->edge_chi2 || res->edge_outlier)) ? 1 : 0;
   bd.spair_ab = pairs_dev;
@@ -3433,7 +3486,9 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
                                     hipMemcpyDeviceToHost, ctx->stream));
   }
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  tph[3] = tc_ms();
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  tph[4] = tc_ms();
   if (res->poses_out) memcpy(res->poses_out, h_pose, sizeof(double) * 7 * d.P);
   if (res->points_out && d.L) memcpy(res->points_out, h_point, sizeof(double) * 3 * d.L);
   if (ext) ext->cur = cur;
@@ -3455,6 +3510,10 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   res->ms_total = ms;
   res->ms_setup = 0.f;
+  if (timing)
+    fprintf(stderr, "ssx_ba_solve P %d L %d E %d: prepare %.3f | records + pairs %.3f | plan + upload %.3f | LM enqueued (and its host round trips) %.3f | "
+                    "last sync %.3f | results %.3f ms (host clock); GPU first to last event %.3f ms\n", d.P, d.L, d.E, tph[0], tph[1] - tph[0],
+            tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3], tc_ms() - tph[4], ms);
   if (stats_guard.mine)
     for (const auto& r : ctx->prof.recs) {
       float t = 0.f;
@@ -3907,11 +3966,39 @@ double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps)
 {
   if (!prob || reps < 1) return -1.0;
   ssx_ctx dummy;
+  static BaWorkspace* wsl = new BaWorkspace();            // (its worker pool: large windows count their observations on several threads)
+  dummy.ba = wsl;
   static thread_local HostPrep h;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < reps; ++i)
-    if (prepare(&dummy, prob, h) != SSX_OK) return -1.0;
-  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+  double best = -1.0;
+  for (int i = 0; i < reps; ++i) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (prepare(&dummy, prob, h) != SSX_OK) { best = -1.0; break; }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (best < 0 || dt < best) best = dt;
+  }
+  dummy.ba = nullptr;
+  return best;
+}
+
+// test hook (no GPU needed): FNV-1a digest of what prepare() hands on for a large window (per-landmark offsets, the rank of
+// every observation inside its landmark, per-pose counts, chunk cuts), counted on `threads` host threads
+uint64_t ssx_ba_debug_prepare_digest(const ssx_ba_problem* prob, int32_t threads)
+{
+  if (!prob) return 0;
+  ssx_ctx dummy;
+  static BaWorkspace* wsl = new BaWorkspace();
+  dummy.ba = wsl;
+  static thread_local HostPrep h;
+  g_prep_threads_override = threads;
+  const ssx_status st = prepare(&dummy, prob, h);
+  g_prep_threads_override = 0;
+  dummy.ba = nullptr;
+  if (st != SSX_OK) return 0;
+  uint64_t d = 1469598103934665603ull;
+  auto eat = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; ++i) { d ^= b[i]; d *= 1099511628211ull; } };
+  eat(h.lm_ptr.data(), sizeof(int) * h.lm_ptr.size()); eat(h.lm_id.data(), sizeof(int) * h.lm_id.size());
+  eat(h.slot8.data(), (size_t)h.E_raw); eat(h.pe_ptr.data(), sizeof(int) * h.pe_ptr.size()); eat(h.ch_lm.data(), sizeof(int) * h.ch_lm.size());
+  return d;
 }
 
 int32_t ssx_ba_debug_upload_format(const ssx_ba_problem* prob)
