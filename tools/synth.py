@@ -280,6 +280,26 @@ def make_stereo_pair(seed=0, h=KITTI_H, w=KITTI_W, n_blobs=4000, bf=KITTI_BF):
     return left, right, disp
 
 
+def fast9_density(img, t=20):
+    """Fraction of the interior pixels of `img` that are FAST-9 corners at threshold t (numpy, ~1 s per KITTI-sized image):
+    what the bench quotes beside the front-end figures (make_stereo_pair: 12.8 % at the default 4000 blobs, 1.5 % at 400 --
+    photographs of streets: 1-3 %)."""
+    I = img.astype(np.int16)
+    h, w = I.shape
+    dx = [0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1]
+    dy = [3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3]
+    c = I[3:h - 3, 3:w - 3]
+    ring = np.stack([I[3 + dy[k]:h - 3 + dy[k], 3 + dx[k]:w - 3 + dx[k]] for k in range(16)])
+
+    def arc(m):
+        m2 = np.concatenate([m, m[:8]])
+        ok = np.zeros(m.shape[1:], bool)
+        for s0 in range(16):
+            ok |= m2[s0:s0 + 9].all(axis=0)
+        return ok
+    return float((arc(ring > c + t) | arc(ring < c - t)).mean())
+
+
 def make_lateral_sequence(n_frames=12, step=0.12, seed=0, h=KITTI_H, w=KITTI_W, n_blobs=4000, bf=KITTI_BF, baseline=KITTI_BASELINE):
     """A stereo SEQUENCE of the make_stereo_pair scene seen from a rig that moves sideways (along +x, the direction of
     the right camera) by `step` baselines per frame: a camera at lateral offset a * baseline sees the texture shifted
