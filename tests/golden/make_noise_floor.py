@@ -79,6 +79,49 @@ def main():
             print(f"{key:14s} |r_oracle - r_ref| px (larger of the two builds): median {r[0]:.2e} p99 {r[1]:.2e} p99.9 {r[2]:.2e} max {r[3]:.2e} <=1e-4 {100 * r[4]:.2f} %  "
                   f"[fma build alone: max {per['fma']['resid'][3]:.2e}, plain: {per['plain']['resid'][3]:.2e}]  chi2 rel {float(g[key + '_chi2_rel']):.1e} "
                   f"lam rel {float(g[key + '_lam_rel']):.1e} poses {float(g[key + '_poses']):.1e} trials equal {bool(g[key + '_same_trials'])}")
+    # ---- the open-loop window drive (tests/test_ba_gpu.py::test_window_drive_matches_the_reference_backend_golden): every keyframe's
+    # window is optimised from the reference's own state and compared with ref_window.npz one to one; worst over the windows pinned by
+    # a fixed map point | over the gauge-free ones, the statistics of the test
+    from tools.mapmodel import ActiveMap, make_window_scenario
+    GW = np.load(os.path.join(OUT, "ref_window.npz"))
+    n_kf, n_active, new_per_kf, track_len, seed = (int(x) for x in GW["cfg"])
+    for jac in (1, 0):
+        per = {}
+        for build, lib in (("plain", plain), ("fma", fma)):
+            po._oracle = lib
+            frames = make_window_scenario(n_kf=n_kf, n_active=n_active, new_per_kf=new_per_kf, track_len=track_len, seed=seed)
+            m = ActiveMap(n_active)
+            worst = {k: dict(pose=0.0, resid=0.0, frac=1.0, p99=0.0, chi2_rel=0.0, n=0, trial_mismatch=0) for k in ("pinned", "free")}
+            for r, fr in enumerate(frames):
+                for l in fr["condemn"]:
+                    m.condemn(l)
+                m.insert_keyframe(fr["kf_id"], fr["pose"], fr["obs"], fr["new_points"], fr["victim"])
+                m.take_edits()
+                pr, kf_ids, lm_ids, e_feat = m.problem()
+                assert list(GW[f"w{r}_kf_ids"]) == kf_ids and list(GW[f"w{r}_lm_ids"]) == lm_ids
+                o = po.ba_solve(pr, "oracle", jac_mode=jac)
+                assert np.array_equal(np.unpackbits(GW[f"w{r}_outlier"])[:pr["E"]], o["edge_outlier"]), (build, jac, r)
+                W = worst["pinned" if pr["point_fixed"].any() else "free"]
+                W["n"] += 1
+                same = len(o["trials"]) == len(GW[f"w{r}_trials"]) and np.array_equal(o["trials"], GW[f"w{r}_trials"])
+                W["trial_mismatch"] += 0 if same else 1
+                n_c = min(len(o["chi2"]), len(GW[f"w{r}_chi2"]))
+                rel = float(np.max(np.abs(o["chi2"][:n_c] - GW[f"w{r}_chi2"][:n_c]) / (np.abs(GW[f"w{r}_chi2"][:n_c]) + 1e-7 * float(GW[f"w{r}_chi2"][0]))))
+                d = np.abs(np.sqrt(o["edge_chi2"][::5]) - np.sqrt(GW[f"w{r}_edge_chi2"]))
+                W["chi2_rel"] = max(W["chi2_rel"], rel); W["resid"] = max(W["resid"], float(d.max()))
+                W["frac"] = min(W["frac"], float((d <= 1e-4).mean())); W["p99"] = max(W["p99"], float(np.percentile(d, 99)))
+                W["pose"] = max(W["pose"], float(np.abs(o["poses"] - GW[f"w{r}_poses"]).max()))
+                m.apply(kf_ids, lm_ids, e_feat, GW[f"w{r}_poses"], GW[f"w{r}_points"], o["edge_outlier"])
+                m.take_edits()
+            per[build] = worst
+        po._oracle = plain
+        for kind in ("pinned", "free"):
+            for st in ("pose", "resid", "p99", "chi2_rel"):
+                g[f"drive_open_jac{jac}_{kind}_{st}"] = np.array(max(per["plain"][kind][st], per["fma"][kind][st]))
+            g[f"drive_open_jac{jac}_{kind}_frac"] = np.array(min(per["plain"][kind]["frac"], per["fma"][kind]["frac"]))
+            g[f"drive_open_jac{jac}_{kind}_trial_mismatch"] = np.array(max(per["plain"][kind]["trial_mismatch"], per["fma"][kind]["trial_mismatch"]))
+            print(f"drive_open jac{jac} {kind}: " + "  ".join(f"{b}: pose {per[b][kind]['pose']:.2e} max {per[b][kind]['resid']:.2e} p99 {per[b][kind]['p99']:.2e} "
+                                                             f"<=1e-4 {100 * per[b][kind]['frac']:.2f} % chi2 {per[b][kind]['chi2_rel']:.1e} trials differ {per[b][kind]['trial_mismatch']}" for b in ("plain", "fma")))
     np.savez_compressed(os.path.join(OUT, "ref_noise_floor.npz"), **g)
     print("ref_noise_floor.npz:", os.path.getsize(os.path.join(OUT, "ref_noise_floor.npz")), "bytes")
 
