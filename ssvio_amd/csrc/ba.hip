@@ -197,7 +197,9 @@ enum { SC_CHI2_CUR = 0, SC_MAXDIAG = 1, SC_SOLVE_OK = 2, SC_SCALE_P = 3, SC_TEMP
        // enqueued without a host round trip.  Kernels launched with cur < 0 take the state buffer from SC_CUR and
        // return at once when SC_STOP is set.
        SC_NI = 8, SC_CUR = 9, SC_IT = 10, SC_QMAX = 11, SC_STOP = 12, SC_NEEDLIN = 13, SC_ITERS = 14, SC_NSTAT = 15,
-       SC_CURCHI = 16, SC_TRIALS_RUN = 17, SC_N = 32 };
+       SC_CURCHI = 16, SC_TRIALS_RUN = 17,
+       SC_TICKET = 18,                // (an unsigned counter in the slot's low word: chunks of k_backsub_residual that have published their sums)
+       SC_N = 32 };
 
 // Workgroup reductions (256 threads), fixed shape, hence deterministic: an xor tree inside each wave, then the four wave
 // results in wave order.  `s` needs 16 doubles; two barriers per call (the tree of barriers it replaces took ten).
@@ -650,6 +652,7 @@ __device__ __forceinline__ void k_lm_begin_body(const BaDev& d, const int bx, in
   d.scal[SC_NI] = 2.0; d.scal[SC_CUR] = (double)cur; d.scal[SC_IT] = 0.0; d.scal[SC_QMAX] = 0.0;
   d.scal[SC_STOP] = (stop || iters <= 0) ? 1.0 : 0.0; d.scal[SC_NEEDLIN] = 1.0; d.scal[SC_ITERS] = (double)iters;
   d.scal[SC_NSTAT] = (double)nstat; d.scal[SC_CURCHI] = 0.0; d.scal[SC_TRIALS_RUN] = 0.0;
+  d.scal[SC_TICKET] = 0.0;
 }
 
 __global__ __launch_bounds__(64) void k_lm_begin(BaDev d, int cur, int iters, int nstat, int stop) { k_lm_begin_body(d, blockIdx.x, cur, iters, nstat, stop); }
@@ -1420,7 +1423,7 @@ __global__ __launch_bounds__(CH) void k_reduce_schur_b(const BaDev* __restrict__
 // residuals / robust chi2 of the TRIAL state (computeActiveErrors + activeRobustChi2,
 // sparse_optimizer.cpp:63-116).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const int bx, int cur, double lambda_arg, int use_dev_lambda)
+__device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const int bx, int cur, double lambda_arg, int use_dev_lambda, int finish)
 {
   __shared__ double sPt[3][CH];
   __shared__ double sPart[3][CH];
@@ -1510,20 +1513,56 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
   }
   double chi = rho0, sl = scale_l, no = nout, unused_max = 0.0;
   block_sum3_max_256(chi, sl, no, unused_max, sRed);
+  if (!finish) {
+    if (t == 0) {
+      d.trial_slab[c * 3] = chi;
+      d.trial_slab[c * 3 + 1] = sl;
+      d.trial_slab[c * 3 + 2] = no;
+    }
+    return;
+  }
+  // finish (device-driven LM on one GPU): the LAST chunk to get here sums the chunks' contributions -- in the fixed order of
+  // k_reduce_trial: same bits whichever chunk it is -- and takes the LM decision; the launch of k_reduce_trial and its boundary
+  // (7 us of a 60 us slot of one window) are gone.  No fences: the three sums leave as device-scope (write-through) stores, the
+  // ticket is taken once they are acknowledged, the last chunk reads them with device-scope loads.
+  __shared__ int sLast;
+  double* slab = d.trial_slab.p;
   if (t == 0) {
-    d.trial_slab[c * 3] = chi;
-    d.trial_slab[c * 3 + 1] = sl;
-    d.trial_slab[c * 3 + 2] = no;
+    __hip_atomic_store(&slab[c * 3], chi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slab[c * 3 + 1], sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slab[c * 3 + 2], no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int* tk = reinterpret_cast<unsigned int*>(d.scal.p + SC_TICKET);
+    const unsigned int prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sLast = prev + 1u == (unsigned int)d.nCh;
+  }
+  __syncthreads();
+  if (!sLast) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int cc = t; cc < d.nCh; cc += CH) {
+    a0 += __hip_atomic_load(&slab[cc * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a1 += __hip_atomic_load(&slab[cc * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a2 += __hip_atomic_load(&slab[cc * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();                                   // (sRed is reused)
+  a0 = block_sum_256(a0, sRed);
+  a1 = block_sum_256(a1, sRed);
+  a2 = block_sum_256(a2, sRed);
+  if (t == 0) {
+    d.scal_comm[0] = a0; d.scal_comm[1] = a1; d.scal_comm[2] = a2;
+    d.scal[SC_TEMP_CHI] = a0; d.scal[SC_SCALE_L] = a1; d.scal[SC_NOUT] = a2;
+    d.scal[SC_TICKET] = 0.0;                         // (for the next trial; ordered by the kernel boundary)
+    lm_step(d);
   }
 }
 
-__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, double lambda_arg, int use_dev_lambda) { k_backsub_residual_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda); }
+__global__ __launch_bounds__(CH) void k_backsub_residual(BaDev d, int cur, double lambda_arg, int use_dev_lambda, int finish) { k_backsub_residual_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda, finish); }
 // batched: blockIdx.y = window; every window brings its own BaDev (device array)
-__global__ __launch_bounds__(CH) void k_backsub_residual_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda)
+__global__ __launch_bounds__(CH) void k_backsub_residual_b(const BaDev* __restrict__ dv, int cur, double lambda_arg, int use_dev_lambda, int finish)
 {
   const BaDev& d = dv[blockIdx.y];       // by reference: a private copy of the 500-byte struct ends up in scratch memory
   if ((int)blockIdx.x >= (d.nCh)) return;
-  k_backsub_residual_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda);
+  k_backsub_residual_body(d, blockIdx.x, cur, lambda_arg, use_dev_lambda, finish);
 }
 
 __device__ __forceinline__ void k_reduce_trial_body(const BaDev& d, const int bx, int lm)
@@ -3326,8 +3365,10 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
           else if (n <= 80) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
           else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
           }
-          if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
-          SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, cm.fn ? 0 : 1));
+          // one GPU: the last chunk of k_backsub_residual sums the trial and takes the LM decision itself (finish)
+          const bool finish = nCh > 0 && !cm.fn;
+          if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1, finish ? 1 : 0));
+          if (!finish) SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, cm.fn ? 0 : 1));
           if (cm.fn) {
             st = allreduce(ctx, cm, d.scal_comm, 3);
             if (st != SSX_OK) return st;
@@ -3384,7 +3425,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
         else if (n <= 80) SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80, dim3(1), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
         else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
         }
-        if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda));
+        if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, cur, lambda, dev_lambda, 0));
         SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, 0));
         if (cm.fn) {
           st = allreduce(ctx, cm, d.scal_comm, 3);
@@ -3556,7 +3597,7 @@ struct ssx_ba_batch {
   const ssx_ba_problem* probs = nullptr;             // (valid during a one-shot call: the dead entries of a window's storage)
   std::vector<size_t> out_off;
   size_t out_total = 0, a_out = 0, a_gather = 0, a_head = 0, in_total = 0, o_dv = 0, o_ctrl = 0, o_ooff = 0;
-  int max_ch = 1, max_rl = 1, max_rs = 1, total_ch = 0;
+  int max_ch = 1, max_rl = 1, max_rs = 1, total_ch = 0, min_ch = 0;
   bool any_solve64 = false, any_solve80 = false, any_solve = false, with_err = false, fresh = false;
   int threads = 1;
   int groups = 0;                                    // ssx_ba_batch_set_groups; 0: batch_groups(n)
@@ -3671,6 +3712,7 @@ ssx_status batch_build(ssx_ctx* ctx, int n, const ssx_ba_problem* probs, const s
   for (int w = 0; w < n; ++w) {
     const BaDev& d = B->devs[w];
     B->max_ch = std::max(B->max_ch, d.nCh);
+    B->min_ch = w == 0 ? d.nCh : std::min(B->min_ch, d.nCh);
     B->total_ch += d.nCh;
     B->max_rl = std::max(B->max_rl, (d.nP * 27 + 63) / 64);
     B->max_rs = std::max(B->max_rs, (d.nBlk * 36 + d.nP * 6 + 63) / 64);
@@ -3817,8 +3859,8 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
           if (B->any_solve64) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve80) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
-          SSX_PROF_ON(ctx, hs, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual_b, gCh, dim3(CH), 0, hs, hv, -1, 0.0, 1));
-          SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial_b, gOne, dim3(CH), 0, hs, hv, 1));
+          SSX_PROF_ON(ctx, hs, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual_b, gCh, dim3(CH), 0, hs, hv, -1, 0.0, 1, B->min_ch > 0 ? 1 : 0));
+          if (B->min_ch <= 0) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial_b, gOne, dim3(CH), 0, hs, hv, 1));   // (a window without chunks: nobody would finish its trial)
         }
         first_slot = false;
       }
