@@ -485,6 +485,24 @@ def test_c4_shape_band_equals_tiles(ctx):
     assert np.abs(g["poses"] - t["poses"]).max() < 1e-8
 
 
+@pytest.mark.parametrize("P,obs,wrap,fix", [(40, 2, False, True), (41, 3, True, False), (57, 4, True, True), (63, 5, False, True),
+                                            (64, 6, True, True), (97, 6, False, False), (131, 6, True, True), (48, 6, True, True)])
+def test_block_cyclic_reduction_shapes_equal_tiles(ctx, P, obs, wrap, fix):
+    """The block cyclic reduction of the cyclic band (ba_bcr.inc) over its shapes: bandwidths w = 1 .. 5 (super-blocks of 24 and of 36
+    unknowns), pose counts that leave 0 .. w - 1 poses over (super-blocks of w + 1 poses at the odd positions), odd and even numbers
+    of super-blocks (the level with two blocks coupled in both directions, the wrap-around), open and closed trajectories, with and
+    without a fixed keyframe -- against the 64 x 64-tile sparse Cholesky on the same system: identical LM decisions, the same cost
+    and poses."""
+    pr = make_ba_problem(P=P, L=60 * P, obs_per_lm=obs, seed=900 + P, loop=True, wrap=wrap, fix_first_pose=fix)
+    g = ba.ba_solve(ctx, pr, outer_rounds=1, iters=4, want_edges=False, large_solver=2)
+    t = ba.ba_solve(ctx, pr, outer_rounds=1, iters=4, want_edges=False, large_solver=1)
+    assert np.array_equal(g["trials"], t["trials"])
+    np.testing.assert_allclose(g["chi2"], t["chi2"], rtol=1e-8)
+    assert np.abs(g["poses"] - t["poses"]).max() < 1e-7
+    again = ba.ba_solve(ctx, pr, outer_rounds=1, iters=4, want_edges=False, large_solver=2)
+    assert np.array_equal(again["poses"], g["poses"]) and np.array_equal(again["chi2"], g["chi2"])      # bit-deterministic
+
+
 def test_batch_groups_do_not_change_the_bits(ctx):
     """A batch of >= 8 windows runs as groups of windows on several streams (ssx_ba_batch_groups / _set_groups): every
     grouping returns, per window, the bits of ssx_ba_solve."""
