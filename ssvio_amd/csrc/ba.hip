@@ -1868,6 +1868,11 @@ struct BaWorkspace {
   ParPool pool;
   DevBuf recs;                        // large windows, device-marshalled: raw inputs + the records / columns built from them
   HostBuf recs_h;
+  // the caller's observation columns of a large window, sent BEFORE prepare() counts them (raw_upload_early): 12 MB at
+  // BASELINE configs[3] cross PCIe beside the host's counting pass instead of after it
+  DevBuf raw_d;
+  HostBuf raw_h;
+  struct RawEarly { bool valid = false; const void* key = nullptr; int E = 0; size_t o_pose = 0, o_point = 0, o_uv = 0, o_cam = 0; } raw_early;
   DevBuf win_stage_d;                 // ssx_ba_window: pending uploads of the windows of a call, one block (ba_window.inc)
   HostBuf win_stage_h;
   hipEvent_t ev_turn = nullptr;       // ssx_ba_device_turns: the end of this context's last device phase
@@ -2677,6 +2682,39 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
 // 480 000-observation window cost), k_prep_scatter / k_prep_chunk build the (landmark, pose) order, the packed records and the
 // structure-of-arrays columns, and a stable radix sort by free pose gives the pose-major edge list.  Everything lives in
 // ws->recs for the duration of the solve; `r` receives the pointers (the pair builder and upload() take them from there).
+// The observation columns as the caller holds them (pose index, landmark index, uv, camera) into pinned staging on the worker
+// pool and on their way to the device; nothing here depends on prepare()'s counting, which then runs beside the copy.
+ssx_status raw_upload_early(ssx_ctx* ctx, const ssx_ba_problem* pr)
+{
+  if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
+  BaWorkspace* ws = ctx->ba;
+  ws->raw_early.valid = false;
+  const int E = pr->E;
+  if (E <= 0 || !pr->edge_pose || !pr->edge_point || !pr->edge_uv) return SSX_OK;      // (prepare() reports it)
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const bool have_cam = pr->edge_cam != nullptr;
+  Layout in;
+  BaWorkspace::RawEarly re;
+  re.o_pose = in.take(sizeof(int) * (size_t)(E + 1)); re.o_point = in.take(sizeof(int) * (size_t)(E + 1));
+  re.o_uv = in.take(sizeof(double) * 2 * (size_t)(E + 1)); re.o_cam = in.take(have_cam ? (size_t)E + 1 : 0);
+  SSX_HIP_TRY(ctx, ws->raw_d.reserve(in.off));
+  SSX_HIP_TRY(ctx, ws->raw_h.reserve(in.off));
+  char* hs = ws->raw_h.as<char>();
+  struct Cp { size_t off; const void* src; size_t n; };
+  std::vector<Cp> cps;
+  auto add = [&](size_t off, const void* src, size_t n) {
+    for (size_t a = 0; a < n; a += (size_t)1 << 20) cps.push_back({off + a, (const char*)src + a, std::min(n - a, (size_t)1 << 20)});
+  };
+  add(re.o_pose, pr->edge_pose, sizeof(int) * (size_t)E); add(re.o_point, pr->edge_point, sizeof(int) * (size_t)E);
+  add(re.o_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E);
+  if (have_cam) add(re.o_cam, pr->edge_cam, (size_t)E);
+  ws->pool.run((int)cps.size(), std::min<int>(8, (int)cps.size()), [&](int q) { memcpy(hs + cps[q].off, cps[q].src, cps[q].n); });
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->raw_d.p, hs, in.off, hipMemcpyHostToDevice, ctx->stream));
+  re.valid = true; re.key = pr->edge_pose; re.E = E;
+  ws->raw_early = re;
+  return SSX_OK;
+}
+
 ssx_status big_records(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, BaDev& r, const int** pe_ptr_dev, const int** pe_edge_dev)
 {
   if (!ctx->ba) { ctx->ba = new BaWorkspace(); ctx->ba_free = ssx_ba_workspace_free; }
@@ -2689,12 +2727,17 @@ ssx_status big_records(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h
   size_t sort_tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned int*)nullptr, (size_t)std::max(E, 1), 0, key_bits, s);
   const bool have_cam = pr->edge_cam != nullptr;
+  // (the observation columns may be on the device already: raw_upload_early)
+  const BaWorkspace::RawEarly early = ws->raw_early;
+  const bool sent = early.valid && early.key == pr->edge_pose && early.E == E && E == h.E_raw;
+  ws->raw_early.valid = false;
   Layout in;
   const size_t o_pose_free = in.take(sizeof(int) * P), o_lm_compact = in.take(sizeof(int) * (size_t)(L + 1));
   const size_t o_lm_ptr = in.take(sizeof(int) * (size_t)(nLm + 1)), o_lm_id = in.take(sizeof(int) * (size_t)(nLm + 1)), o_lm_fixed = in.take((size_t)nLm + 1);
   const size_t o_ch_lm = in.take(sizeof(int) * (size_t)(nCh + 1)), o_ch_desc = in.take(sizeof(int) * 4 * (size_t)(nCh + 1)), o_pe_ptr = in.take(sizeof(int) * (size_t)(nP + 1));
-  const size_t o_r_pose = in.take(sizeof(int) * (size_t)(E + 1)), o_r_point = in.take(sizeof(int) * (size_t)(E + 1)), o_r_uv = in.take(sizeof(double) * 2 * (size_t)(E + 1));
-  const size_t o_r_cam = in.take(have_cam ? (size_t)E + 1 : 0), o_slot8 = in.take((size_t)E + 1);
+  const size_t o_r_pose = in.take(sent ? 0 : sizeof(int) * (size_t)(E + 1)), o_r_point = in.take(sent ? 0 : sizeof(int) * (size_t)(E + 1));
+  const size_t o_r_uv = in.take(sent ? 0 : sizeof(double) * 2 * (size_t)(E + 1));
+  const size_t o_r_cam = in.take(have_cam && !sent ? (size_t)E + 1 : 0), o_slot8 = in.take((size_t)E + 1);
   const size_t in_bytes = in.off;
   Layout all = in;
   const size_t o_perm = all.take(sizeof(int) * (size_t)(E + 1)), o_e_rec = all.take(sizeof(int) * 4 * (size_t)(E + 1)), o_l_rec = all.take(sizeof(int) * 4 * (size_t)(nLm + 1));
@@ -2721,9 +2764,12 @@ ssx_status big_records(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h
     for (size_t a = 0; a < n; a += (size_t)1 << 20) cps.push_back({off + a, (const char*)src + a, std::min(n - a, (size_t)1 << 20)});
   };
   if (E) {
-    add(o_r_pose, pr->edge_pose, sizeof(int) * (size_t)E); add(o_r_point, pr->edge_point, sizeof(int) * (size_t)E);
-    add(o_r_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E); add(o_slot8, h.slot8.data(), (size_t)E);
-    if (have_cam) add(o_r_cam, pr->edge_cam, (size_t)E);
+    if (!sent) {
+      add(o_r_pose, pr->edge_pose, sizeof(int) * (size_t)E); add(o_r_point, pr->edge_point, sizeof(int) * (size_t)E);
+      add(o_r_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E);
+      if (have_cam) add(o_r_cam, pr->edge_cam, (size_t)E);
+    }
+    add(o_slot8, h.slot8.data(), (size_t)E);
   }
   ws->pool.run((int)cps.size(), std::min<int>(8, (int)cps.size()), [&](int q) { memcpy(hs + cps[q].off, cps[q].src, cps[q].n); });
   SSX_HIP_TRY(ctx, hipMemcpyAsync(dv, hs, in_bytes, hipMemcpyHostToDevice, s));
@@ -2733,8 +2779,15 @@ ssx_status big_records(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h
   r.pose_free = (const int*)(dv + o_pose_free); r.lm_compact = (const int*)(dv + o_lm_compact); r.lm_ptr = (const int*)(dv + o_lm_ptr);
   r.lm_id = (const int*)(dv + o_lm_id); r.lm_fixed = (const uint8_t*)(dv + o_lm_fixed); r.ch_lm = (const int*)(dv + o_ch_lm);
   r.ch_desc = (const int4*)(dv + o_ch_desc);
-  r.r_edge_pose = (const int*)(dv + o_r_pose); r.r_edge_point = (const int*)(dv + o_r_point); r.r_edge_uv = (const double*)(dv + o_r_uv);
-  r.r_edge_cam = (const uint8_t*)(have_cam ? dv + o_r_cam : nullptr); r.r_slot8 = (const uint8_t*)(dv + o_slot8);
+  if (sent) {
+    char* rd = ws->raw_d.as<char>();
+    r.r_edge_pose = (const int*)(rd + early.o_pose); r.r_edge_point = (const int*)(rd + early.o_point); r.r_edge_uv = (const double*)(rd + early.o_uv);
+    r.r_edge_cam = (const uint8_t*)(have_cam ? rd + early.o_cam : nullptr);
+  } else {
+    r.r_edge_pose = (const int*)(dv + o_r_pose); r.r_edge_point = (const int*)(dv + o_r_point); r.r_edge_uv = (const double*)(dv + o_r_uv);
+    r.r_edge_cam = (const uint8_t*)(have_cam ? dv + o_r_cam : nullptr);
+  }
+  r.r_slot8 = (const uint8_t*)(dv + o_slot8);
   r.perm = (int*)(dv + o_perm); r.e_rec = (const int4*)(dv + o_e_rec); r.l_rec = (const int4*)(dv + o_l_rec); r.e_dup = (const uint8_t*)(dv + o_e_dup);
   r.e_uv = (const double*)(dv + o_e_uv); r.e_pose = (const int*)(dv + o_e_pose); r.e_lmc = (const int*)(dv + o_e_lmc); r.e_cam = (const uint8_t*)(dv + o_e_cam);
   r.lm_chunk = (int*)(dv + o_lm_chunk); r.c2_out = (double*)(dv + o_c2);
@@ -3101,7 +3154,20 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   const auto tc0 = std::chrono::steady_clock::now();
   auto tc_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(); };
   double tph[6] = {0, 0, 0, 0, 0, 0};
+  {
+    // a LARGE window (more than 16 free keyframes) with many observations: its columns start crossing PCIe before they are counted
+    static const bool host_prep_env = getenv("SSX_BA_HOST_PREP") != nullptr || getenv("SSX_BA_HOST_LISTS") != nullptr;
+    if (!ext && !host_prep_env && prob->E >= (1 << 16) && prob->P > SSX_BA_SMALL_P && prob->poses) {
+      int n_free = 0;
+      for (int i = 0; i < prob->P; ++i) n_free += !(prob->pose_fixed && prob->pose_fixed[i]);
+      if (n_free > SSX_BA_SMALL_P) {
+        const ssx_status st0 = raw_upload_early(ctx, prob);
+        if (st0 != SSX_OK) return st0;
+      }
+    }
+  }
   ssx_status st = prepare(ctx, prob, h, true, ext);
+  if (st != SSX_OK || !(h.big && h.dev_prep)) ctx->ba->raw_early.valid = false;   // (never reaches big_records: the early copy is dropped)
   if (st != SSX_OK) return st;
   tph[0] = tc_ms();
   if (ext && (!h.dev_prep || h.big)) {
@@ -3552,7 +3618,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   res->ms_total = ms;
   res->ms_setup = 0.f;
   if (timing)
-    fprintf(stderr, "ssx_ba_solve P %d L %d E %d: prepare %.3f | records + pairs %.3f | plan + upload %.3f | LM enqueued (and its host round trips) %.3f | "
+    fprintf(stderr, "ssx_ba_solve P %d L %d E %d: (columns staged + sent early, large windows) + prepare %.3f | records + pairs %.3f | plan + upload %.3f | LM enqueued (and its host round trips) %.3f | "
                     "last sync %.3f | results %.3f ms (host clock); GPU first to last event %.3f ms\n", d.P, d.L, d.E, tph[0], tph[1] - tph[0],
             tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3], tc_ms() - tph[4], ms);
   if (stats_guard.mine)
