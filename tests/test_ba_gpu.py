@@ -938,6 +938,63 @@ def test_resident_window_equals_fresh_solves(ctx):
         w.close()
 
 
+def test_window_batches_do_not_depend_on_stream_groups_or_device_turns(ctx):
+    """ssx_ba_set_batch_groups (streams a context's batched window solve is spread over) and ssx_ba_device_turns (the device phases of
+    different contexts alternate) are orchestration: twelve windows solved in one call return, per window, the bits of a fresh
+    ssx_ba_solve of the exported problem, whatever the grouping, with turns on and off, and from two contexts driven by two threads."""
+    import ctypes as C
+    import threading
+    import ssvio_amd
+    lib = ctx.lib
+    lib.ssx_ba_device_turns.restype = None; lib.ssx_ba_device_turns.argtypes = [C.c_int32]
+    lib.ssx_ba_set_batch_groups.restype = C.c_int32; lib.ssx_ba_set_batch_groups.argtypes = [C.c_void_p, C.c_int32]
+    prs = [make_ba_problem(P=6 + (k % 6), L=200 + 150 * k, obs_per_lm=3 + (k % 3), seed=500 + k) for k in range(12)]
+
+    def build(c):
+        wins = []
+        for q in prs:
+            w = ba.BaWindow(c, q["K"], q["cam_ext"])
+            for k, f in enumerate(_window_feed(q)):
+                w.push(k, **f)
+            wins.append(w)
+        return wins
+    wins = build(ctx)
+    fresh = [ba.ba_solve(ctx, w.export()) for w in wins]
+    for w in wins:
+        w.close()
+    try:
+        for groups, turns in ((0, 0), (1, 0), (2, 1), (3, 0), (4, 1)):
+            ctx.check(lib.ssx_ba_set_batch_groups(ctx.handle, groups))
+            lib.ssx_ba_device_turns(turns)
+            wins = build(ctx)
+            for a, b in zip(ba.BaWindow.solve_batch(wins), fresh):
+                _assert_same(a, b, f"groups {groups} turns {turns}")
+            for w in wins:
+                w.close()
+        # two contexts, two host threads, turns on: the same bits from both
+        lib.ssx_ba_device_turns(1)
+        other = ssvio_amd.Context(0)
+        out = {}
+
+        def run(name, c):
+            ws = build(c)
+            out[name] = [ba.BaWindow.solve_batch(ws) for _ in range(1)][0]
+            for w in ws:
+                w.close()
+        th = [threading.Thread(target=run, args=("a", ctx)), threading.Thread(target=run, args=("b", other))]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for name in ("a", "b"):
+            for a, b in zip(out[name], fresh):
+                _assert_same(a, b, f"context {name}, turns on")
+        other.close()
+    finally:
+        lib.ssx_ba_device_turns(0)
+        lib.ssx_ba_set_batch_groups(ctx.handle, 0)
+
+
 def test_resident_window_matches_reference_golden(ctx):
     """The reference's own window (12 keyframes, config/kitti_00.yaml:30) built by PUSHING its keyframes into an ssx_ba_window
     and solved in place, against the vectors of the compiled reference (tests/golden/ref_golden.npz): rounds, LM iterations,
