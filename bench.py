@@ -92,6 +92,25 @@ def main():
                     "profiles: every launch of a kernel then has the same shape, so rocprofv3's per-kernel averages mean something)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` started WITHOUT a launcher: one rank per GPU is this script's job then -- it re-executes itself under
+    # torch.distributed.run (one process per GPU over RCCL, rendezvous on 127.0.0.1) and fails loudly if that cannot be done; it never
+    # measures one GPU and reports N.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        import torch
+        have = torch.cuda.device_count()
+        single_gpu_test = os.environ.get("SSX_BENCH_SINGLE_GPU_GLOO") == "1"
+        if have < args.gpus and not single_gpu_test:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s): refusing to report a {args.gpus}-GPU line")
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        print(f"[bench] no launcher in the environment: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+        sys.exit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     # configs[0] leg: the 200-pair drive is rendered + written as PNGs by a process of its own (numpy ray casting, 0.65 s per pair
     # and core), started before this process touches the GPU and collected when the GPU regions are done
@@ -118,7 +137,7 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{dev_index}"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would claim GPUs that did not run"
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
 
@@ -885,6 +904,7 @@ def main():
                                   "then ssx_ba_window_solve_batch optimises the group's windows where they lie (backend.cpp:88-169, map.cpp:27-56, 89-160)",
                        "window": live_info["window"], "backend_groups": live_info["host_threads"]},
             "live_backend": live_info,
+            "nccl_ranks": (c4.get("rccl_rank_world") if world > 1 else [0, 1]),    # (rank, ranks) of the RCCL communicator inside libssx.so: ssx_comm_info
             "frozen_batch": {"value": round(frozen_value, 2), "unit": "stereo frames/s", "ms_per_step": round(frozen_elapsed / FROZEN_STEPS * 1e3, 4),
                              "what": "rounds 2-4's headline: the same front-end step (host images in, counts out) beside a FROZEN batch of B C3 windows "
                                      "(ssx_ba_batch: marshalled + uploaded before the clock starts, re-solved from the same state every step, poses "

@@ -25,6 +25,11 @@ SSX_API int64_t ssx_debug_kernel_dynamic_lds(const char* kernel);
  * uploaded after the call. */
 SSX_API void ssx_debug_set_dense_slabs(int32_t mode);
 
+/* tests hook: who completes an LM trial of a small window on one GPU.  1 (default) = the last chunk of k_backsub_residual to publish
+ * its three sums adds them and takes the LM step (agent-scope stores + a ticket, no fence); 0 = a launch of k_reduce_trial does (rounds
+ * 1-4).  Same bits either way: tests/test_ba_gpu.py::test_trial_finish_litmus. */
+SSX_API void ssx_debug_set_trial_finish(int32_t mode);
+
 /* tools hook, needs no GPU: seconds of host marshalling (edge sort by landmark, chunks, index lists) for one problem */
 SSX_API double ssx_ba_debug_prepare_seconds(const ssx_ba_problem* prob, int32_t reps);
 

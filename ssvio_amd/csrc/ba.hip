@@ -187,6 +187,7 @@ struct BaDev {
   GPtr<double> scal_comm;        // [tempChi, scale_l, nout]  all-reduced per trial
   GPtr<double> scal;             // SC_N scalars
   GPtr<double> lm_stat;          // device-driven LM: [3][SSX_BA_MAX_STATS] chi2 | lambda | trials per iteration
+  GPtr<unsigned int> ticket;     // one word of its own: chunks of k_backsub_residual that have published their sums in this trial
 };
 
 // scal[] slots
@@ -198,7 +199,7 @@ enum { SC_CHI2_CUR = 0, SC_MAXDIAG = 1, SC_SOLVE_OK = 2, SC_SCALE_P = 3, SC_TEMP
        // return at once when SC_STOP is set.
        SC_NI = 8, SC_CUR = 9, SC_IT = 10, SC_QMAX = 11, SC_STOP = 12, SC_NEEDLIN = 13, SC_ITERS = 14, SC_NSTAT = 15,
        SC_CURCHI = 16, SC_TRIALS_RUN = 17,
-       SC_TICKET = 18,                // (an unsigned counter in the slot's low word: chunks of k_backsub_residual that have published their sums)
+       SC_UNUSED18 = 18,              // (round 5 kept the chunk ticket of k_backsub_residual here, aliased onto a double: BaDev::ticket now)
        SC_N = 32 };
 
 // Workgroup reductions (256 threads), fixed shape, hence deterministic: an xor tree inside each wave, then the four wave
@@ -652,7 +653,7 @@ __device__ __forceinline__ void k_lm_begin_body(const BaDev& d, const int bx, in
   d.scal[SC_NI] = 2.0; d.scal[SC_CUR] = (double)cur; d.scal[SC_IT] = 0.0; d.scal[SC_QMAX] = 0.0;
   d.scal[SC_STOP] = (stop || iters <= 0) ? 1.0 : 0.0; d.scal[SC_NEEDLIN] = 1.0; d.scal[SC_ITERS] = (double)iters;
   d.scal[SC_NSTAT] = (double)nstat; d.scal[SC_CURCHI] = 0.0; d.scal[SC_TRIALS_RUN] = 0.0;
-  d.scal[SC_TICKET] = 0.0;
+  *d.ticket.get() = 0u;
 }
 
 __global__ __launch_bounds__(64) void k_lm_begin(BaDev d, int cur, int iters, int nstat, int stop) { k_lm_begin_body(d, blockIdx.x, cur, iters, nstat, stop); }
@@ -1523,8 +1524,18 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
   }
   // finish (device-driven LM on one GPU): the LAST chunk to get here sums the chunks' contributions -- in the fixed order of
   // k_reduce_trial: same bits whichever chunk it is -- and takes the LM decision; the launch of k_reduce_trial and its boundary
-  // (7 us of a 60 us slot of one window) are gone.  No fences: the three sums leave as device-scope (write-through) stores, the
-  // ticket is taken once they are acknowledged, the last chunk reads them with device-scope loads.
+  // (7 us of a 60 us slot of one window) are gone.
+  // ORDERING.  Formally a release on the ticket + an acquire in the last chunk would do; at agent scope on gfx942 / gfx950 they
+  // compile to buffer_wbl2 sc1 / buffer_inv sc1 -- the XCD's whole L2 written back per chunk (it holds the landmarks and errors this
+  // kernel just wrote): measured 233 instead of 42 us per launch in round 2.  Only three doubles per chunk have to be visible, so
+  // they leave as agent-scope atomic stores (global_store ... sc1: written through to memory, coherent across the XCDs' L2s), the
+  // ticket is taken once the memory system has ACKNOWLEDGED them (s_waitcnt vmcnt(0): on gfx9 vmcnt counts stores as well -- gfx10+
+  // moved them to vscnt, hence the static_assert), and the last chunk reads them with agent-scope atomic loads, which the
+  // workgroup barrier behind the ticket orders after it.  tests/test_ba_gpu.py::test_trial_finish_litmus compares ~10 000
+  // launches x 128 windows with the k_reduce_trial path bit for bit, also with the library built at -O1.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+  static_assert(false, "k_backsub_residual's trial finish relies on gfx9's vmcnt covering stores");
+#endif
   __shared__ int sLast;
   double* slab = d.trial_slab.p;
   if (t == 0) {
@@ -1532,8 +1543,7 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
     __hip_atomic_store(&slab[c * 3 + 1], sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&slab[c * 3 + 2], no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned int* tk = reinterpret_cast<unsigned int*>(d.scal.p + SC_TICKET);
-    const unsigned int prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int prev = __hip_atomic_fetch_add(d.ticket.p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sLast = prev + 1u == (unsigned int)d.nCh;
   }
   __syncthreads();
@@ -1551,7 +1561,7 @@ __device__ __forceinline__ void k_backsub_residual_body(const BaDev& d, const in
   if (t == 0) {
     d.scal_comm[0] = a0; d.scal_comm[1] = a1; d.scal_comm[2] = a2;
     d.scal[SC_TEMP_CHI] = a0; d.scal[SC_SCALE_L] = a1; d.scal[SC_NOUT] = a2;
-    d.scal[SC_TICKET] = 0.0;                         // (for the next trial; ordered by the kernel boundary)
+    *d.ticket.get() = 0u;                            // (for the next trial; ordered by the kernel boundary)
     lm_step(d);
   }
 }
@@ -1679,6 +1689,16 @@ __global__ __launch_bounds__(CH) void k_pack_out_b(const BaDev* __restrict__ dv,
   }
 }
 
+// a packed block of results from HBM into pinned host memory, 16 bytes per lane and step (full-width PCIe writes)
+__global__ __launch_bounds__(CH) void k_stream_out(const double* __restrict__ src, double* __restrict__ dst, size_t n)
+{
+  const size_t n2 = n / 2;
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2* d2 = reinterpret_cast<double2*>(dst);
+  for (size_t i = (size_t)blockIdx.x * CH + threadIdx.x; i < n2; i += (size_t)gridDim.x * CH) d2[i] = s2[i];
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
+
 // the keyframe poses of every window only (what a backend that reads its landmarks lazily needs back per keyframe): [n][7 maxP]
 __global__ __launch_bounds__(CH) void k_pack_poses_b(const BaDev* __restrict__ dv, const int* ctrl, int n, int maxP, double* out)
 {
@@ -1702,6 +1722,9 @@ namespace {
 // 1: round 3's dense slabs (every chunk writes and the reductions read every entry), the cross-check of the sparse form;
 // SSX_BA_DENSE_SLABS=1 in the environment or ssx_debug_set_dense_slabs
 std::atomic<int> g_dense_slabs{-1};
+// 0: the trial's three sums are added by a launch of k_reduce_trial (rounds 1-4) instead of by the last chunk of k_backsub_residual:
+// the cross-check of the ticket protocol (ssx_debug_set_trial_finish; same bits either way)
+std::atomic<int> g_trial_finish{1};
 inline int dense_slabs_mode()
 {
   int m = g_dense_slabs.load(std::memory_order_relaxed);
@@ -2464,6 +2487,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   const size_t o_scal_comm = all.take(sizeof(double) * 4);
   const size_t o_scal = all.take(sizeof(double) * SC_N);
   const size_t o_lmstat = all.take(sizeof(double) * 3 * SSX_BA_MAX_STATS);
+  const size_t o_ticket = all.take(sizeof(unsigned int) * 4);
 
   if (place && place->dry) {                     // sizing pass of a batch
     place->in_bytes = in_bytes;
@@ -2626,6 +2650,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
   d.scal_comm = (double*)(at(o_scal_comm));
   d.scal = (double*)(at(o_scal));
   d.lm_stat = (double*)(at(o_lmstat));
+  d.ticket = (unsigned int*)(at(o_ticket));
   if (rz) {                                      // the records, columns and raw arrays of big_records
     d.dev_prep = 1; d.E_raw = recs->E_raw;
     d.pose_free = recs->pose_free; d.lm_fixed = recs->lm_fixed; d.lm_id = recs->lm_id; d.lm_ptr = recs->lm_ptr; d.ch_lm = recs->ch_lm;
@@ -2656,7 +2681,7 @@ ssx_status upload(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h, dou
         q.p0 = (const int*)(at(o_bcr_p0)); q.elim = (const int4*)(at(o_bcr_elim));
         const size_t mmN = (size_t)q.N * q.m * q.m, mN = (size_t)q.N * q.m;
         double* base = (double*)(at(o_bcr_mem));
-        q.D = base; q.E = q.D + mmN; q.DL = q.E + mmN; q.DR = q.DL + mmN; q.Lf = q.DR + mmN; q.Ul = q.Lf + mmN; q.Ur = q.Ul + mmN;
+        q.D = base; q.E = q.D + mmN; q.DL = q.E + 2 * mmN;   /* E: two buffers, bcr_e_buf */ q.DR = q.DL + mmN; q.Lf = q.DR + mmN; q.Ul = q.Lf + mmN; q.Ur = q.Ul + mmN;
         q.R = q.Ur + mmN; q.RL = q.R + mN; q.RR = q.RL + mN; q.Y = q.RR + mN; q.X = q.Y + mN;
       }
     }
@@ -3432,7 +3457,7 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
           else SSX_PROF(ctx, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve, dim3(1), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1));
           }
           // one GPU: the last chunk of k_backsub_residual sums the trial and takes the LM decision itself (finish)
-          const bool finish = nCh > 0 && !cm.fn;
+          const bool finish = nCh > 0 && !cm.fn && g_trial_finish.load() != 0;
           if (nCh > 0) SSX_PROF(ctx, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual, dim3(nCh), dim3(CH), 0, ctx->stream, d, -1, 0.0, 1, finish ? 1 : 0));
           if (!finish) SSX_PROF(ctx, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(CH), 0, ctx->stream, d, cm.fn ? 0 : 1));
           if (cm.fn) {
@@ -3841,10 +3866,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   char* dev_base = B->arena->as<char>();
   const BaDev* dv = reinterpret_cast<const BaDev*>(dev_base + B->a_head + B->in_total + B->o_dv);
-  int* d_ctrl = reinterpret_cast<int*>(dev_base + B->a_head + B->in_total + B->o_ctrl);
   const size_t* d_ooff = reinterpret_cast<const size_t*>(dev_base + B->a_head + B->in_total + B->o_ooff);
-  double* d_out = reinterpret_cast<double*>(dev_base + B->a_out);
-  double* d_gather = reinterpret_cast<double*>(dev_base + B->a_gather);
   hipStream_t s = ctx->stream;
   const int wg_x = B->max_ch;                                        // workgroups per window of the linearise / Schur kernels
   if (!B->fresh) hipLaunchKernelGGL(k_reset_state_b, dim3(16, n), dim3(CH), 0, s, dv);
@@ -3876,8 +3898,10 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   auto all_done = [&] { for (int w = 0; w < n; ++w) if (!wsn[w].done) return false; return true; };
   while (!all_done() && opt.iters > 0) {
     for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = wsn[w].n_iters; h_ctrl[2 * n + w] = wsn[w].done ? 1 : 0; }
-    SSX_HIP_TRY(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(int) * 3 * n, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_lm_begin_batch, dim3(n), dim3(64), 0, s, dv, (const int*)d_ctrl, n, opt.iters);
+    // (no copies: the control words are READ by the kernel from the pinned block, the state words and results are WRITTEN by the
+    // gather / pack kernels into pinned host memory -- a hipMemcpyAsync of this runtime runs as a blit KERNEL on the compute units
+    // whenever the SDMA engines are taken, tools/microbench/copy_engine.hip, and costs the host ~10 us each)
+    hipLaunchKernelGGL(k_lm_begin_batch, dim3(n), dim3(64), 0, s, dv, (const int*)h_ctrl, n, opt.iters);
     int slots_total = 0;
     bool first_slot = true;
     for (;;) {
@@ -3908,6 +3932,7 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
           const int w0 = (int)((long long)n * g / G), hn = (int)((long long)n * (g + 1) / G) - w0;
           const BaDev* hv = dv + w0;
           const dim3 gCh(B->max_ch, hn), gWg(wg_x, hn), gRl(B->max_rl, hn), gRs(B->max_rs, hn), gOne(1, hn);
+          const bool fin_b = B->min_ch > 0 && g_trial_finish.load() != 0;   // the last chunk of k_backsub_residual finishes the trial
           if (fused) {
             if (opt.jac_mode == SSX_JAC_NUMERIC_G2O) SSX_PROF_ON(ctx, hs, KID_BA_LIN_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_NUMERIC_G2O>, gWg, dim3(CH), lds_fused, hs, hv));
             else SSX_PROF_ON(ctx, hs, KID_BA_LIN_SCHUR, hipLaunchKernelGGL(k_lin_schur_b<SSX_JAC_ANALYTIC>, gWg, dim3(CH), lds_fused, hs, hv));
@@ -3925,8 +3950,8 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
           if (B->any_solve64) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve64_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve80) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve80_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
           if (B->any_solve) SSX_PROF_ON(ctx, hs, KID_BA_SOLVE, hipLaunchKernelGGL(k_solve_b, gOne, dim3(CH), 0, hs, hv, -1, 0.0, 1));
-          SSX_PROF_ON(ctx, hs, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual_b, gCh, dim3(CH), 0, hs, hv, -1, 0.0, 1, B->min_ch > 0 ? 1 : 0));
-          if (B->min_ch <= 0) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial_b, gOne, dim3(CH), 0, hs, hv, 1));   // (a window without chunks: nobody would finish its trial)
+          SSX_PROF_ON(ctx, hs, KID_BA_BACKSUB, hipLaunchKernelGGL(k_backsub_residual_b, gCh, dim3(CH), 0, hs, hv, -1, 0.0, 1, fin_b ? 1 : 0));
+          if (!fin_b) SSX_PROF_ON(ctx, hs, KID_BA_REDUCE_TRIAL, hipLaunchKernelGGL(k_reduce_trial_b, gOne, dim3(CH), 0, hs, hv, 1));   // (a window without chunks: nobody would finish its trial)
         }
         first_slot = false;
       }
@@ -3936,16 +3961,13 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
       }
       slots_total += slots;
       SSX_HIP_TRY(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 0);
-      SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d_gather, sizeof(double) * (size_t)n * SC_N, hipMemcpyDeviceToHost, s));
+      hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, hscal, 0);
       if (spec_poses) {
         // poses-only results ride behind the control words of this round, before the host has looked at them: if the round turns
         // out to be the last one (the usual case) the solve ends on ONE synchronisation instead of two; otherwise the next round
         // overwrites them.  The packing kernel takes the state buffer index from the window's own control block.
-        hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 1);
-        SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal + (size_t)n * SC_N, d_gather, sizeof(double) * (size_t)n * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, s));
-        hipLaunchKernelGGL(k_pack_poses_b, dim3(n), dim3(CH), 0, s, dv, (const int*)nullptr, n, spec_maxP, d_out);
-        SSX_HIP_TRY(ctx, hipMemcpyAsync(B->stage->as<double>(), d_out, sizeof(double) * (size_t)n * 7 * spec_maxP, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, hscal + (size_t)n * SC_N, 1);
+        hipLaunchKernelGGL(k_pack_poses_b, dim3(n), dim3(CH), 0, s, dv, (const int*)nullptr, n, spec_maxP, B->stage->as<double>());
         SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
         spec_done = true;
       }
@@ -3987,15 +4009,20 @@ ssx_status batch_run(ssx_ba_batch* B, ssx_ba_result* results, int32_t* lm_iterat
   double* h_out = B->stage->as<double>();
   if (!poses_only) {
   for (int w = 0; w < n; ++w) { h_ctrl[w] = wsn[w].cur; h_ctrl[n + w] = wsn[w].trial_err ? 1 : 0; h_ctrl[2 * n + w] = 1; }
-  hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, d_gather, 1);
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal + (size_t)n * SC_N, d_gather, sizeof(double) * (size_t)n * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, s));
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(int) * 3 * n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_gather_scal_b, dim3(n), dim3(CH), 0, s, dv, n, hscal + (size_t)n * SC_N, 1);
   if (want_err)                                                       // windows that never ran a trial: errors of the input state
     for (int w = 0; w < n; ++w)
       if (!wsn[w].trial_err && B->devs[w].nCh > 0)
         hipLaunchKernelGGL(k_linearize<SSX_JAC_ANALYTIC>, dim3(B->devs[w].nCh), dim3(CH), LIN_LDS_BYTES, s, B->devs[w], wsn[w].cur);
-  hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)d_ctrl, n, d_ooff, d_out, want_err ? 1 : 0);
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * B->out_total, hipMemcpyDeviceToHost, s));
+  if (want_err) {
+    // (per-edge chi2 goes back in the CALLER's order: a scatter of 8-byte words, which belongs in HBM -- over PCIe every one of them
+    // would be a transaction of its own; a streaming kernel then moves the packed block)
+    double* d_out = reinterpret_cast<double*>(dev_base + B->a_out);
+    hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)h_ctrl, n, d_ooff, d_out, 1);
+    hipLaunchKernelGGL(k_stream_out, dim3((unsigned)std::min<size_t>(1024, (B->out_total + 2 * CH - 1) / (2 * CH))), dim3(CH), 0, s, (const double*)d_out, h_out, B->out_total);
+  } else {
+    hipLaunchKernelGGL(k_pack_out_b, dim3(64, n), dim3(CH), 0, s, dv, (const int*)h_ctrl, n, d_ooff, h_out, 0);
+  }
   SSX_HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
   }   // (!poses_only)
@@ -4057,6 +4084,9 @@ extern "C" {
 // poses a chunk touches (default), < 0 = the environment's choice (SSX_BA_DENSE_SLABS).  Same bits either way.  Applies to problems
 // uploaded after the call.
 void ssx_debug_set_dense_slabs(int32_t mode) { g_dense_slabs.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
+// tests hook: 0 = a trial's sums are added and its LM step is taken by a launch of k_reduce_trial, 1 (default) = by the last chunk of
+// k_backsub_residual (the ticket protocol).  Same bits either way (test_trial_finish_litmus).
+void ssx_debug_set_trial_finish(int32_t mode) { g_trial_finish.store(mode ? 1 : 0); }
 
 int64_t ssx_debug_kernel_dynamic_lds(const char* kernel)
 {

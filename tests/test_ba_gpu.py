@@ -503,6 +503,45 @@ def test_block_cyclic_reduction_shapes_equal_tiles(ctx, P, obs, wrap, fix):
     assert np.array_equal(again["poses"], g["poses"]) and np.array_equal(again["chi2"], g["chi2"])      # bit-deterministic
 
 
+def test_block_cyclic_reduction_on_a_busy_chip_returns_the_idle_bits(ctx):
+    """The BCR_S workgroups that eliminate one super-block share its stores; none of them may write what a sibling still reads (the
+    coupling blocks E live in two buffers: bcr_e_buf).  On an idle GPU all workgroups of a level start together and a violation
+    stays invisible, so the solve is repeated while another context keeps every CU busy with a resident batch of local windows on
+    its own stream (the siblings of a super-block are then dispatched apart): every repeat returns the bits of the idle solve."""
+    import threading
+    import ssvio_amd
+    big = [make_ba_problem(P=131, L=60 * 131, obs_per_lm=6, seed=1031, loop=True, wrap=True, fix_first_pose=True),
+           make_ba_problem(P=500, L=12000, obs_per_lm=6, seed=43, loop=True, fix_first_pose=True)]
+    kw = dict(outer_rounds=1, iters=4, want_edges=False, large_solver=2)
+    idle = [ba.ba_solve(ctx, pr, **kw) for pr in big]
+    ctx2 = ssvio_amd.Context(0)
+    load = ba.BaBatch(ctx2, [make_ba_problem(P=10, L=2000, obs_per_lm=5, seed=70 + k) for k in range(96)], resident=True, with_edge_errors=False)
+    stop, n_load, err = threading.Event(), [0], []
+
+    def keep_busy():
+        try:
+            while not stop.is_set():
+                load.solve(download=False)
+                n_load[0] += 1
+        except Exception as exc:                              # noqa: BLE001 -- reported by the test's thread
+            err.append(exc)
+
+    th = threading.Thread(target=keep_busy)
+    th.start()
+    try:
+        for _ in range(6):
+            for pr, ref in zip(big, idle):
+                g = ba.ba_solve(ctx, pr, **kw)
+                assert np.array_equal(g["trials"], ref["trials"]) and np.array_equal(g["chi2"], ref["chi2"])
+                assert np.array_equal(g["poses"], ref["poses"]) and np.array_equal(g["points"], ref["points"])
+    finally:
+        stop.set()
+        th.join()
+        load.close()
+        ctx2.close()
+    assert not err and n_load[0] >= 2, (err, n_load)
+
+
 def test_batch_groups_do_not_change_the_bits(ctx):
     """A batch of >= 8 windows runs as groups of windows on several streams (ssx_ba_batch_groups / _set_groups): every
     grouping returns, per window, the bits of ssx_ba_solve."""
@@ -523,6 +562,60 @@ def test_batch_groups_do_not_change_the_bits(ctx):
     host = ba.BaBatch(ctx, probs).solve()                     # the one-call form takes the default grouping
     assert all(np.array_equal(b["poses"], one["poses"]) for b, one in zip(host["results"], ones))
     assert ba.BaBatch(ctx, probs[:3], resident=True).groups == 1
+
+
+def test_trial_finish_litmus(ctx):
+    """Litmus test of the ticket protocol that lets the LAST chunk of k_backsub_residual complete an LM trial (agent-scope stores of
+    the chunk's three sums, s_waitcnt vmcnt(0), a relaxed ticket, agent-scope loads; no fence -- ba.hip, k_backsub_residual_body).
+    A chunk's sums that were not visible to the last chunk would change chi2 / the LM decision of that trial.  Reference = the same
+    solves with the trial completed by a launch of k_reduce_trial (ssx_debug_set_trial_finish(0): ordered by the kernel boundary).
+    128 windows of 20 .. 80 chunks x 10 trials x REPS solves = REPS x 1280 protocol runs per round, beside a second context that
+    keeps the chip busy half of the time (chunks of one window then finish far apart).  SSX_LITMUS_REPS raises the count; the
+    default gives >= 10 000 launches-x-windows in a few seconds.  tools/jobs/litmus_O1.sh runs it on a library built at -O1."""
+    import os
+    import threading
+    import ssvio_amd
+    lib = ssvio_amd.load()
+    lib.ssx_debug_set_trial_finish.argtypes = [C.c_int32]; lib.ssx_debug_set_trial_finish.restype = None
+    reps = int(os.environ.get("SSX_LITMUS_REPS", "8"))
+    probs = [make_ba_problem(P=6 + (k % 5), L=1000 + 97 * (k % 31), obs_per_lm=4 + (k % 2), seed=4000 + k, frac_gross=0.3 if k % 9 == 0 else 0.03)
+             for k in range(128)]
+    batch = ba.BaBatch(ctx, probs, resident=True, with_edge_errors=True)
+    try:
+        lib.ssx_debug_set_trial_finish(0)
+        ref = [{k: np.copy(v) for k, v in r.items() if isinstance(v, np.ndarray)} for r in batch.solve()["results"]]   # (solve() reuses its arrays)
+        lib.ssx_debug_set_trial_finish(1)
+        ctx2 = ssvio_amd.Context(0)
+        load = ba.BaBatch(ctx2, probs[:64], resident=True, with_edge_errors=False)
+        stop = threading.Event()
+
+        def keep_busy():
+            while not stop.is_set():
+                load.solve(download=False)
+
+        n_runs = 0
+        for rep in range(reps):
+            th = None
+            if rep % 2:
+                stop.clear()
+                th = threading.Thread(target=keep_busy)
+                th.start()
+            try:
+                got = batch.solve()["results"]
+            finally:
+                if th:
+                    stop.set()
+                    th.join()
+            for w, (a, b) in enumerate(zip(got, ref)):
+                assert np.array_equal(a["trials"], b["trials"]) and np.array_equal(a["chi2"], b["chi2"]) and np.array_equal(a["lam"], b["lam"]), (rep, w)
+                assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"]) and np.array_equal(a["edge_chi2"], b["edge_chi2"]), (rep, w)
+                n_runs += int(np.sum(a["trials"]))
+        assert n_runs >= 1200 * reps
+        load.close()
+        ctx2.close()
+    finally:
+        lib.ssx_debug_set_trial_finish(1)
+        batch.close()
 
 
 def test_sparse_slabs_equal_dense_slabs(ctx):
