@@ -66,9 +66,22 @@ namespace {
 using ssx::Cam;
 
 constexpr int CH = 256;            // threads per chunk workgroup
-constexpr int PW = CH + 1;         // padded LDS pitch (doubles) of [component][edge] tiles
-constexpr int CH_E = 255;          // max edges per chunk (chunk-local edge indices fit a byte)
-constexpr int CH_L = 128;          // max landmarks per chunk (per-landmark LDS arrays of k_schur)
+// (tools/build_variant.py experiments: smaller chunks -> less LDS per workgroup -> more workgroups per CU; profiles/r06/lin_schur_residency.md)
+#ifndef SSX_CHUNK_E
+#define SSX_CHUNK_E 255
+#endif
+#ifndef SSX_CHUNK_L
+#define SSX_CHUNK_L 128
+#endif
+#ifndef SSX_LIN_VA
+#define SSX_LIN_VA 14
+#endif
+#ifndef SSX_LS_WGS
+#define SSX_LS_WGS 3
+#endif
+constexpr int CH_E = SSX_CHUNK_E;  // max edges per chunk (chunk-local edge indices fit a byte)
+constexpr int PW = CH_E + 2;       // padded (odd) LDS pitch (doubles) of [component][edge] tiles
+constexpr int CH_L = SSX_CHUNK_L;  // max landmarks per chunk (per-landmark LDS arrays of k_schur)
 constexpr int PL = CH_L + 1;       // their padded pitch
 constexpr int SSX_BA_SMALL_P = 16; // free poses handled by the owned-entry (deterministic LDS) path
 constexpr int UPPER6 = 21;
@@ -277,18 +290,18 @@ __device__ __forceinline__ void block_sum3_max_256(double& a, double& b, double&
 // ------------------------------------------------------------------------------------------------
 // LDS of the linearisation (carved from the workgroup's dynamic LDS so that the fused k_lin_schur can reuse the same
 // bytes for the Schur phase)
-constexpr int LIN_VA = 14;           // pose-block entries per round: 27 = 14 + 13
+constexpr int LIN_VA = SSX_LIN_VA;   // pose-block entries per round: 27 = 14 + 13
 // One LDS layout for k_linearize, k_schur and the fused k_lin_schur: [0, BA_PHASE_BYTES) belongs to the running phase
 // (linearise: sL 9 x CH + sV 14 x PW doubles; Schur: sY 18 x PW + sG, sGb 9 x PL doubles + sLm CH ints), the lists above
 // it (pose segments, pair list) are loaded ONCE at the top of the kernel and survive the change of phase.
-constexpr size_t BA_PHASE_BYTES = 47360;
-static_assert(sizeof(double) * (9 * CH + LIN_VA * PW) <= BA_PHASE_BYTES, "linearise phase LDS");
-static_assert(sizeof(double) * (18 * PW + 9 * PL) + sizeof(int) * CH <= BA_PHASE_BYTES, "Schur phase LDS");
+constexpr size_t BA_PHASE_LIN = sizeof(double) * (9 * (CH_E + 1) + LIN_VA * PW), BA_PHASE_SCHUR = sizeof(double) * (18 * PW + 9 * PL) + sizeof(int) * (CH_E + 1);
+constexpr size_t BA_PHASE_BYTES = ((BA_PHASE_LIN > BA_PHASE_SCHUR ? BA_PHASE_LIN : BA_PHASE_SCHUR) + 63) & ~size_t(63);   // 47 360 at 255 edges
+static_assert(SSX_CHUNK_E != 255 || BA_PHASE_BYTES == 47360, "the shipped layout");
 constexpr size_t BA_OFF_PPTR = BA_PHASE_BYTES;                                   // uint16 [SSX_BA_SMALL_P + 2]
 constexpr size_t BA_OFF_PAB = BA_OFF_PPTR + 64;                                  // uint16 [MAX_PAIRS]
 constexpr size_t BA_LDS_BYTES = BA_OFF_PAB + ((2 * MAX_PAIRS + 63) & ~size_t(63));   // 51 776 B: three workgroups per CU
 constexpr size_t LIN_LDS_BYTES = BA_LDS_BYTES;
-static_assert(2 * (SSX_BA_SMALL_P + 2) <= 64 && 3 * BA_LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(2 * (SSX_BA_SMALL_P + 2) <= 64 && SSX_LS_WGS * BA_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // threadIdx.x behind an opaque move: everything a phase derives from it (LDS row addresses, quarter pointers ...) is then
 // recomputed per chunk instead of being hoisted out of a persistent workgroup's chunk loop and kept in ~20 registers
@@ -379,8 +392,8 @@ template <int JAC>
 __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, int cur, char* smem, const ChunkLists& cl, double* Wout, double* lmout,
                                                  int* erw_out, double* slab)
 {
-  double (*sL)[CH] = reinterpret_cast<double (*)[CH]>(smem);            // [9]: per-edge landmark contributions (6 Hll + 3 bl), edge order
-  double* sV = reinterpret_cast<double*>(smem) + 9 * CH;                // [LIN_VA][PW]: per-edge pose-block terms, POSE-MAJOR order
+  double (*sL)[CH_E + 1] = reinterpret_cast<double (*)[CH_E + 1]>(smem);   // [9]: per-edge landmark contributions (6 Hll + 3 bl), edge order
+  double* sV = reinterpret_cast<double*>(smem) + 9 * (CH_E + 1);                // [LIN_VA][PW]: per-edge pose-block terms, POSE-MAJOR order
   double* sRed = reinterpret_cast<double*>(smem);                       // 16 doubles over sL, which is dead by then
   const uint16_t* sPptr = reinterpret_cast<const uint16_t*>(smem + BA_OFF_PPTR);
 
@@ -1311,9 +1324,9 @@ __device__ __forceinline__ void k_lin_schur_entry(const BaDev& d, int bx)
   }
 }
 template <int JAC>
-__global__ __launch_bounds__(CH, 3) void k_lin_schur(BaDev d) { k_lin_schur_entry<JAC>(d, blockIdx.x); }
+__global__ __launch_bounds__(CH, SSX_LS_WGS) void k_lin_schur(BaDev d) { k_lin_schur_entry<JAC>(d, blockIdx.x); }
 template <int JAC>
-__global__ __launch_bounds__(CH, 3) void k_lin_schur_b(const BaDev* __restrict__ dv)
+__global__ __launch_bounds__(CH, SSX_LS_WGS) void k_lin_schur_b(const BaDev* __restrict__ dv)
 {
   const BaDev& d = dv[blockIdx.y];
   if ((int)blockIdx.x >= d.nCh) return;
