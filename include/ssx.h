@@ -83,6 +83,11 @@ SSX_API const char* ssx_last_error(const ssx_ctx* ctx);
 SSX_API ssx_status ssx_ctx_synchronize(ssx_ctx* ctx);
 /* hipStream_t the ctx enqueues on (for callers that bracket calls with their own events). */
 SSX_API void* ssx_ctx_stream(ssx_ctx* ctx);
+/* Page-locked (pinned, GPU-readable) host memory for callers without a HIP toolchain of their own: images kept in such a buffer can
+ * be handed to the batched entry points with images_on_device = 1 (the kernels read them over PCIe, nothing is staged).  NULL when
+ * the allocation fails.  (hipHostMalloc / hipHostFree.) */
+SSX_API void* ssx_host_alloc(size_t bytes);
+SSX_API void ssx_host_free(void* p);
 
 /* Per-kernel GPU time, measured with HIP events recorded on the ctx stream around every kernel launch
  * between ssx_profile_begin and ssx_profile_end (the counterpart of g2o's G2OBatchStatistics; bench.py uses it
@@ -373,6 +378,17 @@ SSX_API ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const double
                                      const double* uv, int32_t rounds, int32_t iters, double chi2_th,
                                      double huber_delta, uint8_t* inlier_out, int32_t* n_inliers);
 
+/* n problems in ONE call -- one frame of each of n streams (BASELINE configs[4]; FrontEnd::EstimateCurrentPose is one such problem
+ * per frame, frontend.cpp:184-300): one workgroup per problem, one launch, one synchronisation.  Per problem the arguments of
+ * ssx_pose_only_opt and, bit for bit, its results. */
+typedef struct ssx_pose_only_job {
+  double* pose_io; const double* K4; int32_t M; const double* xyz; const double* uv;
+  int32_t rounds, iters; double chi2_th, huber_delta;
+  uint8_t* inlier_out;        /* nullable */
+  int32_t* n_inliers;         /* nullable */
+} ssx_pose_only_job;
+SSX_API ssx_status ssx_pose_only_opt_batch(ssx_ctx* ctx, int32_t n, const ssx_pose_only_job* jobs);
+
 /* ------------------------------------------------------------------------------------------------
  * ORB extraction -- replaces the bodies of ssvio::ORBextractor::Detect / DetectAndCompute
  * (include/ssvio/orbextractor.hpp:50-59, src/ssvio/orbextractor.cpp:755-842, 687-753) and everything
@@ -567,6 +583,20 @@ SSX_API ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_
 SSX_API ssx_status ssx_lk_track_next(ssx_ctx* ctx, const uint8_t* next, int32_t next_stride, int32_t rows,
                                      int32_t cols, int32_t n, const float* prev_pts, float* next_pts,
                                      uint8_t* status, float* err, const ssx_lk_params* prm, int32_t* top_level);
+/* n_jobs tracking problems in ONE call -- one frame of each of n_jobs streams (BASELINE configs[4]): every kernel of the tracker runs
+ * once for all jobs.  A job names the SLOT of the context that holds its pyramids (0 .. 4095; ssx_lk_track / _next use slot 0; a
+ * slot at most once per call); prev == NULL chains it to the slot's last job like ssx_lk_track_next.  All jobs share rows x cols
+ * and prm.  images_on_device != 0: the image pointers are readable by the GPU -- device memory, or pinned host memory
+ * (hipHostMalloc / hipHostRegister) that the level-0 kernel reads over PCIe -- and nothing is staged; 0: ordinary host memory.
+ * Per job the bits of ssx_lk_track / ssx_lk_track_next. */
+typedef struct ssx_lk_job {
+  int32_t slot;
+  const uint8_t* prev; int32_t prev_stride;      /* NULL: the slot's last `next` image */
+  const uint8_t* next; int32_t next_stride;
+  int32_t n; const float* prev_pts; float* next_pts; uint8_t* status; float* err;   /* err nullable */
+} ssx_lk_job;
+SSX_API ssx_status ssx_lk_track_batch(ssx_ctx* ctx, int32_t n_jobs, const ssx_lk_job* jobs, int32_t rows, int32_t cols,
+                                      const ssx_lk_params* prm, int32_t images_on_device);
 /* Test access to the pyramids (which = 0 previous, 1 next) and the Scharr images (int16 dx, dy interleaved) of
  * the last ssx_lk_track call. */
 SSX_API ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level, uint8_t* out, int32_t out_cap,

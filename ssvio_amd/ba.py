@@ -105,6 +105,34 @@ def pose_only_opt(ctx: Context, pose, K, xyz, uv, rounds=4, iters=10, chi2_th=5.
     return dict(pose=pose, inliers=inl, n_inliers=n.value)
 
 
+class PoseOnlyJob(C.Structure):
+    _fields_ = [("pose_io", dbl_p), ("K4", dbl_p), ("M", C.c_int32), ("xyz", dbl_p), ("uv", dbl_p), ("rounds", C.c_int32), ("iters", C.c_int32),
+                ("chi2_th", C.c_double), ("huber_delta", C.c_double), ("inlier_out", u8_p), ("n_inliers", C.POINTER(C.c_int32))]
+
+
+def pose_only_opt_batch(ctx: Context, problems, rounds=4, iters=10, chi2_th=5.991, huber_delta=1.0):
+    """ssx_pose_only_opt_batch: problems = [dict(pose, K, xyz, uv)] -> [dict(pose, inliers, n_inliers)], one launch for all."""
+    n = len(problems)
+    arr = (PoseOnlyJob * n)()
+    keep, outs = [], []
+    for i, pr in enumerate(problems):
+        pose = np.ascontiguousarray(pr["pose"], dtype=np.float64).copy()
+        K = np.ascontiguousarray(pr["K"], dtype=np.float64)
+        xyz = np.ascontiguousarray(pr["xyz"], dtype=np.float64).reshape(-1, 3)
+        uv = np.ascontiguousarray(pr["uv"], dtype=np.float64).reshape(-1, 2)
+        inl = np.zeros(len(xyz), dtype=np.uint8)
+        cnt = (C.c_int32 * 1)(0)
+        a = arr[i]
+        a.pose_io = ptr(pose, dbl_p); a.K4 = ptr(K, dbl_p); a.M = len(xyz); a.xyz = ptr(xyz, dbl_p); a.uv = ptr(uv, dbl_p)
+        a.rounds = rounds; a.iters = iters; a.chi2_th = chi2_th; a.huber_delta = huber_delta
+        a.inlier_out = ptr(inl, u8_p); a.n_inliers = C.cast(cnt, C.POINTER(C.c_int32))
+        keep.append((K, xyz, uv)); outs.append((pose, inl, cnt))
+    ctx.lib.ssx_pose_only_opt_batch.restype = C.c_int32
+    ctx.lib.ssx_pose_only_opt_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PoseOnlyJob)]
+    ctx.check(ctx.lib.ssx_pose_only_opt_batch(ctx.handle, n, arr))
+    return [dict(pose=p_, inliers=i_, n_inliers=int(c_[0])) for p_, i_, c_ in outs]
+
+
 class PoseGraphProblem(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_edges", C.c_int32), ("poses", C.POINTER(C.c_double)),
                 ("pose_fixed", C.POINTER(C.c_ubyte)), ("edge_i", C.POINTER(C.c_int32)), ("edge_j", C.POINTER(C.c_int32)),

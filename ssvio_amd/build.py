@@ -86,7 +86,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HOST, "libssx_host.so")
 HOST_EXE = os.path.join(HOST, "ssx_run_kitti")
-HOST_LIB_SRCS = ["dataset.cpp", "map.cpp", "frontend.cpp", "backend.cpp", "system.cpp", "ssx_compute.cpp"]
+HOST_LIB_SRCS = ["dataset.cpp", "map.cpp", "frontend.cpp", "backend.cpp", "system.cpp", "ssx_compute.cpp", "stream_batcher.cpp"]
 HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-Wall", "-Wno-unknown-pragmas", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
 
 

@@ -102,6 +102,16 @@ ssx_status ssx_ctx_synchronize(ssx_ctx* ctx)
 
 void* ssx_ctx_stream(ssx_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
 
+// Page-locked host memory the GPU can read and write directly (fine-grained: coherent with the CPU).  What a caller hands to the
+// entry points that take `images_on_device` (ssx_lk_track_batch): the level-0 kernel then reads the image over PCIe, nothing is staged.
+void* ssx_host_alloc(size_t bytes)
+{
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void ssx_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 ssx_status ssx_profile_begin(ssx_ctx* ctx)
 {
   if (!ctx) return SSX_ERR_INVALID_ARG;

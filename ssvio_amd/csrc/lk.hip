@@ -35,32 +35,50 @@ struct LkDev {
   int rows[LK_MAX_LEVELS], cols[LK_MAX_LEVELS], pitch[LK_MAX_LEVELS];
   size_t off[LK_MAX_LEVELS];             // byte offset of a padded level inside one image pyramid
   size_t doff[LK_MAX_LEVELS];            // int32 offset of a padded derivative level
-  uint8_t* pyr[2];                       // [0] previous image, [1] next image
-  uint32_t* deriv;                       // previous image: dx | dy << 16 (int16 each), same padded geometry
   // tracking
-  int n, max_iters, use_initial_flow;
+  int max_iters, use_initial_flow;
   double eps2;
   float min_eig;
-  const float* prev_pts;
+  const float* prev_pts;                 // the points of ALL jobs of the call, job after job (LkJob::pt0)
   float* next_pts;
   uint8_t* status;
   float* err;
 };
 
+// One tracking job of a call (blockIdx.z / .y = job): its two pyramids + derivative images (a SLOT of the context: a stream keeps
+// its slot, so the pyramid of its last `next` image is still there), the level-0 sources and its points.  ssx_lk_track /
+// ssx_lk_track_next are a call with one job on slot 0.
+struct LkJob {
+  uint8_t* pyr[2];                       // [0] previous image, [1] next image
+  uint32_t* deriv;                       // previous image: dx | dy << 16 (int16 each), same padded geometry
+  const uint8_t* img[2];                 // level-0 sources (device memory, or pinned host memory read over PCIe); img[0] null: chained
+  int stride[2];
+  int n, pt0;
+};
+
+struct LkSlot {
+  DevBuf mem;
+  uint8_t* pyr[2] = {nullptr, nullptr};
+  uint32_t* deriv = nullptr;
+  bool have_next = false;                // pyr[1] holds the pyramid of the slot's last `next` image
+};
+
 struct LkWorkspace {
-  DevBuf arena, io;
+  std::vector<LkSlot> slots;
+  DevBuf io;
   HostBuf stage;
   LkDev dev{};
+  size_t pyr_bytes = 0, deriv_words = 0;
   int rows = 0, cols = 0, win = 0, max_level = -1;
   bool planned = false;
-  bool have_next = false;                // pyr[1] holds the pyramid of the last call's next image
 };
 
 void lk_ws_free(void* p)
 {
   LkWorkspace* w = static_cast<LkWorkspace*>(p);
   if (!w) return;
-  w->arena.release(); w->io.release(); w->stage.release();
+  for (LkSlot& sl : w->slots) sl.mem.release();
+  w->io.release(); w->stage.release();
   delete w;
 }
 
@@ -77,25 +95,30 @@ __device__ __forceinline__ int refl101(int i, int n)
   return i;
 }
 
-__global__ __launch_bounds__(256) void k_lk_pad_level0(const uint8_t* __restrict__ img, int stride, LkDev d, int which)
+__global__ __launch_bounds__(256) void k_lk_pad_level0(LkDev d, const LkJob* __restrict__ jobs, int which)
 {
+  const LkJob jb = jobs[blockIdx.z];
+  const uint8_t* img = jb.img[which];
+  if (!img) return;                                                   // chained job: its previous pyramid is resident
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;      // padded coordinates
   const int pw = d.cols[0] + 2 * d.pad;
   if (x >= pw) return;
   const int sy = refl101(y - d.pad, d.rows[0]), sx = refl101(x - d.pad, d.cols[0]);
-  d.pyr[which][d.off[0] + (size_t)y * d.pitch[0] + x] = img[(size_t)sy * stride + sx];
+  jb.pyr[which][d.off[0] + (size_t)y * d.pitch[0] + x] = img[(size_t)sy * jb.stride[which] + sx];
 }
 
 // pyrDown (imgproc/pyramids.cpp, 8u): separable 1-4-6-4-1, (sum + 128) >> 8, BORDER_REFLECT_101; the padded
 // border of the source level already holds the reflected pixels.  Border pixels of the destination are the
 // reflected destination pixels, computed redundantly.
-__global__ __launch_bounds__(256) void k_lk_pyr_down(LkDev d, int which, int level)
+__global__ __launch_bounds__(256) void k_lk_pyr_down(LkDev d, const LkJob* __restrict__ jobs, int which, int level)
 {
+  const LkJob jb = jobs[blockIdx.z];
+  if (!jb.img[which]) return;
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   const int pw = d.cols[level] + 2 * d.pad;
   if (x >= pw) return;
   const int dy = refl101(y - d.pad, d.rows[level]), dx = refl101(x - d.pad, d.cols[level]);
-  const uint8_t* s = d.pyr[which] + d.off[level - 1];
+  const uint8_t* s = jb.pyr[which] + d.off[level - 1];
   const int sp = d.pitch[level - 1];
   const int w[5] = {1, 4, 6, 4, 1};
   int sum = 0;
@@ -107,27 +130,28 @@ __global__ __launch_bounds__(256) void k_lk_pyr_down(LkDev d, int which, int lev
     for (int kx = 0; kx < 5; ++kx) r += w[kx] * row[kx];
     sum += w[ky] * r;
   }
-  d.pyr[which][d.off[level] + (size_t)y * d.pitch[level] + x] = (uint8_t)((sum + 128) >> 8);
+  jb.pyr[which][d.off[level] + (size_t)y * d.pitch[level] + x] = (uint8_t)((sum + 128) >> 8);
 }
 
 // calcSharrDeriv (video/lkpyramid.cpp): dx = [3 10 3]^T (x) [-1 0 1], dy = [-1 0 1]^T (x) [3 10 3]; rows and
 // columns reflect (101) at the image edge = the padded border; the derivative image itself has a zero border.
-__global__ __launch_bounds__(256) void k_lk_scharr(LkDev d, int level)
+__global__ __launch_bounds__(256) void k_lk_scharr(LkDev d, const LkJob* __restrict__ jobs, int level)
 {
+  const LkJob jb = jobs[blockIdx.z];
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;      // padded coordinates
   const int pw = d.cols[level] + 2 * d.pad;
   if (x >= pw) return;
   const int iy = y - d.pad, ix = x - d.pad;
   uint32_t out = 0;
   if (iy >= 0 && iy < d.rows[level] && ix >= 0 && ix < d.cols[level]) {
-    const uint8_t* c = d.pyr[0] + d.off[level] + (size_t)y * d.pitch[level] + x;
+    const uint8_t* c = jb.pyr[0] + d.off[level] + (size_t)y * d.pitch[level] + x;
     const int p = d.pitch[level];
     const int a00 = c[-p - 1], a01 = c[-p], a02 = c[-p + 1], a10 = c[-1], a12 = c[1], a20 = c[p - 1], a21 = c[p], a22 = c[p + 1];
     const int gx = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
     const int gy = ((a20 - a00) + (a22 - a02)) * 3 + (a21 - a01) * 10;
     out = ((uint32_t)gx & 0xFFFFu) | ((uint32_t)gy << 16);
   }
-  d.deriv[d.doff[level] + (size_t)y * d.pitch[level] + x] = out;
+  jb.deriv[d.doff[level] + (size_t)y * d.pitch[level] + x] = out;
 }
 
 // exact 64-bit sum over the wave, the same value in every lane.  Lane exchanges inside a row of 16 run on the VALU (DPP:
@@ -201,12 +225,14 @@ __device__ __forceinline__ bool region_holds(const Region& r, int win, int inx, 
   return inx >= r.ox && iny >= r.oy && inx + win + 1 <= r.ox + RG && iny + win + 1 <= r.oy + RG;
 }
 
-__global__ __launch_bounds__(256) void k_lk_track(LkDev d)
+__global__ __launch_bounds__(256) void k_lk_track(LkDev d, const LkJob* __restrict__ jobs)
 {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
   __shared__ uint8_t sRegion[4][RG * RG];
-  const int i = blockIdx.x * 4 + wave;
-  if (i >= d.n) return;
+  const LkJob jb = jobs[blockIdx.y];
+  const int ij = blockIdx.x * 4 + wave;                               // point of the job
+  if (ij >= jb.n) return;
+  const int i = jb.pt0 + ij;                                          // ... and of the call
   uint8_t* sR = sRegion[wave];
   const int win = d.win, nwin = win * win, pad = d.pad;
   const float half = (float)(win - 1) * 0.5f;
@@ -225,9 +251,9 @@ __global__ __launch_bounds__(256) void k_lk_track(LkDev d)
   float errv = 0.f;
   const int top = d.levels - 1;
   for (int level = top; level >= 0; --level) {
-    const uint8_t* I = d.pyr[0] + d.off[level];
-    const uint8_t* J = d.pyr[1] + d.off[level];
-    const uint32_t* G = d.deriv + d.doff[level];
+    const uint8_t* I = jb.pyr[0] + d.off[level];
+    const uint8_t* J = jb.pyr[1] + d.off[level];
+    const uint32_t* G = jb.deriv + d.doff[level];
     const int pitch = d.pitch[level], rows = d.rows[level], cols = d.cols[level];
     const float sc = (float)(1. / (double)(1 << level));
     float px = ppx * sc, py = ppy * sc;
@@ -365,76 +391,134 @@ ssx_status lk_plan(ssx_ctx* ctx, int rows, int cols, const ssx_lk_params& prm)
     off += (size_t)d.pitch[l] * (d.rows[l] + 2 * d.pad) + 64;
     doff += (size_t)d.pitch[l] * (d.rows[l] + 2 * d.pad) + 64;
   }
-  const size_t pyr_bytes = (off + 255) & ~size_t(255);
-  Layout lay;
-  const size_t o_p0 = lay.take(pyr_bytes), o_p1 = lay.take(pyr_bytes), o_g = lay.take(sizeof(uint32_t) * doff);
-  SSX_HIP_TRY(ctx, ws->arena.reserve(lay.off));
-  char* base = ws->arena.as<char>();
-  d.pyr[0] = (uint8_t*)(base + o_p0); d.pyr[1] = (uint8_t*)(base + o_p1); d.deriv = (uint32_t*)(base + o_g);
+  ws->pyr_bytes = (off + 255) & ~size_t(255);
+  ws->deriv_words = doff;
   ws->dev = d;
   ws->rows = rows; ws->cols = cols; ws->win = prm.win; ws->max_level = prm.max_level;
   ws->planned = true;
-  ws->have_next = false;
+  for (LkSlot& sl : ws->slots) { sl.have_next = false; sl.pyr[0] = sl.pyr[1] = nullptr; sl.deriv = nullptr; }   // (their memory is re-carved on use)
   return SSX_OK;
 }
 
-// One tracking call. prev == nullptr: the previous image is the next image of the last call, whose pyramid is still
-// in pyr[1] -- the two pyramid slots swap roles and only the new image is uploaded and reduced.
-ssx_status lk_run(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const uint8_t* next, int32_t next_stride,
-                  int32_t rows, int32_t cols, int32_t n, const float* prev_pts, float* next_pts, uint8_t* status,
-                  float* err, const ssx_lk_params* prm_in, int32_t* top_level)
+// the slot's two pyramids and its derivative images, carved from a buffer of its own
+ssx_status lk_slot(ssx_ctx* ctx, LkWorkspace* ws, int slot, LkSlot** out)
+{
+  if (slot < 0 || slot >= 4096) { ctx->set_error("ssx_lk: slot %d outside 0..4095", slot); return SSX_ERR_INVALID_ARG; }
+  if ((size_t)slot >= ws->slots.size()) ws->slots.resize((size_t)slot + 1);
+  LkSlot& sl = ws->slots[slot];
+  if (!sl.pyr[0]) {
+    Layout lay;
+    const size_t o_p0 = lay.take(ws->pyr_bytes), o_p1 = lay.take(ws->pyr_bytes), o_g = lay.take(sizeof(uint32_t) * ws->deriv_words);
+    SSX_HIP_TRY(ctx, sl.mem.reserve(lay.off, 1.0));
+    char* base = sl.mem.as<char>();
+    sl.pyr[0] = (uint8_t*)(base + o_p0); sl.pyr[1] = (uint8_t*)(base + o_p1); sl.deriv = (uint32_t*)(base + o_g);
+    sl.have_next = false;
+  }
+  *out = &sl;
+  return SSX_OK;
+}
+
+// One tracking CALL of nj jobs (ssx_lk_job).  A job with prev == nullptr is chained: its previous image is the next image of its
+// slot's last job, whose pyramid is still in pyr[1] -- the two pyramid pointers of the slot swap roles and only the new image is
+// read and reduced.  images_on_device: the image pointers are readable by the GPU (device memory, or pinned host memory that the
+// level-0 kernel then reads over PCIe): nothing is staged; else they go through pinned staging and one copy, with the points.
+ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, int32_t cols, const ssx_lk_params* prm_in, bool images_on_device,
+                  int32_t* top_level)
 {
   ssx_lk_params prm;
   if (prm_in) prm = *prm_in; else ssx_lk_default_params(&prm);
-  if ((prev && prev_stride < cols) || next_stride < cols) { ctx->set_error("ssx_lk: stride smaller than the image width"); return SSX_ERR_INVALID_ARG; }
-  const bool reuse = prev == nullptr;
-  if (reuse) {
-    LkWorkspace* w = lk_ws(ctx);
-    if (!w->planned || !w->have_next || w->rows != rows || w->cols != cols || w->win != prm.win || w->max_level != prm.max_level) {
-      ctx->set_error("ssx_lk_track_next: no previous ssx_lk_track call with the same image size, window and max_level on this context");
-      return SSX_ERR_INVALID_ARG;
-    }
+  LkWorkspace* w0 = lk_ws(ctx);
+  bool any_chained = false, any_fresh = false;
+  for (int j = 0; j < nj; ++j) {
+    const ssx_lk_job& q = jobs[j];
+    if (!q.next || q.n < 0 || (q.n > 0 && (!q.prev_pts || !q.next_pts || !q.status))) return SSX_ERR_INVALID_ARG;
+    if ((q.prev && q.prev_stride < cols) || q.next_stride < cols) { ctx->set_error("ssx_lk: stride smaller than the image width"); return SSX_ERR_INVALID_ARG; }
+    for (int k = 0; k < j; ++k) if (jobs[k].slot == q.slot) { ctx->set_error("ssx_lk_track_batch: slot %d twice in one call", q.slot); return SSX_ERR_INVALID_ARG; }
+    if (!q.prev) {
+      any_chained = true;
+      const bool ok = w0->planned && w0->rows == rows && w0->cols == cols && w0->win == prm.win && w0->max_level == prm.max_level && q.slot >= 0 &&
+                      (size_t)q.slot < w0->slots.size() && w0->slots[q.slot].pyr[0] && w0->slots[q.slot].have_next;
+      if (!ok) {
+        ctx->set_error("ssx_lk_track_next: no previous ssx_lk_track call with the same image size, window and max_level on this context (slot %d)", q.slot);
+        return SSX_ERR_INVALID_ARG;
+      }
+    } else any_fresh = true;
   }
+  (void)any_chained;
   ssx_status st = lk_plan(ctx, rows, cols, prm);
   if (st != SSX_OK) return st;
   LkWorkspace* ws = lk_ws(ctx);
-  if (reuse) std::swap(ws->dev.pyr[0], ws->dev.pyr[1]);
-  ws->have_next = false;
+  std::vector<LkSlot*> slot(nj);
+  {
+    int top = -1;
+    for (int j = 0; j < nj; ++j) top = std::max(top, jobs[j].slot);
+    if (top >= 0 && top < 4096 && (size_t)top >= ws->slots.size()) ws->slots.resize((size_t)top + 1);   // (before any pointer into it is taken)
+  }
+  for (int j = 0; j < nj; ++j) {
+    st = lk_slot(ctx, ws, jobs[j].slot, &slot[j]);
+    if (st != SSX_OK) return st;
+    if (!jobs[j].prev) std::swap(slot[j]->pyr[0], slot[j]->pyr[1]);
+    slot[j]->have_next = false;
+  }
   LkDev d = ws->dev;
   hipStream_t s = ctx->stream;
-  // inputs: the image(s) + points through pinned staging
+  // one pinned block: [job table | (staged images) | prev points | next points] -> one copy -> device; results come back in one
   const size_t img_bytes = (size_t)rows * cols;
+  size_t n_pts = 0;
+  int max_n = 0;
+  for (int j = 0; j < nj; ++j) { n_pts += (size_t)jobs[j].n; max_n = std::max(max_n, jobs[j].n); }
   Layout io;
-  const size_t o_i1 = io.take(img_bytes), o_i0 = reuse ? 0 : io.take(img_bytes);
-  const size_t o_pp = io.take(sizeof(float) * 2 * (size_t)std::max(n, 1));
-  const size_t o_np = io.take(sizeof(float) * 2 * (size_t)std::max(n, 1));
+  const size_t o_tab = io.take(sizeof(LkJob) * (size_t)nj);
+  std::vector<size_t> o_img0(nj, 0), o_img1(nj, 0);
+  if (!images_on_device)
+    for (int j = 0; j < nj; ++j) { o_img1[j] = io.take(img_bytes); if (jobs[j].prev) o_img0[j] = io.take(img_bytes); }
+  const size_t o_pp = io.take(sizeof(float) * 2 * std::max<size_t>(n_pts, 1));
+  const size_t o_np = io.take(sizeof(float) * 2 * std::max<size_t>(n_pts, 1));
   const size_t in_bytes = io.off;
-  const size_t o_st = io.take((size_t)std::max(n, 1));
-  const size_t o_er = io.take(sizeof(float) * (size_t)std::max(n, 1));
-  SSX_HIP_TRY(ctx, ws->io.reserve(io.off));
-  SSX_HIP_TRY(ctx, ws->stage.reserve(io.off));
+  const size_t o_st = io.take(std::max<size_t>(n_pts, 1));
+  const size_t o_er = io.take(sizeof(float) * std::max<size_t>(n_pts, 1));
+  SSX_HIP_TRY(ctx, ws->io.reserve(io.off, 1.5));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(io.off, 1.5));
   char* hs = ws->stage.as<char>();
-  for (int y = 0; y < rows; ++y) {
-    if (!reuse) memcpy(hs + o_i0 + (size_t)y * cols, prev + (size_t)y * prev_stride, cols);
-    memcpy(hs + o_i1 + (size_t)y * cols, next + (size_t)y * next_stride, cols);
-  }
-  if (n > 0) { memcpy(hs + o_pp, prev_pts, sizeof(float) * 2 * n); memcpy(hs + o_np, next_pts, sizeof(float) * 2 * n); }
   char* db = ws->io.as<char>();
+  LkJob* tab = reinterpret_cast<LkJob*>(hs + o_tab);
+  size_t pt0 = 0;
+  for (int j = 0; j < nj; ++j) {
+    const ssx_lk_job& q = jobs[j];
+    LkJob& t = tab[j];
+    t.pyr[0] = slot[j]->pyr[0]; t.pyr[1] = slot[j]->pyr[1]; t.deriv = slot[j]->deriv;
+    if (images_on_device) {
+      t.img[0] = q.prev; t.img[1] = q.next; t.stride[0] = q.prev_stride; t.stride[1] = q.next_stride;
+    } else {
+      for (int y = 0; y < rows; ++y) {
+        if (q.prev) memcpy(hs + o_img0[j] + (size_t)y * cols, q.prev + (size_t)y * q.prev_stride, cols);
+        memcpy(hs + o_img1[j] + (size_t)y * cols, q.next + (size_t)y * q.next_stride, cols);
+      }
+      t.img[0] = q.prev ? (const uint8_t*)(db + o_img0[j]) : nullptr; t.img[1] = (const uint8_t*)(db + o_img1[j]);
+      t.stride[0] = t.stride[1] = cols;
+    }
+    t.n = q.n; t.pt0 = (int)pt0;
+    if (q.n > 0) {
+      memcpy(hs + o_pp + sizeof(float) * 2 * pt0, q.prev_pts, sizeof(float) * 2 * q.n);
+      memcpy(hs + o_np + sizeof(float) * 2 * pt0, q.next_pts, sizeof(float) * 2 * q.n);
+    }
+    pt0 += (size_t)q.n;
+  }
   SSX_HIP_TRY(ctx, hipMemcpyAsync(db, hs, in_bytes, hipMemcpyHostToDevice, s));
-  for (int which = reuse ? 1 : 0; which < 2; ++which) {
-    const dim3 g0((d.cols[0] + 2 * d.pad + 255) / 256, d.rows[0] + 2 * d.pad);
-    hipLaunchKernelGGL(k_lk_pad_level0, g0, dim3(256), 0, s, (const uint8_t*)(db + (which ? o_i1 : o_i0)), cols, d, which);
+  const LkJob* dtab = reinterpret_cast<const LkJob*>(db + o_tab);
+  for (int which = any_fresh ? 0 : 1; which < 2; ++which) {
+    const dim3 g0((d.cols[0] + 2 * d.pad + 255) / 256, d.rows[0] + 2 * d.pad, nj);
+    hipLaunchKernelGGL(k_lk_pad_level0, g0, dim3(256), 0, s, d, dtab, which);
     for (int l = 1; l < d.levels; ++l) {
-      const dim3 g((d.cols[l] + 2 * d.pad + 255) / 256, d.rows[l] + 2 * d.pad);
-      hipLaunchKernelGGL(k_lk_pyr_down, g, dim3(256), 0, s, d, which, l);
+      const dim3 g((d.cols[l] + 2 * d.pad + 255) / 256, d.rows[l] + 2 * d.pad, nj);
+      hipLaunchKernelGGL(k_lk_pyr_down, g, dim3(256), 0, s, d, dtab, which, l);
     }
   }
   for (int l = 0; l < d.levels; ++l) {
-    const dim3 g((d.cols[l] + 2 * d.pad + 255) / 256, d.rows[l] + 2 * d.pad);
-    hipLaunchKernelGGL(k_lk_scharr, g, dim3(256), 0, s, d, l);
+    const dim3 g((d.cols[l] + 2 * d.pad + 255) / 256, d.rows[l] + 2 * d.pad, nj);
+    hipLaunchKernelGGL(k_lk_scharr, g, dim3(256), 0, s, d, dtab, l);
   }
-  if (n > 0) {
-    d.n = n;
+  if (n_pts > 0) {
     d.max_iters = std::min(std::max(prm.max_iters, 0), 100);          // TermCriteria clamps of calcOpticalFlowPyrLK
     const double e = std::min(std::max(prm.eps, 0.), 10.);
     d.eps2 = e * e;
@@ -442,16 +526,22 @@ ssx_status lk_run(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const 
     d.use_initial_flow = prm.use_initial_flow;
     d.prev_pts = (const float*)(db + o_pp); d.next_pts = (float*)(db + o_np);
     d.status = (uint8_t*)(db + o_st); d.err = (float*)(db + o_er);
-    hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_lk_track, dim3((max_n + 3) / 4, nj), dim3(256), 0, s, d, dtab);
     SSX_HIP_TRY(ctx, hipGetLastError());
     SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_np, db + o_np, io.off - o_np, hipMemcpyDeviceToHost, s));
   }
+  SSX_HIP_TRY(ctx, hipGetLastError());
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
-  ws->have_next = true;
-  if (n > 0) {
-    memcpy(next_pts, hs + o_np, sizeof(float) * 2 * n);
-    memcpy(status, hs + o_st, (size_t)n);
-    if (err) memcpy(err, hs + o_er, sizeof(float) * n);
+  pt0 = 0;
+  for (int j = 0; j < nj; ++j) {
+    const ssx_lk_job& q = jobs[j];
+    slot[j]->have_next = true;
+    if (q.n > 0) {
+      memcpy(q.next_pts, hs + o_np + sizeof(float) * 2 * pt0, sizeof(float) * 2 * q.n);
+      memcpy(q.status, hs + o_st + pt0, (size_t)q.n);
+      if (q.err) memcpy(q.err, hs + o_er + sizeof(float) * pt0, sizeof(float) * q.n);
+    }
+    pt0 += (size_t)q.n;
   }
   if (top_level) *top_level = d.levels - 1;
   return SSX_OK;
@@ -473,7 +563,8 @@ ssx_status ssx_lk_track(ssx_ctx* ctx, const uint8_t* prev, int32_t prev_stride, 
                         float* err, const ssx_lk_params* prm_in, int32_t* top_level)
 {
   if (!ctx || !prev || !next || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return SSX_ERR_INVALID_ARG;
-  return lk_run(ctx, prev, prev_stride, next, next_stride, rows, cols, n, prev_pts, next_pts, status, err, prm_in, top_level);
+  const ssx_lk_job q{0, prev, prev_stride, next, next_stride, n, prev_pts, next_pts, status, err};
+  return lk_run(ctx, 1, &q, rows, cols, prm_in, false, top_level);
 }
 
 ssx_status ssx_lk_track_next(ssx_ctx* ctx, const uint8_t* next, int32_t next_stride, int32_t rows, int32_t cols, int32_t n,
@@ -481,7 +572,18 @@ ssx_status ssx_lk_track_next(ssx_ctx* ctx, const uint8_t* next, int32_t next_str
                              const ssx_lk_params* prm_in, int32_t* top_level)
 {
   if (!ctx || !next || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return SSX_ERR_INVALID_ARG;
-  return lk_run(ctx, nullptr, 0, next, next_stride, rows, cols, n, prev_pts, next_pts, status, err, prm_in, top_level);
+  const ssx_lk_job q{0, nullptr, 0, next, next_stride, n, prev_pts, next_pts, status, err};
+  return lk_run(ctx, 1, &q, rows, cols, prm_in, false, top_level);
+}
+
+// n_jobs tracking problems in one call (one frame of each of n_jobs streams: FrontEnd::TrackLastFrame, frontend.cpp:130-182): every
+// kernel of the tracker once for all of them.  Per job the bits of ssx_lk_track / ssx_lk_track_next.
+ssx_status ssx_lk_track_batch(ssx_ctx* ctx, int32_t n_jobs, const ssx_lk_job* jobs, int32_t rows, int32_t cols, const ssx_lk_params* prm_in,
+                              int32_t images_on_device)
+{
+  if (!ctx || n_jobs < 0 || (n_jobs > 0 && !jobs)) return SSX_ERR_INVALID_ARG;
+  if (n_jobs == 0) return SSX_OK;
+  return lk_run(ctx, n_jobs, jobs, rows, cols, prm_in, images_on_device != 0, nullptr);
 }
 
 // test / debug access to the pyramid and derivative images of the last ssx_lk_track call
@@ -494,7 +596,8 @@ ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level, uint8_
   *rows = d.rows[level]; *cols = d.cols[level];
   if (!out) return SSX_OK;
   if (out_cap < d.rows[level] * d.cols[level]) return SSX_ERR_CAPACITY;
-  const uint8_t* src = d.pyr[which] + d.off[level] + (size_t)d.pad * d.pitch[level] + d.pad;
+  if (ws->slots.empty() || !ws->slots[0].pyr[0]) return SSX_ERR_INVALID_ARG;
+  const uint8_t* src = ws->slots[0].pyr[which] + d.off[level] + (size_t)d.pad * d.pitch[level] + d.pad;
   SSX_HIP_TRY(ctx, hipMemcpy2DAsync(out, d.cols[level], src, d.pitch[level], d.cols[level], d.rows[level], hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SSX_OK;
@@ -509,7 +612,8 @@ ssx_status ssx_lk_stage_deriv(ssx_ctx* ctx, int32_t level, int16_t* out, int32_t
   *rows = d.rows[level]; *cols = d.cols[level];
   if (!out) return SSX_OK;
   if (out_cap < 2 * d.rows[level] * d.cols[level]) return SSX_ERR_CAPACITY;
-  const uint32_t* src = d.deriv + d.doff[level] + (size_t)d.pad * d.pitch[level] + d.pad;
+  if (ws->slots.empty() || !ws->slots[0].deriv) return SSX_ERR_INVALID_ARG;
+  const uint32_t* src = ws->slots[0].deriv + d.doff[level] + (size_t)d.pad * d.pitch[level] + d.pad;
   SSX_HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)d.cols[level] * 4, src, (size_t)d.pitch[level] * 4, (size_t)d.cols[level] * 4, d.rows[level],
                                     hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

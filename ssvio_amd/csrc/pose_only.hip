@@ -405,9 +405,13 @@ __device__ __forceinline__ bool solve6(const double* Hb, double lambda, double* 
   return ok;
 }
 
+// dv: one descriptor per problem of the batch (blockIdx.x = problem); ssx_pose_only_opt is a batch of one.  The descriptors
+// and a problem's inputs live in a pinned host block the kernel reads DIRECTLY (each value once, at the top), its results go
+// straight back into that block: one launch and one synchronisation per batch, no copy in either direction.
 template <int EPT>
-__global__ __launch_bounds__(PT) void k_pose_only(PoDev d)
+__global__ __launch_bounds__(PT) void k_pose_only(const PoDev* __restrict__ dv)
 {
+  const PoDev d = dv[blockIdx.x];
   __shared__ double sPart[2][NRED][NW];
   __shared__ double sT[27][PT];
   __shared__ double sTot[27];
@@ -570,14 +574,12 @@ __global__ __launch_bounds__(PT) void k_pose_only(PoDev d)
 
 struct PoWorkspace { DevBuf arena; HostBuf stage; };
 
-extern "C" ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const double* K4, int32_t M, const double* xyz,
-                                        const double* uv, int32_t rounds, int32_t iters, double chi2_th, double huber_delta,
-                                        uint8_t* inlier_out, int32_t* n_inliers)
+namespace {
+
+// the generic kernel (M > 6 x 256 edges: never a front-end's frame) keeps its edges in device memory: one problem per call
+ssx_status pose_only_generic(ssx_ctx* ctx, double* pose_io, const double* K4, int32_t M, const double* xyz, const double* uv, int32_t rounds,
+                             int32_t iters, double chi2_th, double huber_delta, uint8_t* inlier_out, int32_t* n_inliers)
 {
-  if (!ctx || !pose_io || !K4 || M < 0 || (M && (!xyz || !uv)) || rounds < 0 || iters < 0) return SSX_ERR_INVALID_ARG;
-  if (M == 0) { if (n_inliers) *n_inliers = 0; return SSX_OK; }
-  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // reuse the BA-independent scratch: a small private arena hung off the ctx through the generic slot
   DevBuf& arena = ctx->po_arena;
   HostBuf& stage = ctx->po_stage;
   Layout lay;
@@ -604,13 +606,7 @@ extern "C" ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const dou
   d.xyz = (const double*)(base + o_xyz); d.uv = (const double*)(base + o_uv);
   d.err = (double*)(base + o_err); d.level = (uint8_t*)(base + o_level); d.outlier = (uint8_t*)(base + o_out);
   d.pose = (double*)(base + o_pose); d.pose_out = (double*)(base + o_pose_out); d.n_inliers = (int*)(base + o_n);
-  if (M <= PT * 2) {
-    SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only<2>, dim3(1), dim3(PT), 0, ctx->stream, d));
-  } else if (M <= PT * 6) {
-    SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only<6>, dim3(1), dim3(PT), 0, ctx->stream, d));
-  } else {
-    SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only_generic, dim3(1), dim3(PT), 0, ctx->stream, d));
-  }
+  SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only_generic, dim3(1), dim3(PT), 0, ctx->stream, d));
   SSX_HIP_TRY(ctx, hipGetLastError());
   SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_res, base + o_res, sizeof(double) * 8 + sizeof(int) * 2 + (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -618,4 +614,99 @@ extern "C" ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const dou
   if (inlier_out) for (int i = 0; i < M; ++i) inlier_out[i] = !reinterpret_cast<uint8_t*>(hs + o_out)[i];
   if (n_inliers) *n_inliers = *reinterpret_cast<int*>(hs + o_n);
   return SSX_OK;
+}
+
+}  // namespace
+
+// n problems in one call (one frame of each of n streams: FrontEnd::EstimateCurrentPose, frontend.cpp:184-300): one workgroup per
+// problem, ONE launch per register class of the kernel.  Per problem the bits of ssx_pose_only_opt (which is a batch of one).
+extern "C" ssx_status ssx_pose_only_opt_batch(ssx_ctx* ctx, int32_t n, const ssx_pose_only_job* jobs)
+{
+  if (!ctx || n < 0 || (n > 0 && !jobs)) return SSX_ERR_INVALID_ARG;
+  for (int j = 0; j < n; ++j) {
+    const ssx_pose_only_job& q = jobs[j];
+    if (!q.pose_io || !q.K4 || q.M < 0 || (q.M && (!q.xyz || !q.uv)) || q.rounds < 0 || q.iters < 0) return SSX_ERR_INVALID_ARG;
+  }
+  if (n == 0) return SSX_OK;
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // classes: 0 = up to 2 edges per thread, 1 = up to 6 (the register-resident kernels), 2 = generic, 3 = empty
+  std::vector<int> order[2];
+  for (int j = 0; j < n; ++j) {
+    const int M = jobs[j].M;
+    if (M == 0) { if (jobs[j].n_inliers) *jobs[j].n_inliers = 0; continue; }
+    if (M <= PT * 2) order[0].push_back(j); else if (M <= PT * 6) order[1].push_back(j);
+  }
+  const size_t nb = order[0].size() + order[1].size();
+  if (nb) {
+    // one pinned block: [descriptors | per problem: xyz, uv, pose in | pose out, inlier count, outlier flags]
+    Layout lay;
+    const size_t o_desc = lay.take(sizeof(PoDev) * nb);
+    std::vector<size_t> o_in(nb), o_out(nb);
+    size_t k = 0;
+    for (int c = 0; c < 2; ++c)
+      for (int j : order[c]) {
+        const size_t M = (size_t)jobs[j].M;
+        o_in[k] = lay.take(sizeof(double) * (5 * M + 8));
+        o_out[k] = lay.take(sizeof(double) * 8 + sizeof(int) * 2 + M);
+        ++k;
+      }
+    HostBuf& stage = ctx->po_stage;
+    SSX_HIP_TRY(ctx, stage.reserve(lay.off, 2.0));
+    char* hs = stage.as<char>();
+    PoDev* dv = reinterpret_cast<PoDev*>(hs + o_desc);
+    k = 0;
+    for (int c = 0; c < 2; ++c)
+      for (int j : order[c]) {
+        const ssx_pose_only_job& q = jobs[j];
+        const size_t M = (size_t)q.M;
+        double* in = reinterpret_cast<double*>(hs + o_in[k]);
+        memcpy(in, q.xyz, sizeof(double) * 3 * M);
+        memcpy(in + 3 * M, q.uv, sizeof(double) * 2 * M);
+        memcpy(in + 5 * M, q.pose_io, sizeof(double) * 7);
+        PoDev& d = dv[k];
+        d.M = q.M; d.rounds = q.rounds; d.iters = q.iters; d.chi2_th = q.chi2_th; d.huber_delta = q.huber_delta;
+        d.K = ssx::Cam{q.K4[0], q.K4[1], q.K4[2], q.K4[3]};
+        d.xyz = in; d.uv = in + 3 * M; d.pose = in + 5 * M;
+        d.err = nullptr; d.level = nullptr;                          // (the register-resident kernels keep both in registers)
+        d.pose_out = reinterpret_cast<double*>(hs + o_out[k]);
+        d.n_inliers = reinterpret_cast<int*>(hs + o_out[k] + sizeof(double) * 8);
+        d.outlier = reinterpret_cast<uint8_t*>(hs + o_out[k] + sizeof(double) * 8 + sizeof(int) * 2);
+        ++k;
+      }
+    if (!order[0].empty())
+      SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only<2>, dim3((unsigned)order[0].size()), dim3(PT), 0, ctx->stream, (const PoDev*)dv));
+    if (!order[1].empty())
+      SSX_PROF(ctx, KID_POSE_ONLY, hipLaunchKernelGGL(k_pose_only<6>, dim3((unsigned)order[1].size()), dim3(PT), 0, ctx->stream, (const PoDev*)(dv + order[0].size())));
+    SSX_HIP_TRY(ctx, hipGetLastError());
+    SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    k = 0;
+    for (int c = 0; c < 2; ++c)
+      for (int j : order[c]) {
+        const ssx_pose_only_job& q = jobs[j];
+        const char* o = hs + o_out[k];
+        memcpy(q.pose_io, o, sizeof(double) * 7);
+        const uint8_t* ol = reinterpret_cast<const uint8_t*>(o + sizeof(double) * 8 + sizeof(int) * 2);
+        if (q.inlier_out) for (int i = 0; i < q.M; ++i) q.inlier_out[i] = !ol[i];
+        if (q.n_inliers) *q.n_inliers = *reinterpret_cast<const int*>(o + sizeof(double) * 8);
+        ++k;
+      }
+  }
+  for (int j = 0; j < n; ++j) {
+    const ssx_pose_only_job& q = jobs[j];
+    if (q.M <= PT * 6) continue;
+    const ssx_status st = pose_only_generic(ctx, q.pose_io, q.K4, q.M, q.xyz, q.uv, q.rounds, q.iters, q.chi2_th, q.huber_delta, q.inlier_out, q.n_inliers);
+    if (st != SSX_OK) return st;
+  }
+  return SSX_OK;
+}
+
+extern "C" ssx_status ssx_pose_only_opt(ssx_ctx* ctx, double* pose_io, const double* K4, int32_t M, const double* xyz,
+                                        const double* uv, int32_t rounds, int32_t iters, double chi2_th, double huber_delta,
+                                        uint8_t* inlier_out, int32_t* n_inliers)
+{
+  if (!ctx || !pose_io || !K4 || M < 0 || (M && (!xyz || !uv)) || rounds < 0 || iters < 0) return SSX_ERR_INVALID_ARG;
+  ssx_pose_only_job q;
+  q.pose_io = pose_io; q.K4 = K4; q.M = M; q.xyz = xyz; q.uv = uv; q.rounds = rounds; q.iters = iters; q.chi2_th = chi2_th; q.huber_delta = huber_delta;
+  q.inlier_out = inlier_out; q.n_inliers = n_inliers;
+  return ssx_pose_only_opt_batch(ctx, 1, &q);
 }

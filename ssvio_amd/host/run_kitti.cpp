@@ -3,13 +3,17 @@
 // save the keyframe trajectory in TUM format.  Same two flags (gflags spelling), plus a frame limit and an output path.
 //
 //   ssx_run_kitti --config_yaml_path=cfg.yaml --kitti_dataset_path=<sequence dir> [--max_frames=N] [--trajectory=out.txt]
-//                 [--device=0] [--decode_threads=8] [--streams=1] [--preload=0]
+//                 [--device=0] [--decode_threads=8] [--streams=1] [--preload=0] [--batched=0]
 // The PNG pairs are decoded ahead of the tracker on worker threads (StereoPrefetcher); everything else is the
 // reference's single loop.  --streams=K runs K independent copies of the loop in K threads of this process (each with
 // its own System, GPU contexts and prefetcher) on the same sequence: a single stream is latency-bound, several fill the
 // GPU (BASELINE configs[4] runs one stream per GPU; this is the one-GPU version of it).  --kitti_dataset_path may be a
 // comma-separated list: stream k then runs sequence k mod (number of sequences) -- several DIFFERENT sequences at once.
+// --batched=1 (with --streams=K): the streams' per-frame compute calls and window optimisations go to the GPU as batched library
+// calls (StreamBatcher, stream_batcher.hpp); every stream's trajectory stays byte-identical to its single-stream run.
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "stream_batcher.hpp"
 #include "system.hpp"
 
 namespace {
@@ -37,10 +42,10 @@ bool flag(const char* arg, const char* name, std::string& out)
 
 int main(int argc, char** argv)
 {
-  std::string config, dataset, max_frames_s, trajectory, device_s, threads_s, streams_s, preload_s;
+  std::string config, dataset, max_frames_s, trajectory, device_s, threads_s, streams_s, preload_s, batched_s;
   for (int i = 1; i < argc; ++i) {
     if (flag(argv[i], "config_yaml_path", config) || flag(argv[i], "kitti_dataset_path", dataset) || flag(argv[i], "max_frames", max_frames_s) ||
-        flag(argv[i], "trajectory", trajectory) || flag(argv[i], "device", device_s) || flag(argv[i], "decode_threads", threads_s) || flag(argv[i], "streams", streams_s) || flag(argv[i], "preload", preload_s))
+        flag(argv[i], "trajectory", trajectory) || flag(argv[i], "device", device_s) || flag(argv[i], "decode_threads", threads_s) || flag(argv[i], "streams", streams_s) || flag(argv[i], "preload", preload_s) || flag(argv[i], "batched", batched_s))
       continue;
     std::fprintf(stderr, "unknown argument %s\n", argv[i]);
     return 2;
@@ -89,17 +94,37 @@ int main(int argc, char** argv)
           StereoPrefetcher pf(sq.left_paths, sq.right_paths, sq.num_images, 32);
           for (size_t ni = 0; ni < sq.num_images; ++ni) sq.preloaded.push_back(pf.Next());
         }
+      const bool batched = !batched_s.empty() && std::atoi(batched_s.c_str()) != 0;
+      std::unique_ptr<StreamBatcher> batcher;
+      if (batched) batcher = std::make_unique<StreamBatcher>(device, streams);
+      // every stream builds its System (GPU contexts, window) first; the clock of the aggregate figure starts when all are ready
+      std::mutex bm;
+      std::condition_variable bcv;
+      int ready = 0;
+      clk::time_point t_go;
+      std::vector<clk::time_point> t_end(streams);
       std::vector<std::thread> workers;
       const auto t_all0 = clk::now();
       for (int k = 0; k < streams; ++k)
         workers.emplace_back([&, k] {
+          struct Fin { StreamBatcher* b; int k; ~Fin() { if (b) b->Finish(k); } } fin{batcher.get(), k};   // the dispatcher must not wait for a stream that is gone
+          bool counted = false;
+          auto arrive = [&] {
+            std::unique_lock<std::mutex> lk(bm);
+            if (!counted) { counted = true; if (++ready == streams) { t_go = clk::now(); bcv.notify_all(); } }
+            return lk;
+          };
           try {
             const Sequence& sq = seqs[(size_t)k % seqs.size()];
             const size_t num_images = sq.num_images;
             frames[k] = num_images;
-            System sys(config, nullptr, device);
+            System sys(config, batcher ? batcher->MakeCompute(k) : nullptr, device);
             std::unique_ptr<StereoPrefetcher> pf;
             if (sq.preloaded.empty()) pf = std::make_unique<StereoPrefetcher>(sq.left_paths, sq.right_paths, num_images, dthreads);
+            {
+              auto lk = arrive();
+              bcv.wait(lk, [&] { return ready == streams; });
+            }
             const auto t0 = clk::now();
             for (size_t ni = 0; ni < num_images; ++ni) {
               StereoPrefetcher::Pair pair = pf ? pf->Next() : sq.preloaded[ni];
@@ -107,22 +132,38 @@ int main(int argc, char** argv)
               sys.RunStep(pair.left, pair.right, sq.timestamps[ni]);
             }
             sys.backend().WaitIdle();
-            seconds[k] = std::chrono::duration<double>(clk::now() - t0).count();
+            t_end[k] = clk::now();
+            seconds[k] = std::chrono::duration<double>(t_end[k] - t0).count();
             keyframes[k] = sys.map().GetAllKeyFrames().size();
+            fin.b = nullptr;
+            if (batcher) batcher->Finish(k);                                  // before the trajectory is written and the System is torn down
             if (!trajectory.empty()) sys.SaveTrajectoryTUM(trajectory + "." + std::to_string(k));
           } catch (const std::exception& e) {
             errors[k] = e.what();
+            arrive();
           }
         });
       for (auto& w : workers) w.join();
       const double wall = std::chrono::duration<double>(clk::now() - t_all0).count();
       double sum = 0;
+      size_t total_frames = 0;
+      clk::time_point last = t_go;
       for (int k = 0; k < streams; ++k) {
         if (!errors[k].empty()) { std::fprintf(stderr, "fatal (stream %d): %s\n", k, errors[k].c_str()); return 1; }
         sum += frames[k] / std::max(seconds[k], 1e-9);
-        std::printf("stream %d: %.1f frames/s, %zu keyframes\n", k, frames[k] / std::max(seconds[k], 1e-9), keyframes[k]);
+        total_frames += frames[k];
+        last = std::max(last, t_end[k]);
+        if (streams <= 16) std::printf("stream %d: %.1f frames/s, %zu keyframes\n", k, frames[k] / std::max(seconds[k], 1e-9), keyframes[k]);
       }
+      const double span = std::chrono::duration<double>(last - t_go).count();
       std::printf("%d streams: aggregate %.1f frames/s (sum of the streams' loops incl. decoding), wall %.2f s incl. context creation\n", streams, sum, wall);
+      std::printf("%d streams%s: %zu frames in %.4f s from the common start to the last stream's end = %.1f frames/s\n", streams, batched ? " (batched)" : "",
+                  total_frames, span, total_frames / std::max(span, 1e-9));
+      if (batcher) {
+        const StreamBatcher::Stats bs = batcher->stats();
+        std::printf("batched calls: LK %ld (%.1f jobs each), pose-only %ld (%.1f), window solves %ld (%.1f)\n", bs.lk_calls, bs.lk_jobs / std::max(1.0, (double)bs.lk_calls),
+                    bs.po_calls, bs.po_jobs / std::max(1.0, (double)bs.po_calls), bs.ba_calls, bs.ba_jobs / std::max(1.0, (double)bs.ba_calls));
+      }
       return 0;
     }
     System system(config, nullptr, device_s.empty() ? 0 : std::atoi(device_s.c_str()));

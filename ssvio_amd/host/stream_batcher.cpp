@@ -1,0 +1,330 @@
+// ssvio_amd/host/stream_batcher.cpp -- see stream_batcher.hpp
+#include "stream_batcher.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/ssx_shim.hpp"
+
+namespace ssx::host {
+
+namespace {
+enum class St { RUNNING, PENDING_LK, PENDING_PO, PENDING_BA, INFLIGHT, LONGOP, DONE };
+}
+
+struct StreamBatcher::Impl {
+  Impl(int device_, int streams) : device(device_), S(streams), lk_ctx(device_), po_ctx(device_), ba_ctx(device_), state(streams, St::RUNNING),
+                                   lk_req(streams), lk_rows(streams, 0), lk_cols(streams, 0), po_req(streams), ba_win(streams, nullptr),
+                                   ba_res(streams, nullptr), error(streams)
+  {
+    disp = std::thread([this] { DispatchLoop(); });
+    ba_disp = std::thread([this] { BaLoop(); });
+  }
+  ~Impl()
+  {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+    }
+    cv_disp.notify_all();
+    if (disp.joinable()) disp.join();
+    if (ba_disp.joinable()) ba_disp.join();
+  }
+
+  int count(St s) const { int n = 0; for (St x : state) n += x == s ? 1 : 0; return n; }
+
+  // the calling stream sleeps until a dispatcher has served its request; throws what the batch call reported
+  void SubmitAndWait(int k, St pending)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    error[k].clear();
+    state[k] = pending;
+    cv_disp.notify_all();
+    cv_done.wait(lk, [&] { return state[k] == St::RUNNING; });
+    if (!error[k].empty()) throw std::runtime_error(error[k]);
+  }
+  void SetState(int k, St s)
+  {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      state[k] = s;
+    }
+    cv_disp.notify_all();
+  }
+
+  void DispatchLoop()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    std::vector<int> who;
+    for (;;) {
+      cv_disp.wait(lk, [&] { return quit || (count(St::RUNNING) == 0 && count(St::PENDING_LK) + count(St::PENDING_PO) > 0); });
+      if (quit) return;
+      // pose-only first: the cohort then reaches its next LK request where a straggler from a keyframe already waits (see the header)
+      const St kind = count(St::PENDING_PO) > 0 ? St::PENDING_PO : St::PENDING_LK;
+      who.clear();
+      for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); state[k] = St::INFLIGHT; }
+      lk.unlock();
+      std::string err;
+      long d_calls = 0, d_jobs = 0;
+      try {
+        if (kind == St::PENDING_PO) {
+          std::vector<ssx_pose_only_job> jobs;
+          for (int k : who) jobs.push_back(po_req[k]);
+          po_ctx.check(ssx_pose_only_opt_batch(po_ctx.get(), (int32_t)jobs.size(), jobs.data()));
+          ++d_calls; d_jobs += (long)jobs.size();
+        } else {
+          // (jobs of one call share the image size: streams of another size go in a call of their own)
+          std::vector<char> taken(who.size(), 0);
+          for (size_t a = 0; a < who.size(); ++a) {
+            if (taken[a]) continue;
+            std::vector<ssx_lk_job> jobs;
+            const int rows = lk_rows[who[a]], cols = lk_cols[who[a]];
+            for (size_t b = a; b < who.size(); ++b)
+              if (!taken[b] && lk_rows[who[b]] == rows && lk_cols[who[b]] == cols) { jobs.push_back(lk_req[who[b]]); taken[b] = 1; }
+            ssx_lk_params p;
+            ssx_lk_default_params(&p);
+            p.win = 11; p.max_level = 3; p.max_iters = 30; p.eps = 0.01; p.use_initial_flow = 1;
+            lk_ctx.check(ssx_lk_track_batch(lk_ctx.get(), (int32_t)jobs.size(), jobs.data(), rows, cols, &p, 1));
+            ++d_calls; d_jobs += (long)jobs.size();
+          }
+        }
+      } catch (const std::exception& e) {
+        err = e.what();
+      }
+      lk.lock();
+      if (kind == St::PENDING_PO) { st.po_calls += d_calls; st.po_jobs += d_jobs; } else { st.lk_calls += d_calls; st.lk_jobs += d_jobs; }
+      for (int k : who) { error[k] = err; state[k] = St::RUNNING; }
+      cv_done.notify_all();
+    }
+  }
+
+  void BaLoop()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    std::vector<int> who;
+    for (;;) {
+      // streams on a keyframe's path (detection, stereo LK, triangulation: LONGOP) arrive here within a fraction of a millisecond: wait
+      // for them, a batched solve costs what a single one costs
+      cv_disp.wait(lk, [&] { return quit || (count(St::PENDING_BA) > 0 && count(St::RUNNING) == 0 && count(St::LONGOP) == 0); });
+      if (quit) return;
+      who.clear();
+      for (int k = 0; k < S; ++k) if (state[k] == St::PENDING_BA) { who.push_back(k); state[k] = St::INFLIGHT; }
+      lk.unlock();
+      cv_disp.notify_all();                         // (the per-frame dispatcher does not wait for streams that are in flight here)
+      std::string err;
+      try {
+        std::vector<ssx_ba_window*> wins;
+        std::vector<ssx_ba_result> res;
+        for (int k : who) { wins.push_back(ba_win[k]); res.push_back(*ba_res[k]); }
+        ba_ctx.check(ssx_ba_window_solve_batch((int32_t)wins.size(), wins.data(), res.data()));
+        for (size_t i = 0; i < who.size(); ++i) *ba_res[who[i]] = res[i];
+      } catch (const std::exception& e) {
+        err = e.what();
+      }
+      lk.lock();
+      ++st.ba_calls; st.ba_jobs += (long)who.size();
+      for (int k : who) { error[k] = err; state[k] = St::RUNNING; }
+      cv_done.notify_all();
+    }
+  }
+
+  int device, S;
+  ssx::Context lk_ctx, po_ctx, ba_ctx;
+  std::mutex m;
+  std::condition_variable cv_disp, cv_done;
+  std::vector<St> state;
+  std::vector<ssx_lk_job> lk_req;
+  std::vector<int> lk_rows, lk_cols;
+  std::vector<ssx_pose_only_job> po_req;
+  std::vector<ssx_ba_window*> ba_win;
+  std::vector<ssx_ba_result*> ba_res;
+  std::vector<std::string> error;
+  StreamBatcher::Stats st;
+  bool quit = false;
+  std::thread disp, ba_disp;
+};
+
+namespace {
+
+struct LongOp {                                   // a call the stream makes on its own context (a keyframe's path)
+  StreamBatcher::Impl& im; int k;
+  LongOp(StreamBatcher::Impl& i, int k_) : im(i), k(k_) { im.SetState(k, St::LONGOP); }
+  ~LongOp() { im.SetState(k, St::RUNNING); }
+};
+
+class BatchedBaWindow final : public BaWindow {
+ public:
+  BatchedBaWindow(StreamBatcher::Impl& im, int k, const double* K4, const double* cam_ext14, const ssx_ba_options& opt) : im_(im), k_(k)
+  {
+    im_.ba_ctx.check(ssx_ba_window_create(im_.ba_ctx.get(), &opt, K4, cam_ext14, &win_));
+    im_.ba_ctx.check(ssx_ba_window_set_fix_rule(win_, 1));
+  }
+  ~BatchedBaWindow() override { ssx_ba_window_destroy(win_); }
+  void Push(int64_t kf_id, const double* pose7, int n_new, const int64_t* new_ids, const double* new_xyz, const uint8_t* new_fixed, int n_obs,
+            const int64_t* obs_lm, const double* obs_uv, const uint8_t* obs_cam) override
+  {
+    check(ssx_ba_window_push_keyframe(win_, kf_id, pose7, 0, n_new, new_ids, new_xyz, new_fixed, n_obs, obs_lm, obs_uv, obs_cam));
+  }
+  void Pop(int64_t kf_id) override { check(ssx_ba_window_pop_keyframe(win_, kf_id)); }
+  void RemoveLandmarks(int n, const int64_t* lm_ids) override { check(ssx_ba_window_remove_landmarks(win_, n, lm_ids, nullptr)); }
+  void RemoveFlagged(int n_obs, const uint8_t* flags) override { check(ssx_ba_window_remove_flagged(win_, n_obs, flags, nullptr)); }
+  void Size(int& nk, int& nl, int& no) override
+  {
+    int32_t a = 0, b = 0, c = 0;
+    check(ssx_ba_window_size(win_, &a, &b, &c));
+    nk = a; nl = b; no = c;
+  }
+  void Export(int64_t* kf_ids, int64_t* lm_ids, uint8_t* point_fixed, int32_t* edge_pose, int32_t* edge_point, double* edge_uv) override
+  {
+    check(ssx_ba_window_export(win_, kf_ids, nullptr, nullptr, lm_ids, nullptr, point_fixed, edge_pose, edge_point, edge_uv, nullptr));
+  }
+  void Solve(ssx_ba_result& res) override
+  {
+    im_.ba_win[k_] = win_; im_.ba_res[k_] = &res;
+    im_.SubmitAndWait(k_, St::PENDING_BA);
+  }
+
+ private:
+  // (these calls only edit the window's host mirror; the shared context's error text may belong to another stream's call, so the
+  // message names the status instead)
+  void check(ssx_status st) const { if (st != SSX_OK) throw std::runtime_error("ssx_ba_window: edit failed with status " + std::to_string((int)st)); }
+  StreamBatcher::Impl& im_;
+  int k_;
+  ssx_ba_window* win_ = nullptr;
+};
+
+class BatchedCompute final : public Compute {
+ public:
+  BatchedCompute(StreamBatcher::Impl& im, int k) : im_(im), k_(k), frame_(im.device) {}
+  ~BatchedCompute() override { ssx_host_free(pin_[0]); ssx_host_free(pin_[1]); }
+
+  void Detect(const Image& img, const uint8_t* mask, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
+  {
+    LongOp op(im_, k_);
+    kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});
+    int32_t n = 0;
+    ssx_status st = ssx_orb_detect(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, mask, img.cols, &prm, (int32_t)kps.size(), kps.data(), &n);
+    if (st == SSX_ERR_CAPACITY && n > (int32_t)kps.size()) {
+      kps.assign((size_t)n, ssx_keypoint{});
+      st = ssx_orb_detect(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, mask, img.cols, &prm, (int32_t)kps.size(), kps.data(), &n);
+    }
+    frame_.check(st);
+    kps.resize(n);
+  }
+  void DetectBoxes(const Image& img, const std::vector<int32_t>& boxes, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
+  {
+    LongOp op(im_, k_);
+    kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});
+    int32_t n = 0;
+    const int32_t nb = (int32_t)(boxes.size() / 4);
+    ssx_status st = ssx_orb_detect_boxes(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, boxes.data(), nb, &prm, (int32_t)kps.size(), kps.data(), &n);
+    if (st == SSX_ERR_CAPACITY && n > (int32_t)kps.size()) {
+      kps.assign((size_t)n, ssx_keypoint{});
+      st = ssx_orb_detect_boxes(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, boxes.data(), nb, &prm, (int32_t)kps.size(), kps.data(), &n);
+    }
+    frame_.check(st);
+    kps.resize(n);
+  }
+
+  void TrackLK(const Image& prev, const Image& next, const std::vector<float>& prev_pts, std::vector<float>& next_pts, std::vector<uint8_t>& status,
+               bool temporal) override
+  {
+    const int n = (int)(prev_pts.size() / 2);
+    status.assign(n, 0);
+    if (!temporal) {                               // FindFeaturesInRight: a keyframe's own call
+      LongOp op(im_, k_);
+      ssx_lk_params p;
+      ssx_lk_default_params(&p);
+      p.win = 11; p.max_level = 3; p.max_iters = 30; p.eps = 0.01; p.use_initial_flow = 1;
+      frame_.check(ssx_lk_track(frame_.get(), prev.ptr(), prev.cols, next.ptr(), next.cols, prev.rows, prev.cols, n, prev_pts.data(), next_pts.data(),
+                                status.data(), nullptr, &p, nullptr));
+      return;
+    }
+    // the frame-to-frame chain: this stream's slot of the shared LK context keeps the pyramid of its last `next` image.  The new
+    // image goes into the stream's pinned buffer (this thread copies it: S streams copy side by side) and is read from there by the
+    // GPU -- no staging inside the batched call.
+    const size_t bytes = (size_t)next.rows * next.cols;
+    if (bytes > pin_bytes_) {
+      ssx_host_free(pin_[0]); ssx_host_free(pin_[1]);
+      pin_[0] = static_cast<uint8_t*>(ssx_host_alloc(bytes)); pin_[1] = static_cast<uint8_t*>(ssx_host_alloc(bytes));
+      if (!pin_[0] || !pin_[1]) throw std::runtime_error("StreamBatcher: no pinned memory for the stream's images");
+      pin_bytes_ = bytes;
+    }
+    const bool chained = prev.id != 0 && prev.id == chain_next_id_ && prev.rows == chain_rows_ && prev.cols == chain_cols_ && next.rows == prev.rows &&
+                         next.cols == prev.cols;
+    std::memcpy(pin_[0], next.ptr(), bytes);
+    if (!chained) std::memcpy(pin_[1], prev.ptr(), (size_t)prev.rows * prev.cols);
+    ssx_lk_job& q = im_.lk_req[k_];
+    q = ssx_lk_job{};
+    q.slot = k_;
+    q.prev = chained ? nullptr : pin_[1]; q.prev_stride = prev.cols;
+    q.next = pin_[0]; q.next_stride = next.cols;
+    q.n = n; q.prev_pts = prev_pts.data(); q.next_pts = next_pts.data(); q.status = status.data(); q.err = nullptr;
+    im_.lk_rows[k_] = next.rows; im_.lk_cols[k_] = next.cols;
+    chain_next_id_ = 0;                            // (a failed call leaves no chain)
+    im_.SubmitAndWait(k_, St::PENDING_LK);
+    chain_next_id_ = next.id; chain_rows_ = next.rows; chain_cols_ = next.cols;
+  }
+
+  int PoseOnly(double* pose_io, const double* K4, int M, const double* xyz, const double* uv, uint8_t* inlier) override
+  {
+    int32_t n_in = 0;
+    ssx_pose_only_job& q = im_.po_req[k_];
+    q = ssx_pose_only_job{};
+    q.pose_io = pose_io; q.K4 = K4; q.M = M; q.xyz = xyz; q.uv = uv; q.rounds = 4; q.iters = 10; q.chi2_th = 5.991; q.huber_delta = 1.0;
+    q.inlier_out = inlier; q.n_inliers = &n_in;
+    im_.SubmitAndWait(k_, St::PENDING_PO);
+    return n_in;
+  }
+
+  void Triangulate(int n, const double* uvL, const double* uvR, const ssx_stereo_rig& rig, const double* T_wc, double* xyz, uint8_t* ok) override
+  {
+    LongOp op(im_, k_);
+    frame_.check(ssx_triangulate(frame_.get(), n, uvL, uvR, &rig, T_wc, xyz, ok));
+  }
+
+  void BundleAdjust(const ssx_ba_problem& prob, const ssx_ba_options& opt, ssx_ba_result& res) override
+  {
+    LongOp op(im_, k_);                            // (Backend.Window: 0 -- the re-marshalled map, one window per call)
+    frame_.check(ssx_ba_solve(frame_.get(), &prob, &opt, &res));
+  }
+
+  std::unique_ptr<BaWindow> MakeBaWindow(const double* K4, const double* cam_ext14, const ssx_ba_options& opt) override
+  {
+    return std::make_unique<BatchedBaWindow>(im_, k_, K4, cam_ext14, opt);
+  }
+
+ private:
+  StreamBatcher::Impl& im_;
+  int k_;
+  ssx::Context frame_;
+  uint8_t* pin_[2] = {nullptr, nullptr};
+  size_t pin_bytes_ = 0;
+  uint64_t chain_next_id_ = 0;
+  int chain_rows_ = 0, chain_cols_ = 0;
+};
+
+}  // namespace
+
+StreamBatcher::StreamBatcher(int device, int streams) : impl_(std::make_unique<Impl>(device, std::max(streams, 1))) {}
+StreamBatcher::~StreamBatcher() = default;
+
+std::unique_ptr<Compute> StreamBatcher::MakeCompute(int k)
+{
+  if (k < 0 || k >= impl_->S) throw std::invalid_argument("StreamBatcher::MakeCompute: stream index out of range");
+  return std::make_unique<BatchedCompute>(*impl_, k);
+}
+
+void StreamBatcher::Finish(int k)
+{
+  if (k >= 0 && k < impl_->S) impl_->SetState(k, St::DONE);
+}
+
+StreamBatcher::Stats StreamBatcher::stats()
+{
+  std::lock_guard<std::mutex> lk(impl_->m);
+  return impl_->st;
+}
+
+}  // namespace ssx::host

@@ -60,6 +60,40 @@ def calcOpticalFlowPyrLK(ctx: Context, prev, nxt, prev_pts, next_pts=None, winSi
     return npts, status, err, top.value
 
 
+class LkJob(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("prev", u8_p), ("prev_stride", C.c_int32), ("next", u8_p), ("next_stride", C.c_int32), ("n", C.c_int32),
+                ("prev_pts", f32_p), ("next_pts", f32_p), ("status", u8_p), ("err", f32_p)]
+
+
+def track_batch(ctx: Context, jobs, winSize=11, maxLevel=3, maxCount=30, epsilon=0.01, minEigThreshold=1e-4, images_on_device=False):
+    """ssx_lk_track_batch: jobs = [dict(slot, prev (image or None = chained to the slot's last job), next, prev_pts, next_pts or None)];
+    every job with the same image size.  -> [(next_pts, status, err)] per job.  images_on_device: the arrays' memory is readable by
+    the GPU (pinned)."""
+    n = len(jobs)
+    arr = (LkJob * n)()
+    keep, outs = [], []
+    use_init = any(j.get("next_pts") is not None for j in jobs)
+    rows = cols = None
+    for i, j in enumerate(jobs):
+        nxt = _img(j["next"]); prev = None if j.get("prev") is None else _img(j["prev"])
+        rows, cols = nxt.shape
+        pp = np.ascontiguousarray(j["prev_pts"], dtype=np.float32).reshape(-1, 2)
+        npts = np.ascontiguousarray(j["next_pts"], dtype=np.float32).reshape(-1, 2).copy() if j.get("next_pts") is not None else pp.copy()
+        st = np.zeros(len(pp), np.uint8); er = np.zeros(len(pp), np.float32)
+        a = arr[i]
+        a.slot = int(j["slot"])
+        a.prev = None if prev is None else prev.ctypes.data_as(u8_p); a.prev_stride = 0 if prev is None else prev.strides[0]
+        a.next = nxt.ctypes.data_as(u8_p); a.next_stride = nxt.strides[0]
+        a.n = len(pp); a.prev_pts = pp.ctypes.data_as(f32_p); a.next_pts = npts.ctypes.data_as(f32_p)
+        a.status = st.ctypes.data_as(u8_p); a.err = er.ctypes.data_as(f32_p)
+        keep.append((nxt, prev, pp)); outs.append((npts, st, er))
+    prm = LkParams(int(winSize), int(maxLevel), int(maxCount), float(epsilon), float(minEigThreshold), int(use_init))
+    ctx.lib.ssx_lk_track_batch.restype = C.c_int
+    ctx.lib.ssx_lk_track_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(LkJob), C.c_int32, C.c_int32, C.POINTER(LkParams), C.c_int32]
+    ctx.check(ctx.lib.ssx_lk_track_batch(ctx.handle, n, arr, rows, cols, C.byref(prm), 1 if images_on_device else 0))
+    return outs
+
+
 def stage_level(ctx: Context, which, level):
     r = C.c_int32(0); c = C.c_int32(0)
     ctx.check(ctx.lib.ssx_lk_stage_level(ctx.handle, which, level, None, 0, C.byref(r), C.byref(c)))

@@ -197,6 +197,22 @@ def test_pose_only_edge_cases(ctx, po):
     assert np.array_equal(z["pose"], pp["pose"])
 
 
+def test_pose_only_batch_equals_single_calls(ctx):
+    """ssx_pose_only_opt_batch -- one frame of each of n streams in one launch -- returns, per problem, the bits of
+    ssx_pose_only_opt: both register-resident kernel classes, the generic kernel, an empty problem, 40 problems at once."""
+    from tools.synth import make_pose_only_problem
+    sizes = [300, 1, 512, 513, 0, 280, 1536, 1700, 64] + [250 + 3 * k for k in range(31)]
+    probs = [make_pose_only_problem(M=max(M, 1), seed=500 + i, frac_gross=0.05 + 0.01 * (i % 20)) for i, M in enumerate(sizes)]
+    for pr, M in zip(probs, sizes):
+        if M == 0:
+            pr["xyz"], pr["uv"] = pr["xyz"][:0], pr["uv"][:0]
+    ones = [ba.pose_only_opt(ctx, pr["pose"], pr["K"], pr["xyz"], pr["uv"]) for pr in probs]
+    got = ba.pose_only_opt_batch(ctx, probs)
+    for i, (a, b) in enumerate(zip(got, ones)):
+        assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["inliers"], b["inliers"]) and a["n_inliers"] == b["n_inliers"], (i, sizes[i])
+    assert ba.pose_only_opt_batch(ctx, []) == []
+
+
 BIG_CASES = {
     "P24_gauge": dict(P=24, L=1200, obs_per_lm=5, seed=31, fix_first_pose=True),
     "P40": dict(P=40, L=3000, obs_per_lm=6, seed=32, fix_first_pose=True),

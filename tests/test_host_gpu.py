@@ -224,6 +224,36 @@ def test_eight_concurrent_streams_c5_shape(built, tmp_path):
         assert open(f"{many}.{k}").read() == singles[k % 2], k
 
 
+def test_batched_streams_reproduce_the_single_stream_trajectories(built, tmp_path):
+    """--streams=K --batched=1 (ssvio_amd/host/stream_batcher.hpp): the K streams' temporal LK and pose-only LM of every frame and their
+    window optimisations reach the GPU as batched library calls (ssx_lk_track_batch / ssx_pose_only_opt_batch /
+    ssx_ba_window_solve_batch) instead of K separate launches.  Twelve streams over two DIFFERENT sequences of different lengths
+    (the shorter streams finish first: batches shrink, stragglers from keyframes rejoin the cohort): every stream writes, byte for
+    byte, the trajectory of its sequence's single-stream run; the jobs really were batched (more than one job per call on average)."""
+    import re
+    a = hu.write_corridor_sequence(os.path.join(str(tmp_path), "a"), n_frames=24)
+    b = hu.write_sequence(os.path.join(str(tmp_path), "b"), n_frames=12, step=0.6, seed=3)
+    cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {})
+    singles = []
+    for k, seq in enumerate((a, b)):
+        out = os.path.join(str(tmp_path), f"single{k}.txt")
+        r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", f"--trajectory={out}"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        singles.append(open(out).read())
+    assert len(singles[0].splitlines()) >= 2                       # the forward drive inserts keyframes (window BA runs)
+    for rep in range(2):                                           # (thread timing differs from run to run: the files must not)
+        many = os.path.join(str(tmp_path), f"many{rep}.txt")
+        r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={a['dir']},{b['dir']}", f"--trajectory={many}",
+                            "--streams=12", "--preload=1", "--batched=1"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        for k in range(12):
+            assert open(f"{many}.{k}").read() == singles[k % 2], (rep, k)
+        m = re.search(r"batched calls: LK (\d+) \(([\d.]+) jobs each\), pose-only (\d+) \(([\d.]+)\), window solves (\d+) \(([\d.]+)\)", r.stdout)
+        assert m, r.stdout
+        assert float(m.group(2)) > 3.0 and float(m.group(4)) > 3.0 and int(m.group(5)) >= 1, r.stdout
+
+
 def test_runner_arguments(built, tmp_path):
     r = subprocess.run([built["run_kitti"]], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr

@@ -122,3 +122,45 @@ def test_chained_tracking_reuses_the_previous_pyramid(ctx, po):
     with pytest.raises(SsxError):
         lk.calcOpticalFlowPyrLK(fresh, None, frames[3][:100], pts)        # other size
     fresh.close()
+
+
+def test_track_batch_equals_single_calls(ctx, po):
+    """ssx_lk_track_batch -- one frame of each of n streams in one call, every stream on its own slot of the context -- returns,
+    per job, the bits of ssx_lk_track / ssx_lk_track_next on a context of the job's own: fresh and chained jobs mixed in one
+    call, different point counts (one job without points), three chained steps, the jobs listed in another order than their slots."""
+    import ssvio_amd
+    S, steps = 6, 3
+    rng = np.random.default_rng(7)
+    seqs = []
+    for s_ in range(S):
+        base = make_stereo_pair(seed=20 + s_, h=240, w=400, n_blobs=500)[0]
+        seqs.append([np.ascontiguousarray(np.roll(np.roll(base, k * (1 + s_ % 3), axis=1), k * (s_ % 2), axis=0)) for k in range(steps + 1)])
+    pts = [_points(po, seqs[s_][0], 40 + 37 * s_) if s_ != 4 else np.zeros((0, 2), np.float32) for s_ in range(S)]
+    # reference: every stream alone on a context of its own
+    ref = []
+    for s_ in range(S):
+        c = ssvio_amd.Context(0)
+        p = pts[s_]
+        out = []
+        for k in range(steps):
+            prev = seqs[s_][k] if (k == 0 or (s_ == 2 and k == 2)) else None          # stream 2 restarts its chain at step 2
+            g = lk.calcOpticalFlowPyrLK(c, prev, seqs[s_][k + 1], p, p)
+            out.append(g)
+            p = g[0]
+        ref.append(out)
+        c.close()
+    p_cur = [p.copy() for p in pts]
+    order = [3, 0, 5, 1, 4, 2]
+    for k in range(steps):
+        jobs = [dict(slot=s_, prev=(seqs[s_][k] if (k == 0 or (s_ == 2 and k == 2)) else None), next=seqs[s_][k + 1], prev_pts=p_cur[s_], next_pts=p_cur[s_])
+                for s_ in order]
+        got = lk.track_batch(ctx, jobs)
+        for s_, g in zip(order, got):
+            r = ref[s_][k]
+            assert _same(g[0], r[0]) and _same(g[1], r[1]) and _same(g[2], r[2]), (k, s_)
+            p_cur[s_] = g[0]
+    import pytest as _pt
+    with _pt.raises(ssvio_amd.SsxError):                     # a slot twice in one call
+        lk.track_batch(ctx, [dict(slot=1, prev=seqs[0][0], next=seqs[0][1], prev_pts=pts[0]), dict(slot=1, prev=seqs[1][0], next=seqs[1][1], prev_pts=pts[1])])
+    with _pt.raises(ssvio_amd.SsxError):                     # a chained job on a slot that holds nothing
+        lk.track_batch(ctx, [dict(slot=77, prev=None, next=seqs[0][1], prev_pts=pts[0])])
