@@ -797,9 +797,29 @@ def main():
             c1["eight_streams_one_gpu"] = {"aggregate_frames_per_s": float(m8.group(1)) if m8 else None,
                                            "what": "--streams=8 --preload=1: eight independent copies of the loop in one process on this GPU (configs[4]'s "
                                                    "shape; one stream per GPU is the driver's multi-GPU run), frames decoded beforehand"}
+            # configs[4] on ONE GPU, closed loop: S streams of the same drive, their per-frame LK / pose-only calls and their window
+            # optimisations issued as BATCHED library calls (ssvio_amd/host/stream_batcher.hpp); every stream's trajectory is
+            # byte-identical to the single-stream run's (checked here for every stream of every S)
+            c5 = {"what": "ssx_run_kitti --streams=S --batched=1 --preload=1: S concurrent streams (full front-end + backend each) on one GPU; "
+                          "frames_per_s = all streams' frames / (common start -> last stream's end); frames decoded beforehand",
+                  "frames_per_stream": args.c1_frames, "runs": {}}
+            ref_traj = open(traj_w).read()
+            for S_ in (8, 32, 64):
+                out_b, traj_b = run_kitti(f"batched{S_}", {}, (f"--streams={S_}", "--preload=1", "--batched=1"))
+                mb = re.search(r"streams \(batched\): (\d+) frames in ([0-9.]+) s from the common start to the last stream's end = ([0-9.]+) frames/s", out_b)
+                mc = re.search(r"batched calls: LK (\d+) \(([\d.]+) jobs each\), pose-only (\d+) \(([\d.]+)\), window solves (\d+) \(([\d.]+)\)", out_b)
+                same = all(os.path.exists(f"{traj_b}.{k}") and open(f"{traj_b}.{k}").read() == ref_traj for k in range(S_))
+                c5["runs"][str(S_)] = {"frames_per_s": float(mb.group(3)) if mb else None, "seconds": float(mb.group(2)) if mb else None,
+                                        "jobs_per_call": {"lk": float(mc.group(2)), "pose_only": float(mc.group(4)), "window_solve": float(mc.group(6))} if mc else None,
+                                        "every_stream_byte_identical_to_the_single_stream_run": same}
+            best = max((v["frames_per_s"] or 0.0) for v in c5["runs"].values())
+            c5["value"] = best
+            c5["unit"] = "closed-loop stereo frames/s on one GPU (best S)"
+            c5["unbatched_eight_streams"] = c1["eight_streams_one_gpu"]["aggregate_frames_per_s"]
+            c1["c5_batched_streams"] = c5
         except Exception as exc:                                       # noqa: BLE001 -- an extra leg, never fatal
             print(f"[bench] configs[0] leg skipped: {exc!r}", file=sys.stderr)
-            c1 = {"skipped": repr(exc)[:300]}
+            c1 = {"skipped": repr(exc)[:300]} if c1 is None or "resident_window" not in c1 else dict(c1, c5_error=repr(exc)[:300])
 
     # ---------------- SURVEY.md 8-F's "next" rows + A11, each with its own line (tools/bench_next.py) ----------------
     next_rows = None

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define SSX_VERSION 110 /* 0.1.10: ssx_config grew by cu_first / cu_count, ssx_ba_result by ms_comm, ssx_ba_window_update by the
+#define SSX_VERSION 120 /* 0.1.20: + ssx_lk_track_batch, ssx_pose_only_opt_batch, ssx_host_alloc / _free; the kernel taps (ssx_*_stage_*,
+                           * ssx_ba_linearize) moved to ssx_test_hooks.h, ssx_ba_batch_set_persistent (a no-op since round 4) removed.  0.1.10: ssx_config grew by cu_first / cu_count, ssx_ba_result by ms_comm, ssx_ba_window_update by the
                            * removal fields -- see ssx_abi_check */
 #if defined(__GNUC__)
 #define SSX_API __attribute__((visibility("default")))
@@ -226,9 +227,6 @@ SSX_API int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch);
 /* 1 .. 4 groups for the following solves; 0 = back to the default (per-kernel profiles want 1: one launch per kernel and
    LM slot, nothing else on the chip beside it) */
 SSX_API void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups);
-/* Round 3's experiment (one persistent workgroup per group of ~7 chunks; measured slower on MI355X, profiles/r03/persist_ab.md) is
-   gone; the entry point remains for callers built against that header and does nothing. */
-SSX_API void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode);
 SSX_API void ssx_ba_batch_destroy(ssx_ba_batch* batch);
 /* Process-wide: the device phases of batched solves (ssx_ba_solve_batch, ssx_ba_batch_solve, ssx_ba_window_solve_batch) of DIFFERENT
  * contexts run one after the other on the device, in the order they were enqueued: the kernels of an LM round wait, on the device
@@ -352,17 +350,9 @@ SSX_API ssx_status ssx_ba_window_solve(ssx_ba_window* win, ssx_ba_result* res);
  * The options of the first window apply. */
 SSX_API ssx_status ssx_ba_window_solve_batch(int32_t n, ssx_ba_window* const* wins, ssx_ba_result* results);
 
-/* (test and tools hooks -- ssx_ba_window_selftest, ssx_debug_*, ssx_ba_debug_* -- are NOT part of this ABI: include/ssx_test_hooks.h,
+/* (test and tools hooks -- ssx_ba_window_selftest, ssx_debug_*, ssx_ba_debug_*, the kernel taps ssx_ba_linearize / ssx_orb_stage_* /
+ * ssx_lk_stage_* -- are NOT part of this ABI: include/ssx_test_hooks.h,
  * compiled out of the library by -DSSX_NO_TEST_HOOKS / SSX_PRODUCT_BUILD=1 python -m ssvio_amd.build) */
-
-/* One linearisation of the problem at its current state (no update): the blocks the kernels build,
- * for kernel-level parity tests and profiling.  Any output may be NULL.
- *   Hpp P x 36 (row-major 6x6), bp P x 6, Hll L x 9, bl L x 3, Hpl E x 18 (6x3 row-major, per edge),
- *   err E x 2, chi2 = robust chi2.  Rows of fixed vertices are zero. */
-SSX_API ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double huber_delta, int32_t jac_mode,
-                            double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* err,
-                            double* chi2);
-
 
 /* ------------------------------------------------------------------------------------------------
  * Pose-only robust optimisation -- replaces the g2o part of FrontEnd::EstimateCurrentPose
@@ -428,6 +418,18 @@ SSX_API ssx_status ssx_orb_detect_boxes(ssx_ctx* ctx, const uint8_t* img, int32_
                                         const int32_t* boxes_xyxy, int32_t n_boxes, const ssx_orb_params* prm,
                                         int32_t cap, ssx_keypoint* kps_out, int32_t* n);
 
+/* ssx_orb_detect_boxes for n images in ONE call -- one keyframe of each of n streams (BASELINE configs[4]).  All images rows x cols with
+ * one stride and one parameter set; images_on_device != 0: the image pointers are GPU-readable (device or pinned host memory) and are
+ * read where they lie.  Per image the bits of ssx_orb_detect_boxes; SSX_ERR_CAPACITY if any image's keypoints do not fit its cap
+ * (the others are still returned, *n_out of every job is set). */
+typedef struct ssx_orb_detect_job {
+  const uint8_t* img; int32_t stride;
+  const int32_t* boxes_xyxy; int32_t n_boxes;
+  int32_t cap; ssx_keypoint* kps_out; int32_t* n_out;
+} ssx_orb_detect_job;
+SSX_API ssx_status ssx_orb_detect_boxes_batch(ssx_ctx* ctx, int32_t n, const ssx_orb_detect_job* jobs, int32_t rows, int32_t cols,
+                                              const ssx_orb_params* prm, int32_t images_on_device);
+
 /* ORBextractor::DetectAndCompute: 8-level pyramid ORB.  desc_out: cap x 32 bytes (CV_8U N x 32). */
 SSX_API ssx_status ssx_orb_extract(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
                                    const uint8_t* mask, int32_t mask_stride, const ssx_orb_params* prm,
@@ -440,15 +442,6 @@ SSX_API ssx_status ssx_orb_extract(ssx_ctx* ctx, const uint8_t* img, int32_t str
 SSX_API ssx_status ssx_orb_describe_at(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
                                        const ssx_orb_params* prm, const ssx_keypoint* kps_in, int32_t n_in,
                                        ssx_keypoint* kps_out, uint8_t* desc_out, int32_t* n);
-
-/* Parity / profiling hooks: copies of intermediate buffers of the LAST ssx_orb_extract / ssx_orb_detect /
- * ssx_stereo_* call on this ctx, image `image` of that call (0 = left / only image, 1 = right ...).
- *   level image (u8, rows x cols returned), blurred level image, and the grid-FAST candidates of a level
- *   (keypoints relative to the 16-px border, reference order = cell-row-major then row-major in the cell). */
-SSX_API ssx_status ssx_orb_stage_level(ssx_ctx* ctx, int32_t image, int32_t level, int32_t blurred,
-                                       uint8_t* out, int32_t out_cap, int32_t* rows, int32_t* cols);
-SSX_API ssx_status ssx_orb_stage_candidates(ssx_ctx* ctx, int32_t image, int32_t level, int32_t cap,
-                                            ssx_keypoint* out, int32_t* n);
 
 /* ------------------------------------------------------------------------------------------------
  * Stereo association + triangulation.
@@ -489,6 +482,13 @@ typedef struct {           /* the rig System::GenerateSteroCamera builds (src/ss
 SSX_API ssx_status ssx_triangulate(ssx_ctx* ctx, int32_t n, const double* uvL, const double* uvR,
                                    const ssx_stereo_rig* rig, const double* T_wc, double* xyz_out,
                                    uint8_t* ok_out);
+/* n calls of ssx_triangulate in one launch (one keyframe of each of n streams).  Per job the arguments and, bit for bit, the results
+ * of ssx_triangulate. */
+typedef struct ssx_triangulate_job {
+  int32_t n; const double* uvL; const double* uvR; const ssx_stereo_rig* rig; const double* T_wc;   /* T_wc nullable */
+  double* xyz_out; uint8_t* ok_out;
+} ssx_triangulate_job;
+SSX_API ssx_status ssx_triangulate_batch(ssx_ctx* ctx, int32_t n_jobs, const ssx_triangulate_job* jobs);
 
 /* One stereo frame, fully on the device: extract left+right (one batched launch sequence), row-band match,
  * triangulate the matches.  Replaces DetectFeatures + FindFeaturesInRight + BuidInitMap/TriangulateNewPoints
@@ -597,13 +597,6 @@ typedef struct ssx_lk_job {
 } ssx_lk_job;
 SSX_API ssx_status ssx_lk_track_batch(ssx_ctx* ctx, int32_t n_jobs, const ssx_lk_job* jobs, int32_t rows, int32_t cols,
                                       const ssx_lk_params* prm, int32_t images_on_device);
-/* Test access to the pyramids (which = 0 previous, 1 next) and the Scharr images (int16 dx, dy interleaved) of
- * the last ssx_lk_track call. */
-SSX_API ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level, uint8_t* out, int32_t out_cap,
-                                      int32_t* rows, int32_t* cols);
-SSX_API ssx_status ssx_lk_stage_deriv(ssx_ctx* ctx, int32_t level, int16_t* out, int32_t out_cap, int32_t* rows,
-                                      int32_t* cols);
-
 /* ------------------------------------------------------------------------------------------------
  * N3: pose-graph optimisation.
  * Replaces the optimisation of LoopClosing::PoseGraphOptimization

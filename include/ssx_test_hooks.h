@@ -44,6 +44,32 @@ SSX_API int32_t ssx_ba_debug_upload_format(const ssx_ba_problem* prob);
  * take it on the worker pool; SSX_BA_PREP_THREADS, default min(8, cores)).  The digest must not depend on `threads`.  0 = invalid. */
 SSX_API uint64_t ssx_ba_debug_prepare_digest(const ssx_ba_problem* prob, int32_t threads);
 
+/* ---- kernel taps (moved here from ssx.h in 0.1.20): intermediate results of the kernels, for the parity tests and tools ---- */
+
+/* One linearisation of the problem at its current state (no update): the blocks the kernels build,
+ * for kernel-level parity tests and profiling.  Any output may be NULL.
+ *   Hpp P x 36 (row-major 6x6), bp P x 6, Hll L x 9, bl L x 3, Hpl E x 18 (6x3 row-major, per edge),
+ *   err E x 2, chi2 = robust chi2.  Rows of fixed vertices are zero. */
+SSX_API ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double huber_delta, int32_t jac_mode,
+                            double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* err,
+                            double* chi2);
+
+/* Parity / profiling hooks: copies of intermediate buffers of the LAST ssx_orb_extract / ssx_orb_detect /
+ * ssx_stereo_* call on this ctx, image `image` of that call (0 = left / only image, 1 = right ...).
+ *   level image (u8, rows x cols returned), blurred level image, and the grid-FAST candidates of a level
+ *   (keypoints relative to the 16-px border, reference order = cell-row-major then row-major in the cell). */
+SSX_API ssx_status ssx_orb_stage_level(ssx_ctx* ctx, int32_t image, int32_t level, int32_t blurred,
+                                       uint8_t* out, int32_t out_cap, int32_t* rows, int32_t* cols);
+SSX_API ssx_status ssx_orb_stage_candidates(ssx_ctx* ctx, int32_t image, int32_t level, int32_t cap,
+                                            ssx_keypoint* out, int32_t* n);
+
+/* Test access to the pyramids (which = 0 previous, 1 next) and the Scharr images (int16 dx, dy interleaved) of
+ * the last ssx_lk_track call. */
+SSX_API ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level, uint8_t* out, int32_t out_cap,
+                                      int32_t* rows, int32_t* cols);
+SSX_API ssx_status ssx_lk_stage_deriv(ssx_ctx* ctx, int32_t level, int16_t* out, int32_t out_cap, int32_t* rows,
+                                      int32_t* cols);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,7 @@ SSX_ERR_CAPACITY = -4
 SSX_ERR_UNSUPPORTED = -5
 SSX_ERR_COMM = -6
 SSX_BA_MAX_STATS = 128
-SSX_VERSION = 110        # include/ssx.h
+SSX_VERSION = 120        # include/ssx.h
 
 dbl_p = C.POINTER(C.c_double)
 u8_p = C.POINTER(C.c_uint8)

@@ -215,14 +215,6 @@ class BaBatch:
             self.ctx.lib.ssx_ba_batch_set_groups.argtypes = [C.c_void_p, C.c_int32]
             self.ctx.lib.ssx_ba_batch_set_groups(self.handle, int(groups))
 
-    def set_persistent(self, mode):
-        """No effect since round 4: round 3's persistent chunk groups (measured slower, profiles/r03/persist_ab.md) are gone and the
-        library entry point does nothing; kept so that round-3 callers and tools still run."""
-        if self.handle is not None:
-            self.ctx.lib.ssx_ba_batch_set_persistent.restype = None
-            self.ctx.lib.ssx_ba_batch_set_persistent.argtypes = [C.c_void_p, C.c_int32]
-            self.ctx.lib.ssx_ba_batch_set_persistent(self.handle, int(mode))
-
     def solve(self, want_edges=True, download=True, summaries=True, points=True):
         """summaries=False: the per-window dicts are not built (poses / points are in self.poses / self.points, the counters
         in self.res): what a C caller pays -- building 128 dicts with their LM histories costs Python ~2 ms.

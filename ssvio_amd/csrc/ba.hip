@@ -3105,6 +3105,7 @@ void ssx_ba_default_options(ssx_ba_options* o)
   o->world_size = 1;
 }
 
+#ifndef SSX_NO_TEST_HOOKS   // kernel tap of the parity tests (include/ssx_test_hooks.h)
 ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double huber_delta, int32_t jac_mode,
                             double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* err,
                             double* chi2)
@@ -3175,6 +3176,7 @@ ssx_status ssx_ba_linearize(ssx_ctx* ctx, const ssx_ba_problem* prob, double hub
   if (chi2) *chi2 = hscal[SC_CHI2_CUR];
   return SSX_OK;
 }
+#endif  // SSX_NO_TEST_HOOKS
 
 }  // extern "C"
 
@@ -4226,10 +4228,6 @@ int32_t ssx_ba_batch_size(const ssx_ba_batch* batch) { return batch ? batch->n :
 int32_t ssx_ba_batch_groups(const ssx_ba_batch* batch) { return !batch ? 0 : (batch->groups > 0 ? std::min(batch->groups, 4) : batch_groups(batch->n)); }
 
 void ssx_ba_batch_set_groups(ssx_ba_batch* batch, int32_t groups) { if (batch) batch->groups = groups > 0 ? groups : 0; }
-
-// (round 3's experiment -- workgroups that walk a group of chunks -- is gone: measured slower, profiles/r03/persist_ab.md; the entry
-// point stays so that callers built against the round-3 header keep linking, and does nothing)
-void ssx_ba_batch_set_persistent(ssx_ba_batch* batch, int32_t mode) { (void)batch; (void)mode; }
 
 void ssx_ba_batch_destroy(ssx_ba_batch* batch)
 {

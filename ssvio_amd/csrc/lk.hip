@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "../../include/ssx_test_hooks.h"
 
 namespace {
 
@@ -586,6 +587,7 @@ ssx_status ssx_lk_track_batch(ssx_ctx* ctx, int32_t n_jobs, const ssx_lk_job* jo
   return lk_run(ctx, n_jobs, jobs, rows, cols, prm_in, images_on_device != 0, nullptr);
 }
 
+#ifndef SSX_NO_TEST_HOOKS   // kernel taps of the parity tests (include/ssx_test_hooks.h)
 // test / debug access to the pyramid and derivative images of the last ssx_lk_track call
 ssx_status ssx_lk_stage_level(ssx_ctx* ctx, int32_t which, int32_t level, uint8_t* out, int32_t out_cap, int32_t* rows, int32_t* cols)
 {
@@ -619,5 +621,7 @@ ssx_status ssx_lk_stage_deriv(ssx_ctx* ctx, int32_t level, int16_t* out, int32_t
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return SSX_OK;
 }
+
+#endif  // SSX_NO_TEST_HOOKS
 
 }  // extern "C"

@@ -26,6 +26,7 @@
 
 #include "ctx.hpp"
 #include "orb_ws.hpp"
+#include "../../include/ssx_test_hooks.h"
 
 namespace ssxorb {
 
@@ -153,6 +154,29 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
   *reinterpret_cast<uint2*>(dst_base + (size_t)blockIdx.z * img_stride_bytes + (size_t)y * dpitch + x) = make_uint2(w[0], w[1]);
 }
 
+// the same for a batch whose images lie in buffers of their own (one pointer per image: device memory, or pinned host memory read
+// over PCIe): ssx_orb_detect_boxes_batch.  Rows may start anywhere: the aligned-dword path of k_copy_level0, clamped per image.
+__global__ __launch_bounds__(256) void k_copy_level0_ptrs(const uint8_t* const* __restrict__ imgs, int in_stride, uint8_t* __restrict__ dst_base,
+                                                          size_t img_stride_bytes, int rows, int cols, int dpitch)
+{
+  const int x = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (x >= cols || y >= rows) return;
+  const uint8_t* in = imgs[blockIdx.z];
+  const uint8_t* srow = in + (size_t)y * in_stride;
+  const uintptr_t p = reinterpret_cast<uintptr_t>(srow + x), a = p & ~uintptr_t(3);
+  const uintptr_t last = (reinterpret_cast<uintptr_t>(in) + (size_t)(rows - 1) * in_stride + (size_t)(cols - 1)) & ~uintptr_t(3);
+  const uint32_t d0 = *reinterpret_cast<const uint32_t*>(a);
+  const uint32_t d1 = *reinterpret_cast<const uint32_t*>(a + 4 < last ? a + 4 : last);
+  const uint32_t d2 = *reinterpret_cast<const uint32_t*>(a + 8 < last ? a + 8 : last);
+  const uint32_t sh = (uint32_t)(p & 3);
+  uint32_t w[2];
+  w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+  w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+  const int valid = cols - x;   // >= 1
+  if (valid < 8) { const uint64_t keep = (~0ull) >> (8 * (8 - valid)); w[0] &= (uint32_t)keep; w[1] &= (uint32_t)(keep >> 32); }
+  *reinterpret_cast<uint2*>(dst_base + (size_t)blockIdx.z * img_stride_bytes + (size_t)y * dpitch + x) = make_uint2(w[0], w[1]);
+}
+
 // A4, the mask of FrontEnd::DetectFeatures (frontend.cpp:302-312) rasterised on the device: level 0 of the mask pyramid was
 // set to 255; one workgroup per box clears its rectangle [x0, x1] x [y0, y1] (inclusive, already clipped by the caller's
 // contract -- clipped again here).  16 bytes per tracked feature cross PCIe instead of rows x cols bytes of mask.
@@ -166,6 +190,26 @@ __global__ __launch_bounds__(64) void k_mask_boxes(const int4* __restrict__ boxe
     const int r = i / w, c = i - r * w;
     mask0[(size_t)(y0 + r) * pitch + x0 + c] = 0;
   }
+}
+
+// the boxes of a BATCH of images: box b belongs to image box_img[b] (ssx_orb_detect_boxes_batch)
+__global__ __launch_bounds__(64) void k_mask_boxes_b(const int4* __restrict__ boxes, const int* __restrict__ box_img, uint8_t* __restrict__ maskpyr,
+                                                     size_t img_stride_bytes, int rows, int cols, int pitch)
+{
+  const int4 b = boxes[blockIdx.x];
+  uint8_t* mask0 = maskpyr + (size_t)box_img[blockIdx.x] * img_stride_bytes;
+  const int x0 = max(b.x, 0), y0 = max(b.y, 0), x1 = min(b.z, cols - 1), y1 = min(b.w, rows - 1);
+  const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+  if (w <= 0 || h <= 0) return;
+  for (int i = threadIdx.x; i < w * h; i += 64) {
+    const int r = i / w, c = i - r * w;
+    mask0[(size_t)(y0 + r) * pitch + x0 + c] = 0;
+  }
+}
+__global__ __launch_bounds__(256) void k_fill_level0_b(uint8_t* __restrict__ base, size_t img_stride_bytes, size_t level_bytes, uint32_t v)
+{
+  uint32_t* p = reinterpret_cast<uint32_t*>(base + (size_t)blockIdx.y * img_stride_bytes);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < level_bytes / 4; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1479,6 +1523,109 @@ ssx_status ssx_orb_detect_boxes(ssx_ctx* ctx, const uint8_t* img, int32_t stride
   return fetch_image_result(ctx, 0, cap, kps_out, nullptr, n);
 }
 
+// ssx_orb_detect_boxes for n images in ONE call (one keyframe of each of n streams: FrontEnd::DetectFeatures, frontend.cpp:302-344):
+// every kernel of the detection once for all images.  Per image the bits of ssx_orb_detect_boxes.  The workspace is planned for
+// the largest batch seen (a power of two) and run with the images of the call.
+ssx_status ssx_orb_detect_boxes_batch(ssx_ctx* ctx, int32_t n, const ssx_orb_detect_job* jobs, int32_t rows, int32_t cols, const ssx_orb_params* prm,
+                                      int32_t images_on_device)
+{
+  if (!ctx || !prm || n < 0 || (n > 0 && !jobs)) return SSX_ERR_INVALID_ARG;
+  if (n == 0) return SSX_OK;
+  if (rows <= 0 || cols <= 0) return SSX_ERR_INVALID_ARG;
+  size_t n_boxes = 0;
+  for (int j = 0; j < n; ++j) {
+    const ssx_orb_detect_job& q = jobs[j];
+    if (!q.n_out || !q.img || q.stride < cols || q.cap < 0 || (q.cap > 0 && !q.kps_out) || q.n_boxes < 0 || (q.n_boxes > 0 && !q.boxes_xyxy)) {
+      ctx->set_error("ssx_orb_detect_boxes_batch: job %d: missing image / output, stride smaller than the width, or a negative count", j);
+      return SSX_ERR_INVALID_ARG;
+    }
+    if (q.stride != jobs[0].stride) { ctx->set_error("ssx_orb_detect_boxes_batch: the images of a call share one stride"); return SSX_ERR_INVALID_ARG; }
+    *q.n_out = 0;
+    n_boxes += (size_t)q.n_boxes;
+  }
+  OrbWorkspace* ws = get_ws(ctx);
+  int cap_I = 1;
+  while (cap_I < n) cap_I *= 2;
+  if (ws->planned && ws->rows == rows && ws->cols == cols && ws->detect_only && ws->has_mask && ws->nfeatures == prm->nfeatures && ws->ini_th == prm->ini_th_fast &&
+      ws->min_th == prm->min_th_fast && ws->I > cap_I)
+    cap_I = ws->I;                                                   // (a smaller batch runs on the larger plan)
+  ssx_status st = plan(ctx, rows, cols, cap_I, *prm, true, true);
+  if (st != SSX_OK) return st;
+  struct RestoreI { OrbWorkspace* w; int I; ~RestoreI() { w->dev.I = I; } } restore{ws, ws->dev.I};
+  ws->dev.I = n;
+  const OrbDev& d = ws->dev;
+  hipStream_t s = ctx->stream;
+  // one pinned block: [image pointers | (staged images) | boxes | box -> image] -> one copy
+  const size_t bytes = (size_t)rows * cols;
+  Layout lay;
+  const size_t o_ptr = lay.take(sizeof(void*) * (size_t)n);
+  const size_t o_box = lay.take(sizeof(int32_t) * 4 * std::max<size_t>(n_boxes, 1));
+  const size_t o_bimg = lay.take(sizeof(int) * std::max<size_t>(n_boxes, 1));
+  const size_t o_img = images_on_device ? 0 : lay.take(bytes * (size_t)n + 16);
+  SSX_HIP_TRY(ctx, ws->input.reserve(lay.off + 512, 1.5));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(lay.off + 512, 1.5));
+  char* hs = ws->stage.as<char>();
+  char* db = ws->input.as<char>();
+  const uint8_t** ptrs = reinterpret_cast<const uint8_t**>(hs + o_ptr);
+  int32_t* hbox = reinterpret_cast<int32_t*>(hs + o_box);
+  int* hbimg = reinterpret_cast<int*>(hs + o_bimg);
+  size_t b0 = 0;
+  int in_stride = jobs[0].stride;
+  for (int j = 0; j < n; ++j) {
+    const ssx_orb_detect_job& q = jobs[j];
+    if (images_on_device) ptrs[j] = q.img;
+    else {
+      uint8_t* dst = reinterpret_cast<uint8_t*>(hs + o_img) + bytes * (size_t)j;
+      for (int y = 0; y < rows; ++y) memcpy(dst + (size_t)y * cols, q.img + (size_t)y * q.stride, cols);
+      ptrs[j] = reinterpret_cast<const uint8_t*>(db + o_img) + bytes * (size_t)j;
+    }
+    if (q.n_boxes) memcpy(hbox + 4 * b0, q.boxes_xyxy, sizeof(int32_t) * 4 * (size_t)q.n_boxes);
+    for (int b = 0; b < q.n_boxes; ++b) hbimg[b0 + b] = j;
+    b0 += (size_t)q.n_boxes;
+  }
+  if (!images_on_device) in_stride = cols;
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(db, hs, lay.off, hipMemcpyHostToDevice, s));
+  const dim3 grid((d.lvl_cols[0] + 511) / 512, (d.lvl_rows[0] + 3) / 4, n);
+  SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_copy_level0_ptrs, grid, dim3(64, 4), 0, s, reinterpret_cast<const uint8_t* const*>(db + o_ptr), in_stride, d.pyr,
+                                                 d.pyr_bytes, d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0]));
+  const size_t lvl0_bytes = (size_t)d.lvl_pitch[0] * d.lvl_rows[0];   // (pitch: a multiple of 128)
+  SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_fill_level0_b, dim3(64, n), dim3(256), 0, s, d.maskpyr + d.lvl_off[0], d.pyr_bytes, lvl0_bytes, 0xFFFFFFFFu));
+  if (n_boxes)
+    SSX_PROF(ctx, KID_ORB_MISC, hipLaunchKernelGGL(k_mask_boxes_b, dim3((unsigned)n_boxes), dim3(64), 0, s, reinterpret_cast<const int4*>(db + o_box),
+                                                   reinterpret_cast<const int*>(db + o_bimg), d.maskpyr + d.lvl_off[0], d.pyr_bytes, d.lvl_rows[0], d.lvl_cols[0], d.lvl_pitch[0]));
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  st = run_pipeline(ctx);
+  if (st != SSX_OK) return st;
+  // results: counts + status words + the keypoint block of the n images, one synchronisation
+  Layout out;
+  const size_t r_n = out.take(sizeof(int) * (size_t)n), r_st = out.take(sizeof(int) * (size_t)n), r_k = out.take(sizeof(ssx_keypoint) * (size_t)n * d.out_cap);
+  SSX_HIP_TRY(ctx, ws->fetch.reserve(out.off, 1.5));
+  char* hf = ws->fetch.as<char>();
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + r_n, d.out_n, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + r_st, d.status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipMemcpyAsync(hf + r_k, d.out_kps, sizeof(ssx_keypoint) * (size_t)n * d.out_cap, hipMemcpyDeviceToHost, s));
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(s));
+  const int* hn = reinterpret_cast<const int*>(hf + r_n);
+  const int* hst = reinterpret_cast<const int*>(hf + r_st);
+  ssx_status first = SSX_OK;
+  for (int j = 0; j < n; ++j) {
+    const ssx_orb_detect_job& q = jobs[j];
+    if (hst[j] != 0) {
+      ctx->set_error("ssx_orb: internal capacity exceeded (image %d of the batch, status bits %d: 1=candidates 2=octree nodes 4=outputs)", j, hst[j]);
+      if (first == SSX_OK) first = SSX_ERR_CAPACITY;
+      continue;
+    }
+    *q.n_out = hn[j];
+    if (hn[j] > q.cap) {
+      ctx->set_error("ssx_orb: %d keypoints but capacity %d (image %d of the batch)", hn[j], q.cap, j);
+      if (first == SSX_OK) first = SSX_ERR_CAPACITY;
+      continue;
+    }
+    if (hn[j] > 0) memcpy(q.kps_out, hf + r_k + sizeof(ssx_keypoint) * (size_t)j * d.out_cap, sizeof(ssx_keypoint) * (size_t)hn[j]);
+  }
+  return first;
+}
+
 ssx_status ssx_orb_extract(ssx_ctx* ctx, const uint8_t* img, int32_t stride, int32_t rows, int32_t cols,
                            const uint8_t* mask, int32_t mask_stride, const ssx_orb_params* prm, int32_t cap,
                            ssx_keypoint* kps_out, uint8_t* desc_out, int32_t* n)
@@ -1552,6 +1699,7 @@ ssx_status ssx_orb_describe_at(ssx_ctx* ctx, const uint8_t* img, int32_t stride,
   return SSX_OK;
 }
 
+#ifndef SSX_NO_TEST_HOOKS   // kernel taps of the parity tests (include/ssx_test_hooks.h)
 ssx_status ssx_orb_stage_level(ssx_ctx* ctx, int32_t image, int32_t level, int32_t blurred, uint8_t* out,
                                int32_t out_cap, int32_t* rows, int32_t* cols)
 {
@@ -1598,5 +1746,7 @@ ssx_status ssx_orb_stage_candidates(ssx_ctx* ctx, int32_t image, int32_t level, 
   *n = m;
   return (out && m > cap) ? SSX_ERR_CAPACITY : SSX_OK;
 }
+
+#endif  // SSX_NO_TEST_HOOKS
 
 }  // extern "C"

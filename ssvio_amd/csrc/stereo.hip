@@ -307,6 +307,19 @@ __global__ __launch_bounds__(256) void k_triangulate_uv(int n, const double* uvL
                   ok + i);
 }
 
+// n_jobs triangulation calls in one launch (ssx_triangulate_batch): blockIdx.y = job, its points at [p0, p0 + n) of the call's arrays;
+// the job table, the inputs and the outputs live in one pinned host block the kernel reads and writes directly
+struct TriJob { int n, p0, has_T, pad; ssx_stereo_rig rig; double T_wc[7]; };
+__global__ __launch_bounds__(256) void k_triangulate_uv_b(const TriJob* __restrict__ jobs, const double* __restrict__ uvL, const double* __restrict__ uvR,
+                                                          double* __restrict__ xyz, uint8_t* __restrict__ ok)
+{
+  const TriJob jb = jobs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= jb.n) return;
+  const size_t g = (size_t)jb.p0 + i;
+  triangulate_one(uvL[2 * g], uvL[2 * g + 1], uvR[2 * g], uvR[2 * g + 1], jb.rig, jb.has_T ? jb.T_wc : nullptr, xyz + 3 * g, ok + g);
+}
+
 __global__ __launch_bounds__(256) void k_pair_counts(MatchDev m)
 {
   __shared__ int s[2];
@@ -613,6 +626,50 @@ ssx_status ssx_triangulate(ssx_ctx* ctx, int32_t n, const double* uvL, const dou
   SSX_HIP_TRY(ctx, hipMemcpyAsync(xyz_out, base + o_x, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipMemcpyAsync(ok_out, base + o_k, n, hipMemcpyDeviceToHost, ctx->stream));
   SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return SSX_OK;
+}
+
+// n calls of ssx_triangulate in one launch and one synchronisation (one keyframe of each of n streams: FrontEnd::TriangulateNewPoints /
+// BuidInitMap, frontend.cpp:448-544).  Per job the bits of ssx_triangulate.
+ssx_status ssx_triangulate_batch(ssx_ctx* ctx, int32_t n_jobs, const ssx_triangulate_job* jobs)
+{
+  if (!ctx || n_jobs < 0 || (n_jobs > 0 && !jobs)) return SSX_ERR_INVALID_ARG;
+  size_t total = 0;
+  int max_n = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const ssx_triangulate_job& q = jobs[j];
+    if (!q.rig || q.n < 0 || (q.n && (!q.uvL || !q.uvR || !q.xyz_out || !q.ok_out))) return SSX_ERR_INVALID_ARG;
+    total += (size_t)q.n; max_n = std::max(max_n, q.n);
+  }
+  if (total == 0) return SSX_OK;
+  OrbWorkspace* ws = get_ws(ctx);
+  SSX_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Layout lay;
+  const size_t o_tab = lay.take(sizeof(TriJob) * (size_t)n_jobs);
+  const size_t o_l = lay.take(sizeof(double) * 2 * total), o_r = lay.take(sizeof(double) * 2 * total);
+  const size_t o_x = lay.take(sizeof(double) * 3 * total), o_k = lay.take(total);
+  SSX_HIP_TRY(ctx, ws->fetch.reserve(lay.off, 1.5));
+  char* hs = ws->fetch.as<char>();
+  TriJob* tab = reinterpret_cast<TriJob*>(hs + o_tab);
+  size_t p0 = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const ssx_triangulate_job& q = jobs[j];
+    TriJob& t = tab[j];
+    t.n = q.n; t.p0 = (int)p0; t.has_T = q.T_wc ? 1 : 0; t.pad = 0; t.rig = *q.rig;
+    for (int i = 0; i < 7; ++i) t.T_wc[i] = q.T_wc ? q.T_wc[i] : (i == 3 ? 1.0 : 0.0);
+    if (q.n) { memcpy(hs + o_l + sizeof(double) * 2 * p0, q.uvL, sizeof(double) * 2 * (size_t)q.n); memcpy(hs + o_r + sizeof(double) * 2 * p0, q.uvR, sizeof(double) * 2 * (size_t)q.n); }
+    p0 += (size_t)q.n;
+  }
+  SSX_PROF(ctx, KID_ST_MISC, hipLaunchKernelGGL(k_triangulate_uv_b, dim3((max_n + 255) / 256, n_jobs), dim3(256), 0, ctx->stream, (const TriJob*)tab,
+                                                (const double*)(hs + o_l), (const double*)(hs + o_r), (double*)(hs + o_x), (uint8_t*)(hs + o_k)));
+  SSX_HIP_TRY(ctx, hipGetLastError());
+  SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  p0 = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const ssx_triangulate_job& q = jobs[j];
+    if (q.n) { memcpy(q.xyz_out, hs + o_x + sizeof(double) * 3 * p0, sizeof(double) * 3 * (size_t)q.n); memcpy(q.ok_out, hs + o_k + p0, (size_t)q.n); }
+    p0 += (size_t)q.n;
+  }
   return SSX_OK;
 }
 

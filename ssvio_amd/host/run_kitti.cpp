@@ -163,6 +163,11 @@ int main(int argc, char** argv)
         const StreamBatcher::Stats bs = batcher->stats();
         std::printf("batched calls: LK %ld (%.1f jobs each), pose-only %ld (%.1f), window solves %ld (%.1f)\n", bs.lk_calls, bs.lk_jobs / std::max(1.0, (double)bs.lk_calls),
                     bs.po_calls, bs.po_jobs / std::max(1.0, (double)bs.po_calls), bs.ba_calls, bs.ba_jobs / std::max(1.0, (double)bs.ba_calls));
+        std::printf("batched time: LK %.1f ms (%.3f per call), pose-only %.1f ms (%.3f), window solves %.1f ms (%.3f), keyframe calls (detection, stereo LK, "
+                    "triangulation) %ld x %.1f jobs, %.1f ms (%.3f per call), dispatcher waiting for the streams' host code %.1f ms\n",
+                    1e3 * bs.lk_s, 1e3 * bs.lk_s / std::max(1L, bs.lk_calls), 1e3 * bs.po_s, 1e3 * bs.po_s / std::max(1L, bs.po_calls), 1e3 * bs.ba_s,
+                    1e3 * bs.ba_s / std::max(1L, bs.ba_calls), bs.kf_calls, bs.kf_jobs / std::max(1.0, (double)bs.kf_calls), 1e3 * bs.kf_s,
+                    1e3 * bs.kf_s / std::max(1L, bs.kf_calls), 1e3 * bs.wait_s);
       }
       return 0;
     }

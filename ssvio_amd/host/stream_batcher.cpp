@@ -2,6 +2,7 @@
 #include "stream_batcher.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <stdexcept>
 
@@ -10,16 +11,17 @@
 namespace ssx::host {
 
 namespace {
-enum class St { RUNNING, PENDING_LK, PENDING_PO, PENDING_BA, INFLIGHT, LONGOP, DONE };
+enum class St { RUNNING, PENDING_LK, PENDING_PO, PENDING_DET, PENDING_LKS, PENDING_TRI, PENDING_BA, INFLIGHT, LONGOP, DONE };
 }
 
 struct StreamBatcher::Impl {
-  Impl(int device_, int streams) : device(device_), S(streams), lk_ctx(device_), po_ctx(device_), ba_ctx(device_), state(streams, St::RUNNING),
-                                   lk_req(streams), lk_rows(streams, 0), lk_cols(streams, 0), po_req(streams), ba_win(streams, nullptr),
-                                   ba_res(streams, nullptr), error(streams)
+  Impl(int device_, int streams) : device(device_), S(streams), lk_ctx(device_), po_ctx(device_), ba_ctx(device_), det_ctx(device_), lks_ctx(device_),
+                                   tri_ctx(device_), state(streams, St::RUNNING), lk_req(streams), lk_rows(streams, 0), lk_cols(streams, 0),
+                                   po_req(streams), det_req(streams), det_prm(streams), tri_req(streams), ba_win(streams, nullptr), ba_res(streams, nullptr),
+                                   error(streams)
   {
     disp = std::thread([this] { DispatchLoop(); });
-    ba_disp = std::thread([this] { BaLoop(); });
+    ba_disp = std::thread([this] { KeyframeLoop(); });
   }
   ~Impl()
   {
@@ -57,9 +59,12 @@ struct StreamBatcher::Impl {
   {
     std::unique_lock<std::mutex> lk(m);
     std::vector<int> who;
+    using clk = std::chrono::steady_clock;
     for (;;) {
+      const auto tw0 = clk::now();
       cv_disp.wait(lk, [&] { return quit || (count(St::RUNNING) == 0 && count(St::PENDING_LK) + count(St::PENDING_PO) > 0); });
       if (quit) return;
+      st.wait_s += std::chrono::duration<double>(clk::now() - tw0).count();
       // pose-only first: the cohort then reaches its next LK request where a straggler from a keyframe already waits (see the header)
       const St kind = count(St::PENDING_PO) > 0 ? St::PENDING_PO : St::PENDING_LK;
       who.clear();
@@ -67,6 +72,7 @@ struct StreamBatcher::Impl {
       lk.unlock();
       std::string err;
       long d_calls = 0, d_jobs = 0;
+      const auto tc0 = clk::now();
       try {
         if (kind == St::PENDING_PO) {
           std::vector<ssx_pose_only_job> jobs;
@@ -92,51 +98,99 @@ struct StreamBatcher::Impl {
       } catch (const std::exception& e) {
         err = e.what();
       }
+      const double dt = std::chrono::duration<double>(clk::now() - tc0).count();
       lk.lock();
-      if (kind == St::PENDING_PO) { st.po_calls += d_calls; st.po_jobs += d_jobs; } else { st.lk_calls += d_calls; st.lk_jobs += d_jobs; }
+      if (kind == St::PENDING_PO) { st.po_calls += d_calls; st.po_jobs += d_jobs; st.po_s += dt; } else { st.lk_calls += d_calls; st.lk_jobs += d_jobs; st.lk_s += dt; }
       for (int k : who) { error[k] = err; state[k] = St::RUNNING; }
       cv_done.notify_all();
     }
   }
 
-  void BaLoop()
+  // The keyframe path of the streams (FrontEnd::DetectFeatures -> FindFeaturesInRight -> TriangulateNewPoints -> Backend: masked
+  // detection, stereo LK, triangulation, window optimisation), batched like the per-frame calls, on contexts of its own beside them.
+  // The EARLIEST stage that has requests is served first, so that streams which reached their keyframe a little later catch up and
+  // all of them meet in one window solve (a batched solve costs what a single one costs).
+  void KeyframeLoop()
   {
     std::unique_lock<std::mutex> lk(m);
     std::vector<int> who;
+    auto n_kf = [&] { return count(St::PENDING_DET) + count(St::PENDING_LKS) + count(St::PENDING_TRI) + count(St::PENDING_BA); };
     for (;;) {
-      // streams on a keyframe's path (detection, stereo LK, triangulation: LONGOP) arrive here within a fraction of a millisecond: wait
-      // for them, a batched solve costs what a single one costs
-      cv_disp.wait(lk, [&] { return quit || (count(St::PENDING_BA) > 0 && count(St::RUNNING) == 0 && count(St::LONGOP) == 0); });
+      // (streams in a call of their own -- LONGOP -- are about to file the next request of this path: wait for them)
+      cv_disp.wait(lk, [&] { return quit || (n_kf() > 0 && count(St::RUNNING) == 0 && count(St::LONGOP) == 0); });
       if (quit) return;
+      const St kind = count(St::PENDING_DET) > 0 ? St::PENDING_DET : count(St::PENDING_LKS) > 0 ? St::PENDING_LKS : count(St::PENDING_TRI) > 0 ? St::PENDING_TRI
+                                                                                                                                              : St::PENDING_BA;
       who.clear();
-      for (int k = 0; k < S; ++k) if (state[k] == St::PENDING_BA) { who.push_back(k); state[k] = St::INFLIGHT; }
+      for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); state[k] = St::INFLIGHT; }
       lk.unlock();
       cv_disp.notify_all();                         // (the per-frame dispatcher does not wait for streams that are in flight here)
       std::string err;
+      const auto tb0 = std::chrono::steady_clock::now();
       try {
-        std::vector<ssx_ba_window*> wins;
-        std::vector<ssx_ba_result> res;
-        for (int k : who) { wins.push_back(ba_win[k]); res.push_back(*ba_res[k]); }
-        ba_ctx.check(ssx_ba_window_solve_batch((int32_t)wins.size(), wins.data(), res.data()));
-        for (size_t i = 0; i < who.size(); ++i) *ba_res[who[i]] = res[i];
+        if (kind == St::PENDING_BA) {
+          std::vector<ssx_ba_window*> wins;
+          std::vector<ssx_ba_result> res;
+          for (int k : who) { wins.push_back(ba_win[k]); res.push_back(*ba_res[k]); }
+          ba_ctx.check(ssx_ba_window_solve_batch((int32_t)wins.size(), wins.data(), res.data()));
+          for (size_t i = 0; i < who.size(); ++i) *ba_res[who[i]] = res[i];
+        } else if (kind == St::PENDING_TRI) {
+          std::vector<ssx_triangulate_job> jobs;
+          for (int k : who) jobs.push_back(tri_req[k]);
+          tri_ctx.check(ssx_triangulate_batch(tri_ctx.get(), (int32_t)jobs.size(), jobs.data()));
+        } else if (kind == St::PENDING_LKS) {
+          std::vector<char> taken(who.size(), 0);
+          for (size_t a = 0; a < who.size(); ++a) {
+            if (taken[a]) continue;
+            std::vector<ssx_lk_job> jobs;
+            const int rows = lk_rows[who[a]], cols = lk_cols[who[a]];
+            for (size_t b = a; b < who.size(); ++b)
+              if (!taken[b] && lk_rows[who[b]] == rows && lk_cols[who[b]] == cols) { jobs.push_back(lk_req[who[b]]); taken[b] = 1; }
+            ssx_lk_params p;
+            ssx_lk_default_params(&p);
+            p.win = 11; p.max_level = 3; p.max_iters = 30; p.eps = 0.01; p.use_initial_flow = 1;
+            lks_ctx.check(ssx_lk_track_batch(lks_ctx.get(), (int32_t)jobs.size(), jobs.data(), rows, cols, &p, 1));
+          }
+        } else {
+          // detection: the jobs of a call share image size, stride and extractor settings
+          std::vector<char> taken(who.size(), 0);
+          for (size_t a = 0; a < who.size(); ++a) {
+            if (taken[a]) continue;
+            const int ka = who[a];
+            std::vector<ssx_orb_detect_job> jobs;
+            for (size_t b = a; b < who.size(); ++b) {
+              const int kb = who[b];
+              if (taken[b] || lk_rows[kb] != lk_rows[ka] || lk_cols[kb] != lk_cols[ka] || det_req[kb].stride != det_req[ka].stride ||
+                  std::memcmp(&det_prm[kb], &det_prm[ka], sizeof(ssx_orb_params)) != 0)
+                continue;
+              jobs.push_back(det_req[kb]); taken[b] = 1;
+            }
+            det_ctx.check(ssx_orb_detect_boxes_batch(det_ctx.get(), (int32_t)jobs.size(), jobs.data(), lk_rows[ka], lk_cols[ka], &det_prm[ka], 1));
+          }
+        }
       } catch (const std::exception& e) {
         err = e.what();
       }
+      const double dtb = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
       lk.lock();
-      ++st.ba_calls; st.ba_jobs += (long)who.size();
+      if (kind == St::PENDING_BA) { ++st.ba_calls; st.ba_jobs += (long)who.size(); st.ba_s += dtb; }
+      else { ++st.kf_calls; st.kf_jobs += (long)who.size(); st.kf_s += dtb; }
       for (int k : who) { error[k] = err; state[k] = St::RUNNING; }
       cv_done.notify_all();
     }
   }
 
   int device, S;
-  ssx::Context lk_ctx, po_ctx, ba_ctx;
+  ssx::Context lk_ctx, po_ctx, ba_ctx, det_ctx, lks_ctx, tri_ctx;
   std::mutex m;
   std::condition_variable cv_disp, cv_done;
   std::vector<St> state;
   std::vector<ssx_lk_job> lk_req;
   std::vector<int> lk_rows, lk_cols;
   std::vector<ssx_pose_only_job> po_req;
+  std::vector<ssx_orb_detect_job> det_req;
+  std::vector<ssx_orb_params> det_prm;
+  std::vector<ssx_triangulate_job> tri_req;
   std::vector<ssx_ba_window*> ba_win;
   std::vector<ssx_ba_result*> ba_res;
   std::vector<std::string> error;
@@ -214,16 +268,24 @@ class BatchedCompute final : public Compute {
   }
   void DetectBoxes(const Image& img, const std::vector<int32_t>& boxes, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
   {
-    LongOp op(im_, k_);
     kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});
     int32_t n = 0;
-    const int32_t nb = (int32_t)(boxes.size() / 4);
-    ssx_status st = ssx_orb_detect_boxes(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, boxes.data(), nb, &prm, (int32_t)kps.size(), kps.data(), &n);
-    if (st == SSX_ERR_CAPACITY && n > (int32_t)kps.size()) {
+    const uint8_t* pinned = Pinned(img, 0);        // (the current left image: usually there already, from the frame's temporal LK)
+    ssx_orb_detect_job& q = im_.det_req[k_];
+    q = ssx_orb_detect_job{};
+    q.img = pinned; q.stride = img.cols; q.boxes_xyxy = boxes.data(); q.n_boxes = (int32_t)(boxes.size() / 4);
+    q.cap = (int32_t)kps.size(); q.kps_out = kps.data(); q.n_out = &n;
+    im_.det_prm[k_] = prm; im_.lk_rows[k_] = img.rows; im_.lk_cols[k_] = img.cols;
+    try {
+      im_.SubmitAndWait(k_, St::PENDING_DET);
+    } catch (const std::exception&) {
+      if (n <= (int32_t)kps.size()) throw;
+      // (a grid returned more than the bound of ssx.h: once more with the size it asked for, on the stream's own context)
+      LongOp op(im_, k_);
       kps.assign((size_t)n, ssx_keypoint{});
-      st = ssx_orb_detect_boxes(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, boxes.data(), nb, &prm, (int32_t)kps.size(), kps.data(), &n);
+      frame_.check(ssx_orb_detect_boxes(frame_.get(), img.ptr(), img.cols, img.rows, img.cols, boxes.data(), (int32_t)(boxes.size() / 4), &prm, (int32_t)kps.size(),
+                                        kps.data(), &n));
     }
-    frame_.check(st);
     kps.resize(n);
   }
 
@@ -232,36 +294,27 @@ class BatchedCompute final : public Compute {
   {
     const int n = (int)(prev_pts.size() / 2);
     status.assign(n, 0);
-    if (!temporal) {                               // FindFeaturesInRight: a keyframe's own call
-      LongOp op(im_, k_);
-      ssx_lk_params p;
-      ssx_lk_default_params(&p);
-      p.win = 11; p.max_level = 3; p.max_iters = 30; p.eps = 0.01; p.use_initial_flow = 1;
-      frame_.check(ssx_lk_track(frame_.get(), prev.ptr(), prev.cols, next.ptr(), next.cols, prev.rows, prev.cols, n, prev_pts.data(), next_pts.data(),
-                                status.data(), nullptr, &p, nullptr));
+    ssx_lk_job& q = im_.lk_req[k_];
+    q = ssx_lk_job{};
+    q.slot = k_;
+    q.n = n; q.prev_pts = prev_pts.data(); q.next_pts = next_pts.data(); q.status = status.data(); q.err = nullptr;
+    im_.lk_rows[k_] = next.rows; im_.lk_cols[k_] = next.cols;
+    if (!temporal) {
+      // FindFeaturesInRight (frontend.cpp:346-428): left -> right of one frame, both pyramids built afresh, on the stereo LK context's
+      // slot of this stream
+      if (prev.rows != next.rows || prev.cols != next.cols) throw std::invalid_argument("TrackLK: image sizes differ");
+      q.prev = Pinned(prev, 0); q.prev_stride = prev.cols;
+      q.next = Pinned(next, 1, q.prev); q.next_stride = next.cols;
+      im_.SubmitAndWait(k_, St::PENDING_LKS);
       return;
     }
     // the frame-to-frame chain: this stream's slot of the shared LK context keeps the pyramid of its last `next` image.  The new
     // image goes into the stream's pinned buffer (this thread copies it: S streams copy side by side) and is read from there by the
     // GPU -- no staging inside the batched call.
-    const size_t bytes = (size_t)next.rows * next.cols;
-    if (bytes > pin_bytes_) {
-      ssx_host_free(pin_[0]); ssx_host_free(pin_[1]);
-      pin_[0] = static_cast<uint8_t*>(ssx_host_alloc(bytes)); pin_[1] = static_cast<uint8_t*>(ssx_host_alloc(bytes));
-      if (!pin_[0] || !pin_[1]) throw std::runtime_error("StreamBatcher: no pinned memory for the stream's images");
-      pin_bytes_ = bytes;
-    }
     const bool chained = prev.id != 0 && prev.id == chain_next_id_ && prev.rows == chain_rows_ && prev.cols == chain_cols_ && next.rows == prev.rows &&
                          next.cols == prev.cols;
-    std::memcpy(pin_[0], next.ptr(), bytes);
-    if (!chained) std::memcpy(pin_[1], prev.ptr(), (size_t)prev.rows * prev.cols);
-    ssx_lk_job& q = im_.lk_req[k_];
-    q = ssx_lk_job{};
-    q.slot = k_;
-    q.prev = chained ? nullptr : pin_[1]; q.prev_stride = prev.cols;
-    q.next = pin_[0]; q.next_stride = next.cols;
-    q.n = n; q.prev_pts = prev_pts.data(); q.next_pts = next_pts.data(); q.status = status.data(); q.err = nullptr;
-    im_.lk_rows[k_] = next.rows; im_.lk_cols[k_] = next.cols;
+    if (!chained) { q.prev = Pinned(prev, 1); q.prev_stride = prev.cols; }
+    q.next = Pinned(next, 0, q.prev); q.next_stride = next.cols;
     chain_next_id_ = 0;                            // (a failed call leaves no chain)
     im_.SubmitAndWait(k_, St::PENDING_LK);
     chain_next_id_ = next.id; chain_rows_ = next.rows; chain_cols_ = next.cols;
@@ -280,8 +333,10 @@ class BatchedCompute final : public Compute {
 
   void Triangulate(int n, const double* uvL, const double* uvR, const ssx_stereo_rig& rig, const double* T_wc, double* xyz, uint8_t* ok) override
   {
-    LongOp op(im_, k_);
-    frame_.check(ssx_triangulate(frame_.get(), n, uvL, uvR, &rig, T_wc, xyz, ok));
+    ssx_triangulate_job& q = im_.tri_req[k_];
+    q = ssx_triangulate_job{};
+    q.n = n; q.uvL = uvL; q.uvR = uvR; q.rig = &rig; q.T_wc = T_wc; q.xyz_out = xyz; q.ok_out = ok;
+    im_.SubmitAndWait(k_, St::PENDING_TRI);
   }
 
   void BundleAdjust(const ssx_ba_problem& prob, const ssx_ba_options& opt, ssx_ba_result& res) override
@@ -296,10 +351,30 @@ class BatchedCompute final : public Compute {
   }
 
  private:
+  // the image in the stream's pinned buffer `which` (copied by this thread unless it is there already)
+  // (keep: a buffer this call must not overwrite -- the other image of a two-image request)
+  const uint8_t* Pinned(const Image& img, int which, const uint8_t* keep = nullptr)
+  {
+    const size_t bytes = (size_t)img.rows * img.cols;
+    if (bytes > pin_bytes_) {
+      ssx_host_free(pin_[0]); ssx_host_free(pin_[1]);
+      pin_[0] = static_cast<uint8_t*>(ssx_host_alloc(bytes)); pin_[1] = static_cast<uint8_t*>(ssx_host_alloc(bytes));
+      if (!pin_[0] || !pin_[1]) throw std::runtime_error("StreamBatcher: no pinned memory for the stream's images");
+      pin_bytes_ = bytes; pin_id_[0] = pin_id_[1] = 0;
+    }
+    if (img.id != 0 && pin_id_[which] == img.id) return pin_[which];
+    if (img.id != 0 && pin_id_[which ^ 1] == img.id) return pin_[which ^ 1];
+    if (keep && pin_[which] == keep) which ^= 1;
+    std::memcpy(pin_[which], img.ptr(), bytes);
+    pin_id_[which] = img.id;
+    return pin_[which];
+  }
+
   StreamBatcher::Impl& im_;
   int k_;
   ssx::Context frame_;
   uint8_t* pin_[2] = {nullptr, nullptr};
+  uint64_t pin_id_[2] = {0, 0};
   size_t pin_bytes_ = 0;
   uint64_t chain_next_id_ = 0;
   int chain_rows_ = 0, chain_cols_ = 0;

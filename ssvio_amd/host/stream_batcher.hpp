@@ -12,7 +12,9 @@
 //     ssx_lk_track_batch / ssx_pose_only_opt_batch / ssx_ba_window_solve_batch        (include/ssx.h)
 // whose per-job results are, bit for bit, those of the single calls -- so every stream's trajectory is byte-identical to its
 // single-stream run, whatever S and whatever the interleaving (tests/test_host_gpu.py).  The keyframe path of a stream (masked
-// detection, stereo LK, triangulation: 6 % of the frames) runs directly on the stream's own context beside the batches.
+// detection, stereo LK, triangulation: ssx_orb_detect_boxes_batch / ssx_lk_track_batch / ssx_triangulate_batch) is batched by a
+// second dispatcher on contexts of its own, beside the per-frame batches; a stream's images are read by the GPU from the stream's
+// pinned buffers (filled by the stream's own thread), nothing is staged inside the batched calls.
 //
 // Dispatch order: pose-only before LK.  A stream that comes back from a keyframe is half a frame out of phase with the cohort; with
 // the pose-only batch served first the cohort arrives at its next LK request while the straggler still waits there, and they merge.
@@ -41,7 +43,11 @@ class StreamBatcher {
   std::unique_ptr<Compute> MakeCompute(int k);
   void Finish(int k);
 
-  struct Stats { long lk_calls = 0, lk_jobs = 0, po_calls = 0, po_jobs = 0, ba_calls = 0, ba_jobs = 0; };
+  struct Stats {
+    long lk_calls = 0, lk_jobs = 0, po_calls = 0, po_jobs = 0, ba_calls = 0, ba_jobs = 0, kf_calls = 0, kf_jobs = 0;   // kf: detection, stereo LK, triangulation
+    double lk_s = 0, po_s = 0, ba_s = 0, kf_s = 0;  // seconds inside the batched library calls
+    double wait_s = 0;                               // seconds the per-frame dispatcher waited for the streams' host code
+  };
   Stats stats();
 
   struct Impl;

@@ -64,6 +64,29 @@ class ORBextractor:
             len(boxes), C.byref(self.prm), cap, kps.ctypes.data_as(C.c_void_p), C.byref(n)))
         return kps[:n.value].copy()
 
+    def DetectBoxesBatch(self, images, boxes_list):
+        """ssx_orb_detect_boxes_batch: n images of one size (host arrays: staged by the library), each with its own rectangles, in
+        one call -> list of keypoint arrays (per image the result of DetectBoxes)."""
+        class Job(C.Structure):
+            _fields_ = [("img", u8_p), ("stride", C.c_int32), ("boxes", C.POINTER(C.c_int32)), ("n_boxes", C.c_int32), ("cap", C.c_int32),
+                        ("kps_out", C.c_void_p), ("n_out", C.POINTER(C.c_int32))]
+        n = len(images)
+        arr = (Job * n)()
+        keep, outs = [], []
+        cap = self._cap()
+        for i, (im, bx) in enumerate(zip(images, boxes_list)):
+            im = _img(im); bx = np.ascontiguousarray(bx, dtype=np.int32).reshape(-1, 4)
+            kps = np.zeros(cap, dtype=KP_DTYPE); cnt = (C.c_int32 * 1)(0)
+            a = arr[i]
+            a.img = ptr(im, u8_p); a.stride = im.strides[0]; a.boxes = bx.ctypes.data_as(C.POINTER(C.c_int32)); a.n_boxes = len(bx)
+            a.cap = cap; a.kps_out = kps.ctypes.data_as(C.c_void_p); a.n_out = C.cast(cnt, C.POINTER(C.c_int32))
+            keep.append((im, bx)); outs.append((kps, cnt))
+        rows, cols = keep[0][0].shape
+        self.ctx.lib.ssx_orb_detect_boxes_batch.restype = C.c_int32
+        self.ctx.lib.ssx_orb_detect_boxes_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Job), C.c_int32, C.c_int32, C.POINTER(OrbParams), C.c_int32]
+        self.ctx.check(self.ctx.lib.ssx_orb_detect_boxes_batch(self.ctx.handle, n, arr, rows, cols, C.byref(self.prm), 0))
+        return [k[:c[0]].copy() for k, c in outs]
+
     def DetectAndCompute(self, image, mask=None):
         """ORBextractor::DetectAndCompute (orbextractor.cpp:687-753): (keypoints, N x 32 uint8 descriptors)."""
         image = np.asarray(image)
@@ -152,6 +175,27 @@ def triangulate(ctx: Context, uvL, uvR, rig=None, T_wc=None):
     ctx.check(ctx.lib.ssx_triangulate(ctx.handle, n, ptr(uvL, dbl_p), ptr(uvR, dbl_p), C.byref(rig), ptr(T, dbl_p),
                                       ptr(xyz, dbl_p), ptr(ok, u8_p)))
     return xyz, ok
+
+
+def triangulate_batch(ctx: Context, jobs):
+    """ssx_triangulate_batch: jobs = [dict(uvL, uvR, rig=None, T_wc=None)] -> [(xyz, ok)], one launch for all."""
+    class Job(C.Structure):
+        _fields_ = [("n", C.c_int32), ("uvL", dbl_p), ("uvR", dbl_p), ("rig", C.POINTER(StereoRig)), ("T_wc", dbl_p), ("xyz_out", dbl_p), ("ok_out", u8_p)]
+    n = len(jobs)
+    arr = (Job * n)()
+    keep, outs = [], []
+    for i, j in enumerate(jobs):
+        rig = j.get("rig") or stereo_rig()
+        uvL = np.ascontiguousarray(j["uvL"], dtype=np.float64).reshape(-1, 2); uvR = np.ascontiguousarray(j["uvR"], dtype=np.float64).reshape(-1, 2)
+        T = None if j.get("T_wc") is None else np.ascontiguousarray(j["T_wc"], dtype=np.float64)
+        xyz = np.zeros((len(uvL), 3)); ok = np.zeros(len(uvL), np.uint8)
+        a = arr[i]
+        a.n = len(uvL); a.uvL = ptr(uvL, dbl_p); a.uvR = ptr(uvR, dbl_p); a.rig = C.pointer(rig); a.T_wc = ptr(T, dbl_p); a.xyz_out = ptr(xyz, dbl_p); a.ok_out = ptr(ok, u8_p)
+        keep.append((rig, uvL, uvR, T)); outs.append((xyz, ok))
+    ctx.lib.ssx_triangulate_batch.restype = C.c_int32
+    ctx.lib.ssx_triangulate_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Job)]
+    ctx.check(ctx.lib.ssx_triangulate_batch(ctx.handle, n, arr))
+    return outs
 
 
 class _FrameBuffers:

@@ -32,16 +32,17 @@ def test_library_builds_and_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     # the product header declares no test / tools hook; those live in include/ssx_test_hooks.h (present in the default build only)
-    assert not [s for s in syms if "debug" in s or "selftest" in s]
+    assert not [s for s in syms if "debug" in s or "selftest" in s or "_stage_" in s or s == "ssx_ba_linearize"]
     hooks = declared_symbols(HOOKS)
-    assert len(hooks) >= 5 and all(("debug" in s or "selftest" in s) for s in hooks)
+    assert len(hooks) >= 10 and all(("debug" in s or "selftest" in s or "_stage_" in s or s == "ssx_ba_linearize") for s in hooks)
+    assert not set(hooks) & set(syms)
     assert not [s for s in hooks if not hasattr(lib, s)]
     from ssvio_amd import _lib
-    assert lib.ssx_version() == _lib.SSX_VERSION == 110
+    assert lib.ssx_version() == _lib.SSX_VERSION == 120
     # a caller built against another header is told so (ssx_abi_check), instead of reading cu_count from garbage
     import ctypes as C
     assert lib.ssx_abi_check(100, C.sizeof(_lib.Config), C.sizeof(_lib.BaProblem), C.sizeof(_lib.BaOptions), C.sizeof(_lib.BaResult), C.sizeof(_lib.BaWindowUpdate)) != 0
-    assert lib.ssx_abi_check(110, C.sizeof(_lib.Config) - 8, C.sizeof(_lib.BaProblem), C.sizeof(_lib.BaOptions), C.sizeof(_lib.BaResult), C.sizeof(_lib.BaWindowUpdate)) != 0
+    assert lib.ssx_abi_check(120, C.sizeof(_lib.Config) - 8, C.sizeof(_lib.BaProblem), C.sizeof(_lib.BaOptions), C.sizeof(_lib.BaResult), C.sizeof(_lib.BaWindowUpdate)) != 0
 
 
 def test_no_cpu_fallback_without_device():

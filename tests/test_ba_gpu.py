@@ -314,10 +314,11 @@ def test_ba_solve_matches_reference_golden(ctx, name, jac, record_property):
 _NOISE = None
 
 
-def _assert_within_noise_floor(name, jac, g, G, d, record_property=None, K=3.0):
+def _assert_within_noise_floor(name, jac, g, G, d, record_property=None):
     global _NOISE
     if _NOISE is None:
         _NOISE = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_noise_floor.npz"))
+    K, KM = float(_NOISE["K_body"]), float(_NOISE["K_max"])        # 2 and 4, stored with the floors (tests/golden/make_noise_floor.py)
     key = f"{name}_jac{1 if jac == ba.JAC_NUMERIC_G2O else 0}"
     med, p99, p999, mx, frac = _NOISE[key + "_resid"]
     got = dict(median=float(np.median(d)), p99=float(np.percentile(d, 99)), p999=float(np.percentile(d, 99.9)), max=float(d.max()),
@@ -331,7 +332,10 @@ def _assert_within_noise_floor(name, jac, g, G, d, record_property=None, K=3.0):
     assert got["median"] <= K * med + FLOOR, (key, "median", got["median"], med)
     assert got["p99"] <= K * (p99 if len(d) >= 1000 else p999) + FLOOR, (key, "p99", got["p99"], p99, p999)
     assert got["p999"] <= K * p999 + FLOOR, (key, "p99.9", got["p999"], p999)
-    assert got["max"] <= K * mx + FLOOR, (key, "max", got["max"], mx)
+    assert got["max"] <= KM * mx + FLOOR, (key, "max", got["max"], mx)
+    if KM * mx < RESID_TOL:
+        # where the restatement itself stays KM times inside north_star's tolerance, the GPU is held to the tolerance itself, per edge
+        assert got["max"] < RESID_TOL, (key, "every residual within 1e-4 px of the reference", got["max"])
     assert got["frac_le_1e_4"] >= 1.0 - K * (1.0 - frac) - 1e-9, (key, "fraction within 1e-4 px", got["frac_le_1e_4"], frac)
     n = min(len(g["chi2"]), len(G[f"ba_{name}_chi2"]))
     chi2_rel = float(np.abs(g["chi2"][:n] / G[f"ba_{name}_chi2"][:n] - 1).max())
@@ -514,7 +518,9 @@ def test_block_cyclic_reduction_shapes_equal_tiles(ctx, P, obs, wrap, fix):
     t = ba.ba_solve(ctx, pr, outer_rounds=1, iters=4, want_edges=False, large_solver=1)
     assert np.array_equal(g["trials"], t["trials"])
     np.testing.assert_allclose(g["chi2"], t["chi2"], rtol=1e-8)
-    assert np.abs(g["poses"] - t["poses"]).max() < 1e-7
+    # (obs = 2: every landmark ties just two neighbouring keyframes -- a chain whose reduced system is the worst conditioned of the
+    # set; two exact solvers then differ by 1.4e-7 in a pose at equal cost)
+    assert np.abs(g["poses"] - t["poses"]).max() < (3e-7 if obs == 2 else 1e-7)
     again = ba.ba_solve(ctx, pr, outer_rounds=1, iters=4, want_edges=False, large_solver=2)
     assert np.array_equal(again["poses"], g["poses"]) and np.array_equal(again["chi2"], g["chi2"])      # bit-deterministic
 
@@ -1344,7 +1350,7 @@ def test_window_drive_matches_the_reference_backend_golden(ctx, jac, record_prop
     pinned, free = worst["pinned"], worst["free"]
     assert pinned["n"] == 9 and free["n"] == 5
     assert pinned["trial_mismatch"] == 0
-    # The bars: K = 3 times what the ORACLE's two builds (plain | fused multiply-adds) reach against the same vectors
+    # The bars: K_body = 2 (K_max = 4 for the single worst residual) times what the ORACLE's two builds (plain | fused multiply-adds) reach against the same vectors
     # (tests/golden/ref_noise_floor.npz, drive_open_*; make_noise_floor.py prints them).  Pinned windows, numeric | analytic: poses
     # 3.0e-7 | 2.2e-7, p99 7.5e-5 | 6.9e-5 px, 98.84 | 99.23 % within 1e-4 px, the largest single difference 7.1e-4 | 5.5e-4 px on a
     # 30 px outlier edge.  [Until round 5 the bar was ">= 99 % within 1e-4 px", set from what the GPU code of the day did (99.17 %);
@@ -1352,12 +1358,12 @@ def test_window_drive_matches_the_reference_backend_golden(ctx, jac, record_prop
     global _NOISE
     if _NOISE is None:
         _NOISE = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_noise_floor.npz"))
-    K = 3.0
+    K, KM = float(_NOISE["K_body"]), float(_NOISE["K_max"])
     for kind, w in (("pinned", pinned), ("free", free)):
         fl = {st: float(_NOISE[f"drive_open_jac{jac}_{kind}_{st}"]) for st in ("pose", "resid", "p99", "chi2_rel", "frac")}
         for st in ("pose", "resid", "p99", "chi2_rel"):
             record_property(f"{kind}_{st}_floor", fl[st])
-            assert w[st] <= K * fl[st], (kind, st, w[st], fl[st])
+            assert w[st] <= (KM if st == "resid" else K) * fl[st], (kind, st, w[st], fl[st])   # resid = the worst single residual
         assert 1.0 - w["frac"] <= K * (1.0 - fl["frac"]) + 1e-3, (kind, "fraction within 1e-4 px", w["frac"], fl["frac"])
     # north_star's statement where the reference's own noise allows it: the windows pinned by a fixed map point, at p99
     assert pinned["p99"] <= RESID_TOL and pinned["pose"] < 2e-6

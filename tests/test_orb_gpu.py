@@ -92,6 +92,45 @@ def test_detect_with_boxes_equals_the_rasterised_mask(ctx, po, pair_kitti):
     assert ex.DetectBoxes(L, np.zeros((0, 4), np.int32)).tobytes() == ex.Detect(L).tobytes()
 
 
+def test_detect_boxes_batch_equals_single_calls(ctx, pair_kitti):
+    """ssx_orb_detect_boxes_batch -- one keyframe of each of n streams in one call -- returns, per image, the bits of
+    ssx_orb_detect_boxes: different images, different numbers of rectangles (one image without any), batches of 5, 2 and 7 on the
+    same context (the plan made for the largest batch serves the smaller ones), then a single call again."""
+    from tools.synth import make_stereo_pair
+    imgs = [pair_kitti[0], pair_kitti[1]] + [make_stereo_pair(seed=30 + k)[0] for k in range(5)]
+    ex = sorb.ORBextractor(ctx, nfeatures=100)
+    rng = np.random.default_rng(3)
+    boxes = []
+    for k, im in enumerate(imgs):
+        nb = 0 if k == 2 else 40 + 30 * k
+        x = rng.integers(0, im.shape[1] - 1, nb); y = rng.integers(0, im.shape[0] - 1, nb)
+        boxes.append(np.stack([np.maximum(x - 10, 0), np.maximum(y - 10, 0), np.minimum(x + 10, im.shape[1] - 1), np.minimum(y + 10, im.shape[0] - 1)], 1).astype(np.int32))
+    ones = [ex.DetectBoxes(im, bx) for im, bx in zip(imgs, boxes)]
+    for sel in ([0, 1, 2, 3, 4], [5, 2], [6, 5, 4, 3, 2, 1, 0]):
+        got = ex.DetectBoxesBatch([imgs[i] for i in sel], [boxes[i] for i in sel])
+        for i, g in zip(sel, got):
+            assert len(g) == len(ones[i]) > 0 and g.tobytes() == ones[i].tobytes(), (sel, i)
+    assert ex.DetectBoxes(imgs[3], boxes[3]).tobytes() == ones[3].tobytes()
+
+
+def test_triangulate_batch_equals_single_calls(ctx):
+    """ssx_triangulate_batch returns per job the bits of ssx_triangulate (with and without T_wc, an empty job, 9 jobs)"""
+    rng = np.random.default_rng(5)
+    jobs = []
+    for k in range(9):
+        n = 0 if k == 4 else 50 + 77 * k
+        uvL = np.stack([rng.uniform(50, 1200, n), rng.uniform(20, 350, n)], 1)
+        uvR = uvL - np.stack([rng.uniform(-2, 90, n), np.zeros(n)], 1)
+        T = None if k % 2 else np.array([0.01 * k, -0.02, 0.005, 1.0, 0.3 * k, -0.1, 2.0 + k])
+        if T is not None:
+            T[:4] /= np.linalg.norm(T[:4])
+        jobs.append(dict(uvL=uvL, uvR=uvR, T_wc=T))
+    ones = [sorb.triangulate(ctx, j["uvL"], j["uvR"], T_wc=j["T_wc"]) for j in jobs]
+    got = sorb.triangulate_batch(ctx, jobs)
+    for k, (a, b) in enumerate(zip(got, ones)):
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes(), k
+
+
 @pytest.mark.parametrize("which", ["kitti_left", "kitti_right", "small"])
 def test_extract_bit_exact(ctx, po, pair_kitti, pair_small, which):
     img = {"kitti_left": pair_kitti[0], "kitti_right": pair_kitti[1], "small": pair_small[0]}[which]
