@@ -20,6 +20,8 @@ struct StreamBatcher::Impl {
                                    po_req(streams), det_req(streams), det_prm(streams), tri_req(streams), ba_win(streams, nullptr), ba_res(streams, nullptr),
                                    error(streams)
   {
+    n_in[(int)St::RUNNING] = streams;
+    for (int k = 0; k < streams; ++k) sleeper.push_back(std::make_unique<Sleeper>());
     disp = std::thread([this] { DispatchLoop(); });
     ba_disp = std::thread([this] { KeyframeLoop(); });
   }
@@ -34,25 +36,55 @@ struct StreamBatcher::Impl {
     if (ba_disp.joinable()) ba_disp.join();
   }
 
-  int count(St s) const { int n = 0; for (St x : state) n += x == s ? 1 : 0; return n; }
+  int count(St s) const { return n_in[(int)s]; }
+  // (m held) -- the dispatchers' conditions can only BECOME true when the last running stream stops running: they are woken then,
+  // not at every one of the S state changes of a round
+  bool Move(int k, St s)
+  {
+    --n_in[(int)state[k]]; ++n_in[(int)s];
+    state[k] = s;
+    return n_in[(int)St::RUNNING] == 0;
+  }
 
-  // the calling stream sleeps until a dispatcher has served its request; throws what the batch call reported
+  // the calling stream sleeps until a dispatcher has served its request; throws what the batch call reported.  Every stream sleeps
+  // on a condition variable of its own: S streams woken through one shared mutex queue up behind each other (64 wake-ups x a futex
+  // round trip each: more than the batched call they waited for).
   void SubmitAndWait(int k, St pending)
   {
-    std::unique_lock<std::mutex> lk(m);
-    error[k].clear();
-    state[k] = pending;
-    cv_disp.notify_all();
-    cv_done.wait(lk, [&] { return state[k] == St::RUNNING; });
+    bool wake;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      error[k].clear();
+      wake = Move(k, pending);
+    }
+    if (wake) cv_disp.notify_all();
+    Sleeper& sl = *sleeper[k];
+    std::unique_lock<std::mutex> lk(sl.mu);
+    sl.cv.wait(lk, [&] { return sl.done; });
+    sl.done = false;
     if (!error[k].empty()) throw std::runtime_error(error[k]);
   }
   void SetState(int k, St s)
   {
+    bool wake;
     {
       std::lock_guard<std::mutex> lk(m);
-      state[k] = s;
+      wake = Move(k, s);
     }
-    cv_disp.notify_all();
+    if (wake) cv_disp.notify_all();
+  }
+  // (m held by the caller) the streams of a finished batch run again
+  void Release(const std::vector<int>& who, const std::string& err)
+  {
+    for (int k : who) { error[k] = err; Move(k, St::RUNNING); }
+  }
+  void WakeStreams(const std::vector<int>& who)
+  {
+    for (int k : who) {
+      Sleeper& sl = *sleeper[k];
+      { std::lock_guard<std::mutex> lk(sl.mu); sl.done = true; }
+      sl.cv.notify_one();
+    }
   }
 
   void DispatchLoop()
@@ -68,7 +100,7 @@ struct StreamBatcher::Impl {
       // pose-only first: the cohort then reaches its next LK request where a straggler from a keyframe already waits (see the header)
       const St kind = count(St::PENDING_PO) > 0 ? St::PENDING_PO : St::PENDING_LK;
       who.clear();
-      for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); state[k] = St::INFLIGHT; }
+      for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); Move(k, St::INFLIGHT); }
       lk.unlock();
       std::string err;
       long d_calls = 0, d_jobs = 0;
@@ -101,8 +133,10 @@ struct StreamBatcher::Impl {
       const double dt = std::chrono::duration<double>(clk::now() - tc0).count();
       lk.lock();
       if (kind == St::PENDING_PO) { st.po_calls += d_calls; st.po_jobs += d_jobs; st.po_s += dt; } else { st.lk_calls += d_calls; st.lk_jobs += d_jobs; st.lk_s += dt; }
-      for (int k : who) { error[k] = err; state[k] = St::RUNNING; }
-      cv_done.notify_all();
+      Release(who, err);
+      lk.unlock();
+      WakeStreams(who);
+      lk.lock();
     }
   }
 
@@ -122,7 +156,7 @@ struct StreamBatcher::Impl {
       const St kind = count(St::PENDING_DET) > 0 ? St::PENDING_DET : count(St::PENDING_LKS) > 0 ? St::PENDING_LKS : count(St::PENDING_TRI) > 0 ? St::PENDING_TRI
                                                                                                                                               : St::PENDING_BA;
       who.clear();
-      for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); state[k] = St::INFLIGHT; }
+      for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); Move(k, St::INFLIGHT); }
       lk.unlock();
       cv_disp.notify_all();                         // (the per-frame dispatcher does not wait for streams that are in flight here)
       std::string err;
@@ -175,15 +209,20 @@ struct StreamBatcher::Impl {
       lk.lock();
       if (kind == St::PENDING_BA) { ++st.ba_calls; st.ba_jobs += (long)who.size(); st.ba_s += dtb; }
       else { ++st.kf_calls; st.kf_jobs += (long)who.size(); st.kf_s += dtb; }
-      for (int k : who) { error[k] = err; state[k] = St::RUNNING; }
-      cv_done.notify_all();
+      Release(who, err);
+      lk.unlock();
+      WakeStreams(who);
+      lk.lock();
     }
   }
 
   int device, S;
   ssx::Context lk_ctx, po_ctx, ba_ctx, det_ctx, lks_ctx, tri_ctx;
   std::mutex m;
-  std::condition_variable cv_disp, cv_done;
+  std::condition_variable cv_disp;
+  struct Sleeper { std::mutex mu; std::condition_variable cv; bool done = false; };
+  std::vector<std::unique_ptr<Sleeper>> sleeper;
+  int n_in[16] = {0};                               // streams per state
   std::vector<St> state;
   std::vector<ssx_lk_job> lk_req;
   std::vector<int> lk_rows, lk_cols;
