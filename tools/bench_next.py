@@ -62,6 +62,17 @@ def next_rows(ssvio_amd, ctx, cpu=True, voc_levels=6):
         row["cpu"] = {"ms_per_call": round(tc * 1e3, 3), "points_per_s": round(n / tc, 1), "cores": 1, "kind": "port",
                       "what": "oracle restatement of OpenCV's pyramidal LK (OpenCV itself cannot be built here)"}
         row["identical_to_cpu"] = bool(np.array_equal(rc[1], r[1]) and np.array_equal(rc[0][rc[1] > 0], r[0][r[1] > 0]))
+    # the batched form (one frame of each of S streams in one call: ssx_lk_track_batch, chained jobs on S slots of the context)
+    S_B = 64
+    imgs = [np.ascontiguousarray(np.roll(R, s_ % 7, axis=1)) for s_ in range(S_B)]
+    lk.track_batch(ctx, [dict(slot=s_, prev=L, next=imgs[s_], prev_pts=pts, next_pts=guess) for s_ in range(S_B)])          # fills the slots
+    jobs_b = [dict(slot=s_, prev=None, next=imgs[(s_ + 1) % S_B], prev_pts=pts, next_pts=guess) for s_ in range(S_B)]
+    dt_b, _ = _time(lambda: lk.track_batch(ctx, jobs_b), 10, warm=1)
+    lk_bytes_chained = (sum(px) + sum(px[1:])) + 2 * 4 * sum(px) + n * 4 * (169 * 5 + 1024)      # one new pyramid per job
+    row["batched"] = {"jobs_per_call": S_B, "ms_per_call": round(dt_b * 1e3, 4), "points_per_s": round(S_B * n / dt_b, 1),
+                      "hbm_frac": round(S_B * lk_bytes_chained / dt_b / 1e9 / HBM_PEAK_GBS, 6),
+                      "what": "ssx_lk_track_batch: 64 chained jobs (one frame of each of 64 streams) per call, host images staged by the call "
+                              "(StreamBatcher hands pinned images: nothing is staged then)"}
     out["lk"] = row
 
     # ---- A11: pose-only LM --------------------------------------------------------------------------------------------------
@@ -81,6 +92,11 @@ def next_rows(ssvio_amd, ctx, cpu=True, voc_levels=6):
                       "kind": "reference" if have_ref else "port",
                       "what": "the reference's own VertexPose + EdgeProjectionPoseOnly on g2o (oracle/_ref)" if have_ref else "oracle port"}
         row["max_pose_diff_vs_cpu"] = float(np.abs(rc["pose"] - r["pose"]).max())
+    probs_b = [synth.make_pose_only_problem(M=200, seed=100 + s_, frac_gross=0.05) for s_ in range(64)]
+    dt_b, _ = _time(lambda: ba.pose_only_opt_batch(ctx, probs_b), 20, warm=2)
+    row["batched"] = {"problems_per_call": 64, "ms_per_call": round(dt_b * 1e3, 4), "solves_per_s": round(64 / dt_b, 1),
+                      "flops_frac": round(64 * po_flops / dt_b / 1e12 / F64_PEAK_TFLOPS, 8),
+                      "what": "ssx_pose_only_opt_batch: one workgroup per problem, one launch, one synchronisation (Python builds the 64 job structs inside the clock)"}
     out["pose_only"] = row
 
     # ---- N2: vocabulary transform -------------------------------------------------------------------------------------------
@@ -123,7 +139,8 @@ def next_rows(ssvio_amd, ctx, cpu=True, voc_levels=6):
     row = {"keyframes": 500, "edges": int(E), "lm_iterations": nit, "ms_per_solve": round(dt * 1e3, 3), "iterations_per_s": round(nit / dt, 1),
            "chi2_first_last": [float(r["chi2_initial"]), float(r["chi2_final"])], "algorithmic_flops_per_solve": int(pg_flops),
            "flops_frac": round(pg_flops / dt / 1e12 / F64_PEAK_TFLOPS, 8),
-           "bound": "latency: the panel chain of the block-banded Cholesky (k_potrf64 / k_trsm64 / k_syrk64) per LM trial",
+           "bound": "latency: per LM trial 2 x 8 levels of block cyclic reduction (the free keyframes couple to their neighbours only: loop edges end at "
+                    "fixed keyframes, loopclosing.cpp:484-489) + one host synchronisation for the LM decision",
            "what": "ssx_pose_graph_opt, host arrays in / poses out"}
     if po:
         which = "ref" if have_ref else "oracle"

@@ -493,11 +493,13 @@ if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "corridor":
         n = int(sys.argv[3])
         nw = int(sys.argv[4]) if len(sys.argv) > 4 else max(1, min(os.cpu_count() or 1, 32))
-        fr, _, cen = make_corridor_sequence(n_frames=n, workers=nw)
+        step = float(sys.argv[5]) if len(sys.argv) > 5 else 0.8
+        amp = float(sys.argv[6]) if len(sys.argv) > 6 else 0.3
+        fr, _, cen = make_corridor_sequence(n_frames=n, workers=nw, step=step, lateral_amp=amp)
         os.makedirs(sys.argv[2], exist_ok=True)
         np.save(os.path.join(sys.argv[2], "centres.npy"), cen)
         write_kitti_sequence(sys.argv[2], fr)
         print(f"wrote {n} stereo pairs to {sys.argv[2]}")
     else:
-        print("usage: python -m tools.synth corridor <dir> <n_frames> [workers]", file=sys.stderr)
+        print("usage: python -m tools.synth corridor <dir> <n_frames> [workers [step_m [lateral_amp_m]]]", file=sys.stderr)
         sys.exit(2)
