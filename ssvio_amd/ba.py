@@ -110,8 +110,10 @@ class PoseOnlyJob(C.Structure):
                 ("chi2_th", C.c_double), ("huber_delta", C.c_double), ("inlier_out", u8_p), ("n_inliers", C.POINTER(C.c_int32))]
 
 
-def pose_only_opt_batch(ctx: Context, problems, rounds=4, iters=10, chi2_th=5.991, huber_delta=1.0):
-    """ssx_pose_only_opt_batch: problems = [dict(pose, K, xyz, uv)] -> [dict(pose, inliers, n_inliers)], one launch for all."""
+def pose_only_opt_batch(ctx: Context, problems, rounds=4, iters=10, chi2_th=5.991, huber_delta=1.0, prepared=False):
+    """ssx_pose_only_opt_batch: problems = [dict(pose, K, xyz, uv)] -> [dict(pose, inliers, n_inliers)], one launch for all.
+    prepared=True: -> a callable that restores the initial poses and makes the library call alone (the job structs built once, as a C
+    caller holds them)."""
     n = len(problems)
     arr = (PoseOnlyJob * n)()
     keep, outs = [], []
@@ -129,6 +131,16 @@ def pose_only_opt_batch(ctx: Context, problems, rounds=4, iters=10, chi2_th=5.99
         keep.append((K, xyz, uv)); outs.append((pose, inl, cnt))
     ctx.lib.ssx_pose_only_opt_batch.restype = C.c_int32
     ctx.lib.ssx_pose_only_opt_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PoseOnlyJob)]
+    if prepared:
+        init = [np.ascontiguousarray(pr["pose"], dtype=np.float64).copy() for pr in problems]
+
+        def run():
+            for (p_, _, _), p0 in zip(outs, init):
+                p_[:] = p0
+            ctx.check(ctx.lib.ssx_pose_only_opt_batch(ctx.handle, n, arr))
+            return [dict(pose=p_, inliers=i_, n_inliers=int(c_[0])) for p_, i_, c_ in outs]
+        run.keep = (keep, arr, outs)
+        return run
     ctx.check(ctx.lib.ssx_pose_only_opt_batch(ctx.handle, n, arr))
     return [dict(pose=p_, inliers=i_, n_inliers=int(c_[0])) for p_, i_, c_ in outs]
 

@@ -65,6 +65,54 @@ class LkJob(C.Structure):
                 ("prev_pts", f32_p), ("next_pts", f32_p), ("status", u8_p), ("err", f32_p)]
 
 
+class PreparedTrackBatch:
+    """ssx_lk_track_batch with everything a C caller holds between frames prepared once: the job structs, the points, and the images in
+    PINNED memory (ssx_host_alloc) handed over with images_on_device = 1 -- what ssvio_amd/host/stream_batcher.cpp does per frame.
+    run() is the library call alone; outputs in .outs [(next_pts, status, err)] (the guesses are restored before every run)."""
+
+    def __init__(self, ctx: Context, jobs, winSize=11, maxLevel=3, maxCount=30, epsilon=0.01, minEigThreshold=1e-4):
+        self.ctx = ctx
+        lib = ctx.lib
+        lib.ssx_host_alloc.restype = C.c_void_p; lib.ssx_host_alloc.argtypes = [C.c_size_t]
+        lib.ssx_host_free.restype = None; lib.ssx_host_free.argtypes = [C.c_void_p]
+        n = len(jobs)
+        self.arr = (LkJob * n)()
+        self.keep, self.outs, self.guess, self.pins = [], [], [], []
+        use_init = any(j.get("next_pts") is not None for j in jobs)
+        for i, j in enumerate(jobs):
+            nxt = _img(j["next"])
+            self.rows, self.cols = nxt.shape
+            pin = lib.ssx_host_alloc(nxt.size)
+            if not pin:
+                raise MemoryError("ssx_host_alloc")
+            C.memmove(pin, nxt.ctypes.data, nxt.size)
+            self.pins.append(pin)
+            pp = np.ascontiguousarray(j["prev_pts"], dtype=np.float32).reshape(-1, 2)
+            g = np.ascontiguousarray(j["next_pts"], dtype=np.float32).reshape(-1, 2).copy() if j.get("next_pts") is not None else pp.copy()
+            npts = g.copy(); st = np.zeros(len(pp), np.uint8); er = np.zeros(len(pp), np.float32)
+            a = self.arr[i]
+            a.slot = int(j["slot"]); a.prev = None; a.prev_stride = 0
+            a.next = C.cast(pin, u8_p); a.next_stride = self.cols
+            a.n = len(pp); a.prev_pts = pp.ctypes.data_as(f32_p); a.next_pts = npts.ctypes.data_as(f32_p)
+            a.status = st.ctypes.data_as(u8_p); a.err = er.ctypes.data_as(f32_p)
+            self.keep.append(pp); self.outs.append((npts, st, er)); self.guess.append(g)
+        self.n = n
+        self.prm = LkParams(int(winSize), int(maxLevel), int(maxCount), float(epsilon), float(minEigThreshold), int(use_init))
+        lib.ssx_lk_track_batch.restype = C.c_int
+        lib.ssx_lk_track_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(LkJob), C.c_int32, C.c_int32, C.POINTER(LkParams), C.c_int32]
+
+    def run(self):
+        for (npts, _, _), g in zip(self.outs, self.guess):
+            npts[:] = g
+        self.ctx.check(self.ctx.lib.ssx_lk_track_batch(self.ctx.handle, self.n, self.arr, self.rows, self.cols, C.byref(self.prm), 1))
+        return self.outs
+
+    def close(self):
+        for p_ in self.pins:
+            self.ctx.lib.ssx_host_free(p_)
+        self.pins = []
+
+
 def track_batch(ctx: Context, jobs, winSize=11, maxLevel=3, maxCount=30, epsilon=0.01, minEigThreshold=1e-4, images_on_device=False):
     """ssx_lk_track_batch: jobs = [dict(slot, prev (image or None = chained to the slot's last job), next, prev_pts, next_pts or None)];
     every job with the same image size.  -> [(next_pts, status, err)] per job.  images_on_device: the arrays' memory is readable by
