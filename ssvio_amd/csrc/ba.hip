@@ -2010,7 +2010,7 @@ ssx_status prepare(ssx_ctx* ctx, const ssx_ba_problem* pr, HostPrep& h, bool all
   // inside the range), the per-landmark offsets of the ranges are summed landmark-parallel, a second pass adds them -- the same
   // ranks as the serial loop, whatever the number of threads.
   static const int prep_threads = [] { const char* e = getenv("SSX_BA_PREP_THREADS"); const int v = e ? atoi(e) : 0;
-                                       return v > 0 ? std::min(v, 32) : std::min(8, std::max(1, (int)std::thread::hardware_concurrency())); }();
+                                       return v > 0 ? std::min(v, 32) : std::min(32, std::max(std::min(8, std::max(1, (int)std::thread::hardware_concurrency())), (int)std::thread::hardware_concurrency() / 2)); }();   // (measured at configs[3] on a 256-core host: 1.70 / 1.27 / 0.74 ms of prepare() on 8 / 16 / 32 threads, profiles/r06/c4_prepare_threads.txt)
   const int T = (big_dev && !dead_ok && E >= (1 << 16) && ctx->ba) ? (g_prep_threads_override > 0 ? g_prep_threads_override : prep_threads) : 1;
   if (T > 1) {
     h.thr_cnt.resize((size_t)T * L); h.thr_pe.resize((size_t)T * (h.nP + 1));
