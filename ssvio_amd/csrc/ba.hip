@@ -2746,7 +2746,7 @@ ssx_status raw_upload_early(ssx_ctx* ctx, const ssx_ba_problem* pr)
   add(re.o_pose, pr->edge_pose, sizeof(int) * (size_t)E); add(re.o_point, pr->edge_point, sizeof(int) * (size_t)E);
   add(re.o_uv, pr->edge_uv, sizeof(double) * 2 * (size_t)E);
   if (have_cam) add(re.o_cam, pr->edge_cam, (size_t)E);
-  ws->pool.run((int)cps.size(), std::min<int>(8, (int)cps.size()), [&](int q) { memcpy(hs + cps[q].off, cps[q].src, cps[q].n); });
+  ws->pool.run((int)cps.size(), std::min<int>(16, (int)cps.size()), [&](int q) { memcpy(hs + cps[q].off, cps[q].src, cps[q].n); });
   SSX_HIP_TRY(ctx, hipMemcpyAsync(ws->raw_d.p, hs, in.off, hipMemcpyHostToDevice, ctx->stream));
   re.valid = true; re.key = pr->edge_pose; re.E = E;
   ws->raw_early = re;
@@ -2809,7 +2809,7 @@ ssx_status big_records(ssx_ctx* ctx, const ssx_ba_problem* pr, const HostPrep& h
     }
     add(o_slot8, h.slot8.data(), (size_t)E);
   }
-  ws->pool.run((int)cps.size(), std::min<int>(8, (int)cps.size()), [&](int q) { memcpy(hs + cps[q].off, cps[q].src, cps[q].n); });
+  ws->pool.run((int)cps.size(), std::min<int>(16, (int)cps.size()), [&](int q) { memcpy(hs + cps[q].off, cps[q].src, cps[q].n); });
   SSX_HIP_TRY(ctx, hipMemcpyAsync(dv, hs, in_bytes, hipMemcpyHostToDevice, s));
   r = BaDev{};
   r.P = P; r.L = L; r.E = E; r.E_raw = h.E_raw; r.nP = nP; r.nLm = nLm; r.nCh = nCh; r.nBlk = 0; r.big = 1; r.dev_prep = 1; r.bseg_cap = 0;
