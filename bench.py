@@ -810,16 +810,17 @@ def main():
             # configs[4] on ONE GPU, closed loop: S streams of the same drive, their per-frame LK / pose-only calls and their window
             # optimisations issued as BATCHED library calls (ssvio_amd/host/stream_batcher.hpp); every stream's trajectory is
             # byte-identical to the single-stream run's (checked here for every stream of every S)
-            c5 = {"what": "ssx_run_kitti --streams=S --batched=1 --preload=1: S concurrent streams (full front-end + backend each) on one GPU; "
+            c5 = {"what": "ssx_run_kitti --streams=S --batched=C --preload=1 (C cohorts of streams, each batched on its own): S concurrent streams (full front-end + backend each) on one GPU; "
                           "frames_per_s = all streams' frames / (common start -> last stream's end); frames decoded beforehand",
                   "frames_per_stream": args.c1_frames, "runs": {}}
             ref_traj = open(traj_w).read()
-            for S_ in (8, 32, 64):
-                out_b, traj_b = run_kitti(f"batched{S_}", {}, (f"--streams={S_}", "--preload=1", "--batched=1"))
+            for S_ in (8, 32, 64, 128):
+                cohorts = 2 if S_ >= 64 else 1                           # (two cohorts: one's images cross PCIe while the other's kernels run)
+                out_b, traj_b = run_kitti(f"batched{S_}", {}, (f"--streams={S_}", "--preload=1", f"--batched={cohorts}"))
                 mb = re.search(r"streams \(batched\): (\d+) frames in ([0-9.]+) s from the common start to the last stream's end = ([0-9.]+) frames/s", out_b)
                 mc = re.search(r"batched calls: LK (\d+) \(([\d.]+) jobs each\), pose-only (\d+) \(([\d.]+)\), window solves (\d+) \(([\d.]+)\)", out_b)
                 same = all(os.path.exists(f"{traj_b}.{k}") and open(f"{traj_b}.{k}").read() == ref_traj for k in range(S_))
-                c5["runs"][str(S_)] = {"frames_per_s": float(mb.group(3)) if mb else None, "seconds": float(mb.group(2)) if mb else None,
+                c5["runs"][str(S_)] = {"frames_per_s": float(mb.group(3)) if mb else None, "seconds": float(mb.group(2)) if mb else None, "cohorts": cohorts,
                                         "jobs_per_call": {"lk": float(mc.group(2)), "pose_only": float(mc.group(4)), "window_solve": float(mc.group(6))} if mc else None,
                                         "every_stream_byte_identical_to_the_single_stream_run": same}
             # the hard drive: the closed loop with a backend that works (>= 40 windows of >= 4000 edges in 240 frames)

@@ -478,8 +478,22 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
   const size_t in_bytes = io.off;
   const size_t o_st = io.take(std::max<size_t>(n_pts, 1));
   const size_t o_er = io.take(sizeof(float) * std::max<size_t>(n_pts, 1));
+  const size_t host_end = io.off;                                    // (what has a pinned mirror: inputs by copy + results)
+  // images_on_device: when the callers' `next` images lie at a constant distance from each other (one pinned arena, a slice per stream:
+  // ssvio_amd/host/stream_batcher.cpp) ONE copy on the DMA engine brings them into a staging block in HBM -- 54 GB/s, against 32 GB/s for
+  // the level-0 kernel reading the host pixels itself (0.95 ms of a 1.4 ms call for 64 frames; a kernel with 16-byte loads: no better --
+  // profiles/r06/c5_kernel_stats.txt).  Images elsewhere are read where they lie.
+  auto span = [&](int stride) { return (size_t)(rows - 1) * (size_t)stride + (size_t)cols; };
+  size_t arena_bytes = 0, o_arena = 0;                              // the range [jobs[0].next, last job's end) when it is worth one copy
+  if (images_on_device && nj >= 2) {
+    bool ok = true;
+    for (int j = 1; ok && j < nj; ++j)
+      ok = jobs[j].next_stride == jobs[0].next_stride && jobs[j].next > jobs[j - 1].next && (size_t)(jobs[j].next - jobs[j - 1].next) >= span(jobs[0].next_stride);
+    const size_t range = ok ? (size_t)(jobs[nj - 1].next - jobs[0].next) + span(jobs[0].next_stride) : 0;
+    if (ok && range <= 2 * (size_t)nj * span(jobs[0].next_stride)) { arena_bytes = range; o_arena = io.take(range + 16); }   // (gaps: streams that sit this call out)
+  }
   SSX_HIP_TRY(ctx, ws->io.reserve(io.off, 1.5));
-  SSX_HIP_TRY(ctx, ws->stage.reserve(io.off, 1.5));
+  SSX_HIP_TRY(ctx, ws->stage.reserve(host_end, 1.5));
   char* hs = ws->stage.as<char>();
   char* db = ws->io.as<char>();
   LkJob* tab = reinterpret_cast<LkJob*>(hs + o_tab);
@@ -490,6 +504,7 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
     t.pyr[0] = slot[j]->pyr[0]; t.pyr[1] = slot[j]->pyr[1]; t.deriv = slot[j]->deriv;
     if (images_on_device) {
       t.img[0] = q.prev; t.img[1] = q.next; t.stride[0] = q.prev_stride; t.stride[1] = q.next_stride;
+      if (arena_bytes) t.img[1] = (const uint8_t*)(db + o_arena) + (size_t)(q.next - jobs[0].next);
     } else {
       for (int y = 0; y < rows; ++y) {
         if (q.prev) memcpy(hs + o_img0[j] + (size_t)y * cols, q.prev + (size_t)y * q.prev_stride, cols);
@@ -507,6 +522,7 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
   }
   SSX_HIP_TRY(ctx, hipMemcpyAsync(db, hs, in_bytes, hipMemcpyHostToDevice, s));
   const LkJob* dtab = reinterpret_cast<const LkJob*>(db + o_tab);
+  if (arena_bytes) SSX_HIP_TRY(ctx, hipMemcpyAsync(db + o_arena, jobs[0].next, arena_bytes, hipMemcpyDefault, s));
   for (int which = any_fresh ? 0 : 1; which < 2; ++which) {
     const dim3 g0((d.cols[0] + 2 * d.pad + 255) / 256, d.rows[0] + 2 * d.pad, nj);
     hipLaunchKernelGGL(k_lk_pad_level0, g0, dim3(256), 0, s, d, dtab, which);
@@ -529,7 +545,7 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
     d.status = (uint8_t*)(db + o_st); d.err = (float*)(db + o_er);
     hipLaunchKernelGGL(k_lk_track, dim3((max_n + 3) / 4, nj), dim3(256), 0, s, d, dtab);
     SSX_HIP_TRY(ctx, hipGetLastError());
-    SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_np, db + o_np, io.off - o_np, hipMemcpyDeviceToHost, s));
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(hs + o_np, db + o_np, host_end - o_np, hipMemcpyDeviceToHost, s));
   }
   SSX_HIP_TRY(ctx, hipGetLastError());
   SSX_HIP_TRY(ctx, hipStreamSynchronize(s));

@@ -9,8 +9,9 @@
 // its own System, GPU contexts and prefetcher) on the same sequence: a single stream is latency-bound, several fill the
 // GPU (BASELINE configs[4] runs one stream per GPU; this is the one-GPU version of it).  --kitti_dataset_path may be a
 // comma-separated list: stream k then runs sequence k mod (number of sequences) -- several DIFFERENT sequences at once.
-// --batched=1 (with --streams=K): the streams' per-frame compute calls and window optimisations go to the GPU as batched library
-// calls (StreamBatcher, stream_batcher.hpp); every stream's trajectory stays byte-identical to its single-stream run.
+// --batched=C (with --streams=K): the streams' per-frame compute calls and window optimisations go to the GPU as batched library
+// calls (StreamBatcher, stream_batcher.hpp), the streams dealt to C cohorts that are batched independently (C = 2: one cohort's call
+// on the GPU while the other's streams run their host code); every stream's trajectory stays byte-identical to its single-stream run.
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -94,9 +95,10 @@ int main(int argc, char** argv)
           StereoPrefetcher pf(sq.left_paths, sq.right_paths, sq.num_images, 32);
           for (size_t ni = 0; ni < sq.num_images; ++ni) sq.preloaded.push_back(pf.Next());
         }
-      const bool batched = !batched_s.empty() && std::atoi(batched_s.c_str()) != 0;
+      const int cohorts = batched_s.empty() ? 0 : std::atoi(batched_s.c_str());      // --batched=C: C cohorts of streams, each batched on its own
+      const bool batched = cohorts > 0;
       std::unique_ptr<StreamBatcher> batcher;
-      if (batched) batcher = std::make_unique<StreamBatcher>(device, streams);
+      if (batched) batcher = std::make_unique<StreamBatcher>(device, streams, cohorts);
       // every stream builds its System (GPU contexts, window) first; the clock of the aggregate figure starts when all are ready
       std::mutex bm;
       std::condition_variable bcv;

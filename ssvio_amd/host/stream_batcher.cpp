@@ -34,6 +34,22 @@ struct StreamBatcher::Impl {
     cv_disp.notify_all();
     if (disp.joinable()) disp.join();
     if (ba_disp.joinable()) ba_disp.join();
+    ssx_host_free(pin_arena);
+  }
+
+  // The streams' pinned image buffers are slices of ONE arena: buffer `which` of stream k at (which * S + k) * slice.  The `next`
+  // images of a cohort's LK jobs then lie at a constant distance and cross PCIe in one DMA copy (ssx_lk_track_batch).
+  uint8_t* PinSlice(int k, int which, size_t bytes)
+  {
+    std::lock_guard<std::mutex> lk(pin_mu);
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (!pin_arena) {
+      pin_slice = need;
+      pin_arena = static_cast<uint8_t*>(ssx_host_alloc(pin_slice * 2 * (size_t)S));
+      if (!pin_arena) throw std::runtime_error("StreamBatcher: no pinned memory for the streams' images");
+    }
+    if (need > pin_slice) return nullptr;           // (a stream with larger images than the first one: it keeps buffers of its own)
+    return pin_arena + ((size_t)which * S + k) * pin_slice;
   }
 
   int count(St s) const { return n_in[(int)s]; }
@@ -216,6 +232,9 @@ struct StreamBatcher::Impl {
     }
   }
 
+  std::mutex pin_mu;
+  uint8_t* pin_arena = nullptr;
+  size_t pin_slice = 0;
   int device, S;
   ssx::Context lk_ctx, po_ctx, ba_ctx, det_ctx, lks_ctx, tri_ctx;
   std::mutex m;
@@ -290,7 +309,7 @@ class BatchedBaWindow final : public BaWindow {
 class BatchedCompute final : public Compute {
  public:
   BatchedCompute(StreamBatcher::Impl& im, int k) : im_(im), k_(k), frame_(im.device) {}
-  ~BatchedCompute() override { ssx_host_free(pin_[0]); ssx_host_free(pin_[1]); }
+  ~BatchedCompute() override { if (own_pins_) { ssx_host_free(pin_[0]); ssx_host_free(pin_[1]); } }
 
   void Detect(const Image& img, const uint8_t* mask, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
   {
@@ -396,8 +415,10 @@ class BatchedCompute final : public Compute {
   {
     const size_t bytes = (size_t)img.rows * img.cols;
     if (bytes > pin_bytes_) {
-      ssx_host_free(pin_[0]); ssx_host_free(pin_[1]);
-      pin_[0] = static_cast<uint8_t*>(ssx_host_alloc(bytes)); pin_[1] = static_cast<uint8_t*>(ssx_host_alloc(bytes));
+      if (own_pins_) { ssx_host_free(pin_[0]); ssx_host_free(pin_[1]); }
+      pin_[0] = im_.PinSlice(k_, 0, bytes); pin_[1] = im_.PinSlice(k_, 1, bytes);
+      own_pins_ = !pin_[0] || !pin_[1];
+      if (own_pins_) { pin_[0] = static_cast<uint8_t*>(ssx_host_alloc(bytes)); pin_[1] = static_cast<uint8_t*>(ssx_host_alloc(bytes)); }
       if (!pin_[0] || !pin_[1]) throw std::runtime_error("StreamBatcher: no pinned memory for the stream's images");
       pin_bytes_ = bytes; pin_id_[0] = pin_id_[1] = 0;
     }
@@ -415,30 +436,47 @@ class BatchedCompute final : public Compute {
   uint8_t* pin_[2] = {nullptr, nullptr};
   uint64_t pin_id_[2] = {0, 0};
   size_t pin_bytes_ = 0;
+  bool own_pins_ = false;
   uint64_t chain_next_id_ = 0;
   int chain_rows_ = 0, chain_cols_ = 0;
 };
 
 }  // namespace
 
-StreamBatcher::StreamBatcher(int device, int streams) : impl_(std::make_unique<Impl>(device, std::max(streams, 1))) {}
+// `cohorts` independent batchers, stream k in cohort k mod cohorts: while one cohort's batch is on the GPU the other cohort's streams do
+// their host work (bookkeeping, the copy of the next frame into pinned memory, the wake-ups) -- two cohorts ping-pong
+StreamBatcher::StreamBatcher(int device, int streams, int cohorts)
+{
+  streams = std::max(streams, 1);
+  const int C = std::max(1, std::min(cohorts, streams));
+  for (int c = 0; c < C; ++c) impls_.push_back(std::make_unique<Impl>(device, (streams - c + C - 1) / C));
+  n_streams_ = streams;
+}
 StreamBatcher::~StreamBatcher() = default;
 
 std::unique_ptr<Compute> StreamBatcher::MakeCompute(int k)
 {
-  if (k < 0 || k >= impl_->S) throw std::invalid_argument("StreamBatcher::MakeCompute: stream index out of range");
-  return std::make_unique<BatchedCompute>(*impl_, k);
+  if (k < 0 || k >= n_streams_) throw std::invalid_argument("StreamBatcher::MakeCompute: stream index out of range");
+  const int C = (int)impls_.size();
+  return std::make_unique<BatchedCompute>(*impls_[k % C], k / C);
 }
 
 void StreamBatcher::Finish(int k)
 {
-  if (k >= 0 && k < impl_->S) impl_->SetState(k, St::DONE);
+  const int C = (int)impls_.size();
+  if (k >= 0 && k < n_streams_) impls_[k % C]->SetState(k / C, St::DONE);
 }
 
 StreamBatcher::Stats StreamBatcher::stats()
 {
-  std::lock_guard<std::mutex> lk(impl_->m);
-  return impl_->st;
+  Stats t;
+  for (auto& im : impls_) {
+    std::lock_guard<std::mutex> lk(im->m);
+    const Stats& a = im->st;
+    t.lk_calls += a.lk_calls; t.lk_jobs += a.lk_jobs; t.po_calls += a.po_calls; t.po_jobs += a.po_jobs; t.ba_calls += a.ba_calls; t.ba_jobs += a.ba_jobs;
+    t.kf_calls += a.kf_calls; t.kf_jobs += a.kf_jobs; t.lk_s += a.lk_s; t.po_s += a.po_s; t.ba_s += a.ba_s; t.kf_s += a.kf_s; t.wait_s += a.wait_s;
+  }
+  return t;
 }
 
 }  // namespace ssx::host

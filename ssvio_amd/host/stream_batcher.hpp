@@ -33,7 +33,9 @@ namespace ssx::host {
 
 class StreamBatcher {
  public:
-  StreamBatcher(int device, int streams);
+  // cohorts > 1: the streams are dealt to that many independent batchers (stream k -> cohort k mod cohorts), each with its own
+  // dispatchers and contexts: one cohort's batched call runs on the GPU while the other cohort's streams run their host code
+  StreamBatcher(int device, int streams, int cohorts = 1);
   ~StreamBatcher();
   StreamBatcher(const StreamBatcher&) = delete;
   StreamBatcher& operator=(const StreamBatcher&) = delete;
@@ -53,7 +55,8 @@ class StreamBatcher {
   struct Impl;
 
  private:
-  std::unique_ptr<Impl> impl_;
+  std::vector<std::unique_ptr<Impl>> impls_;
+  int n_streams_ = 0;
 };
 
 }  // namespace ssx::host

@@ -314,13 +314,13 @@ def test_batched_streams_reproduce_the_single_stream_trajectories(built, tmp_pat
     for rep in range(2):                                           # (thread timing differs from run to run: the files must not)
         many = os.path.join(str(tmp_path), f"many{rep}.txt")
         r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={a['dir']},{b['dir']}", f"--trajectory={many}",
-                            "--streams=12", "--preload=1", "--batched=1"], capture_output=True, text=True, timeout=600)
+                            "--streams=12", "--preload=1", f"--batched={1 + rep}"], capture_output=True, text=True, timeout=600)   # one cohort, then two
         assert r.returncode == 0, r.stdout + r.stderr
         for k in range(12):
             assert open(f"{many}.{k}").read() == singles[k % 2], (rep, k)
         m = re.search(r"batched calls: LK (\d+) \(([\d.]+) jobs each\), pose-only (\d+) \(([\d.]+)\), window solves (\d+) \(([\d.]+)\)", r.stdout)
         assert m, r.stdout
-        assert float(m.group(2)) > 3.0 and float(m.group(4)) > 3.0 and int(m.group(5)) >= 1, r.stdout
+        assert float(m.group(2)) > (3.0 if rep == 0 else 1.5) and float(m.group(4)) > (3.0 if rep == 0 else 1.5) and int(m.group(5)) >= 1, r.stdout
 
 
 def test_runner_arguments(built, tmp_path):

@@ -26,8 +26,9 @@ ref = open(t1).read()
 print(re.search(r"RunStep.*", out1).group(0))
 for S in Ss:
     if S == 1: continue
-    for batched in (0, 1):
+    for batched in (0, 1, 2, 3):
         if not batched and S > 16: continue
+        if batched > 1 and S < 16: continue
         out, tr = run((f"--streams={S}", "--preload=1", f"--batched={batched}"), f"s{S}b{batched}")
         same = all(open(f"{tr}.{k}").read() == ref for k in range(S))
         m = re.search(r"from the common start to the last stream's end = ([0-9.]+) frames/s", out)
