@@ -434,6 +434,7 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
     const ssx_lk_job& q = jobs[j];
     if (!q.next || q.n < 0 || (q.n > 0 && (!q.prev_pts || !q.next_pts || !q.status))) return SSX_ERR_INVALID_ARG;
     if ((q.prev && q.prev_stride < cols) || q.next_stride < cols) { ctx->set_error("ssx_lk: stride smaller than the image width"); return SSX_ERR_INVALID_ARG; }
+    if (q.slot < 0 || q.slot >= 4096) { ctx->set_error("ssx_lk: slot %d outside 0..4095", q.slot); return SSX_ERR_INVALID_ARG; }   // (before any slot is touched)
     for (int k = 0; k < j; ++k) if (jobs[k].slot == q.slot) { ctx->set_error("ssx_lk_track_batch: slot %d twice in one call", q.slot); return SSX_ERR_INVALID_ARG; }
     if (!q.prev) {
       any_chained = true;

@@ -90,9 +90,48 @@ struct StreamBatcher::Impl {
     if (wake) cv_disp.notify_all();
   }
   // (m held by the caller) the streams of a finished batch run again
-  void Release(const std::vector<int>& who, const std::string& err)
+  void Release(const std::vector<int>& who, const std::vector<std::string>& errs)
   {
-    for (int k : who) { error[k] = err; Move(k, St::RUNNING); }
+    for (size_t i = 0; i < who.size(); ++i) { error[who[i]] = errs[i]; Move(who[i], St::RUNNING); }
+  }
+  // One batched call for the requests idx (positions in `who`).  If it fails, every request goes once more in a call of its own:
+  // only the stream whose request is at fault sees the error, the others get their results (the library validates a job table before
+  // it touches anything, so a rejected call has not run any of its jobs).
+  template <class F>
+  static void Isolated(const std::vector<size_t>& idx, std::vector<std::string>& errs, long& calls, long& jobs, F&& call)
+  {
+    try {
+      call(idx);
+      ++calls; jobs += (long)idx.size();
+      return;
+    } catch (const std::exception& e) {
+      if (idx.size() == 1) { errs[idx[0]] = e.what(); return; }
+    }
+    for (size_t i : idx) {
+      try { call(std::vector<size_t>{i}); ++calls; ++jobs; } catch (const std::exception& e) { errs[i] = e.what(); }
+    }
+  }
+  // the requests of `who` in groups of equal key (image size, extractor settings ...): one call per group
+  template <class Same>
+  static std::vector<std::vector<size_t>> Groups(size_t n, Same&& same)
+  {
+    std::vector<std::vector<size_t>> g;
+    std::vector<char> taken(n, 0);
+    for (size_t a = 0; a < n; ++a) {
+      if (taken[a]) continue;
+      g.emplace_back();
+      for (size_t b = a; b < n; ++b) if (!taken[b] && same(a, b)) { g.back().push_back(b); taken[b] = 1; }
+    }
+    return g;
+  }
+  void LkCall(ssx::Context& ctx, const std::vector<int>& who, const std::vector<size_t>& sub)
+  {
+    std::vector<ssx_lk_job> jobs;
+    for (size_t i : sub) jobs.push_back(lk_req[who[i]]);
+    ssx_lk_params p;
+    ssx_lk_default_params(&p);
+    p.win = 11; p.max_level = 3; p.max_iters = 30; p.eps = 0.01; p.use_initial_flow = 1;
+    ctx.check(ssx_lk_track_batch(ctx.get(), (int32_t)jobs.size(), jobs.data(), lk_rows[who[sub[0]]], lk_cols[who[sub[0]]], &p, 1));
   }
   void WakeStreams(const std::vector<int>& who)
   {
@@ -118,38 +157,26 @@ struct StreamBatcher::Impl {
       who.clear();
       for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); Move(k, St::INFLIGHT); }
       lk.unlock();
-      std::string err;
+      std::vector<std::string> errs(who.size());
       long d_calls = 0, d_jobs = 0;
       const auto tc0 = clk::now();
-      try {
-        if (kind == St::PENDING_PO) {
+      if (kind == St::PENDING_PO) {
+        std::vector<size_t> all(who.size());
+        for (size_t i = 0; i < all.size(); ++i) all[i] = i;
+        Isolated(all, errs, d_calls, d_jobs, [&](const std::vector<size_t>& sub) {
           std::vector<ssx_pose_only_job> jobs;
-          for (int k : who) jobs.push_back(po_req[k]);
+          for (size_t i : sub) jobs.push_back(po_req[who[i]]);
           po_ctx.check(ssx_pose_only_opt_batch(po_ctx.get(), (int32_t)jobs.size(), jobs.data()));
-          ++d_calls; d_jobs += (long)jobs.size();
-        } else {
-          // (jobs of one call share the image size: streams of another size go in a call of their own)
-          std::vector<char> taken(who.size(), 0);
-          for (size_t a = 0; a < who.size(); ++a) {
-            if (taken[a]) continue;
-            std::vector<ssx_lk_job> jobs;
-            const int rows = lk_rows[who[a]], cols = lk_cols[who[a]];
-            for (size_t b = a; b < who.size(); ++b)
-              if (!taken[b] && lk_rows[who[b]] == rows && lk_cols[who[b]] == cols) { jobs.push_back(lk_req[who[b]]); taken[b] = 1; }
-            ssx_lk_params p;
-            ssx_lk_default_params(&p);
-            p.win = 11; p.max_level = 3; p.max_iters = 30; p.eps = 0.01; p.use_initial_flow = 1;
-            lk_ctx.check(ssx_lk_track_batch(lk_ctx.get(), (int32_t)jobs.size(), jobs.data(), rows, cols, &p, 1));
-            ++d_calls; d_jobs += (long)jobs.size();
-          }
-        }
-      } catch (const std::exception& e) {
-        err = e.what();
+        });
+      } else {
+        // (jobs of one call share the image size: streams of another size go in a call of their own)
+        for (const auto& g : Groups(who.size(), [&](size_t a, size_t b) { return lk_rows[who[a]] == lk_rows[who[b]] && lk_cols[who[a]] == lk_cols[who[b]]; }))
+          Isolated(g, errs, d_calls, d_jobs, [&](const std::vector<size_t>& sub) { LkCall(lk_ctx, who, sub); });
       }
       const double dt = std::chrono::duration<double>(clk::now() - tc0).count();
       lk.lock();
       if (kind == St::PENDING_PO) { st.po_calls += d_calls; st.po_jobs += d_jobs; st.po_s += dt; } else { st.lk_calls += d_calls; st.lk_jobs += d_jobs; st.lk_s += dt; }
-      Release(who, err);
+      Release(who, errs);
       lk.unlock();
       WakeStreams(who);
       lk.lock();
@@ -175,57 +202,51 @@ struct StreamBatcher::Impl {
       for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); Move(k, St::INFLIGHT); }
       lk.unlock();
       cv_disp.notify_all();                         // (the per-frame dispatcher does not wait for streams that are in flight here)
-      std::string err;
+      std::vector<std::string> errs(who.size());
+      long d_calls = 0, d_jobs = 0;
       const auto tb0 = std::chrono::steady_clock::now();
-      try {
-        if (kind == St::PENDING_BA) {
+      std::vector<size_t> all(who.size());
+      for (size_t i = 0; i < all.size(); ++i) all[i] = i;
+      if (kind == St::PENDING_BA) {
+        Isolated(all, errs, d_calls, d_jobs, [&](const std::vector<size_t>& sub) {
           std::vector<ssx_ba_window*> wins;
           std::vector<ssx_ba_result> res;
-          for (int k : who) { wins.push_back(ba_win[k]); res.push_back(*ba_res[k]); }
+          for (size_t i : sub) { wins.push_back(ba_win[who[i]]); res.push_back(*ba_res[who[i]]); }
           ba_ctx.check(ssx_ba_window_solve_batch((int32_t)wins.size(), wins.data(), res.data()));
-          for (size_t i = 0; i < who.size(); ++i) *ba_res[who[i]] = res[i];
-        } else if (kind == St::PENDING_TRI) {
+          for (size_t j = 0; j < sub.size(); ++j) *ba_res[who[sub[j]]] = res[j];
+        });
+      } else if (kind == St::PENDING_TRI) {
+        Isolated(all, errs, d_calls, d_jobs, [&](const std::vector<size_t>& sub) {
           std::vector<ssx_triangulate_job> jobs;
-          for (int k : who) jobs.push_back(tri_req[k]);
+          for (size_t i : sub) jobs.push_back(tri_req[who[i]]);
           tri_ctx.check(ssx_triangulate_batch(tri_ctx.get(), (int32_t)jobs.size(), jobs.data()));
-        } else if (kind == St::PENDING_LKS) {
-          std::vector<char> taken(who.size(), 0);
-          for (size_t a = 0; a < who.size(); ++a) {
-            if (taken[a]) continue;
-            std::vector<ssx_lk_job> jobs;
-            const int rows = lk_rows[who[a]], cols = lk_cols[who[a]];
-            for (size_t b = a; b < who.size(); ++b)
-              if (!taken[b] && lk_rows[who[b]] == rows && lk_cols[who[b]] == cols) { jobs.push_back(lk_req[who[b]]); taken[b] = 1; }
-            ssx_lk_params p;
-            ssx_lk_default_params(&p);
-            p.win = 11; p.max_level = 3; p.max_iters = 30; p.eps = 0.01; p.use_initial_flow = 1;
-            lks_ctx.check(ssx_lk_track_batch(lks_ctx.get(), (int32_t)jobs.size(), jobs.data(), rows, cols, &p, 1));
-          }
-        } else {
-          // detection: the jobs of a call share image size, stride and extractor settings
-          std::vector<char> taken(who.size(), 0);
-          for (size_t a = 0; a < who.size(); ++a) {
-            if (taken[a]) continue;
-            const int ka = who[a];
+        });
+      } else if (kind == St::PENDING_LKS) {
+        for (const auto& g : Groups(who.size(), [&](size_t a, size_t b) { return lk_rows[who[a]] == lk_rows[who[b]] && lk_cols[who[a]] == lk_cols[who[b]]; }))
+          Isolated(g, errs, d_calls, d_jobs, [&](const std::vector<size_t>& sub) { LkCall(lks_ctx, who, sub); });
+      } else {
+        // detection: the jobs of a call share image size, stride and extractor settings
+        auto same = [&](size_t a, size_t b) {
+          const int ka = who[a], kb = who[b];
+          return lk_rows[kb] == lk_rows[ka] && lk_cols[kb] == lk_cols[ka] && det_req[kb].stride == det_req[ka].stride &&
+                 std::memcmp(&det_prm[kb], &det_prm[ka], sizeof(ssx_orb_params)) == 0;
+        };
+        for (const auto& g : Groups(who.size(), same))
+          Isolated(g, errs, d_calls, d_jobs, [&](const std::vector<size_t>& sub) {
             std::vector<ssx_orb_detect_job> jobs;
-            for (size_t b = a; b < who.size(); ++b) {
-              const int kb = who[b];
-              if (taken[b] || lk_rows[kb] != lk_rows[ka] || lk_cols[kb] != lk_cols[ka] || det_req[kb].stride != det_req[ka].stride ||
-                  std::memcmp(&det_prm[kb], &det_prm[ka], sizeof(ssx_orb_params)) != 0)
-                continue;
-              jobs.push_back(det_req[kb]); taken[b] = 1;
-            }
-            det_ctx.check(ssx_orb_detect_boxes_batch(det_ctx.get(), (int32_t)jobs.size(), jobs.data(), lk_rows[ka], lk_cols[ka], &det_prm[ka], 1));
-          }
-        }
-      } catch (const std::exception& e) {
-        err = e.what();
+            for (size_t i : sub) jobs.push_back(det_req[who[i]]);
+            const int k0 = who[sub[0]];
+            const ssx_status rc = ssx_orb_detect_boxes_batch(det_ctx.get(), (int32_t)jobs.size(), jobs.data(), lk_rows[k0], lk_cols[k0], &det_prm[k0], 1);
+            // (SSX_ERR_CAPACITY is per image -- the other images of the call are complete: every stream looks at its own count)
+            if (rc != SSX_ERR_CAPACITY) det_ctx.check(rc);
+          });
       }
+      (void)d_calls; (void)d_jobs;
       const double dtb = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
       lk.lock();
       if (kind == St::PENDING_BA) { ++st.ba_calls; st.ba_jobs += (long)who.size(); st.ba_s += dtb; }
       else { ++st.kf_calls; st.kf_jobs += (long)who.size(); st.kf_s += dtb; }
-      Release(who, err);
+      Release(who, errs);
       lk.unlock();
       WakeStreams(who);
       lk.lock();
@@ -334,10 +355,8 @@ class BatchedCompute final : public Compute {
     q.img = pinned; q.stride = img.cols; q.boxes_xyxy = boxes.data(); q.n_boxes = (int32_t)(boxes.size() / 4);
     q.cap = (int32_t)kps.size(); q.kps_out = kps.data(); q.n_out = &n;
     im_.det_prm[k_] = prm; im_.lk_rows[k_] = img.rows; im_.lk_cols[k_] = img.cols;
-    try {
-      im_.SubmitAndWait(k_, St::PENDING_DET);
-    } catch (const std::exception&) {
-      if (n <= (int32_t)kps.size()) throw;
+    im_.SubmitAndWait(k_, St::PENDING_DET);
+    if (n > (int32_t)kps.size()) {
       // (a grid returned more than the bound of ssx.h: once more with the size it asked for, on the stream's own context)
       LongOp op(im_, k_);
       kps.assign((size_t)n, ssx_keypoint{});

@@ -111,4 +111,8 @@ def build_test_binaries():
         subprocess.check_call(["g++", *flags, os.path.join(src, "test_units.cpp"), host_lib, b.LIB, "-lpthread", *rpath, "-o", units])
     if not (os.path.exists(runner) and os.path.getmtime(runner) >= newest):
         subprocess.check_call(["g++", *flags, os.path.join(src, "oracle_runner.cpp"), host_lib, b.LIB, oracle_lib, "-lpthread", *rpath, "-o", runner])
-    return dict(units=units, oracle_runner=runner, run_kitti=host_exe, host_lib=host_lib)
+    batcher = os.path.join(OUT, "test_batcher_gpu")
+    bsrc = os.path.join(src, "test_batcher_gpu.cpp")
+    if not (os.path.exists(batcher) and os.path.getmtime(batcher) >= max(os.path.getmtime(host_lib), os.path.getmtime(bsrc))):
+        subprocess.check_call(["g++", *flags, bsrc, host_lib, b.LIB, "-lpthread", *rpath, "-o", batcher])
+    return dict(units=units, oracle_runner=runner, run_kitti=host_exe, host_lib=host_lib, batcher_gpu=batcher)

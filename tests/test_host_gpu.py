@@ -293,6 +293,17 @@ def test_eight_concurrent_streams_c5_shape(built, tmp_path):
         assert open(f"{many}.{k}").read() == singles[k % 2], k
 
 
+@pytest.mark.parametrize("streams,cohorts", [(6, 1), (9, 2)])
+def test_stream_batcher_results_and_error_isolation(built, streams, cohorts):
+    """tests/host/test_batcher_gpu.cpp: the StreamBatcher driven directly by S threads (masked detection, stereo LK, triangulation, two
+    chained temporal LK calls, pose-only -- one frame's calls of FrontEnd); every stream's results are byte for byte those of the same
+    calls made one by one through SsxCompute, and a stream that files a request the library rejects gets the exception ALONE: the
+    other streams of the same batched call get their results."""
+    r = subprocess.run([built["batcher_gpu"], str(streams), str(cohorts)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "test_batcher_gpu: ok" in r.stdout
+
+
 def test_batched_streams_reproduce_the_single_stream_trajectories(built, tmp_path):
     """--streams=K --batched=1 (ssvio_amd/host/stream_batcher.hpp): the K streams' temporal LK and pose-only LM of every frame and their
     window optimisations reach the GPU as batched library calls (ssx_lk_track_batch / ssx_pose_only_opt_batch /

@@ -173,3 +173,139 @@ def test_vocabulary_entry_points_reject_bad_arguments(ctx, po):
     assert np.array_equal(gi, oi) and gv.tobytes() == ov.tobytes()
     V.close()
     _usable(ctx, po)
+
+
+def test_batched_entry_points_reject_bad_arguments(ctx, po):
+    """ssx_lk_track_batch / ssx_pose_only_opt_batch / ssx_orb_detect_boxes_batch / ssx_triangulate_batch: a bad job anywhere in the
+    table fails the CALL with a status before anything is launched; an empty table is OK; the slots of an earlier good call stay
+    usable afterwards."""
+    lib, h = ctx.lib, ctx.handle
+    L, R = make_stereo_pair(seed=5, h=120, w=200, n_blobs=200)[:2]
+    pts = np.array([[60.0, 50.0], [100.0, 70.0], [150.0, 90.0]], np.float32)
+    good = lk.track_batch(ctx, [dict(slot=0, prev=L, next=R, prev_pts=pts), dict(slot=1, prev=R, next=L, prev_pts=pts)])
+    lib.ssx_lk_track_batch.restype = C.c_int
+    lib.ssx_lk_track_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(lk.LkJob), C.c_int32, C.c_int32, C.POINTER(lk.LkParams), C.c_int32]
+    prm = lk.LkParams(11, 3, 30, 0.01, 1e-4, 0)
+    out = pts.copy(); st = np.zeros(3, np.uint8)
+
+    def job(slot, prev, nxt, n=3, stride=200, status=st):
+        q = lk.LkJob()
+        q.slot = slot; q.prev = None if prev is None else prev.ctypes.data_as(_lib.u8_p); q.prev_stride = 0 if prev is None else stride
+        q.next = None if nxt is None else nxt.ctypes.data_as(_lib.u8_p); q.next_stride = stride; q.n = n
+        q.prev_pts = pts.ctypes.data_as(_lib.f32_p); q.next_pts = out.ctypes.data_as(_lib.f32_p)
+        q.status = None if status is None else status.ctypes.data_as(_lib.u8_p); q.err = None
+        return q
+
+    def call(jobs, n=None, rows=120, cols=200):
+        arr = (lk.LkJob * max(len(jobs), 1))(*jobs)
+        return lib.ssx_lk_track_batch(h, len(jobs) if n is None else n, arr, rows, cols, C.byref(prm), 0)
+
+    bad = [
+        call([job(0, L, R)], n=-1),                              # negative job count
+        lib.ssx_lk_track_batch(h, 2, None, 120, 200, C.byref(prm), 0),   # no table
+        lib.ssx_lk_track_batch(None, 0, None, 120, 200, C.byref(prm), 0),  # no context
+        call([job(0, L, R), job(0, R, L)]),                      # one slot twice
+        call([job(0, L, R), job(-1, R, L)]),                     # slot below 0
+        call([job(0, L, R), job(4096, R, L)]),                   # slot above the limit
+        call([job(0, L, R), job(7, None, L)]),                   # chained job on a slot that never tracked
+        call([job(0, L, None)]),                                 # no image
+        call([job(0, L, R, stride=100)]),                        # stride < cols
+        call([job(0, L, R, n=-3)]),                              # negative point count
+        call([job(0, L, R, status=None)]),                       # points but no status array
+        call([job(0, L, R)], rows=1),                            # 1-row image
+    ]
+    assert all(s_ != _lib.SSX_OK for s_ in bad), [int(x) for x in bad]
+    assert call([], n=0) == _lib.SSX_OK
+    # the slots of the good call are untouched by the rejected ones: the chained continuation equals a fresh call
+    nxt = lk.track_batch(ctx, [dict(slot=0, prev=None, next=L, prev_pts=pts), dict(slot=1, prev=None, next=R, prev_pts=pts)])
+    ref = lk.track_batch(ctx, [dict(slot=2, prev=R, next=L, prev_pts=pts), dict(slot=3, prev=L, next=R, prev_pts=pts)])
+    for a, b in zip(nxt, ref):
+        assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
+    assert len(good) == 2
+
+    # pose-only table
+    pr = make_pose_only_problem(seed=4, M=120)
+    lib.ssx_pose_only_opt_batch.restype = C.c_int32
+    lib.ssx_pose_only_opt_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ba.PoseOnlyJob)]
+    pose = np.ascontiguousarray(pr["pose"], dtype=np.float64).copy(); K = np.ascontiguousarray(pr["K"], dtype=np.float64)
+    xyz = np.ascontiguousarray(pr["xyz"], dtype=np.float64); uv = np.ascontiguousarray(pr["uv"], dtype=np.float64)
+
+    def pjob(M=120, pose_=pose, K_=K, xyz_=xyz, rounds=4, iters=10):
+        q = ba.PoseOnlyJob()
+        q.pose_io = None if pose_ is None else pose_.ctypes.data_as(_lib.dbl_p); q.K4 = None if K_ is None else K_.ctypes.data_as(_lib.dbl_p)
+        q.M = M; q.xyz = None if xyz_ is None else xyz_.ctypes.data_as(_lib.dbl_p); q.uv = uv.ctypes.data_as(_lib.dbl_p)
+        q.rounds = rounds; q.iters = iters; q.chi2_th = 5.991; q.huber_delta = 1.0; q.inlier_out = None; q.n_inliers = None
+        return q
+
+    def pcall(jobs, n=None):
+        arr = (ba.PoseOnlyJob * max(len(jobs), 1))(*jobs)
+        return lib.ssx_pose_only_opt_batch(h, len(jobs) if n is None else n, arr)
+
+    p0 = pose.copy()
+    bad = [pcall([pjob()], n=-1), lib.ssx_pose_only_opt_batch(h, 1, None), lib.ssx_pose_only_opt_batch(None, 0, None),
+           pcall([pjob(), pjob(pose_=None)]), pcall([pjob(), pjob(K_=None)]), pcall([pjob(), pjob(M=-1)]), pcall([pjob(), pjob(xyz_=None)]),
+           pcall([pjob(), pjob(rounds=-1)]), pcall([pjob(), pjob(iters=-1)])]
+    assert all(s_ != _lib.SSX_OK for s_ in bad), [int(x) for x in bad]
+    assert np.array_equal(pose, p0), "a rejected table must not have run its valid jobs"
+    assert pcall([], n=0) == _lib.SSX_OK
+    # an empty problem and a NaN problem beside a good one: the good one's result is the single call's
+    one = ba.pose_only_opt(ctx, pr["pose"], pr["K"], pr["xyz"], pr["uv"])
+    nanp = dict(pr, xyz=np.full_like(xyz, np.nan))
+    emp = dict(pr, xyz=np.zeros((0, 3)), uv=np.zeros((0, 2)))
+    res = ba.pose_only_opt_batch(ctx, [nanp, pr, emp])
+    assert res[1]["pose"].tobytes() == one["pose"].tobytes() and np.array_equal(res[1]["inliers"], one["inliers"])
+    assert res[2]["n_inliers"] == 0 and np.array_equal(res[2]["pose"], np.asarray(pr["pose"], dtype=np.float64))
+    single_nan = ba.pose_only_opt(ctx, nanp["pose"], nanp["K"], nanp["xyz"], nanp["uv"])
+    assert res[0]["pose"].tobytes() == single_nan["pose"].tobytes() and res[0]["n_inliers"] == single_nan["n_inliers"]
+
+    # detection and triangulation tables
+    class DJob(C.Structure):
+        _fields_ = [("img", _lib.u8_p), ("stride", C.c_int32), ("boxes", C.POINTER(C.c_int32)), ("n_boxes", C.c_int32), ("cap", C.c_int32),
+                    ("kps_out", C.c_void_p), ("n_out", C.POINTER(C.c_int32))]
+    lib.ssx_orb_detect_boxes_batch.restype = C.c_int32
+    lib.ssx_orb_detect_boxes_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(DJob), C.c_int32, C.c_int32, C.POINTER(orb.OrbParams), C.c_int32]
+    oprm = orb.OrbParams(100, 1.2, 3, 20, 7)
+    kps = np.zeros(600, dtype=orb.KP_DTYPE); cnt = (C.c_int32 * 1)(0)
+
+    def djob(img=L, stride=200, cap=600, n_boxes=0, n_out=cnt):
+        q = DJob()
+        q.img = None if img is None else img.ctypes.data_as(_lib.u8_p); q.stride = stride; q.boxes = None; q.n_boxes = n_boxes; q.cap = cap
+        q.kps_out = kps.ctypes.data_as(C.c_void_p); q.n_out = None if n_out is None else C.cast(n_out, C.POINTER(C.c_int32))
+        return q
+
+    def dcall(jobs, n=None, rows=120, cols=200, prm_=oprm):
+        arr = (DJob * max(len(jobs), 1))(*jobs)
+        return lib.ssx_orb_detect_boxes_batch(h, len(jobs) if n is None else n, arr, rows, cols, None if prm_ is None else C.byref(prm_), 0)
+
+    bad = [dcall([djob()], n=-1), dcall([djob()], prm_=None), dcall([djob()], rows=0), dcall([djob(), djob(img=None)]), dcall([djob(), djob(stride=100)]),
+           dcall([djob(), djob(cap=-1)]), dcall([djob(), djob(n_boxes=2)]), dcall([djob(), djob(n_out=None)]), dcall([djob(stride=200), djob(stride=256)]),
+           lib.ssx_orb_detect_boxes_batch(h, 2, None, 120, 200, C.byref(oprm), 0)]
+    assert all(s_ != _lib.SSX_OK for s_ in bad), [int(x) for x in bad]
+    assert dcall([], n=0) == _lib.SSX_OK
+    assert dcall([djob(cap=1)]) == _lib.SSX_ERR_CAPACITY                     # the image has more than one corner
+
+    class TJob(C.Structure):
+        _fields_ = [("n", C.c_int32), ("uvL", _lib.dbl_p), ("uvR", _lib.dbl_p), ("rig", C.POINTER(orb.StereoRig)), ("T_wc", _lib.dbl_p),
+                    ("xyz_out", _lib.dbl_p), ("ok_out", _lib.u8_p)]
+    lib.ssx_triangulate_batch.restype = C.c_int32
+    lib.ssx_triangulate_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(TJob)]
+    rig = orb.stereo_rig(); uvL = np.array([[100.0, 60.0], [np.nan, 5.0]]); uvR = np.array([[90.0, 60.0], [1.0, 5.0]])
+    xo = np.zeros((2, 3)); ok = np.zeros(2, np.uint8)
+
+    def tjob(n=2, rig_=rig, uvR_=uvR, ok_=ok):
+        q = TJob()
+        q.n = n; q.uvL = uvL.ctypes.data_as(_lib.dbl_p); q.uvR = None if uvR_ is None else uvR_.ctypes.data_as(_lib.dbl_p)
+        q.rig = None if rig_ is None else C.pointer(rig_); q.T_wc = None; q.xyz_out = xo.ctypes.data_as(_lib.dbl_p)
+        q.ok_out = None if ok_ is None else ok_.ctypes.data_as(_lib.u8_p)
+        return q
+
+    def tcall(jobs, n=None):
+        arr = (TJob * max(len(jobs), 1))(*jobs)
+        return lib.ssx_triangulate_batch(h, len(jobs) if n is None else n, arr)
+
+    bad = [tcall([tjob()], n=-1), lib.ssx_triangulate_batch(h, 1, None), lib.ssx_triangulate_batch(None, 0, None), tcall([tjob(), tjob(n=-1)]),
+           tcall([tjob(), tjob(rig_=None)]), tcall([tjob(), tjob(uvR_=None)]), tcall([tjob(), tjob(ok_=None)])]
+    assert all(s_ != _lib.SSX_OK for s_ in bad), [int(x) for x in bad]
+    assert tcall([], n=0) == _lib.SSX_OK and tcall([tjob(n=0, uvR_=None, ok_=None)]) == _lib.SSX_OK
+    assert tcall([tjob()]) == _lib.SSX_OK and ok[0] == 1 and ok[1] == 0          # the NaN point is flagged, not propagated
+    _usable(ctx, po)
