@@ -1,6 +1,8 @@
 // ssvio_amd/host/backend.cpp -- see backend.hpp
 #include "backend.hpp"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
@@ -8,6 +10,14 @@
 #include <tuple>
 
 namespace ssx::host {
+
+namespace {
+struct Timed {
+  double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit Timed(double& a) : acc(a) {}
+  ~Timed() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 Backend::Backend(const Setting& cfg, Compute& compute, std::shared_ptr<Map> map, const Camera& left, const Camera& right)
     : compute_(compute), map_(std::move(map)), camera_left_(left), camera_right_(right)
@@ -236,6 +246,7 @@ void Backend::Apply(Window& w)
 
 void Backend::InsertIntoMap(const KeyFramePtr& kf)
 {
+  Timed tm(stats_.t_insert);
   map_->InsertKeyFrame(kf);
   if (window_) WindowMirrorInsert(kf);
 }
@@ -293,6 +304,7 @@ void Backend::WindowDropCondemned()
 
 void Backend::WindowSolve(WindowResult& r)
 {
+  Timed tm(stats_.t_solve);
   int nk = 0, nl = 0, no = 0;
   window_->Size(nk, nl, no);
   if (nk == 0 || no == 0) return;
@@ -309,6 +321,7 @@ void Backend::WindowSolve(WindowResult& r)
 // backend.cpp:205-244 on the map, and the same edits on the window
 void Backend::WindowApply(WindowResult& r)
 {
+  Timed tm(stats_.t_apply);
   stats_.windows++; stats_.lm_iterations += r.lm_iterations; stats_.edges += (long)r.edge_outlier.size();
   const auto& all_mps = map_->GetAllMapPoints();
   for (size_t e = 0; e < r.edge_outlier.size(); ++e) {

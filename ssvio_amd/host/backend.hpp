@@ -51,7 +51,11 @@ class Backend {
   bool async() const { return async_; }
   bool resident_window() const { return window_ != nullptr; }
 
-  struct Stats { long windows = 0, lm_iterations = 0, edges = 0, outlier_edges = 0; };
+  struct Stats {
+    long windows = 0, lm_iterations = 0, edges = 0, outlier_edges = 0;
+    // seconds on the host side of a keyframe: the map + window edits of an insertion, the export + solve call, the write-back
+    double t_insert = 0, t_solve = 0, t_apply = 0;
+  };
   const Stats& stats() const { return stats_; }
 
  private:

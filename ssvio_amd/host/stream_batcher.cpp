@@ -486,6 +486,14 @@ void StreamBatcher::Finish(int k)
   if (k >= 0 && k < n_streams_) impls_[k % C]->SetState(k / C, St::DONE);
 }
 
+void StreamBatcher::ResetStats()
+{
+  for (auto& im : impls_) {
+    std::lock_guard<std::mutex> lk(im->m);
+    im->st = Stats{};
+  }
+}
+
 StreamBatcher::Stats StreamBatcher::stats()
 {
   Stats t;

@@ -51,6 +51,7 @@ class StreamBatcher {
     double wait_s = 0;                               // seconds the per-frame dispatcher waited for the streams' host code
   };
   Stats stats();
+  void ResetStats();                                 // (after the streams' warm-up: the counters then describe the frames alone)
 
   struct Impl;
 

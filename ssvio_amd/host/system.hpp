@@ -22,6 +22,11 @@ class System {
   explicit System(const std::string& config_file_path, std::unique_ptr<Compute> compute = nullptr, int device = 0);
 
   bool RunStep(ImagePtr left, ImagePtr right, double timestamp);
+  // One synthetic keyframe + two tracked frames of rows x cols through every compute call the loop makes (masked detection, stereo
+  // and chained temporal LK, triangulation, pose-only LM, a window that grows to Map.ActiveMap.Size keyframes and slides once), results discarded: the GPU library loads
+  // its kernels and sizes its workspaces here (15 - 20 ms for the first window solve alone) instead of inside the first frames.
+  // Touches neither the map nor the tracker; a run with and without it writes the same trajectory.
+  void Warmup(int rows, int cols);
   void SaveTrajectoryTUM(const std::string& path = std::string()) const;   // empty: Trajectory.Save.Path of the settings
 
   const Setting& setting() const { return setting_; }

@@ -101,7 +101,7 @@ static void run_stream(Compute& c, const StreamData& d, Results& r, Fault fault)
   r.next2 = r.next1;
   c.TrackLK(d.L1, d.L2, r.next1, r.next2, r.st2, true);          // chained: L1's pyramid is resident
   const double K4[4] = {rig.fx, rig.fy, rig.cx, rig.cy};
-  const double p0[7] = {1, 0, 0, 0, 0.01, -0.01, 0.02};
+  const double p0[7] = {0, 0, 0, 1, 0.01, -0.01, 0.02};      // qx qy qz qw tx ty tz
   std::memcpy(r.pose, p0, sizeof(p0));
   std::vector<double> uv(2 * (size_t)n);
   for (int i = 0; i < 2 * n; ++i) uv[i] = r.next2[i];

@@ -293,6 +293,29 @@ def test_eight_concurrent_streams_c5_shape(built, tmp_path):
         assert open(f"{many}.{k}").read() == singles[k % 2], k
 
 
+def test_warmup_changes_no_trajectory(built, tmp_path):
+    """System::Warmup (one synthetic keyframe + two tracked frames through every compute call, before the first frame) loads kernels
+    and sizes workspaces; it touches neither the map nor the tracker: the run with --warmup=0 writes the same bytes -- alone and as
+    batched streams, where the streams' warm-up calls go through the batcher too."""
+    seq = hu.write_corridor_sequence(os.path.join(str(tmp_path), "a"), n_frames=16)
+    cfg = hu.write_config(os.path.join(str(tmp_path), "cfg.yaml"), {"Map.ActiveMap.Size": 4, "numFeatures.trackingGood": 100000})   # a keyframe per frame
+    out = {}
+    for w in (1, 0):
+        traj = os.path.join(str(tmp_path), f"w{w}.txt")
+        r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", f"--trajectory={traj}", f"--warmup={w}"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("warm-up" in r.stdout) == (w == 1)
+        out[w] = open(traj).read()
+    assert out[1] == out[0] and len(out[1].splitlines()) >= 2
+    many = os.path.join(str(tmp_path), "many.txt")
+    r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", f"--trajectory={many}", "--streams=5", "--batched=2",
+                        "--preload=1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in range(5):
+        assert open(f"{many}.{k}").read() == out[0], k
+
+
 @pytest.mark.parametrize("streams,cohorts", [(6, 1), (9, 2)])
 def test_stream_batcher_results_and_error_isolation(built, streams, cohorts):
     """tests/host/test_batcher_gpu.cpp: the StreamBatcher driven directly by S threads (masked detection, stereo LK, triangulation, two
