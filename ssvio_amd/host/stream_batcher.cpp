@@ -11,17 +11,22 @@
 namespace ssx::host {
 
 namespace {
-enum class St { RUNNING, PENDING_LK, PENDING_PO, PENDING_DET, PENDING_LKS, PENDING_TRI, PENDING_BA, INFLIGHT, LONGOP, DONE };
+enum class St { RUNNING, PENDING_LK, PENDING_PO, PENDING_DET, PENDING_LKS, PENDING_TRI, PENDING_BA, INFLIGHT, LONGOP, DONE, IDLE };
 }
 
 struct StreamBatcher::Impl {
+  // Request slots: k < S is stream k's own thread (one request at a time); S + k is the worker thread of stream k's backend when the
+  // backend is asynchronous (Backend.Async: 1 -- it files window solves while the stream's thread goes on tracking).  A backend slot
+  // rests in IDLE, which no dispatcher waits for.
   Impl(int device_, int streams) : device(device_), S(streams), lk_ctx(device_), po_ctx(device_), ba_ctx(device_), det_ctx(device_), lks_ctx(device_),
-                                   tri_ctx(device_), state(streams, St::RUNNING), lk_req(streams), lk_rows(streams, 0), lk_cols(streams, 0),
-                                   po_req(streams), det_req(streams), det_prm(streams), tri_req(streams), ba_win(streams, nullptr), ba_res(streams, nullptr),
-                                   error(streams)
+                                   tri_ctx(device_), state(2 * (size_t)streams, St::RUNNING), lk_req(streams), lk_rows(streams, 0), lk_cols(streams, 0),
+                                   po_req(streams), det_req(streams), det_prm(streams), tri_req(streams), ba_win(2 * (size_t)streams, nullptr),
+                                   ba_res(2 * (size_t)streams, nullptr), error(2 * (size_t)streams)
   {
     n_in[(int)St::RUNNING] = streams;
-    for (int k = 0; k < streams; ++k) sleeper.push_back(std::make_unique<Sleeper>());
+    n_in[(int)St::IDLE] = streams;
+    for (int k = 0; k < streams; ++k) state[(size_t)S + k] = St::IDLE;
+    for (int k = 0; k < 2 * streams; ++k) sleeper.push_back(std::make_unique<Sleeper>());
     disp = std::thread([this] { DispatchLoop(); });
     ba_disp = std::thread([this] { KeyframeLoop(); });
   }
@@ -92,7 +97,7 @@ struct StreamBatcher::Impl {
   // (m held by the caller) the streams of a finished batch run again
   void Release(const std::vector<int>& who, const std::vector<std::string>& errs)
   {
-    for (size_t i = 0; i < who.size(); ++i) { error[who[i]] = errs[i]; Move(who[i], St::RUNNING); }
+    for (size_t i = 0; i < who.size(); ++i) { error[who[i]] = errs[i]; Move(who[i], who[i] < S ? St::RUNNING : St::IDLE); }
   }
   // One batched call for the requests idx (positions in `who`).  If it fails, every request goes once more in a call of its own:
   // only the stream whose request is at fault sees the error, the others get their results (the library validates a job table before
@@ -194,12 +199,19 @@ struct StreamBatcher::Impl {
     auto n_kf = [&] { return count(St::PENDING_DET) + count(St::PENDING_LKS) + count(St::PENDING_TRI) + count(St::PENDING_BA); };
     for (;;) {
       // (streams in a call of their own -- LONGOP -- are about to file the next request of this path: wait for them)
-      cv_disp.wait(lk, [&] { return quit || (n_kf() > 0 && count(St::RUNNING) == 0 && count(St::LONGOP) == 0); });
+      const bool at_rest = cv_disp.wait_for(lk, std::chrono::milliseconds(2), [&] { return quit || (n_kf() > 0 && count(St::RUNNING) == 0 && count(St::LONGOP) == 0); });
       if (quit) return;
+      if (!at_rest) {
+        // An asynchronous backend's window solve has waited 2 ms for the front-ends to come to rest -- they may be waiting for IT
+        // (Backend::WaitIdle at the end of a sequence, the map mutex): it is served with what has gathered so far.
+        bool backend_waits = false;
+        for (int k = S; k < 2 * S; ++k) backend_waits = backend_waits || state[k] == St::PENDING_BA;
+        if (!backend_waits) continue;
+      }
       const St kind = count(St::PENDING_DET) > 0 ? St::PENDING_DET : count(St::PENDING_LKS) > 0 ? St::PENDING_LKS : count(St::PENDING_TRI) > 0 ? St::PENDING_TRI
                                                                                                                                               : St::PENDING_BA;
       who.clear();
-      for (int k = 0; k < S; ++k) if (state[k] == kind) { who.push_back(k); Move(k, St::INFLIGHT); }
+      for (int k = 0; k < 2 * S; ++k) if (state[k] == kind) { who.push_back(k); Move(k, St::INFLIGHT); }
       lk.unlock();
       cv_disp.notify_all();                         // (the per-frame dispatcher does not wait for streams that are in flight here)
       std::vector<std::string> errs(who.size());
@@ -288,7 +300,8 @@ struct LongOp {                                   // a call the stream makes on 
 
 class BatchedBaWindow final : public BaWindow {
  public:
-  BatchedBaWindow(StreamBatcher::Impl& im, int k, const double* K4, const double* cam_ext14, const ssx_ba_options& opt) : im_(im), k_(k)
+  BatchedBaWindow(StreamBatcher::Impl& im, int k, const double* K4, const double* cam_ext14, const ssx_ba_options& opt)
+      : im_(im), k_(k), owner_(std::this_thread::get_id())
   {
     im_.ba_ctx.check(ssx_ba_window_create(im_.ba_ctx.get(), &opt, K4, cam_ext14, &win_));
     im_.ba_ctx.check(ssx_ba_window_set_fix_rule(win_, 1));
@@ -314,8 +327,11 @@ class BatchedBaWindow final : public BaWindow {
   }
   void Solve(ssx_ba_result& res) override
   {
-    im_.ba_win[k_] = win_; im_.ba_res[k_] = &res;
-    im_.SubmitAndWait(k_, St::PENDING_BA);
+    // the stream's own thread files the request in the stream's slot; the worker thread of an asynchronous backend has a slot of its
+    // own (the stream's thread goes on filing per-frame requests meanwhile)
+    const int slot = std::this_thread::get_id() == owner_ ? k_ : im_.S + k_;
+    im_.ba_win[slot] = win_; im_.ba_res[slot] = &res;
+    im_.SubmitAndWait(slot, St::PENDING_BA);
   }
 
  private:
@@ -324,6 +340,7 @@ class BatchedBaWindow final : public BaWindow {
   void check(ssx_status st) const { if (st != SSX_OK) throw std::runtime_error("ssx_ba_window: edit failed with status " + std::to_string((int)st)); }
   StreamBatcher::Impl& im_;
   int k_;
+  std::thread::id owner_;                            // the stream's thread (it makes the window: Backend's constructor)
   ssx_ba_window* win_ = nullptr;
 };
 
@@ -334,6 +351,7 @@ class BatchedCompute final : public Compute {
 
   void Detect(const Image& img, const uint8_t* mask, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
   {
+    owner_ = std::this_thread::get_id();           // (the front-end calls come from the stream's thread)
     LongOp op(im_, k_);
     kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});
     int32_t n = 0;
@@ -347,6 +365,7 @@ class BatchedCompute final : public Compute {
   }
   void DetectBoxes(const Image& img, const std::vector<int32_t>& boxes, const ssx_orb_params& prm, std::vector<ssx_keypoint>& kps) override
   {
+    owner_ = std::this_thread::get_id();           // (the front-end calls come from the stream's thread)
     kps.assign((size_t)prm.nfeatures + 260 + 64, ssx_keypoint{});
     int32_t n = 0;
     const uint8_t* pinned = Pinned(img, 0);        // (the current left image: usually there already, from the frame's temporal LK)
@@ -369,6 +388,7 @@ class BatchedCompute final : public Compute {
   void TrackLK(const Image& prev, const Image& next, const std::vector<float>& prev_pts, std::vector<float>& next_pts, std::vector<uint8_t>& status,
                bool temporal) override
   {
+    owner_ = std::this_thread::get_id();           // (the front-end calls come from the stream's thread)
     const int n = (int)(prev_pts.size() / 2);
     status.assign(n, 0);
     ssx_lk_job& q = im_.lk_req[k_];
@@ -399,6 +419,7 @@ class BatchedCompute final : public Compute {
 
   int PoseOnly(double* pose_io, const double* K4, int M, const double* xyz, const double* uv, uint8_t* inlier) override
   {
+    owner_ = std::this_thread::get_id();           // (the front-end calls come from the stream's thread)
     int32_t n_in = 0;
     ssx_pose_only_job& q = im_.po_req[k_];
     q = ssx_pose_only_job{};
@@ -410,6 +431,7 @@ class BatchedCompute final : public Compute {
 
   void Triangulate(int n, const double* uvL, const double* uvR, const ssx_stereo_rig& rig, const double* T_wc, double* xyz, uint8_t* ok) override
   {
+    owner_ = std::this_thread::get_id();           // (the front-end calls come from the stream's thread)
     ssx_triangulate_job& q = im_.tri_req[k_];
     q = ssx_triangulate_job{};
     q.n = n; q.uvL = uvL; q.uvR = uvR; q.rig = &rig; q.T_wc = T_wc; q.xyz_out = xyz; q.ok_out = ok;
@@ -418,7 +440,14 @@ class BatchedCompute final : public Compute {
 
   void BundleAdjust(const ssx_ba_problem& prob, const ssx_ba_options& opt, ssx_ba_result& res) override
   {
-    LongOp op(im_, k_);                            // (Backend.Window: 0 -- the re-marshalled map, one window per call)
+    // (Backend.Window: 0 -- the re-marshalled map, one window per call)
+    if (std::this_thread::get_id() != owner_) {
+      // the worker thread of an asynchronous backend: a context of its own, and the stream's slot is not touched (its thread is tracking)
+      if (!async_ba_) async_ba_ = std::make_unique<ssx::Context>(im_.device);
+      async_ba_->check(ssx_ba_solve(async_ba_->get(), &prob, &opt, &res));
+      return;
+    }
+    LongOp op(im_, k_);
     frame_.check(ssx_ba_solve(frame_.get(), &prob, &opt, &res));
   }
 
@@ -451,6 +480,8 @@ class BatchedCompute final : public Compute {
 
   StreamBatcher::Impl& im_;
   int k_;
+  std::thread::id owner_ = std::this_thread::get_id();
+  std::unique_ptr<ssx::Context> async_ba_;
   ssx::Context frame_;
   uint8_t* pin_[2] = {nullptr, nullptr};
   uint64_t pin_id_[2] = {0, 0};

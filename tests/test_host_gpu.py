@@ -316,6 +316,23 @@ def test_warmup_changes_no_trajectory(built, tmp_path):
         assert open(f"{many}.{k}").read() == out[0], k
 
 
+def test_batched_streams_with_asynchronous_backends_finish(built, tmp_path):
+    """Backend.Async: 1 under --batched: the backend's worker thread files its window solves in a request slot of its own while the
+    stream's thread goes on tracking, and a front-end that waits for its backend (WaitIdle at the end of the sequence) cannot starve
+    the dispatcher (a backend's request is served after 2 ms whatever the front-ends do).  Every stream finishes and writes its
+    keyframes -- resident window and re-marshalled window (the worker then solves on a context of its own)."""
+    seq = hu.write_corridor_sequence(os.path.join(str(tmp_path), "a"), n_frames=14)
+    for window in (1, 0):
+        cfg = hu.write_config(os.path.join(str(tmp_path), f"cfg{window}.yaml"), {"Map.ActiveMap.Size": 4, "numFeatures.trackingGood": 100000, "Backend.Async": 1,
+                                                                              "Backend.Window": window})
+        many = os.path.join(str(tmp_path), f"many{window}.txt")
+        r = subprocess.run([built["run_kitti"], f"--config_yaml_path={cfg}", f"--kitti_dataset_path={seq['dir']}", f"--trajectory={many}", "--streams=6", "--batched=2",
+                            "--preload=1"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for k in range(6):
+            assert len(open(f"{many}.{k}").read().splitlines()) == 14, (window, k)
+
+
 @pytest.mark.parametrize("streams,cohorts", [(6, 1), (9, 2)])
 def test_stream_batcher_results_and_error_isolation(built, streams, cohorts):
     """tests/host/test_batcher_gpu.cpp: the StreamBatcher driven directly by S threads (masked detection, stereo LK, triangulation, two
