@@ -9,7 +9,8 @@
 // converted to float once) instead of in float -- the result does not depend on the order of the parallel
 // reduction, so the device is bit-identical to the CPU restatement.
 //
-//   k_lk_pad_level0   image -> level 0 with a BORDER_REFLECT_101 border of win+1 pixels (what
+//   k_lk_pyramid      calls of <= 16 jobs: padded pyramid + derivative images of one image in ONE launch (LDS tiles with halo)
+//   k_lk_pad_level0   (wider calls, > 4 levels) image -> level 0 with a BORDER_REFLECT_101 border of win+1 pixels (what
 //                     buildOpticalFlowPyramid's copyMakeBorder produces), pitch a multiple of 64
 //   k_lk_pyr_down     level l-1 -> level l (+ border): 5x5 binomial, (sum + 128) >> 8, one thread per padded pixel
 //   k_lk_scharr       Scharr dx|dy packed as int16x2 per pixel, ZERO border (BORDER_CONSTANT, as calcOpticalFlowPyrLK)
@@ -52,6 +53,7 @@ struct LkDev {
 struct LkJob {
   uint8_t* pyr[2];                       // [0] previous image, [1] next image
   uint32_t* deriv;                       // previous image: dx | dy << 16 (int16 each), same padded geometry
+  uint32_t* deriv1;                      // the same of the next image, written by k_lk_pyramid for the job that will be chained to this one
   const uint8_t* img[2];                 // level-0 sources (device memory, or pinned host memory read over PCIe); img[0] null: chained
   int stride[2];
   int n, pt0;
@@ -60,8 +62,9 @@ struct LkJob {
 struct LkSlot {
   DevBuf mem;
   uint8_t* pyr[2] = {nullptr, nullptr};
-  uint32_t* deriv = nullptr;
+  uint32_t* deriv = nullptr, *deriv1 = nullptr;
   bool have_next = false;                // pyr[1] holds the pyramid of the slot's last `next` image
+  bool have_next_deriv = false;          // ... and deriv1 its derivative images (fused pyramid kernel)
 };
 
 struct LkWorkspace {
@@ -72,6 +75,7 @@ struct LkWorkspace {
   size_t pyr_bytes = 0, deriv_words = 0;
   int rows = 0, cols = 0, win = 0, max_level = -1;
   bool planned = false;
+  bool fused = false;                    // k_lk_pyramid builds the pyramids (<= 4 levels, border <= 16)
 };
 
 void lk_ws_free(void* p)
@@ -153,6 +157,165 @@ __global__ __launch_bounds__(256) void k_lk_scharr(LkDev d, const LkJob* __restr
     out = ((uint32_t)gx & 0xFFFFu) | ((uint32_t)gy << 16);
   }
   jb.deriv[d.doff[level] + (size_t)y * d.pitch[level] + x] = out;
+}
+
+// ---- one launch per image instead of 1 + (levels - 1) + levels --------------------------------------------------------------
+// k_lk_pyramid: the padded pyramid AND the derivative images of one image in ONE launch (k_lk_pad_level0, k_lk_pyr_down per level
+// and k_lk_scharr per level are eight dependent launches of 5 - 17 us each for a 1241x376 frame: 78 us of kernels + their
+// boundaries, against the ~0.1 ms the tracking kernel itself takes).  A workgroup owns FT x FT pixels of the PADDED top level and,
+// nested below them, the 2^k times larger blocks of the padded lower levels (ext coordinate e = padded coordinate - border; level
+// l - 1 block = [2 lo, 2 hi + 1]).  It reads the patch of the source image everything it owns depends on (101 x 101 pixels for four
+// levels) into LDS once, and goes up level by level inside LDS: outputs of level l (padded pixels = BORDER_REFLECT_101 of the level,
+// Scharr pair with a zero border) from the level's LDS patch, then the patch of level l + 1 by the 5x5 binomial, (sum + 128) >> 8.
+// The patches hold IMAGE coordinates; every read folds its coordinate (refl101), as the kernels it replaces do through the padded
+// borders -- same integers, same results (tests/test_lk_gpu.py compares every level and derivative image with the oracle's).
+// The halo is recomputed per workgroup (level 0 is read 2.5 times, in L2), nothing crosses workgroups.
+constexpr int FT = 8;
+constexpr int FUSED_MAX_LEVELS = 4;
+constexpr int FUSED_MAX_JOBS = 16;
+constexpr int FD_0 = FT + 2, FD_1 = 2 * FD_0 + 3, FD_2 = 2 * FD_1 + 3, FD_3 = 2 * FD_2 + 3;       // patch sides by distance from the top: 10, 23, 49, 101
+constexpr int FOFF_0 = 0, FOFF_1 = FOFF_0 + ((FD_0 * FD_0 + 15) & ~15), FOFF_2 = FOFF_1 + ((FD_1 * FD_1 + 15) & ~15), FOFF_3 = FOFF_2 + ((FD_2 * FD_2 + 15) & ~15);
+constexpr int FUSED_LDS = FOFF_3 + ((FD_3 * FD_3 + 15) & ~15);
+static_assert(FD_3 <= 128, "k_lk_pyramid loads its level-0 patch one column per thread of half a workgroup");
+
+struct Iv { int lo, hi; };                                             // closed interval; lo > hi = empty
+__device__ __forceinline__ Iv iv_hull(Iv a, Iv b)
+{
+  if (a.lo > a.hi) return b;
+  if (b.lo > b.hi) return a;
+  return Iv{min(a.lo, b.lo), max(a.hi, b.hi)};
+}
+// the image coordinates the ext interval folds onto (BORDER_REFLECT_101 on [0, n)), as one interval
+__device__ __forceinline__ Iv iv_fold(Iv e, int n)
+{
+  if (e.lo > e.hi) return e;
+  if (n == 1) return Iv{0, 0};
+  if (e.lo < -(n - 1) || e.hi > 2 * (n - 1)) return Iv{0, n - 1};       // (more than one fold: tiny levels under a wide border)
+  Iv r{max(e.lo, 0), min(e.hi, n - 1)};
+  if (e.lo < 0) r = iv_hull(r, Iv{max(1, -e.hi), -e.lo});
+  if (e.hi > n - 1) r = iv_hull(r, Iv{2 * (n - 1) - e.hi, 2 * (n - 1) - max(e.lo, n)});
+  return Iv{max(r.lo, 0), min(r.hi, n - 1)};
+}
+__device__ __forceinline__ int fold1(int i, int n) { return (unsigned)i < (unsigned)n ? i : refl101(i, n); }
+
+__global__ __launch_bounds__(256) void k_lk_pyramid(LkDev d, const LkJob* __restrict__ jobs)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t sP[FUSED_LDS];
+  const LkJob jb = jobs[blockIdx.z >> 1];
+  const int which = blockIdx.z & 1;
+  const uint8_t* img = jb.img[which];
+  if (!img) return;                                                   // chained job: the previous image's pyramid and derivatives are resident
+  uint8_t* pyr = jb.pyr[which];
+  uint32_t* der = which ? jb.deriv1 : jb.deriv;
+  const int top = d.levels - 1, pad = d.pad, t = threadIdx.x, tx = t & 63, ty = t >> 6;
+  // what this workgroup owns (ext coordinates, clipped to the padded level) and the patch (image coordinates) it needs, per level
+  Iv ox[FUSED_MAX_LEVELS], oy[FUSED_MAX_LEVELS], vx[FUSED_MAX_LEVELS], vy[FUSED_MAX_LEVELS];
+  {
+    const int lx = (int)blockIdx.x * FT - pad, ly = (int)blockIdx.y * FT - pad;
+#pragma unroll
+    for (int l = FUSED_MAX_LEVELS - 1; l >= 0; --l) {
+      if (l > top) continue;
+      const int k = top - l, f = 1 << k;
+      ox[l] = Iv{max(lx * f, -pad), min((lx + FT) * f - 1, d.cols[l] - 1 + pad)};
+      oy[l] = Iv{max(ly * f, -pad), min((ly + FT) * f - 1, d.rows[l] - 1 + pad)};
+      if (ox[l].lo > ox[l].hi || oy[l].lo > oy[l].hi) { ox[l] = Iv{0, -1}; oy[l] = Iv{0, -1}; }
+      const bool own = ox[l].lo <= ox[l].hi;
+      Iv nx = own ? iv_fold(Iv{ox[l].lo - 1, ox[l].hi + 1}, d.cols[l]) : Iv{0, -1};
+      Iv ny = own ? iv_fold(Iv{oy[l].lo - 1, oy[l].hi + 1}, d.rows[l]) : Iv{0, -1};
+      if (l < top && vx[l + 1].lo <= vx[l + 1].hi) {
+        nx = iv_hull(nx, iv_fold(Iv{2 * vx[l + 1].lo - 2, 2 * vx[l + 1].hi + 2}, d.cols[l]));
+        ny = iv_hull(ny, iv_fold(Iv{2 * vy[l + 1].lo - 2, 2 * vy[l + 1].hi + 2}, d.rows[l]));
+      }
+      vx[l] = nx; vy[l] = ny;
+    }
+  }
+  if (vx[0].lo > vx[0].hi) return;                                    // (a tile beyond the padded top level owns nothing)
+  auto patch = [&](int l) -> uint8_t* {
+    const int k = top - l;
+    return sP + (k == 0 ? FOFF_0 : k == 1 ? FOFF_1 : k == 2 ? FOFF_2 : FOFF_3);
+  };
+  // level 0 patch <- the image
+  {
+    const int W = vx[0].hi - vx[0].lo + 1, H = vy[0].hi - vy[0].lo + 1;
+    uint8_t* S = patch(0);
+    const uint8_t* src = img + (size_t)vy[0].lo * jb.stride[which] + vx[0].lo;
+    // (thread = one column of the patch, every second row; 16 loads in flight per round: a loop of load -> store pairs waits a memory
+    // round trip per pixel, 40 of them in a row)
+    const int x = t & 127, y0 = t >> 7;
+    const bool xin = x < W;
+    for (int j0 = 0; j0 < H; j0 += 32) {
+      uint8_t v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int y = j0 + y0 + 2 * u;
+        v[u] = (xin && y < H) ? src[(size_t)y * jb.stride[which] + x] : (uint8_t)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int y = j0 + y0 + 2 * u;
+        if (xin && y < H) S[y * W + x] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < FUSED_MAX_LEVELS; ++l) {
+    if (l > top) continue;
+    const int W = vx[l].hi - vx[l].lo + 1;
+    const int rows = d.rows[l], cols = d.cols[l], pitch = d.pitch[l];
+    const uint8_t* S = patch(l);
+    // the owned padded pixels of level l and their Scharr pairs
+    if (ox[l].lo <= ox[l].hi) {
+      uint8_t* P = pyr + d.off[l];
+      uint32_t* G = der + d.doff[l];
+      for (int ey = oy[l].lo + ty; ey <= oy[l].hi; ey += 4) {
+        const int iy = fold1(ey, rows), ym = fold1(iy - 1, rows), yp = fold1(iy + 1, rows);
+        const uint8_t* r0 = S + (ym - vy[l].lo) * W - vx[l].lo;
+        const uint8_t* r1 = S + (iy - vy[l].lo) * W - vx[l].lo;
+        const uint8_t* r2 = S + (yp - vy[l].lo) * W - vx[l].lo;
+        for (int ex = ox[l].lo + tx; ex <= ox[l].hi; ex += 64) {
+          const int ix = fold1(ex, cols);
+          const size_t o = (size_t)(ey + pad) * pitch + (ex + pad);
+          P[o] = r1[ix];
+          uint32_t g = 0;
+          if (ey == iy && ex == ix) {                                  // inside the image: the derivative; the border of G is zero
+            const int xm = fold1(ix - 1, cols), xp = fold1(ix + 1, cols);
+            const int a00 = r0[xm], a01 = r0[ix], a02 = r0[xp], a10 = r1[xm], a12 = r1[xp], a20 = r2[xm], a21 = r2[ix], a22 = r2[xp];
+            const int gx = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
+            const int gy = ((a20 - a00) + (a22 - a02)) * 3 + (a21 - a01) * 10;
+            g = ((uint32_t)gx & 0xFFFFu) | ((uint32_t)gy << 16);
+          }
+          G[o] = g;
+        }
+      }
+    }
+    // the patch of level l + 1
+    if (l < top) {
+      const int W1 = vx[l + 1].hi - vx[l + 1].lo + 1, H1 = vy[l + 1].hi - vy[l + 1].lo + 1;
+      uint8_t* D = patch(l + 1);
+      for (int y = ty; y < H1; y += 4) {
+        const int cy = 2 * (vy[l + 1].lo + y);
+        const uint8_t* rr[5];
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) rr[ky] = S + (fold1(cy + ky - 2, rows) - vy[l].lo) * W - vx[l].lo;
+        for (int x = tx; x < W1; x += 64) {
+          const int cx = 2 * (vx[l + 1].lo + x);
+          int xi[5];
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) xi[kx] = fold1(cx + kx - 2, cols);
+          int sum = 0;
+#pragma unroll
+          for (int ky = 0; ky < 5; ++ky) {
+            const uint8_t* r = rr[ky];
+            const int h = r[xi[0]] + r[xi[4]] + 4 * (r[xi[1]] + r[xi[3]]) + 6 * r[xi[2]];
+            sum += (ky == 0 || ky == 4) ? h : (ky == 2 ? 6 * h : 4 * h);
+          }
+          D[y * W1 + x] = (uint8_t)((sum + 128) >> 8);
+        }
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // exact 64-bit sum over the wave, the same value in every lane.  Lane exchanges inside a row of 16 run on the VALU (DPP:
@@ -395,9 +558,12 @@ ssx_status lk_plan(ssx_ctx* ctx, int rows, int cols, const ssx_lk_params& prm)
   ws->pyr_bytes = (off + 255) & ~size_t(255);
   ws->deriv_words = doff;
   ws->dev = d;
+  // k_lk_pyramid: at most four levels in LDS, and every level at least border + 2 pixels a side (one fold per coordinate)
+  static const bool unfused = getenv("SSX_LK_UNFUSED") != nullptr;     // (A/B: the per-level kernels)
+  ws->fused = !unfused && d.levels <= FUSED_MAX_LEVELS && std::min(d.rows[d.levels - 1], d.cols[d.levels - 1]) >= d.pad + 2;
   ws->rows = rows; ws->cols = cols; ws->win = prm.win; ws->max_level = prm.max_level;
   ws->planned = true;
-  for (LkSlot& sl : ws->slots) { sl.have_next = false; sl.pyr[0] = sl.pyr[1] = nullptr; sl.deriv = nullptr; }   // (their memory is re-carved on use)
+  for (LkSlot& sl : ws->slots) { sl.have_next = sl.have_next_deriv = false; sl.pyr[0] = sl.pyr[1] = nullptr; sl.deriv = sl.deriv1 = nullptr; }   // (their memory is re-carved on use)
   return SSX_OK;
 }
 
@@ -410,10 +576,11 @@ ssx_status lk_slot(ssx_ctx* ctx, LkWorkspace* ws, int slot, LkSlot** out)
   if (!sl.pyr[0]) {
     Layout lay;
     const size_t o_p0 = lay.take(ws->pyr_bytes), o_p1 = lay.take(ws->pyr_bytes), o_g = lay.take(sizeof(uint32_t) * ws->deriv_words);
+    const size_t o_g1 = lay.take(sizeof(uint32_t) * ws->deriv_words);
     SSX_HIP_TRY(ctx, sl.mem.reserve(lay.off, 1.0));
     char* base = sl.mem.as<char>();
-    sl.pyr[0] = (uint8_t*)(base + o_p0); sl.pyr[1] = (uint8_t*)(base + o_p1); sl.deriv = (uint32_t*)(base + o_g);
-    sl.have_next = false;
+    sl.pyr[0] = (uint8_t*)(base + o_p0); sl.pyr[1] = (uint8_t*)(base + o_p1); sl.deriv = (uint32_t*)(base + o_g); sl.deriv1 = (uint32_t*)(base + o_g1);
+    sl.have_next = sl.have_next_deriv = false;
   }
   *out = &sl;
   return SSX_OK;
@@ -456,11 +623,20 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
     for (int j = 0; j < nj; ++j) top = std::max(top, jobs[j].slot);
     if (top >= 0 && top < 4096 && (size_t)top >= ws->slots.size()) ws->slots.resize((size_t)top + 1);   // (before any pointer into it is taken)
   }
+  // One launch per image (k_lk_pyramid) for calls of a few jobs -- a single stream's frame is a chain of dependent launches, and the
+  // fused kernel replaces eight of them (chained call 0.158 -> 0.122 ms, two fresh images 0.242 -> 0.151 ms); in a call of many jobs
+  // the per-level kernels are wide launches already and do less work per pixel (64 jobs: 0.53 against 0.75 ms): they stay for those
+  // (profiles/r06/lk_pyramid_ab.txt).
+  const bool use_fused = ws->fused && nj <= FUSED_MAX_JOBS;
+  bool scharr_now = !use_fused;                                       // (the derivative images of the previous image: per-level kernel, this call)
   for (int j = 0; j < nj; ++j) {
     st = lk_slot(ctx, ws, jobs[j].slot, &slot[j]);
     if (st != SSX_OK) return st;
-    if (!jobs[j].prev) std::swap(slot[j]->pyr[0], slot[j]->pyr[1]);
-    slot[j]->have_next = false;
+    if (!jobs[j].prev) {
+      if (!slot[j]->have_next_deriv) scharr_now = true;               // its last call was a wide one: no derivative images were kept
+      std::swap(slot[j]->pyr[0], slot[j]->pyr[1]); std::swap(slot[j]->deriv, slot[j]->deriv1);
+    }
+    slot[j]->have_next = slot[j]->have_next_deriv = false;
   }
   LkDev d = ws->dev;
   hipStream_t s = ctx->stream;
@@ -486,12 +662,26 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
   // profiles/r06/c5_kernel_stats.txt).  Images elsewhere are read where they lie.
   auto span = [&](int stride) { return (size_t)(rows - 1) * (size_t)stride + (size_t)cols; };
   size_t arena_bytes = 0, o_arena = 0;                              // the range [jobs[0].next, last job's end) when it is worth one copy
-  if (images_on_device && nj >= 2) {
+  if (images_on_device && nj >= 2) {                                 // (one job: stage_each below, if the image is in host memory)
     bool ok = true;
     for (int j = 1; ok && j < nj; ++j)
       ok = jobs[j].next_stride == jobs[0].next_stride && jobs[j].next > jobs[j - 1].next && (size_t)(jobs[j].next - jobs[j - 1].next) >= span(jobs[0].next_stride);
     const size_t range = ok ? (size_t)(jobs[nj - 1].next - jobs[0].next) + span(jobs[0].next_stride) : 0;
     if (ok && range <= 2 * (size_t)nj * span(jobs[0].next_stride)) { arena_bytes = range; o_arena = io.take(range + 16); }   // (gaps: streams that sit this call out)
+  }
+  // k_lk_pyramid reads its patches with a halo (level 0 about 2.5 times): images that lie in HOST memory (pinned, not in one arena) come
+  // over by one DMA copy each instead of being read through PCIe by the kernel
+  bool stage_each = false;
+  size_t o_each = 0, each_span = 0;
+  if (images_on_device && use_fused && !arena_bytes) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, jobs[0].next) == hipSuccess) stage_each = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();
+    if (stage_each) {
+      for (int j = 0; j < nj; ++j) each_span = std::max(each_span, std::max(span(jobs[j].next_stride), jobs[j].prev ? span(jobs[j].prev_stride) : (size_t)0));
+      each_span = (each_span + 63) & ~size_t(63);
+      o_each = io.take(2 * (size_t)nj * each_span);
+    }
   }
   SSX_HIP_TRY(ctx, ws->io.reserve(io.off, 1.5));
   SSX_HIP_TRY(ctx, ws->stage.reserve(host_end, 1.5));
@@ -502,10 +692,14 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
   for (int j = 0; j < nj; ++j) {
     const ssx_lk_job& q = jobs[j];
     LkJob& t = tab[j];
-    t.pyr[0] = slot[j]->pyr[0]; t.pyr[1] = slot[j]->pyr[1]; t.deriv = slot[j]->deriv;
+    t.pyr[0] = slot[j]->pyr[0]; t.pyr[1] = slot[j]->pyr[1]; t.deriv = slot[j]->deriv; t.deriv1 = slot[j]->deriv1;
     if (images_on_device) {
       t.img[0] = q.prev; t.img[1] = q.next; t.stride[0] = q.prev_stride; t.stride[1] = q.next_stride;
       if (arena_bytes) t.img[1] = (const uint8_t*)(db + o_arena) + (size_t)(q.next - jobs[0].next);
+      if (stage_each) {
+        t.img[1] = (const uint8_t*)(db + o_each + (size_t)(2 * j) * each_span);
+        if (q.prev) t.img[0] = (const uint8_t*)(db + o_each + (size_t)(2 * j + 1) * each_span);
+      }
     } else {
       for (int y = 0; y < rows; ++y) {
         if (q.prev) memcpy(hs + o_img0[j] + (size_t)y * cols, q.prev + (size_t)y * q.prev_stride, cols);
@@ -524,7 +718,17 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
   SSX_HIP_TRY(ctx, hipMemcpyAsync(db, hs, in_bytes, hipMemcpyHostToDevice, s));
   const LkJob* dtab = reinterpret_cast<const LkJob*>(db + o_tab);
   if (arena_bytes) SSX_HIP_TRY(ctx, hipMemcpyAsync(db + o_arena, jobs[0].next, arena_bytes, hipMemcpyDefault, s));
-  for (int which = any_fresh ? 0 : 1; which < 2; ++which) {
+  if (stage_each)
+    for (int j = 0; j < nj; ++j) {
+      SSX_HIP_TRY(ctx, hipMemcpyAsync(db + o_each + (size_t)(2 * j) * each_span, jobs[j].next, span(jobs[j].next_stride), hipMemcpyHostToDevice, s));
+      if (jobs[j].prev) SSX_HIP_TRY(ctx, hipMemcpyAsync(db + o_each + (size_t)(2 * j + 1) * each_span, jobs[j].prev, span(jobs[j].prev_stride), hipMemcpyHostToDevice, s));
+    }
+  if (use_fused) {
+    const int top = d.levels - 1;
+    const dim3 g((d.cols[top] + 2 * d.pad + FT - 1) / FT, (d.rows[top] + 2 * d.pad + FT - 1) / FT, 2 * nj);   // z = job x {previous, next} image
+    hipLaunchKernelGGL(k_lk_pyramid, g, dim3(256), 0, s, d, dtab);
+  }
+  for (int which = use_fused ? 2 : any_fresh ? 0 : 1; which < 2; ++which) {
     const dim3 g0((d.cols[0] + 2 * d.pad + 255) / 256, d.rows[0] + 2 * d.pad, nj);
     hipLaunchKernelGGL(k_lk_pad_level0, g0, dim3(256), 0, s, d, dtab, which);
     for (int l = 1; l < d.levels; ++l) {
@@ -532,7 +736,7 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
       hipLaunchKernelGGL(k_lk_pyr_down, g, dim3(256), 0, s, d, dtab, which, l);
     }
   }
-  for (int l = 0; l < d.levels; ++l) {
+  for (int l = scharr_now ? 0 : d.levels; l < d.levels; ++l) {
     const dim3 g((d.cols[l] + 2 * d.pad + 255) / 256, d.rows[l] + 2 * d.pad, nj);
     hipLaunchKernelGGL(k_lk_scharr, g, dim3(256), 0, s, d, dtab, l);
   }
@@ -554,6 +758,7 @@ ssx_status lk_run(ssx_ctx* ctx, int nj, const ssx_lk_job* jobs, int32_t rows, in
   for (int j = 0; j < nj; ++j) {
     const ssx_lk_job& q = jobs[j];
     slot[j]->have_next = true;
+    slot[j]->have_next_deriv = use_fused;
     if (q.n > 0) {
       memcpy(q.next_pts, hs + o_np + sizeof(float) * 2 * pt0, sizeof(float) * 2 * q.n);
       memcpy(q.status, hs + o_st + pt0, (size_t)q.n);

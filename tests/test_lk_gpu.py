@@ -164,3 +164,72 @@ def test_track_batch_equals_single_calls(ctx, po):
         lk.track_batch(ctx, [dict(slot=1, prev=seqs[0][0], next=seqs[0][1], prev_pts=pts[0]), dict(slot=1, prev=seqs[1][0], next=seqs[1][1], prev_pts=pts[1])])
     with _pt.raises(ssvio_amd.SsxError):                     # a chained job on a slot that holds nothing
         lk.track_batch(ctx, [dict(slot=77, prev=None, next=seqs[0][1], prev_pts=pts[0])])
+
+
+@pytest.mark.parametrize("h,w,win,max_level", [(120, 160, 11, 3), (121, 163, 11, 3), (97, 250, 7, 3), (113, 113, 15, 2), (200, 333, 5, 3), (64, 90, 11, 3),
+                                               (111, 112, 11, 1), (130, 97, 13, 3), (376, 1241, 11, 2)])
+def test_pyramids_borders_and_chains_over_sizes_and_windows(ctx, po, h, w, win, max_level):
+    """Odd and even sizes at every level, windows 5 .. 15 (border 6 .. 16), 1 - 3 pyramid levels above the image, small top levels: the
+    pyramid / derivative images of both frames level by level, points on a grid that reaches into the image corners (their windows
+    read the reflected border of every level), and a chained third frame (the derivative images of a chained job's previous image were
+    written one call earlier) -- all bit for bit the oracle's.  Covers k_lk_pyramid (one launch per image) and, where a level is too
+    small for it, the per-level kernels."""
+    from ssvio_amd import Context
+    rng = np.random.default_rng(h * 1000 + w)
+    L, R, _ = make_stereo_pair(seed=40 + h % 7, h=h, w=w, n_blobs=max(60, h * w // 150))
+    T = np.clip(np.roll(L, (1, 2), (0, 1)).astype(np.int16) + rng.integers(-2, 3, L.shape), 0, 255).astype(np.uint8)
+    gx, gy = np.meshgrid(np.linspace(0.5, w - 1.5, 12), np.linspace(0.5, h - 1.5, 9))
+    pts = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    pts = np.concatenate([pts, np.array([[0, 0], [w - 1, h - 1], [w - 1, 0], [0, h - 1], [-3.5, 4.0], [w + 2.0, h / 2]], np.float32)])
+    c = Context(0)
+    prm = po.lk_params(win=win, max_level=max_level)
+    g = lk.calcOpticalFlowPyrLK(c, L, R, pts, pts, winSize=win, maxLevel=max_level)
+    o = po.lk_track(L, R, pts, pts, prm=prm)
+    assert g[3] == o[3]
+    assert _same(g[1], o[1]) and _same(g[0], o[0]) and _same(g[2], o[2])
+    prev, nxt = L, R
+    for level in range(g[3] + 1):
+        if level > 0:
+            prev, nxt = po.lk_pyr_down(prev), po.lk_pyr_down(nxt)
+        assert np.array_equal(lk.stage_level(c, 0, level), prev) and np.array_equal(lk.stage_level(c, 1, level), nxt), level
+        assert np.array_equal(lk.stage_deriv(c, level), po.lk_scharr(prev)), level
+    # chained: R is now the previous image
+    g2 = lk.calcOpticalFlowPyrLK(c, None, T, pts, pts, winSize=win, maxLevel=max_level)
+    o2 = po.lk_track(R, T, pts, pts, prm=prm)
+    assert _same(g2[1], o2[1]) and _same(g2[0], o2[0]) and _same(g2[2], o2[2])
+    prev = R
+    for level in range(g2[3] + 1):
+        if level > 0:
+            prev = po.lk_pyr_down(prev)
+        assert np.array_equal(lk.stage_deriv(c, level), po.lk_scharr(prev)), ("chained", level)
+    c.close()
+
+
+def test_wide_and_narrow_calls_interleave(ctx, po):
+    """Calls of up to 16 jobs build their pyramids and derivative images with k_lk_pyramid (one launch per image, the derivative
+    images of the new frame kept for the chained job that follows); wider calls use the per-level kernels and keep none.  A slot that
+    goes wide -> narrow -> narrow -> wide gets the oracle's bits at every step (the narrow call after a wide one computes the missing
+    derivative images itself), and so do the slots that only see the wide calls."""
+    from ssvio_amd import Context
+    c = Context(0)
+    S, few = 20, 4
+    base = [make_stereo_pair(seed=60 + s_, h=120, w=168, n_blobs=200)[0] for s_ in range(S)]
+    frames = [[np.ascontiguousarray(np.roll(base[s_], (k * (s_ % 2), k * (1 + s_ % 3)), (0, 1))) for k in range(5)] for s_ in range(S)]
+    gx, gy = np.meshgrid(np.linspace(6, 160, 8), np.linspace(6, 112, 6))
+    pts = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    cur = [0] * S                                                       # the frame each slot's kept pyramid belongs to
+
+    def call(slots, fresh):
+        jobs = [dict(slot=s_, prev=frames[s_][cur[s_]] if fresh else None, next=frames[s_][cur[s_] + 1], prev_pts=pts, next_pts=pts) for s_ in slots]
+        got = lk.track_batch(c, jobs)
+        for s_, g in zip(slots, got):
+            o = po.lk_track(frames[s_][cur[s_]], frames[s_][cur[s_] + 1], pts, pts)
+            assert _same(g[0], o[0]) and _same(g[1], o[1]) and _same(g[2], o[2]), (s_, cur[s_], fresh, len(slots))
+            cur[s_] += 1
+
+    call(range(S), True)                   # wide, fresh
+    call(range(few), False)                # narrow, chained to a wide call
+    call(range(few), False)                # narrow, chained to a narrow call
+    call(range(S), False)                  # wide, chained: slots 0 .. 3 come from a narrow call, the others from the first wide one
+    call(range(few, 2 * few), False)       # narrow after wide for other slots
+    c.close()
