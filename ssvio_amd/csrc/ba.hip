@@ -1051,6 +1051,7 @@ __device__ __forceinline__ void k_c2_out_body(const BaDev& d, const int bx, int 
 {
   const int sidx = bx * CH + threadIdx.x;
   if (sidx >= d.E) return;
+  if (trial_err == 2) trial_err = d.scal[SC_TRIALS_RUN] > 0.0;        // enqueued before the host has seen the control block
   const double* err = trial_err ? (const double*)d.err_trial : (const double*)d.err_lin;
   const double a = err[sidx], b = err[(size_t)d.E + sidx];
   d.c2_out[d.perm[sidx]] = chi2_of(a, b);
@@ -1710,6 +1711,21 @@ __global__ __launch_bounds__(CH) void k_stream_out(const double* __restrict__ sr
   double2* d2 = reinterpret_cast<double2*>(dst);
   for (size_t i = (size_t)blockIdx.x * CH + threadIdx.x; i < n2; i += (size_t)gridDim.x * CH) d2[i] = s2[i];
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
+
+// ONE window's control block, LM statistics and current estimate into pinned host memory, straight from the kernel (the single-window
+// path's three downloads -- state words, statistics, poses + landmarks -- each cost a copy and a stream synchronisation of their own:
+// ~25 us of host round trip apiece in a 0.74 ms solve).  Enqueued behind the last slot of an optimize(): `cur` is read on the device.
+__global__ __launch_bounds__(CH) void k_pack_one(BaDev d, double* __restrict__ hscal, double* __restrict__ hpose, double* __restrict__ hpoint)
+{
+  const int cur = (int)d.scal[SC_CUR];
+  const size_t n0 = SC_N, n1 = n0 + 3 * SSX_BA_MAX_STATS, n2 = n1 + 7 * (size_t)d.P, n3 = n2 + 3 * (size_t)d.L;
+  for (size_t i = (size_t)blockIdx.x * CH + threadIdx.x; i < n3; i += (size_t)gridDim.x * CH) {
+    if (i < n0) hscal[i] = d.scal[i];
+    else if (i < n1) hscal[i] = d.lm_stat[i - n0];                     // (the statistics sit behind the control block in the pinned buffer)
+    else if (i < n2) hpose[i - n1] = d.pose[cur][i - n1];
+    else hpoint[i - n2] = d.point[cur][i - n2];
+  }
 }
 
 // the keyframe poses of every window only (what a backend that reads its landmarks lazily needs back per keyframe): [n][7 maxP]
@@ -3396,6 +3412,14 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
 
   res->rounds = 0; res->n_iters = 0; res->n_inliers = 0; res->n_outliers = 0;
   int cur = ext ? ext->cur : 0; // index of the accepted state buffer
+  // the download block in pinned memory (poses | points | errors), written by k_pack_one behind the last slot of an optimize() on one rank
+  double* const pk_pose = reinterpret_cast<double*>(ws->stage.as<char>());
+  double* const pk_point = pk_pose + 7 * (size_t)d.P;
+  double* const pk_err = pk_point + 3 * (size_t)d.L;
+  static const bool no_pack_env = getenv("SSX_BA_NO_PACK") != nullptr;       // (tools: the three copies of before, for A/B timing)
+  const bool pack_ok = !cm.fn && !no_pack_env;
+  const bool pack_err = pack_ok && (res->edge_chi2 || res->edge_outlier) && d.E > 0 && d.dev_prep;
+  bool packed = false;                                                       // the pinned block holds the state the stream will end with
   bool have_trial_err = false; // err_trial holds the errors of the last trial evaluated
   int round = 0;
   // with several ranks every rank must take part in every collective, even with an empty shard
@@ -3483,7 +3507,20 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
         }
         slots_total += slots;
         SSX_HIP_TRY(ctx, hipGetLastError());
-        SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, ctx->stream));
+        if (pack_ok) {
+          // one rank: the control block, the statistics and the estimate (and the per-edge chi2 of a device-marshalled window) leave in
+          // ONE kernel-written block behind the last slot -- if this optimize() was the last one the download below finds everything there
+          if (pack_err) {
+            hipLaunchKernelGGL(k_c2_out, dim3((d.E + CH - 1) / CH), dim3(CH), 0, ctx->stream, d, have_trial_err ? 1 : 2);
+            hipLaunchKernelGGL(k_stream_out, dim3((unsigned)std::min<size_t>(256, ((size_t)d.E_raw + 2 * CH - 1) / (2 * CH))), dim3(CH), 0, ctx->stream, (const double*)d.c2_out, pk_err, (size_t)d.E_raw);
+          }
+          const size_t n_pack = SC_N + 3 * SSX_BA_MAX_STATS + 7 * (size_t)d.P + 3 * (size_t)d.L;
+          hipLaunchKernelGGL(k_pack_one, dim3((unsigned)std::min<size_t>(256, (n_pack + CH - 1) / CH)), dim3(CH), 0, ctx->stream, d, hscal, pk_pose, pk_point);
+          SSX_HIP_TRY(ctx, hipGetLastError());
+          packed = true;
+        } else {
+          SSX_HIP_TRY(ctx, hipMemcpyAsync(hscal, d.scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, ctx->stream));
+        }
         SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the one host round trip of an optimize(iters)
         if (hscal[SC_STOP] != 0.0) break;
       }
@@ -3494,8 +3531,10 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
         const int n_done = (int)hscal[SC_NSTAT];
         if (n_done > res->n_iters) {
           double* hstat = hscal + SC_N;                                // pinned, behind the scalar block
-          SSX_HIP_TRY(ctx, hipMemcpyAsync(hstat, d.lm_stat, sizeof(double) * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, ctx->stream));
-          SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+          if (!packed) {                                               // (k_pack_one brought them along)
+            SSX_HIP_TRY(ctx, hipMemcpyAsync(hstat, d.lm_stat, sizeof(double) * 3 * SSX_BA_MAX_STATS, hipMemcpyDeviceToHost, ctx->stream));
+            SSX_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+          }
           for (int k = res->n_iters; k < n_done && k < SSX_BA_MAX_STATS; ++k) {
             res->iter_chi2[k] = hstat[k];
             res->iter_lambda[k] = hstat[SSX_BA_MAX_STATS + k];
@@ -3616,10 +3655,12 @@ static ssx_status ba_solve_impl(ssx_ctx* ctx, const ssx_ba_problem* prob, const 
   double* h_pose = reinterpret_cast<double*>(hs);
   double* h_point = h_pose + 7 * (size_t)d.P;
   double* h_err = h_point + 3 * (size_t)d.L;
-  SSX_HIP_TRY(ctx, hipMemcpyAsync(h_pose, d.pose[cur], sizeof(double) * 7 * d.P, hipMemcpyDeviceToHost, ctx->stream));
-  if (d.L) SSX_HIP_TRY(ctx, hipMemcpyAsync(h_point, d.point[cur], sizeof(double) * 3 * d.L, hipMemcpyDeviceToHost, ctx->stream));
+  if (!packed) {
+    SSX_HIP_TRY(ctx, hipMemcpyAsync(h_pose, d.pose[cur], sizeof(double) * 7 * d.P, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.L) SSX_HIP_TRY(ctx, hipMemcpyAsync(h_point, d.point[cur], sizeof(double) * 3 * d.L, hipMemcpyDeviceToHost, ctx->stream));
+  }
   const bool want_err = (res->edge_chi2 || res->edge_outlier) && d.E > 0;
-  if (want_err) {
+  if (want_err && !(packed && pack_err)) {
     if (!have_trial_err) {   // iters == 0: errors of the input state
       Comm none;
       st = launch_linearize(ctx, d, bd, none, SSX_JAC_ANALYTIC, cur, 0);
