@@ -89,7 +89,25 @@ class LiveBackend:
         K = np.array(KITTI_K, dtype=np.float64)
         from tools.synth import stereo_cam_ext
         ext = stereo_cam_ext() if cam_ext is None else np.asarray(cam_ext, dtype=np.float64)
-        self.ctx = [ssvio_amd.Context(dev_index) for _ in range(G)]
+        # SSX_BENCH_GROUP_PRIO="-1,0,1": the groups' streams at different HIP priorities (-1 high .. 1 low; group g takes entry g mod len).
+        # Equal priorities share the chip evenly, so the groups finish -- and enter their host phases -- together (a convoy: the 9 %
+        # of idle span in profiles/r06/live_idle_gaps.txt); unequal ones finish one after the other.
+        prio = [int(x) for x in os.environ.get("SSX_BENCH_GROUP_PRIO", "").split(",") if x.strip()]
+        self._prio_streams = []
+        if prio:
+            # the HIP runtime this process already holds (torch's bundled copy): a second copy would not know the library's device
+            hip_path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), "libamdhip64.so")
+            hip = C.CDLL(hip_path)
+            hip.hipSetDevice(C.c_int(dev_index))
+            for g in range(G):
+                st = C.c_void_p()
+                rc = hip.hipStreamCreateWithPriority(C.byref(st), C.c_uint(1), C.c_int(prio[g % len(prio)]))    # 1 = hipStreamNonBlocking
+                if rc != 0 or not st.value:
+                    raise RuntimeError(f"hipStreamCreateWithPriority -> {rc}")
+                self._prio_streams.append(st.value)
+            self.ctx = [ssvio_amd.Context(dev_index, stream=self._prio_streams[g]) for g in range(G)]
+        else:
+            self.ctx = [ssvio_amd.Context(dev_index) for _ in range(G)]
         lib = self.lib = self.ctx[0].lib
         lib.ssx_ba_device_turns.restype = None
         lib.ssx_ba_device_turns.argtypes = [C.c_int32]
