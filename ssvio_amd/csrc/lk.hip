@@ -201,7 +201,7 @@ __device__ __forceinline__ int fold1(int i, int n) { return (unsigned)i < (unsig
 __global__ __launch_bounds__(256) void k_lk_pyramid(LkDev d, const LkJob* __restrict__ jobs)
 {
   __shared__ __attribute__((aligned(16))) uint8_t sP[FUSED_LDS];
-  const LkJob jb = jobs[blockIdx.z >> 1];
+  const LkJob& jb = jobs[blockIdx.z >> 1];                             // by reference: a private copy indexed by `which` lives in scratch memory
   const int which = blockIdx.z & 1;
   const uint8_t* img = jb.img[which];
   if (!img) return;                                                   // chained job: the previous image's pyramid and derivatives are resident
