@@ -161,6 +161,15 @@ def main():
     from tools.synth import KITTI_H, KITTI_W, make_ba_problem, make_stereo_pair
 
     stream = torch.cuda.Stream(device=dev)
+    # SSX_BENCH_FE_PRIO=1 (tools): the front-end's stream at a LOW HIP priority -- its kernels then fill the spans the backend groups
+    # leave idle instead of competing with them (profiles/r06/live_fe_priority_sweep.txt)
+    if os.environ.get("SSX_BENCH_FE_PRIO", "").strip() not in ("", "0"):
+        import ctypes as _C
+        _hip = _C.CDLL(next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), "libamdhip64.so"))
+        _st = _C.c_void_p()
+        _rc = _hip.hipStreamCreateWithPriority(_C.byref(_st), _C.c_uint(1), _C.c_int(int(os.environ["SSX_BENCH_FE_PRIO"])))
+        assert _rc == 0 and _st.value, f"hipStreamCreateWithPriority -> {_rc}"
+        stream = torch.cuda.ExternalStream(_st.value, device=dev)
     ctx = ssvio_amd.Context(dev_index, stream=stream.cuda_stream)     # front-end
     ctx_ba = ssvio_amd.Context(dev_index)                             # local BA windows, its own stream (the backend thread)
 

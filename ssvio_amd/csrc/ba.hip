@@ -1807,12 +1807,16 @@ class ParPool {
  public:
   ~ParPool()
   {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_.fetch_add(1, std::memory_order_release); }
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
   // fn(w) for w in [0, n) on at least T threads when the pool has them (the caller is one of them; threads created by an earlier,
-  // wider call join in as well); returns when all are done
+  // wider call join in as well); returns when all are done.
+  // The per-window pieces of a batched call are SHORT (a 10 KB copy, a counting pass over 2 000 observations) and a call runs five
+  // such phases back to back: items are claimed in runs (one lock per run, not two per item -- 258 copies of 10 KB took 0.28 ms,
+  // most of it on the mutex: 0.12 - 0.16 now); with SSX_POOL_SPIN=1 a worker that ran out of work polls the generation counter for
+  // a moment before it parks on the condition variable, and so does the caller before it waits for the stragglers.
   template <class F>
   void run(int n, int T, F&& fn)
   {
@@ -1821,10 +1825,17 @@ class ParPool {
     {
       std::unique_lock<std::mutex> lk(mu_);
       while ((int)th_.size() < T - 1) th_.emplace_back([this] { loop(); });
-      job_ = &f; n_ = n; next_ = 0; pending_ = n; ++gen_;
+      job_ = &f; n_ = n; next_ = 0; pending_ = n;
+      grain_ = std::max(1, n / (4 * (int)(th_.size() + 1)));
+      gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
     work();
+    if (spin_) {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (done_gen_.load(std::memory_order_acquire) != gen_.load(std::memory_order_relaxed) &&
+             std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) __builtin_ia32_pause();
+    }
     std::unique_lock<std::mutex> lk(mu_);
     done_cv_.wait(lk, [this] { return pending_ == 0; });
     job_ = nullptr;
@@ -1834,27 +1845,32 @@ class ParPool {
   void work()
   {
     for (;;) {
-      int w;
+      int w0, w1;
       const std::function<void(int)>* f;
       {
         std::lock_guard<std::mutex> lk(mu_);
         if (!job_ || next_ >= n_) return;
-        w = next_++; f = job_;
+        w0 = next_; w1 = std::min(n_, next_ + grain_); next_ = w1; f = job_;
       }
-      (*f)(w);
+      for (int w = w0; w < w1; ++w) (*f)(w);
       std::lock_guard<std::mutex> lk(mu_);
-      if (--pending_ == 0) done_cv_.notify_all();
+      pending_ -= w1 - w0;
+      if (pending_ == 0) { done_gen_.store(gen_.load(std::memory_order_relaxed), std::memory_order_release); done_cv_.notify_all(); }
     }
   }
   void loop()
   {
     unsigned long seen = 0;
     for (;;) {
+      if (spin_) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (gen_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(150)) __builtin_ia32_pause();
+      }
       {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_relaxed) != seen; });
         if (stop_) return;
-        seen = gen_;
+        seen = gen_.load(std::memory_order_relaxed);
       }
       work();
     }
@@ -1863,9 +1879,11 @@ class ParPool {
   std::condition_variable cv_, done_cv_;
   std::vector<std::thread> th_;
   const std::function<void(int)>* job_ = nullptr;
-  int n_ = 0, next_ = 0, pending_ = 0;
-  unsigned long gen_ = 0;
+  int n_ = 0, next_ = 0, pending_ = 0, grain_ = 1;
+  std::atomic<unsigned long> gen_{0}, done_gen_{0};
   bool stop_ = false;
+  // polling is OFF by default: measured in the headline region it changes nothing (profiles/r06/host_pool_ab.txt); SSX_POOL_SPIN=1 turns it on
+  const bool spin_ = [] { const char* e = getenv("SSX_POOL_SPIN"); return e ? atoi(e) != 0 : false; }();
 };
 
 // ssx_ba_device_turns: the device phases of batched solves of DIFFERENT contexts run one after the other on the device (FIFO).
