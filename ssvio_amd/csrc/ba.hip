@@ -439,6 +439,9 @@ __device__ __forceinline__ void k_linearize_body(const BaDev& d, const int bx, i
     wq = w; r0 = -er[0] * w; r1 = -er[1] * w;
     // W = Ji^T w Jj  (6x3), only when both vertices are free (block_solver.hpp:196-222).  The conditions go into the WEIGHT (one
     // select each) instead of into every entry (27 selects of a double = 54 v_cndmask): a vanishing weight gives (signed) zeros.
+    // (Non-finite Jacobians -- a point in the camera plane -- make the masked products NaN instead of 0.  They do not reach a sum that is
+    // used: W of an edge with a fixed vertex is read by leaders only (k_schur_body: `leader` excludes it, its Y row is zeroed), and the
+    // landmark sums sL of a FIXED landmark feed that landmark's own D / L^-1 bl, which only leader edges of the landmark would read.)
     const bool both = (pf >= 0) && lfree;
     const double wb = both ? w : 0.0, wl = lfree ? w : 0.0;
     const double r0l = -er[0] * wl, r1l = -er[1] * wl;
