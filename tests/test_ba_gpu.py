@@ -721,7 +721,8 @@ def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
     (k_prep_scatter / k_prep_chunk) and the pair lists + work items (k_build_lists) from the caller's raw arrays.
     SSX_BA_HOST_PREP=1 keeps the sort and the records on the host, SSX_BA_HOST_LISTS=1 everything; and the two slab reductions
     of an LM slot run as one launch (k_reduce_both: the Schur reduction sums its share of Hpp / bp itself) or, with
-    SSX_BA_SPLIT_REDUCE=1, as two.  All four must give the same bits: single solves (duplicate observations, fixed
+    SSX_BA_SPLIT_REDUCE=1, as two; a single solve's results leave in one kernel-written pinned block (k_pack_one) or, with SSX_BA_NO_PACK=1,
+    by the three copies of before.  All five must give the same bits: single solves (duplicate observations, fixed
     poses and landmarks, 4 .. 16 keyframes, sparse co-visibility) and a resident batch in two groups."""
     import subprocess, sys as _sys
     cases = [dict(P=10, L=700, seed=41), dict(P=12, L=500, obs_per_lm=4, seed=42), dict(P=16, L=600, obs_per_lm=5, seed=43, fix_first_pose=True),
@@ -735,11 +736,14 @@ def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
     cases = [{k: v for k, v in kw.items() if k in accepted} for kw in cases]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for mode in ("device", "host", "hostprep", "splitreduce"):
+    for mode in ("device", "host", "hostprep", "splitreduce", "nopack"):
         env = dict(os.environ)
         env.pop("SSX_BA_HOST_LISTS", None)
         env.pop("SSX_BA_HOST_PREP", None)
         env.pop("SSX_BA_SPLIT_REDUCE", None)
+        env.pop("SSX_BA_NO_PACK", None)
+        if mode == "nopack":
+            env["SSX_BA_NO_PACK"] = "1"                 # a single solve's control block / statistics / estimate / chi2 by three copies instead of k_pack_one's block
         if mode == "splitreduce":
             env["SSX_BA_SPLIT_REDUCE"] = "1"            # k_reduce_lin and k_reduce_schur as two launches per LM slot instead of k_reduce_both
         if mode == "host":
@@ -755,6 +759,7 @@ def test_device_built_lists_equal_host_built_lists(ctx, tmp_path):
         assert np.array_equal(outs["device"][k], outs["host"][k]), k
         assert np.array_equal(outs["device"][k], outs["hostprep"][k]), k
         assert np.array_equal(outs["device"][k], outs["splitreduce"][k]), k
+        assert np.array_equal(outs["device"][k], outs["nopack"][k]), k
 
 
 def test_poses_only_download_equals_the_full_download(ctx):
