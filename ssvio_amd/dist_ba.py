@@ -90,8 +90,13 @@ def init_native_comm(ctx, rank: int, world: int, group=None):
     import torch.distributed as dist
     lib = ctx.lib
     ident = (C.c_char * 128)()
+    failed = None
     if rank == 0:
-        ctx.check(lib.ssx_comm_unique_id(ctx.handle, ident))
+        try:
+            ctx.check(lib.ssx_comm_unique_id(ctx.handle, ident))
+        except Exception as exc:                                       # noqa: BLE001 -- the other ranks are waiting in the broadcast below:
+            failed = exc                                               # they get an all-zero id and fail the same way (no rank is left behind)
+            ident = (C.c_char * 128)()
     if world > 1:
         t = torch.frombuffer(bytearray(bytes(ident)), dtype=torch.uint8).clone()
         backend = dist.get_backend(group)
@@ -99,6 +104,9 @@ def init_native_comm(ctx, rank: int, world: int, group=None):
             t = t.to(torch.device("cuda", ctx.device))
         dist.broadcast(t, src=0, group=group)
         ident = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+    if failed is not None or not any(bytes(ident)):
+        raise RuntimeError(f"ssx_comm: rank 0 could not draw an ncclUniqueId ({failed})" if failed is not None else
+                           "ssx_comm: rank 0 could not draw an ncclUniqueId (all-zero id received)")
     h = C.c_void_p()
     ctx.check(lib.ssx_comm_init(ctx.handle, ident, int(rank), int(world), C.byref(h)))
     return h
