@@ -94,7 +94,22 @@ class LiveBackend:
         # of idle span in profiles/r06/live_idle_gaps.txt); unequal ones finish one after the other.
         prio = [int(x) for x in os.environ.get("SSX_BENCH_GROUP_PRIO", "").split(",") if x.strip()]
         self._prio_streams = []
-        if prio:
+        # SSX_BENCH_PAIR_STREAMS=k: k consecutive groups share ONE stream (their contexts are created on it): a group's kernels then queue
+        # behind its siblings' instead of beside them, and its host phases lie beside the siblings' kernels -- a pipeline of half-groups
+        # without more streams than today (profiles/r06/live_pair_streams.txt)
+        pair = int(os.environ.get("SSX_BENCH_PAIR_STREAMS", "0") or 0)
+        if pair > 1 and not prio:
+            hip_path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), "libamdhip64.so")
+            hip = C.CDLL(hip_path)
+            hip.hipSetDevice(C.c_int(dev_index))
+            for q in range((G + pair - 1) // pair):
+                st = C.c_void_p()
+                rc = hip.hipStreamCreateWithFlags(C.byref(st), C.c_uint(1))                                   # hipStreamNonBlocking
+                if rc != 0 or not st.value:
+                    raise RuntimeError(f"hipStreamCreateWithFlags -> {rc}")
+                self._prio_streams.append(st.value)
+            self.ctx = [ssvio_amd.Context(dev_index, stream=self._prio_streams[g // pair]) for g in range(G)]
+        elif prio:
             # the HIP runtime this process already holds (torch's bundled copy): a second copy would not know the library's device
             hip_path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), "libamdhip64.so")
             hip = C.CDLL(hip_path)
