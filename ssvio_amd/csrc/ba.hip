@@ -1900,29 +1900,37 @@ class DeviceTurns {
  public:
   void enable(bool on) { on_.store(on, std::memory_order_relaxed); }
   bool enabled() const { return on_.load(std::memory_order_relaxed); }
-  // (mutex held from begin to end: the rounds of different contexts are enqueued one after the other, in the order of the chain)
+  // ONE chain (mutex, last event) PER DEVICE: contexts on different GPUs never wait for each other, on the host or on the device.
+  // (mutex held from begin to end: the rounds of the contexts of one device are enqueued one after the other, in the order of the chain)
   void begin(const void* owner, int device, hipStream_t s)
   {
-    mu_.lock();
-    if (last_ && owner_ != owner && device_ == device) (void)hipStreamWaitEvent(s, last_, 0);
+    Chain& c = chain(device);
+    c.mu.lock();
+    if (c.last && c.owner != owner && hipStreamWaitEvent(s, c.last, 0) != hipSuccess) {
+      (void)hipGetLastError();                       // the chain is broken: this round runs unordered, the next one starts a new chain
+      c.last = nullptr; c.owner = nullptr;
+    }
   }
   void end(const void* owner, int device, hipEvent_t ev, hipStream_t s)
   {
-    if (ev && hipEventRecord(ev, s) == hipSuccess) { last_ = ev; owner_ = owner; device_ = device; }
-    else { (void)hipGetLastError(); last_ = nullptr; owner_ = nullptr; }
-    mu_.unlock();
+    Chain& c = chain(device);
+    if (ev && hipEventRecord(ev, s) == hipSuccess) { c.last = ev; c.owner = owner; }
+    else { (void)hipGetLastError(); c.last = nullptr; c.owner = nullptr; }
+    c.mu.unlock();
   }
   void forget(const void* owner)                       // the owner's event is about to be destroyed
   {
-    std::lock_guard<std::mutex> lk(mu_);
-    if (owner_ == owner) { last_ = nullptr; owner_ = nullptr; }
+    for (Chain& c : chains_) {
+      std::lock_guard<std::mutex> lk(c.mu);
+      if (c.owner == owner) { c.last = nullptr; c.owner = nullptr; }
+    }
   }
  private:
+  struct Chain { std::mutex mu; hipEvent_t last = nullptr; const void* owner = nullptr; };
+  static constexpr int MAX_DEV = 16;
+  Chain& chain(int device) { return chains_[(device >= 0 && device < MAX_DEV) ? device : 0]; }
   std::atomic<bool> on_{false};
-  std::mutex mu_;
-  hipEvent_t last_ = nullptr;
-  const void* owner_ = nullptr;
-  int device_ = -1;
+  Chain chains_[MAX_DEV];
 };
 static DeviceTurns g_turns;
 
